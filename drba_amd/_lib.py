@@ -1,0 +1,79 @@
+"""ctypes binding of libdrba_hip.so (C ABI declared in include/drba_hip.h).
+
+There is exactly one compute backend.  If the library is missing or a call returns an
+error code this module raises — nothing in drba_amd falls back to torch or CPU math.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdrba_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/drba_hip.h one to one
+SIGNATURES = {
+    "drba_abi_version": (_i, []),
+    "drba_error_string": (C.c_char_p, [_i]),
+    "drba_softsplat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_softsplat_ws_floats": (_z, [_i, _i, _i, _i]),
+    "drba_backwarp": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "drba_flow_distance": (_i, [_p, _p, _i, _i, _i, _p]),
+    "drba_flow_reverse": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "drba_drm_rife_linear": (_i, [_p, _p, _f, _f, _p, _p, _i, _i, _i, _p]),
+    "drba_drm_ratio": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _p]),
+    "drba_affine": (_i, [_p, _f, _f, _p, _z, _p]),
+    "drba_mul_map": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "drba_fill_holes": (_i, [_p, _p, _p, _p, _z, _p]),
+    "drba_drm_retime": (_i, [_p, _p, _d, _d, _z, _p]),
+    "drba_resize_bilinear": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
+    "drba_u8hwc_to_f32nchw": (_i, [_p, _p, _i, _i, _p]),
+    "drba_f32nchw_to_u8hwc": (_i, [_p, _p, _i, _i, _p]),
+    "drba_ssim3d_32": (_i, [_p, _p, _p, _p]),
+    "drba_conv3x3_pick_cfg": (_i, [_i, _i, _i, _i, _i]),
+    "drba_conv3x3_packed_floats": (_z, [_i, _i, _i]),
+    "drba_conv3x3_pack": (_i, [_p, _p, _i, _i, _i]),
+    "drba_conv3x3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_deconv4x4_pick_cfg": (_i, [_i, _i, _i, _i]),
+    "drba_deconv4x4_packed_floats": (_z, [_i, _i, _i]),
+    "drba_deconv4x4_pack": (_i, [_p, _p, _i, _i, _i]),
+    "drba_deconv4x4s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_ifblock_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_warp_blend": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class DrbaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library with all prototypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DrbaHipError(
+            f"{LIB_PATH} not found: the HIP kernel library is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C drba_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().drba_error_string(code).decode()
+        raise DrbaHipError(f"{what} failed: {msg} ({code})")

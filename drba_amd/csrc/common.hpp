@@ -1,0 +1,95 @@
+// Shared helpers for the gfx950 kernel library.  Written for MI355X only: wave64,
+// 256 CUs in 8 XCDs, fp32 hardware atomics to device (coarse-grained) memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/drba_hip.h"
+
+#define DRBA_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    if (hipGetLastError() != hipSuccess) return DRBA_ELAUNCH; \
+  } while (0)
+
+namespace drba {
+
+constexpr int kBlock = 256;      // 4 waves: one per SIMD of a CU
+constexpr int kMaxBlocks = 2048; // 256 CUs x 8: grid-stride beyond this (guide G11)
+
+static inline int grid_for(size_t n, int per_block = kBlock) {
+  size_t b = (n + per_block - 1) / per_block;
+  if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// fp32 atomic add that lowers to global_atomic_add_f32 (no CAS loop).  All buffers we
+// scatter into are torch device allocations (coarse-grained), where the hardware op is valid.
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+__device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// torch.linspace(-1, 1, n)[i] in fp32: symmetric two-sided formula (ATen RangeFactories).
+__device__ __forceinline__ float linspace_m1p1(int i, int n) {
+  const float step = 2.0f / (float)(n - 1);
+  return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+// Pixel-space sampling coordinate of warp(): base grid + flow/((size-1)/2), then
+// grid_sample's align_corners=True un-normalisation (g+1)*((size-1)/2) (the form ATen's
+// vectorised CPU kernel uses).  Reproduces the reference's fp32 round trip
+// (warplayer.py:17-22) instead of the algebraic x+flow.
+__device__ __forceinline__ float warp_coord(int i, int n, float flow) {
+  const float half = ((float)n - 1.0f) / 2.0f;
+  const float g = linspace_m1p1(i, n) + flow / half;
+  return (g + 1.0f) * half;
+}
+
+struct Taps {  // bilinear taps of grid_sample: clamped indices + weights
+  int x0, x1, y0, y1;
+  float wnw, wne, wsw, wse;
+};
+
+// padding_mode='border': clip the coordinate to [0, size-1] first, then bilinear.
+__device__ __forceinline__ Taps taps_border(float x, float y, int W, int H) {
+  x = fminf(fmaxf(x, 0.f), (float)(W - 1));
+  y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+  const float fx = floorf(x), fy = floorf(y);
+  Taps t;
+  t.x0 = (int)fx;
+  t.y0 = (int)fy;
+  const float wx1 = x - fx, wy1 = y - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  t.wnw = wx0 * wy0;
+  t.wne = wx1 * wy0;
+  t.wsw = wx0 * wy1;
+  t.wse = wx1 * wy1;
+  t.x1 = min(t.x0 + 1, W - 1);  // the clamped-away tap always carries weight 0
+  t.y1 = min(t.y0 + 1, H - 1);
+  // NaN coordinates: fminf/fmaxf drop the NaN -> sample at (W-1 or 0); matches clip semantics
+  t.x0 = min(max(t.x0, 0), W - 1);
+  t.y0 = min(max(t.y0, 0), H - 1);
+  return t;
+}
+
+__device__ __forceinline__ float sample(const float *__restrict__ p, int W, const Taps &t) {
+  const float *r0 = p + (size_t)t.y0 * W, *r1 = p + (size_t)t.y1 * W;
+  return r0[t.x0] * t.wnw + r0[t.x1] * t.wne + r1[t.x0] * t.wsw + r1[t.x1] * t.wse;
+}
+
+// Source taps of F.interpolate(bilinear, align_corners=False) along one axis.
+struct Lerp {
+  int i0, i1;
+  float w0, w1;
+};
+__device__ __forceinline__ Lerp lerp_src(int dst, float scale, int size) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  Lerp l;
+  l.i0 = min((int)s, size - 1);
+  l.i1 = l.i0 + (l.i0 < size - 1 ? 1 : 0);
+  l.w1 = s - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+
+}  // namespace drba

@@ -1,0 +1,251 @@
+// Non-GEMM pieces of the IFNet pipeline, fused so that no full-resolution concat, warped
+// feature map or intermediate resize ever reaches HBM:
+//   ifblock_input : warp x4 + concat + bilinear downsample  -> the stage's conv input
+//   ifblock_update: PixelShuffle'd head output -> bilinear upsample + flow accumulate
+//   warp_blend    : final two warps + sigmoid blend
+// plus bilinear resize and the uint8<->fp32 frame conversions used by to_inp/to_out.
+#include "common.hpp"
+
+using namespace drba;
+
+namespace {
+
+// F.interpolate(bilinear, align_corners=False): out = wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d)
+// (ATen's separable evaluation order: innermost axis first).
+__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float *__restrict__ in, float *__restrict__ out, int NC, int Hin,
+                                       int Win, int Hout, int Wout, float sy, float sx) {
+  const size_t total = (size_t)NC * Hout * Wout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wout);
+    const int oy = (int)((i / Wout) % Hout);
+    const int c = (int)(i / ((size_t)Wout * Hout));
+    const Lerp ly = lerp_src(oy, sy, Hin), lx = lerp_src(ox, sx, Win);
+    const float *p = in + (size_t)c * Hin * Win;
+    const float *r0 = p + (size_t)ly.i0 * Win, *r1 = p + (size_t)ly.i1 * Win;
+    const float top = lx.w0 * r0[lx.i0] + lx.w1 * r0[lx.i1];
+    const float bot = lx.w0 * r1[lx.i0] + lx.w1 * r1[lx.i1];
+    out[i] = ly.w0 * top + ly.w1 * bot;
+  }
+}
+
+// tools.py:33-34: HWC uint8 -> [1,3,H,W] fp32 / 255.
+__global__ void __launch_bounds__(256) u8_to_f32_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int H, int W) {
+  const size_t P = (size_t)H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const uint8_t *s = in + p * 3;
+    out[p] = (float)s[0] / 255.f;
+    out[P + p] = (float)s[1] / 255.f;
+    out[2 * P + p] = (float)s[2] / 255.f;
+  }
+}
+
+// tools.py:37-38: (x*255.).astype(uint8): truncation toward zero, no clamp, no rounding
+// (out-of-range values wrap modulo 256 like the x86 float->int32->uint8 conversion numpy performs).
+__global__ void __launch_bounds__(256) f32_to_u8_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, int H, int W) {
+  const size_t P = (size_t)H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = in[(size_t)c * P + p] * 255.f;
+      out[p * 3 + c] = (uint8_t)(int)v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// IFNet_HDv3.py:146 / :151-156 + IFBlock.forward :85-88.
+// One lane per LOW-RES output pixel.  For integer scale s >= 2 the align_corners=False
+// downsample touches only the central 2x2 full-res samples of each s x s cell, so the four
+// warps are evaluated at 4/s^2 of the full-res pixels (all of them only at s <= 2).
+template <bool HAS_FLOW>
+__global__ void __launch_bounds__(256) ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ img1,
+                                     const float *__restrict__ f0, const float *__restrict__ f1,
+                                     const float *__restrict__ tmap, float tscalar,
+                                     const float *__restrict__ flow, const float *__restrict__ mask,
+                                     const float *__restrict__ feat, float *__restrict__ out, int H, int W,
+                                     int h, int w, float scale) {
+  const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < p_lo; o += (size_t)gridDim.x * blockDim.x) {
+    const int oy = (int)(o / w), ox = (int)(o - (size_t)oy * w);
+    const Lerp ly = lerp_src(oy, scale, H), lx = lerp_src(ox, scale, W);
+    // zero-weight taps (scale == 1) are skipped: they would contribute exactly +0.
+    const bool use_x1 = lx.w1 != 0.f, use_y1 = ly.w1 != 0.f;
+    const int Xs[2] = {lx.i0, lx.i1}, Ys[2] = {ly.i0, ly.i1};
+    size_t q[2][2];
+    bool live[2][2];
+    Taps t0[2][2], t1[2][2];
+    float fl[2][2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        live[j][i] = (i == 0 || use_x1) && (j == 0 || use_y1);
+        q[j][i] = (size_t)Ys[j] * W + Xs[i];
+        if (HAS_FLOW && live[j][i]) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) fl[j][i][c] = flow[(size_t)c * P + q[j][i]];
+          t0[j][i] = taps_border(warp_coord(Xs[i], W, fl[j][i][0]), warp_coord(Ys[j], H, fl[j][i][1]), W, H);
+          t1[j][i] = taps_border(warp_coord(Xs[i], W, fl[j][i][2]), warp_coord(Ys[j], H, fl[j][i][3]), W, H);
+        }
+      }
+    // separable lerp, innermost axis first: wy0*(wx0*V00 + wx1*V01) + wy1*(wx0*V10 + wx1*V11)
+    auto lerp4 = [&](auto &&val) -> float {
+      const float v00 = val(0, 0);
+      const float v01 = live[0][1] ? val(0, 1) : 0.f;
+      const float top = lx.w0 * v00 + lx.w1 * v01;
+      float bot = 0.f;
+      if (use_y1) {
+        const float v10 = val(1, 0);
+        const float v11 = live[1][1] ? val(1, 1) : 0.f;
+        bot = lx.w0 * v10 + lx.w1 * v11;
+      }
+      return ly.w0 * top + ly.w1 * bot;
+    };
+    float *dst = out + o;
+    if (HAS_FLOW) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float *pl0 = img0 + (size_t)c * P, *pl1 = img1 + (size_t)c * P;
+        dst[(size_t)c * p_lo] = lerp4([&](int j, int i) { return sample(pl0, W, t0[j][i]); });
+        dst[(size_t)(3 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl1, W, t1[j][i]); });
+      }
+      for (int c = 0; c < 16; ++c) {
+        const float *pl0 = f0 + (size_t)c * P, *pl1 = f1 + (size_t)c * P;
+        dst[(size_t)(6 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl0, W, t0[j][i]); });
+        dst[(size_t)(22 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl1, W, t1[j][i]); });
+      }
+      dst[(size_t)38 * p_lo] = lerp4([&](int j, int i) { return tmap ? tmap[q[j][i]] : tscalar; });
+      dst[(size_t)39 * p_lo] = lerp4([&](int j, int i) { return mask[q[j][i]]; });
+      for (int c = 0; c < 8; ++c) {
+        const float *pl = feat + (size_t)c * P;
+        dst[(size_t)(40 + c) * p_lo] = lerp4([&](int j, int i) { return pl[q[j][i]]; });
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float v = lerp4([&](int j, int i) { return fl[j][i][c]; });
+        dst[(size_t)(48 + c) * p_lo] = (v * 1.f) / scale;  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
+      }
+    } else {
+      for (int c = 0; c < 3; ++c) {
+        const float *pl0 = img0 + (size_t)c * P, *pl1 = img1 + (size_t)c * P;
+        dst[(size_t)c * p_lo] = lerp4([&](int j, int i) { return pl0[q[j][i]]; });
+        dst[(size_t)(3 + c) * p_lo] = lerp4([&](int j, int i) { return pl1[q[j][i]]; });
+      }
+      for (int c = 0; c < 16; ++c) {
+        const float *pl0 = f0 + (size_t)c * P, *pl1 = f1 + (size_t)c * P;
+        dst[(size_t)(6 + c) * p_lo] = lerp4([&](int j, int i) { return pl0[q[j][i]]; });
+        dst[(size_t)(22 + c) * p_lo] = lerp4([&](int j, int i) { return pl1[q[j][i]]; });
+      }
+      dst[(size_t)38 * p_lo] = lerp4([&](int j, int i) { return tmap ? tmap[q[j][i]] : tscalar; });
+    }
+  }
+}
+
+// IFNet_HDv3.py:92-95 + :160: tmp [13,h,w] -> x`scale` bilinear; flow += tmp[:4]*scale; mask; feat.
+__global__ void __launch_bounds__(256) ifblock_update_kernel(const float *__restrict__ tmp, const float *flow_in, float *flow_out,
+                                      float *__restrict__ mask, float *__restrict__ feat, int h, int w, int H,
+                                      int W, float scale, float inv_scale) {
+  const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
+    const size_t o00 = (size_t)ly.i0 * w + lx.i0, o01 = (size_t)ly.i0 * w + lx.i1;
+    const size_t o10 = (size_t)ly.i1 * w + lx.i0, o11 = (size_t)ly.i1 * w + lx.i1;
+#pragma unroll
+    for (int c = 0; c < 13; ++c) {
+      const float *t = tmp + (size_t)c * p_lo;
+      const float top = lx.w0 * t[o00] + lx.w1 * t[o01];
+      const float bot = lx.w0 * t[o10] + lx.w1 * t[o11];
+      const float v = ly.w0 * top + ly.w1 * bot;
+      if (c < 4) {
+        const float fd = v * scale;
+        flow_out[(size_t)c * P + p] = flow_in ? flow_in[(size_t)c * P + p] + fd : fd;
+      } else if (c == 4) {
+        mask[p] = v;
+      } else {
+        feat[(size_t)(c - 5) * P + p] = v;
+      }
+    }
+  }
+}
+
+// IFNet_HDv3.py:163-167: warped_img0*sigmoid(mask) + warped_img1*(1-sigmoid(mask)).
+__global__ void __launch_bounds__(256) warp_blend_kernel(const float *__restrict__ img0, const float *__restrict__ img1,
+                                  const float *__restrict__ flow, const float *__restrict__ mask,
+                                  float *__restrict__ out, int H, int W) {
+  const size_t P = (size_t)H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const Taps t0 = taps_border(warp_coord(x, W, flow[p]), warp_coord(y, H, flow[P + p]), W, H);
+    const Taps t1 = taps_border(warp_coord(x, W, flow[2 * P + p]), warp_coord(y, H, flow[3 * P + p]), W, H);
+    const float m = 1.f / (1.f + expf(-mask[p]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a = sample(img0 + (size_t)c * P, W, t0), b = sample(img1 + (size_t)c * P, W, t1);
+      out[(size_t)c * P + p] = a * m + b * (1.f - m);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int drba_resize_bilinear(const float *in, float *out, int NC, int Hin, int Win, int Hout, int Wout, float scale_y,
+                         float scale_x, void *stream) {
+  if (!in || !out || NC <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for((size_t)NC * Hout * Wout)), dim3(kBlock), 0,
+                     (hipStream_t)stream, in, out, NC, Hin, Win, Hout, Wout, scale_y, scale_x);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_u8hwc_to_f32nchw(const uint8_t *in, float *out, int H, int W, void *stream) {
+  if (!in || !out || H <= 0 || W <= 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, in, out, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *stream) {
+  if (!in || !out || H <= 0 || W <= 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(f32_to_u8_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, in, out, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_ifblock_input(const float *img0, const float *img1, const float *f0, const float *f1,
+                       const float *timestep_map, float timestep_scalar, const float *flow, const float *mask,
+                       const float *feat, float *out, int H, int W, int h, int w, float scale, void *stream) {
+  if (!img0 || !img1 || !f0 || !f1 || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
+  if (flow && (!mask || !feat)) return DRBA_EINVAL;
+  dim3 g(grid_for((size_t)h * w)), b(kBlock);
+  if (flow)
+    hipLaunchKernelGGL(ifblock_input_kernel<true>, g, b, 0, (hipStream_t)stream, img0, img1, f0, f1, timestep_map,
+                       timestep_scalar, flow, mask, feat, out, H, W, h, w, scale);
+  else
+    hipLaunchKernelGGL(ifblock_input_kernel<false>, g, b, 0, (hipStream_t)stream, img0, img1, f0, f1, timestep_map,
+                       timestep_scalar, flow, mask, feat, out, H, W, h, w, scale);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_ifblock_update(const float *tmp, const float *flow_in, float *flow_out, float *mask, float *feat, int h,
+                        int w, int H, int W, float scale, void *stream) {
+  if (!tmp || !flow_out || !mask || !feat || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
+  hipLaunchKernelGGL(ifblock_update_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, tmp,
+                     flow_in, flow_out, mask, feat, h, w, H, W, scale, (float)(1.0 / (double)scale));
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_warp_blend(const float *img0, const float *img1, const float *flow, const float *mask, float *out, int H,
+                    int W, void *stream) {
+  if (!img0 || !img1 || !flow || !mask || !out || H <= 1 || W <= 1) return DRBA_EINVAL;
+  hipLaunchKernelGGL(warp_blend_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1,
+                     flow, mask, out, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+}  // extern "C"

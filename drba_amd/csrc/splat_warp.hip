@@ -1,0 +1,401 @@
+// Forward splat (softsplat), backward warp, flow distance and the fused RIFE/DRM splat
+// pipelines.  All HBM-bound: one lane per pixel, coalesced NCHW plane reads, fp32 hardware
+// atomics into a pixel-interleaved accumulator ([H*W][C+1]) so the 4 bilinear corners of a
+// source pixel touch at most two cache-line runs regardless of C.
+#include "common.hpp"
+
+using namespace drba;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// softsplat.py:312-357 — scatter.  Reference launches one thread per (n,c,y,x) element and
+// recomputes the target/weights per channel; here one lane owns a source pixel and loops
+// channels, so flow, floor() and the 4 weights are computed once.
+// mode: 0 sum, 1 avg, 2 linear, 3 soft.  CP = channels in the accumulator (C or C+1).
+__global__ void __launch_bounds__(256) splat_scatter(const float *__restrict__ in, const float *__restrict__ flow,
+                              const float *__restrict__ metric, float *__restrict__ acc, int C, int H,
+                              int W, int mode) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  const int CP = (mode == 0) ? C : C + 1;
+  in += (size_t)n * C * P;
+  flow += (size_t)n * 2 * P;
+  if (metric) metric += (size_t)n * P;
+  acc += (size_t)n * P * CP;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const float X = (float)x + flow[p], Y = (float)y + flow[P + p];
+    if (!(isfinite(X) && isfinite(Y))) continue;
+    const float fx = floorf(X), fy = floorf(Y);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx0 = (fx + 1.f) - X, wx1 = X - fx, wy0 = (fy + 1.f) - Y, wy1 = Y - fy;
+    const float wgt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};  // NW NE SW SE
+    const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+    const bool ok[4] = {okx0 && oky0, okx1 && oky0, okx0 && oky1, okx1 && oky1};
+    if (!(ok[0] || ok[1] || ok[2] || ok[3])) continue;
+    float *dst[4];
+    const long long base = (long long)y0 * W + x0;  // may be negative when out of bounds; only used if ok
+    dst[0] = acc + (base)*CP;
+    dst[1] = acc + (base + 1) * CP;
+    dst[2] = acc + (base + W) * CP;
+    dst[3] = acc + (base + W + 1) * CP;
+    float m = 1.f;
+    if (mode == 2) m = metric[p];
+    if (mode == 3) m = expf(metric[p]);
+    for (int c = 0; c < C; ++c) {
+      const float v = (mode >= 2) ? in[(size_t)c * P + p] * m : in[(size_t)c * P + p];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ok[k]) atomic_add_f32(dst[k] + c, v * wgt[k]);
+    }
+    if (mode != 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ok[k]) atomic_add_f32(dst[k] + C, m * wgt[k]);
+    }
+  }
+}
+
+// softsplat_torch.py:48-65 — divide by the splatted normaliser.
+__global__ void __launch_bounds__(256) splat_normalize(const float *__restrict__ acc, float *__restrict__ out, int C, int H, int W,
+                                int mode, int eps) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  const int CP = (mode == 0) ? C : C + 1;
+  acc += (size_t)n * P * CP;
+  out += (size_t)n * C * P;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const float *a = acc + p * CP;
+    if (mode == 0) {
+      for (int c = 0; c < C; ++c) out[(size_t)c * P + p] = a[c];
+      continue;
+    }
+    float nrm = a[C];
+    if (eps == 0) nrm = nrm + 0.0000001f;
+    else if (eps == 1) nrm = (nrm == 0.f) ? 1.f : nrm;
+    else nrm = fmaxf(nrm, 0.0000001f) + (nrm != nrm ? nrm : 0.f);  // clip(min=1e-7); NaN stays NaN
+    for (int c = 0; c < C; ++c) out[(size_t)c * P + p] = a[c] / nrm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// warplayer.py:8-22 / MetricNet.py:10-20.  One lane per output pixel; taps computed once and
+// reused by every channel plane (gathers are L2-served: neighbouring lanes hit neighbouring
+// source pixels for smooth flows).
+template <bool ZEROS>
+__global__ void __launch_bounds__(256) backwarp_kernel(const float *__restrict__ in, const float *__restrict__ flow,
+                                float *__restrict__ out, int C, int H, int W) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  in += (size_t)n * C * P;
+  flow += (size_t)n * 2 * P;
+  out += (size_t)n * C * P;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const float sx = warp_coord(x, W, flow[p]), sy = warp_coord(y, H, flow[P + p]);
+    if (!ZEROS) {
+      const Taps t = taps_border(sx, sy, W, H);
+      for (int c = 0; c < C; ++c) out[(size_t)c * P + p] = sample(in + (size_t)c * P, W, t);
+    } else {
+      const float fx = floorf(sx), fy = floorf(sy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float wx1 = sx - fx, wy1 = sy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+      const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+      const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+      const bool fin = isfinite(sx) && isfinite(sy);
+      for (int c = 0; c < C; ++c) {
+        const float *pl = in + (size_t)c * P;
+        float v = 0.f;
+        if (fin) {
+          if (okx0 && oky0) v += pl[(size_t)y0 * W + x0] * (wx0 * wy0);
+          if (okx1 && oky0) v += pl[(size_t)y0 * W + x0 + 1] * (wx1 * wy0);
+          if (okx0 && oky1) v += pl[(size_t)(y0 + 1) * W + x0] * (wx0 * wy1);
+          if (okx1 && oky1) v += pl[(size_t)(y0 + 1) * W + x0 + 1] * (wx1 * wy1);
+        }
+        out[(size_t)c * P + p] = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) distance_kernel(const float *__restrict__ flow, float *__restrict__ out, int H, int W) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  flow += (size_t)n * 2 * P;
+  out += (size_t)n * P;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const float u = flow[p], v = flow[P + p];
+    out[p] = sqrtf(u * u + v * v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic "value + ones" avg-splat scatter shared by the fused pipelines: accumulates
+// [v0*w, (v1*w,) w] at (x+fx, y+fy).  NV = number of value channels (1 or 2).
+template <int NV>
+__device__ __forceinline__ void scatter_avg(float *__restrict__ acc, int x, int y, float fx_, float fy_,
+                                            const float (&v)[NV], int H, int W) {
+  const float X = (float)x + fx_, Y = (float)y + fy_;
+  if (!(isfinite(X) && isfinite(Y))) return;
+  const float fx = floorf(X), fy = floorf(Y);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx0 = (fx + 1.f) - X, wx1 = X - fx, wy0 = (fy + 1.f) - Y, wy1 = Y - fy;
+  const float wgt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+  const bool okx[2] = {x0 >= 0 && x0 < W, x0 + 1 >= 0 && x0 + 1 < W};
+  const bool oky[2] = {y0 >= 0 && y0 < H, y0 + 1 >= 0 && y0 + 1 < H};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!(okx[k & 1] && oky[k >> 1])) continue;
+    float *d = acc + ((long long)(y0 + (k >> 1)) * W + (x0 + (k & 1))) * (NV + 1);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) atomic_add_f32(d + c, v[c] * wgt[k]);
+    atomic_add_f32(d + NV, wgt[k]);
+  }
+}
+
+// rife.py:59-60 + :62-64: splat (fx, fy, 1) along the flow itself.
+__global__ void __launch_bounds__(256) flow_reverse_scatter(const float *__restrict__ flow, float *__restrict__ acc, int H, int W) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  flow += (size_t)n * 2 * P;
+  acc += (size_t)n * P * 3;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const float v[2] = {flow[p], flow[P + p]};
+    scatter_avg<2>(acc, x, y, v[0], v[1], v, H, W);
+  }
+}
+
+// rife.py:59-73: flow05 = -avg; holes (ones-splat n/(n+1e-7) < 0.999) -> max(H,W); then *2.
+__global__ void __launch_bounds__(256) flow_reverse_finish(const float *__restrict__ acc, float *__restrict__ out, int H, int W) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  acc += (size_t)n * P * 3;
+  out += (size_t)n * 2 * P;
+  const float fill = (float)max(H, W);
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const float s = acc[p * 3 + 2];
+    const float nrm = s + 0.0000001f;
+    const bool gap = (s / nrm) < 0.999f;
+    const float u = gap ? fill : -1.f * (acc[p * 3 + 0] / nrm);
+    const float v = gap ? fill : -1.f * (acc[p * 3 + 1] / nrm);
+    out[p] = u * 2.f;
+    out[P + p] = v * 2.f;
+  }
+}
+
+// drm.py:67-76 (linear) + :89/:94 scatter: u = d_other/(d_self+d_other)*t*2, splat (u, 1) along self*u.
+// `unaligned` keeps u for the hole fill.
+__global__ void __launch_bounds__(256) drm_scatter(const float *__restrict__ fs, const float *__restrict__ fo, float t, float eps,
+                            float *__restrict__ unaligned, float *__restrict__ acc, int H, int W) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  fs += (size_t)n * 2 * P;
+  fo += (size_t)n * 2 * P;
+  unaligned += (size_t)n * P;
+  acc += (size_t)n * P * 2;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const float su = fs[p], sv = fs[P + p], ou = fo[p], ov = fo[P + p];
+    const float ds = sqrtf(su * su + sv * sv) + eps, d_o = sqrtf(ou * ou + ov * ov) + eps;
+    const float u = (d_o / (ds + d_o)) * t * 2.f;  // same operand order as d10+d12 / d12+d10 (commutative)
+    unaligned[p] = u;
+    const float v[1] = {u};
+    scatter_avg<1>(acc, x, y, su * u, sv * u, v, H, W);
+  }
+}
+
+// `unaligned` and `out` may alias (same index read-then-written by the same lane).
+__global__ void __launch_bounds__(256) drm_finish(const float *__restrict__ acc, const float *unaligned, float *out, int H, int W) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  acc += (size_t)n * P * 2;
+  unaligned += (size_t)n * P;
+  out += (size_t)n * P;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const float s = acc[p * 2 + 1];
+    const float nrm = s + 0.0000001f;
+    out[p] = ((s / nrm) < 0.999f) ? unaligned[p] : acc[p * 2] / nrm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ small elementwise
+__global__ void __launch_bounds__(256) drm_ratio_kernel(const float *__restrict__ f10, const float *__restrict__ f12, float eps,
+                                 float *__restrict__ r10, float *__restrict__ r12, int H, int W) {
+  const int n = blockIdx.y;
+  const size_t P = (size_t)H * W;
+  f10 += (size_t)n * 2 * P;
+  f12 += (size_t)n * 2 * P;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    float a = sqrtf(f10[p] * f10[p] + f10[P + p] * f10[P + p]);
+    float b = sqrtf(f12[p] * f12[p] + f12[P + p] * f12[P + p]);
+    if (eps != 0.f) {
+      a += eps;
+      b += eps;
+    }
+    const float s = a + b;
+    if (r10) r10[(size_t)n * P + p] = a / s;
+    if (r12) r12[(size_t)n * P + p] = b / s;
+  }
+}
+
+__global__ void __launch_bounds__(256) affine_kernel(const float *__restrict__ a, float mul, float add, float *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = a[i] * mul + add;
+}
+
+__global__ void __launch_bounds__(256) mul_map_kernel(const float *__restrict__ x, const float *__restrict__ map, float *__restrict__ out,
+                               int C, size_t P) {
+  const int n = blockIdx.y;
+  x += (size_t)n * C * P;
+  out += (size_t)n * C * P;
+  map += (size_t)n * P;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+    const float m = map[p];
+    for (int c = 0; c < C; ++c) out[(size_t)c * P + p] = x[(size_t)c * P + p] * m;
+  }
+}
+
+__global__ void __launch_bounds__(256) fill_holes_kernel(const float *__restrict__ aligned, const float *__restrict__ cover,
+                                  const float *__restrict__ value, float *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (cover[i] < 0.999f) ? value[i] : aligned[i];
+}
+
+// drm.py:10-62.  The scalar bracket walk (double, like Python floats) is data independent;
+// every lane replays it and applies the matching map update in fp32.
+__global__ void __launch_bounds__(256) drm_retime_kernel(const float *__restrict__ drm, float *__restrict__ out, double t, double prec, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double x = 0.5, lo = 0.0, hi = 1.0;
+    const double frac = 0.5;
+    const float fm = drm[i];
+    float xm = fm, lom = xm * 0.f, him = xm * 0.f + 1.f;
+    int guard = 0;
+    while (fabs(x - t) > prec && guard++ < 4096) {
+      if (x > t) {
+        hi = x;
+        x = x - (x - lo) * frac;
+        him = xm;
+        xm = xm - (xm - lom) * fm;
+      }
+      if (x < t) {
+        lo = x;
+        x = x + (hi - x) * frac;
+        lom = xm;
+        xm = xm + (him - xm) * fm;
+      }
+    }
+    out[i] = xm;
+  }
+}
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+size_t drba_softsplat_ws_floats(int N, int C, int H, int W) { return (size_t)N * H * W * (C + 1); }
+
+int drba_softsplat(const float *in, const float *flow, const float *metric, float *out, float *ws, int N, int C,
+                   int H, int W, int mode, int eps, void *stream) {
+  if (!in || !flow || !out || !ws || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  if (mode < 0 || mode > 3 || eps < 0 || eps > 2) return DRBA_EINVAL;
+  if (mode >= 2 && !metric) return DRBA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t P = (size_t)H * W;
+  const int CP = mode == 0 ? C : C + 1;
+  if (hipMemsetAsync(ws, 0, (size_t)N * P * CP * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
+  dim3 g(grid_for(P), N);
+  hipLaunchKernelGGL(splat_scatter, g, dim3(kBlock), 0, s, in, flow, metric, ws, C, H, W, mode);
+  hipLaunchKernelGGL(splat_normalize, g, dim3(kBlock), 0, s, ws, out, C, H, W, mode, eps);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_backwarp(const float *in, const float *flow, float *out, int N, int C, int H, int W, int padding,
+                  void *stream) {
+  if (!in || !flow || !out || N <= 0 || C <= 0 || H <= 1 || W <= 1 || padding < 0 || padding > 1) return DRBA_EINVAL;
+  dim3 g(grid_for((size_t)H * W), N);
+  if (padding == 0)
+    hipLaunchKernelGGL(backwarp_kernel<false>, g, dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H, W);
+  else
+    hipLaunchKernelGGL(backwarp_kernel<true>, g, dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_flow_distance(const float *flow, float *out, int N, int H, int W, void *stream) {
+  if (!flow || !out || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  dim3 g(grid_for((size_t)H * W), N);
+  hipLaunchKernelGGL(distance_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, flow, out, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, int W, void *stream) {
+  if (!flow || !out || !ws || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t P = (size_t)H * W;
+  if (hipMemsetAsync(ws, 0, (size_t)N * P * 3 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
+  dim3 g(grid_for(P), N);
+  hipLaunchKernelGGL(flow_reverse_scatter, g, dim3(kBlock), 0, s, flow, ws, H, W);
+  hipLaunchKernelGGL(flow_reverse_finish, g, dim3(kBlock), 0, s, ws, out, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float t, float eps, float *out, float *ws,
+                         int N, int H, int W, void *stream) {
+  if (!flow_self || !flow_other || !out || !ws || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t P = (size_t)H * W;
+  // ws layout: [N*P*2] accumulator (value, weight)  — `out` doubles as the unaligned map until the finish pass
+  if (hipMemsetAsync(ws, 0, (size_t)N * P * 2 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
+  dim3 g(grid_for(P), N);
+  hipLaunchKernelGGL(drm_scatter, g, dim3(kBlock), 0, s, flow_self, flow_other, t, eps, out, ws, H, W);
+  hipLaunchKernelGGL(drm_finish, g, dim3(kBlock), 0, s, ws, out, out, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_drm_ratio(const float *flow10, const float *flow12, float eps, float *drm10, float *drm12, int N, int H,
+                   int W, void *stream) {
+  if (!flow10 || !flow12 || (!drm10 && !drm12) || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  dim3 g(grid_for((size_t)H * W), N);
+  hipLaunchKernelGGL(drm_ratio_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, flow10, flow12, eps, drm10, drm12, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_affine(const float *a, float mul, float add, float *out, size_t n, void *stream) {
+  if (!a || !out || n == 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, a, mul, add, out, n);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_mul_map(const float *x, const float *map, float *out, int N, int C, int H, int W, void *stream) {
+  if (!x || !map || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  dim3 g(grid_for((size_t)H * W), N);
+  hipLaunchKernelGGL(mul_map_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, x, map, out, C, (size_t)H * W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_fill_holes(const float *aligned, const float *cover, const float *value, float *out, size_t n, void *stream) {
+  if (!aligned || !cover || !value || !out || n == 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(fill_holes_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, aligned, cover, value, out, n);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_drm_retime(const float *drm, float *out, double t, double precision, size_t n, void *stream) {
+  if (!drm || !out || n == 0 || !(precision > 0)) return DRBA_EINVAL;
+  hipLaunchKernelGGL(drm_retime_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, drm, out, t, precision, n);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""DRBA command line and per-frame driver loop (same CLI as the reference's infer.py).
+
+    python infer.py -m rife -i in.npz -o out.npz [-fps 60 | -t 2] [-s] [-st 0.3] [-hw] [-scale 1.0]
+
+The driver logic is host-side Python like the reference; the model calls it makes run on
+the HIP library.  `interpolate_stream` is the loop of reference infer.py:58-174 with the
+module globals turned into arguments, so tests can drive it with any model object.
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from drba_amd.models.utils import tools as _tools
+
+
+def parse_args(argv=None):
+    """Same flags, defaults and dest names as reference infer.py:18-36."""
+    p = argparse.ArgumentParser(description="Interpolation a video with DRBA")
+    p.add_argument("-m", "--model_type", dest="model_type", type=str, default="rife",
+                   help="model network type, current support rife/gmfss/gmfss_union")
+    p.add_argument("-i", "--input", dest="input", type=str, default="input.mp4", help="absolute path of input video")
+    p.add_argument("-o", "--output", dest="output", type=str, default="output.mp4", help="absolute path of output video")
+    p.add_argument("-fps", "--dst_fps", dest="dst_fps", type=float, default=60, help="interpolate to ? fps")
+    p.add_argument("-t", "--times", dest="times", type=int, default=-1, help="interpolate to ?x fps")
+    p.add_argument("-s", "--enable_scdet", dest="enable_scdet", action="store_true", default=False,
+                   help="enable scene change detection")
+    p.add_argument("-st", "--scdet_threshold", dest="scdet_threshold", type=float, default=0.3,
+                   help="ssim scene detection threshold")
+    p.add_argument("-hw", "--hwaccel", dest="hwaccel", action="store_true", default=False,
+                   help="enable hardware acceleration encode")
+    p.add_argument("-scale", "--scale", dest="scale", type=float, default=1.0,
+                   help="flow scale, generally use 1.0 with 1080P and 0.5 with 4K resolution")
+    return p.parse_args(argv)
+
+
+def load_model(model_type, scale=1.0, device=None, weights=None):
+    """Model factory (reference infer.py:39-55); unknown type -> ValueError."""
+    kw = {} if device is None else {"device": device}
+    if model_type == "rife":
+        from drba_amd.models.rife import RIFE
+        return RIFE(weights=weights or r"weights/train_log_rife_426_heavy", scale=scale, **kw)
+    if model_type == "gmfss":
+        from drba_amd.models.gmfss import GMFSS
+        return GMFSS(weights=weights or r"weights/train_log_gmfss", scale=scale, **kw)
+    if model_type == "gmfss_union":
+        from drba_amd.models.gmfss_union import GMFSS_UNION
+        return GMFSS_UNION(weights=weights or r"weights/train_log_gmfss_union", scale=scale, **kw)
+    raise ValueError(f"model_type must in {model_type}")
+
+
+def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, scdet_threshold=0.3,
+                       to_inp=None, to_out=None, check_scene=None, on_step=None):
+    """Run the whole clip.  Returns the number of frames written.
+
+    Schedule quirks kept from the reference: calc_t is evaluated at an
+    index one behind the centre frame in the loop and tail (infer.py:118,159); the
+    left/right split uses `ts < 1` when the left pair is unusable and `ts <= 1` when the
+    right pair is (infer.py:102-103,127-128 vs :135-136,160-161); after any scene cut the
+    model's `reuse` state is dropped.
+    """
+    to_inp = to_inp or _tools.to_inp
+    to_out = to_out or _tools.to_out
+    check_scene = check_scene or _tools.check_scene
+    src_fps = video_io.src_fps
+    if dst_fps <= src_fps:
+        raise ValueError(f"dst fps should be greater than src fps, but got dst_fps={dst_fps} and src_fps={src_fps}")
+
+    written = 0
+
+    def emit(frames, src_size):
+        nonlocal written
+        for x in frames:
+            video_io.write_frame(to_out(x, src_size))
+            written += 1
+
+    i0, i1 = video_io.read_frame(), video_io.read_frame()
+    size = _tools.get_valid_net_inp_size(i0, model.scale, div=model.pad_size)
+    src_size, dst_size = size["src_size"], size["dst_size"]
+    I0, I1 = to_inp(i0, dst_size), to_inp(i1, dst_size)
+    mapper = _tools.TMapper(src_fps, dst_fps, times)
+    idx = 0
+
+    # ---- head: frames before/around the first source frame
+    ts = _tools.calc_t(idx, times, mapper)
+    cut_left = bool(check_scene(I0, I1, scdet_threshold)) if enable_scdet else False
+    reuse = None
+    if cut_left:
+        out = [I0 for _ in ts]
+    else:
+        out = [I0 for _ in ts[ts < 1]]
+        out.extend(model.inference_ts(I0, I1, ts[ts >= 1] - 1))
+    emit(out, src_size)
+    if on_step:
+        on_step(idx)
+
+    # ---- steady state: one (I0, I1, I2) triplet per source frame
+    while True:
+        i2 = video_io.read_frame()
+        if i2 is None:
+            break
+        I2 = to_inp(i2, dst_size)
+        ts = _tools.calc_t(idx, times, mapper)
+        cut_right = bool(check_scene(I1, I2, scdet_threshold)) if enable_scdet else False
+        if cut_left and cut_right:
+            out, reuse = [I1 for _ in ts], None
+        elif cut_left:
+            reuse = None
+            out = [I1 for _ in ts[ts < 1]]
+            out.extend(model.inference_ts(I1, I2, ts[ts >= 1] - 1))
+        elif cut_right:
+            reuse = None
+            out = model.inference_ts(I0, I1, ts[ts <= 1])
+            out.extend([I1 for _ in ts[ts > 1] - 1])
+        else:
+            out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)
+        emit(out, src_size)
+        I0, I1 = I1, I2
+        cut_left = cut_right
+        idx += 1
+        if on_step:
+            on_step(idx)
+
+    # ---- tail: the last pair
+    ts = _tools.calc_t(idx, times, mapper)
+    out = model.inference_ts(I0, I1, ts[ts <= 1])
+    out.extend([I1 for _ in ts[ts > 1] - 1])
+    emit(out, src_size)
+    if on_step:
+        on_step(idx + 1)
+    return written
+
+
+def inference(model, args):
+    video_io = _tools.VideoFI_IO(args.input, args.output, dst_fps=args.dst_fps, times=args.times, hwaccel=args.hwaccel)
+    try:
+        from tqdm import tqdm
+        bar = tqdm(total=video_io.total_frames_count)
+        step = lambda _i: bar.update(1)  # noqa: E731
+    except ImportError:
+        bar, step = None, None
+    n = interpolate_stream(model, video_io, args.dst_fps, times=args.times, enable_scdet=args.enable_scdet,
+                           scdet_threshold=args.scdet_threshold, on_step=step)
+    while not video_io.finish_writing():
+        time.sleep(0.01)
+    video_io.close()
+    if bar is not None:
+        bar.close()
+    return n
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if not os.path.exists(args.input):
+        raise FileNotFoundError(f"can't find the video file {args.input}")
+    model = load_model(args.model_type, scale=args.scale)
+    return inference(model, args)
+
+
+if __name__ == "__main__":
+    main()

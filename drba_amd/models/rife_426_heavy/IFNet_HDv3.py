@@ -1,0 +1,115 @@
+"""RIFE v4.26-heavy IFNet on the HIP library.
+
+Same module tree / state-dict keys as the reference network
+(models/rife_426_heavy/IFNet_HDv3.py:28-47 Head, :50-59 ResConv, :62-96 IFBlock, :99-177 IFNet)
+so reference checkpoints load unchanged, but no torch.nn compute: every layer is a call into
+libdrba_hip.so.  What the reference does with cat / interpolate / grid_sample between the
+convolutions is fused into three glue kernels (drba_amd/csrc/ifnet_glue.hip):
+
+    stage input  = warp x4 + concat + 1/s bilinear downsample   (drba_ifblock_input)
+    stage output = PixelShuffle + x s bilinear upsample + flow accumulate (deconv epilogue + drba_ifblock_update)
+    synthesis    = warp x2 + sigmoid blend                       (drba_warp_blend)
+"""
+import torch
+
+from drba_amd import ops as _ops
+
+BLOCK_C = (192, 128, 96, 64, 32)
+
+
+class Head:
+    """Context encoder (IFNet_HDv3.py:28-47): conv s2 -> conv -> conv (LeakyReLU 0.2 each) -> deconv 4x4 s2."""
+
+    def __init__(self, sd, prefix, device):
+        g = lambda k: sd[prefix + k]  # noqa: E731
+        self.cnn0 = _ops.Conv3x3(g("cnn0.weight"), g("cnn0.bias"), stride=2, act=True, device=device)
+        self.cnn1 = _ops.Conv3x3(g("cnn1.weight"), g("cnn1.bias"), stride=1, act=True, device=device)
+        self.cnn2 = _ops.Conv3x3(g("cnn2.weight"), g("cnn2.bias"), stride=1, act=True, device=device)
+        self.cnn3 = _ops.Deconv4x4(g("cnn3.weight"), g("cnn3.bias"), pixel_shuffle=False, device=device)
+
+    def __call__(self, x, feat=False):
+        x0 = self.cnn0(x)
+        x1 = self.cnn1(x0)
+        x2 = self.cnn2(x1)
+        x3 = self.cnn3(x2)
+        return [x0, x1, x2, x3] if feat else x3  # NB: x0..x2 are post-activation, like the reference's in-place ReLU
+
+    forward = __call__
+
+
+class IFBlock:
+    """IFNet_HDv3.py:62-96.  `core` is conv0 -> 8 x ResConv -> deconv(+PixelShuffle)."""
+
+    def __init__(self, sd, prefix, device):
+        g = lambda k: sd[prefix + k]  # noqa: E731
+        self.conv0_0 = _ops.Conv3x3(g("conv0.0.0.weight"), g("conv0.0.0.bias"), stride=2, act=True, device=device)
+        self.conv0_1 = _ops.Conv3x3(g("conv0.1.0.weight"), g("conv0.1.0.bias"), stride=2, act=True, device=device)
+        self.convblock = [
+            _ops.Conv3x3(g(f"convblock.{j}.conv.weight"), g(f"convblock.{j}.conv.bias"), stride=1, act=True,
+                         beta=g(f"convblock.{j}.beta"), device=device) for j in range(8)]
+        self.lastconv = _ops.Deconv4x4(g("lastconv.0.weight"), g("lastconv.0.bias"), pixel_shuffle=True, device=device)
+
+    def core(self, x):
+        x = self.conv0_1(self.conv0_0(x))
+        for rc in self.convblock:
+            x = rc(x, residual=x)  # lrelu(conv(x) * beta + x)
+        return self.lastconv(x)  # [1, 13, 4h, 4w]
+
+    def __call__(self, x, flow=None, scale=1):
+        """Reference call form: x is the already concatenated full-resolution input (IFNet_HDv3.py:84-96)."""
+        _, _, H, W = x.shape
+        h, w = int(H * (1.0 / scale)), int(W * (1.0 / scale))
+        x = _ops.resize_bilinear_scale(x, (h, w), scale)
+        if flow is not None:
+            fl = _ops.affine(_ops.resize_bilinear_scale(flow, (h, w), scale), 1.0 / scale, 0.0)
+            x = torch.cat((x, fl), 1)
+        tmp = self.core(x)
+        return _ops.ifblock_update(tmp, None, H, W, scale)
+
+    forward = __call__
+
+
+class IFNet:
+    def __init__(self, device=None):
+        self.device = device
+        self.block = [None] * 5
+        self.encode = None
+
+    # --- torch.nn.Module-like surface used by models/rife.py:17-20
+    def to(self, device):
+        self.device = device
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, sd, strict=False):
+        dev = self.device if self.device is not None else _ops.default_device()
+        self.device = dev
+        for i in range(5):
+            self.block[i] = IFBlock(sd, f"block{i}.", dev)
+        self.block0, self.block1, self.block2, self.block3, self.block4 = self.block
+        self.encode = Head(sd, "encode.", dev)
+        return self
+
+    def forward_pair(self, img0, img1, timestep=0.5, scale_list=(8, 4, 2, 1), f0=None, f1=None):
+        """IFNet.forward (IFNet_HDv3.py:126-177) on separate frames (no 6-channel concat)."""
+        _, _, H, W = img0.shape
+        f0 = self.encode(img0) if f0 is None else f0
+        f1 = self.encode(img1) if f1 is None else f1
+        flow = mask = feat = None
+        flow_list = []
+        for i in range(5):
+            s = scale_list[i]
+            xin = _ops.ifblock_input(img0, img1, f0, f1, timestep, flow, mask, feat, s)
+            tmp = self.block[i].core(xin)
+            flow, mask, feat = _ops.ifblock_update(tmp, flow, H, W, s)
+            flow_list.append(flow)
+        return _ops.warp_blend(img0, img1, flow, mask), flow_list
+
+    def __call__(self, x, timestep=0.5, scale_list=(8, 4, 2, 1), training=False, fastmode=True, ensemble=False,
+                 f0=None, f1=None):
+        c = x.shape[1] // 2
+        return self.forward_pair(x[:, :3].contiguous(), x[:, c:c + 3].contiguous(), timestep, scale_list, f0, f1)
+
+    forward = __call__

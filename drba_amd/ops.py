@@ -1,0 +1,320 @@
+"""Tensor-level wrappers over the C ABI (include/drba_hip.h).
+
+torch is used for device memory and the current HIP stream only: every function here
+takes CUDA tensors, hands raw pointers to libdrba_hip.so on torch's current stream and
+returns freshly allocated output tensors.  No arithmetic happens in torch.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from drba_amd import _lib
+
+_MODES = {"sum": 0, "avg": 1, "linear": 2, "soft": 3}
+_EPS = {None: 0, "addeps": 0, "zeroeps": 1, "clipeps": 2}
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise _lib.DrbaHipError("drba_amd needs an MI355X (no GPU visible and there is no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name="tensor"):
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.DrbaHipError(f"{name} is on {t.device}: drba_amd ops run on the GPU only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nfloats):
+    """Grow-only scratch per (device, stream): kernels on one stream are ordered, so reuse is safe."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- splat / warp / drm
+def softsplat(tenIn, tenFlow, tenMetric, strMode):
+    parts = strMode.split("-")
+    main, sub = parts[0], (parts[1] if len(parts) > 1 else None)
+    assert main in ("sum", "avg", "linear", "soft")
+    if main in ("sum", "avg"):
+        assert tenMetric is None
+    if main in ("linear", "soft"):
+        assert tenMetric is not None
+    x, f = _f32(tenIn, "tenIn"), _f32(tenFlow, "tenFlow")
+    m = None if tenMetric is None else _f32(tenMetric, "tenMetric")
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    ws = _workspace(x.device, n * h * w * (c + 1))
+    lib = _lib.load()
+    _lib.check(lib.drba_softsplat(_p(x), _p(f), _p(m), _p(out), _p(ws), n, c, h, w, _MODES[main], _EPS.get(sub, 0),
+                                  _stream()), "drba_softsplat")
+    return out
+
+
+def backwarp(x, flow, padding="border"):
+    x, flow = _f32(x, "input"), _f32(flow, "flow")
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().drba_backwarp(_p(x), _p(flow), _p(out), n, c, h, w, 0 if padding == "border" else 1,
+                                         _stream()), "drba_backwarp")
+    return out
+
+
+def flow_distance(flow):
+    flow = _f32(flow, "flow")
+    n, _, h, w = flow.shape
+    out = torch.empty((n, 1, h, w), dtype=torch.float32, device=flow.device)
+    _lib.check(_lib.load().drba_flow_distance(_p(flow), _p(out), n, h, w, _stream()), "drba_flow_distance")
+    return out
+
+
+def flow_reverse(flow):
+    flow = _f32(flow, "flow")
+    n, _, h, w = flow.shape
+    out = torch.empty_like(flow)
+    ws = _workspace(flow.device, n * h * w * 3)
+    _lib.check(_lib.load().drba_flow_reverse(_p(flow), _p(out), _p(ws), n, h, w, _stream()), "drba_flow_reverse")
+    return out
+
+
+def drm_rife_linear(flow_self, flow_other, t, eps=1e-4):
+    a, b = _f32(flow_self, "flow_self"), _f32(flow_other, "flow_other")
+    n, _, h, w = a.shape
+    out = torch.empty((n, 1, h, w), dtype=torch.float32, device=a.device)
+    ws = _workspace(a.device, n * h * w * 2)
+    _lib.check(_lib.load().drba_drm_rife_linear(_p(a), _p(b), float(t), float(eps), _p(out), _p(ws), n, h, w,
+                                                _stream()), "drba_drm_rife_linear")
+    return out
+
+
+def drm_ratio(flow10, flow12, eps):
+    a, b = _f32(flow10), _f32(flow12)
+    n, _, h, w = a.shape
+    r10 = torch.empty((n, 1, h, w), dtype=torch.float32, device=a.device)
+    r12 = torch.empty_like(r10)
+    _lib.check(_lib.load().drba_drm_ratio(_p(a), _p(b), float(eps), _p(r10), _p(r12), n, h, w, _stream()),
+               "drba_drm_ratio")
+    return r10, r12
+
+
+def affine(a, mul, add):
+    a = _f32(a)
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().drba_affine(_p(a), float(mul), float(add), _p(out), a.numel(), _stream()), "drba_affine")
+    return out
+
+
+def mul_map(x, m):
+    x, m = _f32(x), _f32(m)
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().drba_mul_map(_p(x), _p(m), _p(out), n, c, h, w, _stream()), "drba_mul_map")
+    return out
+
+
+def fill_holes(aligned, cover, value):
+    a, c, v = _f32(aligned), _f32(cover), _f32(value)
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().drba_fill_holes(_p(a), _p(c), _p(v), _p(out), a.numel(), _stream()), "drba_fill_holes")
+    return out
+
+
+def drm_retime(drm, t, precision=1e-3):
+    d = _f32(drm)
+    out = torch.empty_like(d)
+    _lib.check(_lib.load().drba_drm_retime(_p(d), _p(out), float(t), float(precision), d.numel(), _stream()),
+               "drba_drm_retime")
+    return out
+
+
+# ----------------------------------------------------------------------------- resize / frames / scdet
+def resize_bilinear(x, size):
+    x = _f32(x)
+    n, c, h, w = x.shape
+    ho, wo = int(size[0]), int(size[1])
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    sy = float(np.float32(h) / np.float32(ho))  # ATen: static_cast<float>(in) / out
+    sx = float(np.float32(w) / np.float32(wo))
+    _lib.check(_lib.load().drba_resize_bilinear(_p(x), _p(out), n * c, h, w, ho, wo, sy, sx, _stream()),
+               "drba_resize_bilinear")
+    return out
+
+
+def resize_bilinear_scale(x, size, src_scale):
+    """F.interpolate(scale_factor=...) form: the coordinate multiplier is given explicitly (1/scale_factor)."""
+    x = _f32(x)
+    n, c, h, w = x.shape
+    ho, wo = int(size[0]), int(size[1])
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().drba_resize_bilinear(_p(x), _p(out), n * c, h, w, ho, wo, float(src_scale), float(src_scale),
+                                                _stream()), "drba_resize_bilinear")
+    return out
+
+
+def u8hwc_to_f32nchw(img_u8):
+    if not (img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3):
+        raise _lib.DrbaHipError("expected a CUDA uint8 [H,W,3] tensor")
+    img_u8 = img_u8.contiguous()
+    h, w = img_u8.shape[:2]
+    out = torch.empty((1, 3, h, w), dtype=torch.float32, device=img_u8.device)
+    _lib.check(_lib.load().drba_u8hwc_to_f32nchw(_p(img_u8), _p(out), h, w, _stream()), "drba_u8hwc_to_f32nchw")
+    return out
+
+
+def f32nchw_to_u8hwc(x):
+    x = _f32(x)
+    assert x.shape[0] == 1 and x.shape[1] == 3
+    h, w = x.shape[2:]
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().drba_f32nchw_to_u8hwc(_p(x), _p(out), h, w, _stream()), "drba_f32nchw_to_u8hwc")
+    return out
+
+
+def ssim_thumb32(x1, x2):
+    """check_scene's metric: 32x32 bilinear thumbnails -> 3-D gaussian SSIM.  Returns a Python float
+    (one D2H read: the driver branches on it, exactly like the reference's `if check_scene(...)`)."""
+    a, b = resize_bilinear(x1, (32, 32)), resize_bilinear(x2, (32, 32))
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().drba_ssim3d_32(_p(a), _p(b), _p(out), _stream()), "drba_ssim3d_32")
+    return float(out.item())
+
+
+# ----------------------------------------------------------------------------- convolutions
+class Conv3x3:
+    """One 3x3 conv layer (pad 1) with fused epilogue; weights are packed per kernel config on first use."""
+
+    def __init__(self, weight, bias, stride=1, act=True, beta=None, device=None):
+        self.w_host = weight.detach().float().cpu().contiguous()
+        self.cout, self.cin = self.w_host.shape[:2]
+        self.device = device
+        self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
+        self.beta = None if beta is None else beta.detach().float().reshape(-1).to(device).contiguous()
+        self.stride, self.act = int(stride), 1 if act else 0
+        self._packed = {}
+
+    def _pack(self, cfg):
+        if cfg not in self._packed:
+            lib = _lib.load()
+            n = lib.drba_conv3x3_packed_floats(self.cin, self.cout, cfg)
+            buf = torch.empty(n, dtype=torch.float32)
+            _lib.check(lib.drba_conv3x3_pack(C.c_void_p(self.w_host.data_ptr()), C.c_void_p(buf.data_ptr()), self.cin,
+                                             self.cout, cfg), "drba_conv3x3_pack")
+            self._packed[cfg] = buf.to(self.device)
+        return self._packed[cfg]
+
+    def __call__(self, x, residual=None, out=None):
+        x = _f32(x)
+        n, cin, h, w = x.shape
+        assert cin == self.cin, (cin, self.cin)
+        ho, wo = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+        lib = _lib.load()
+        cfg = lib.drba_conv3x3_pick_cfg(self.cin, self.cout, ho, wo, self.stride)
+        _lib.check(min(cfg, 0), "drba_conv3x3_pick_cfg")
+        wp = self._pack(cfg)
+        if out is None:
+            out = torch.empty((n, self.cout, ho, wo), dtype=torch.float32, device=x.device)
+        if self.beta is not None:
+            assert residual is not None
+            residual = _f32(residual)
+        _lib.check(lib.drba_conv3x3(_p(x), _p(wp), _p(self.bias), _p(self.beta), _p(residual if self.beta is not None else None),
+                                    _p(out), n, cin, h, w, self.cout, self.stride, self.act, cfg, _stream()), "drba_conv3x3")
+        return out
+
+
+class Deconv4x4:
+    """ConvTranspose2d(k=4, s=2, p=1), optionally fused with PixelShuffle(2)."""
+
+    def __init__(self, weight, bias, pixel_shuffle=False, device=None):
+        self.w_host = weight.detach().float().cpu().contiguous()  # [Cin, Cout, 4, 4]
+        self.cin, self.cout = self.w_host.shape[:2]
+        self.device = device
+        self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
+        self.ps = 1 if pixel_shuffle else 0
+        self._packed = {}
+
+    def _pack(self, cfg):
+        if cfg not in self._packed:
+            lib = _lib.load()
+            n = lib.drba_deconv4x4_packed_floats(self.cin, self.cout, cfg)
+            buf = torch.empty(n, dtype=torch.float32)
+            _lib.check(lib.drba_deconv4x4_pack(C.c_void_p(self.w_host.data_ptr()), C.c_void_p(buf.data_ptr()), self.cin,
+                                               self.cout, cfg), "drba_deconv4x4_pack")
+            self._packed[cfg] = buf.to(self.device)
+        return self._packed[cfg]
+
+    def __call__(self, x, out=None):
+        x = _f32(x)
+        n, cin, h, w = x.shape
+        assert cin == self.cin
+        lib = _lib.load()
+        cfg = lib.drba_deconv4x4_pick_cfg(self.cin, self.cout, h, w)
+        wp = self._pack(cfg)
+        if out is None:
+            shape = (n, self.cout // 4, 4 * h, 4 * w) if self.ps else (n, self.cout, 2 * h, 2 * w)
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        _lib.check(lib.drba_deconv4x4s2(_p(x), _p(wp), _p(self.bias), _p(out), n, cin, h, w, self.cout, self.ps, cfg,
+                                        _stream()), "drba_deconv4x4s2")
+        return out
+
+
+# ----------------------------------------------------------------------------- IFNet glue
+def ifblock_input(img0, img1, f0, f1, timestep, flow, mask, feat, scale):
+    """Stage input at 1/scale resolution (52 ch with flow, 39 without).  `timestep`: float or [1,1,H,W] map."""
+    img0, img1, f0, f1 = _f32(img0), _f32(img1), _f32(f0), _f32(f1)
+    _, _, H, W = img0.shape
+    h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
+    tmap, tsc = (None, float(timestep)) if not torch.is_tensor(timestep) else (_f32(timestep), 0.0)
+    nch = 52 if flow is not None else 39
+    out = torch.empty((1, nch, h, w), dtype=torch.float32, device=img0.device)
+    if flow is not None:
+        flow, mask, feat = _f32(flow), _f32(mask), _f32(feat)
+    _lib.check(_lib.load().drba_ifblock_input(_p(img0), _p(img1), _p(f0), _p(f1), _p(tmap), tsc, _p(flow), _p(mask),
+                                              _p(feat), _p(out), H, W, h, w, float(scale), _stream()),
+               "drba_ifblock_input")
+    return out
+
+
+def ifblock_update(tmp, flow_in, H, W, scale):
+    """(flow, mask, feat) at full resolution from the 13-channel head output at 1/scale."""
+    tmp = _f32(tmp)
+    _, c, h, w = tmp.shape
+    assert c == 13
+    dev = tmp.device
+    flow = torch.empty((1, 4, H, W), dtype=torch.float32, device=dev)
+    mask = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
+    feat = torch.empty((1, 8, H, W), dtype=torch.float32, device=dev)
+    if flow_in is not None:
+        flow_in = _f32(flow_in)
+    _lib.check(_lib.load().drba_ifblock_update(_p(tmp), _p(flow_in), _p(flow), _p(mask), _p(feat), h, w, H, W,
+                                               float(scale), _stream()), "drba_ifblock_update")
+    return flow, mask, feat
+
+
+def warp_blend(img0, img1, flow, mask):
+    img0, img1, flow, mask = _f32(img0), _f32(img1), _f32(flow), _f32(mask)
+    _, _, H, W = img0.shape
+    out = torch.empty((1, 3, H, W), dtype=torch.float32, device=img0.device)
+    _lib.check(_lib.load().drba_warp_blend(_p(img0), _p(img1), _p(flow), _p(mask), _p(out), H, W, _stream()),
+               "drba_warp_blend")
+    return out

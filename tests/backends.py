@@ -1,0 +1,51 @@
+"""Executors for tests/cases.py: the CPU oracle and the HIP product path."""
+import torch
+
+
+class OracleBackend:
+    """CPU fp32 oracle (oracle/) — the checker."""
+    name = "oracle"
+    dev = torch.device("cpu")
+
+    def __init__(self):
+        import oracle
+        self._o = oracle
+        self.warp = oracle.ops.backwarp
+        self.softsplat = oracle.ops.softsplat
+        self.distance = oracle.ops.distance
+        self.resize = oracle.ops.resize
+        self.calc_drm_rife = oracle.drm.calc_drm_rife
+        self.calc_drm_gmfss = oracle.drm.calc_drm_gmfss
+        self.calc_drm_rife_auxiliary = oracle.drm.calc_drm_rife_auxiliary
+        self.get_drm_t = oracle.drm.drm_to_t
+        self.ssim_matlab = oracle.scdet.ssim_matlab
+        self.check_scene = oracle.scdet.check_scene
+
+    def make_rife(self, sd, scale):
+        return self._o.rife.RifeOracle(sd, scale)
+
+
+class HipBackend:
+    """The product: drba_amd's reference-named call surface running on the HIP library."""
+    name = "hip"
+
+    def __init__(self):
+        from drba_amd.models import drm
+        from drba_amd.models.rife import RIFE
+        from drba_amd.models.rife_426_heavy.warplayer import warp
+        from drba_amd.models.softsplat.softsplat import softsplat
+        from drba_amd.models.utils import tools
+        self.dev = torch.device("cuda:0")
+        self._RIFE = RIFE
+        self.warp = warp
+        self.softsplat = softsplat
+        self.distance = tools.distance_calculator
+        self.resize = tools.resize
+        self.calc_drm_rife = drm.calc_drm_rife
+        self.calc_drm_gmfss = drm.calc_drm_gmfss
+        self.calc_drm_rife_auxiliary = drm.calc_drm_rife_auxiliary
+        self.get_drm_t = drm.get_drm_t
+        self.check_scene = tools.check_scene
+
+    def make_rife(self, sd, scale):
+        return self._RIFE(weights=sd, scale=scale, device=self.dev)

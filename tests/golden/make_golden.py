@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference).  For every fixture it
+  1. evaluates the reference's own function in fp32 (autocast/inference_mode decorators
+     stripped via __wrapped__),
+  2. evaluates the oracle restatement (oracle/) on the same seeded inputs,
+  3. asserts the two agree BIT-FOR-BIT (this is what pins the oracle), and
+  4. stores the reference output (whole, or a strided sample for large tensors) as data.
+
+Inputs are never stored: they regenerate from seeds via drba_amd/utils/synth.py; the
+fixtures carry float64 checksums of the inputs so generator drift is diagnosable.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz|json
+"""
+import json
+import os
+import sys
+import tempfile
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+for name in ("cv2", "torchvision", "torchvision.transforms"):  # absent here; only video IO/debug use them
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+sys.path = [REF] + [p for p in sys.path if p not in ("", ROOT, HERE)] + [ROOT]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import models.drm as ref_drm  # noqa: E402  (reference)
+import models.rife as ref_rife  # noqa: E402
+import models.softsplat.softsplat_torch as ref_splat  # noqa: E402
+import models.utils.tools as ref_tools  # noqa: E402
+from models.rife_426_heavy.IFNet_HDv3 import IFNet as RefIFNet  # noqa: E402
+from models.rife_426_heavy.warplayer import warp as ref_warp  # noqa: E402
+from models.pytorch_msssim import ssim_matlab as ref_ssim  # noqa: E402
+
+import oracle  # noqa: E402  (repo)
+from drba_amd.utils import synth  # noqa: E402
+
+torch.set_num_threads(8)
+
+from tests import cases  # noqa: E402
+from tests.backends import OracleBackend  # noqa: E402
+
+
+class _RefRife:
+    """The reference RIFE evaluated in fp32: decorators stripped."""
+
+    def __init__(self, sd, scale):
+        d = tempfile.mkdtemp()
+        torch.save({"module." + k: v for k, v in sd.items()}, os.path.join(d, "flownet.pkl"))
+        self.m = ref_rife.RIFE(weights=d, scale=scale, device=torch.device("cpu"))
+        self._ts = ref_rife.RIFE.inference_ts.__wrapped__.__wrapped__
+        self._drba = ref_rife.RIFE.inference_ts_drba.__wrapped__.__wrapped__
+
+    def encode(self, x):
+        return self.m.ifnet.encode(x)
+
+    def inference_ts(self, I0, I1, ts):
+        return self._ts(self.m, I0, I1, ts)
+
+    def calc_flow(self, a, b, f0=None, f1=None):
+        return self.m.calc_flow(a, b, f0, f1)
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False):
+        return self._drba(self.m, I0, I1, I2, ts, reuse, linear)
+
+
+class ReferenceBackend:
+    name = "reference"
+    dev = torch.device("cpu")
+    warp = staticmethod(ref_warp)
+    softsplat = staticmethod(ref_splat.softsplat)
+    distance = staticmethod(ref_tools.distance_calculator)
+    resize = staticmethod(ref_tools.resize)
+    calc_drm_rife = staticmethod(ref_drm.calc_drm_rife)
+    calc_drm_gmfss = staticmethod(ref_drm.calc_drm_gmfss)
+    calc_drm_rife_auxiliary = staticmethod(ref_drm.calc_drm_rife_auxiliary)
+    get_drm_t = staticmethod(ref_drm.get_drm_t)
+    ssim_matlab = staticmethod(ref_ssim)
+    check_scene = staticmethod(ref_tools.check_scene)
+    make_rife = staticmethod(_RefRife)
+
+
+REFB, ORAB = ReferenceBackend(), OracleBackend()
+
+
+def same(a, b, what):
+    a, b = a.detach().contiguous(), b.detach().contiguous()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    eq = torch.equal(a, b) or bool(((a == b) | (a.isnan() & b.isnan())).all())
+    assert eq, f"oracle != reference for {what}: max|d|={float((a - b).abs().max())}"
+
+
+def save(name, groups):
+    flat = {}
+    for g, d in groups.items():
+        for k, v in d.items():
+            flat[f"{g}/{k}"] = v
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **flat)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(groups)} entries")
+
+
+def run_cases(case_list, fname, extra=None):
+    out = {}
+    with torch.inference_mode():
+        for name, fn in case_list:
+            r, o = fn(REFB), fn(ORAB)
+            for (k, rv), (_, ov) in zip(cases.flatten(name, r), cases.flatten(name, o)):
+                same(ov, rv, k)
+                out[k] = cases.pack(rv)
+    if extra:
+        out.update(extra)
+    save(fname, out)
+
+
+def golden_ops():
+    run_cases(cases.ops_cases(), "ops.npz",
+              {"_inputs": {k: np.float64(torch.nan_to_num(v, 0.0, 0.0, 0.0).double().sum()) for k, v in cases.ops_inputs().items()}})
+
+
+def golden_drm():
+    run_cases(cases.drm_cases(), "drm.npz",
+              {"_inputs": {k: np.float64(v.double().sum()) for k, v in cases.drm_inputs().items()}})
+
+
+def golden_rife():
+    sd = synth.ifnet_state_dict(seed=0)
+    ref_sd = RefIFNet().state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), "synthetic state-dict keys differ from the reference IFNet"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    out = {}
+    meta = {"weights_sum": float(sum(v.double().sum() for v in sd.values()))}
+    for scale, (H, W) in cases.RIFE_CONFIGS:
+        meta[f"frames_sum_s{scale}"] = float(sum(f.double().sum() for f in cases.rife_frames(H, W)))
+        with torch.inference_mode():
+            r = cases.rife_run(REFB, sd, scale, H, W)
+            o = cases.rife_run(ORAB, sd, scale, H, W)
+        assert list(r) == list(o)
+        for k in r:
+            same(o[k], r[k], k)
+            out[k] = cases.pack(r[k])
+    # per-stage flows of one plain IFNet pass (pins every IFBlock + warp of the oracle)
+    H, W = cases.RIFE_CONFIGS[0][1]
+    I0, I1 = cases.rife_frames(H, W)[:2]
+    m = _RefRife(sd, 1.0)
+    with torch.inference_mode():
+        _, rfl = m.m.ifnet(torch.cat((I0, I1), 1), timestep=0.5, scale_list=m.m.scale_list)
+        tr = {}
+        oracle.ifnet.ifnet(sd, torch.cat((I0, I1), 1), 0.5, m.m.scale_list, trace=tr)
+        for i in range(5):
+            same(tr[f"flow{i}"], rfl[i], f"ifnet flow{i}")
+            out[f"ifnet_flow{i}"] = cases.pack(rfl[i])
+        # the reference as shipped (bf16 CPU autocast): its own deviation from its fp32 evaluation
+        I2 = cases.rife_frames(H, W)[2]
+        rf, _ = m.inference_ts_drba(I0, I1, I2, np.array([0.75, 1.25]), None, True)
+    rb, _ = m.m.inference_ts_drba(I0, I1, I2, np.array([0.75, 1.25]), None, linear=True)
+    meta["ref_bf16_vs_fp32_maxabs"] = float(max((a.float() - b).abs().max() for a, b in zip(rb, rf)))
+    out["_meta"] = {k: np.float64(v) for k, v in meta.items()}
+    save("rife.npz", out)
+    print("reference bf16-autocast vs its own fp32 evaluation, max-abs:", meta["ref_bf16_vs_fp32_maxabs"])
+
+
+def golden_scdet():
+    T = cases.scdet_frames()
+    vals, dec = [], []
+    for a, b in cases.SCDET_PAIRS:
+        x1 = torch.nn.functional.interpolate(T[a], (32, 32), mode="bilinear", align_corners=False)
+        x2 = torch.nn.functional.interpolate(T[b], (32, 32), mode="bilinear", align_corners=False)
+        r = ref_ssim(x1, x2)
+        same(oracle.scdet.ssim_matlab(x1, x2), r, f"ssim {a},{b}")
+        vals.append(float(r))
+        d = bool(ref_tools.check_scene(T[a], T[b], 0.3))
+        assert d == bool(oracle.scdet.check_scene(T[a], T[b], 0.3))
+        dec.append(d)
+    save("scdet.npz", {"ssim": {"values": np.array(vals, np.float64), "cut": np.array(dec)}})
+    print("ssim values:", vals, "cuts:", dec)
+
+
+# ------------------------------------------------------------------------------------------ driver schedule
+class _FakeIO:
+    frames, fps = [], 24.0
+    written = None
+
+    def __init__(self, input_path, output_path, dst_fps=60, times=-1, hwaccel=False):
+        self.src_fps = _FakeIO.fps
+        self.total_frames_count = len(_FakeIO.frames)
+        self._it = iter(list(_FakeIO.frames) + [None])
+        _FakeIO.written = []
+
+    def read_frame(self):
+        return next(self._it)
+
+    def write_frame(self, x):
+        _FakeIO.written.append(x)
+
+    def finish_writing(self):
+        return True
+
+
+class _FakeModel:
+    """Records the calls the reference driver makes; generated frames are constant images whose
+    value encodes a running id, pass-through frames are the input tensors themselves."""
+
+    def __init__(self, frame_of):
+        self.scale, self.pad_size = 1.0, 64
+        self.frame_of = frame_of
+        self.log = []
+        self.n_gen = 0
+
+    def _gen(self, like):
+        self.n_gen += 1
+        return torch.full_like(like, ((self.n_gen % 250) + 0.5) / 255.0)
+
+    def inference_ts(self, I0, I1, ts):
+        self.log.append(["ts", self.frame_of(I0), self.frame_of(I1), [float(t) for t in ts]])
+        return [I0 if t == 0 else I1 if t == 1 else self._gen(I0) for t in ts]
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False):
+        self.log.append(["drba", self.frame_of(I0), self.frame_of(I1), self.frame_of(I2), [float(t) for t in ts],
+                         reuse is None, bool(linear)])
+        out = [I0 if t == 0 else I1 if t == 1 else I2 if t == 2 else self._gen(I0) for t in ts]
+        return out, ("reuse", self.frame_of(I2))
+
+
+def run_ref_driver(frames, fps, dst_fps, times, scdet, thr=0.3):
+    import infer as ref_infer  # reference infer.py
+    keys = {}
+    for k, f in enumerate(frames):
+        keys[ref_tools.to_inp(f, ref_tools.get_valid_net_inp_size(f, 1.0, 64)["dst_size"]).numpy().tobytes()] = k
+    assert len(keys) == len(frames), "frame identification needs distinct frames"
+    model = _FakeModel(lambda t: keys[t.numpy().tobytes()])
+    _FakeIO.frames, _FakeIO.fps = frames, fps
+    ref_infer.VideoFI_IO = _FakeIO
+    ref_infer.model = model
+    ref_infer.input_path, ref_infer.output_path = "in", "out"
+    ref_infer.dst_fps, ref_infer.times, ref_infer.hwaccel = dst_fps, times, False
+    ref_infer.enable_scdet, ref_infer.scdet_threshold = scdet, thr
+    ref_infer.tqdm = lambda total=None: types.SimpleNamespace(update=lambda n: None, close=lambda: None)
+    ref_infer.inference()
+    src = {}
+    for k, f in enumerate(frames):
+        size = ref_tools.get_valid_net_inp_size(f, 1.0, 64)
+        src[ref_tools.to_out(ref_tools.to_inp(f, size["dst_size"]), size["src_size"]).tobytes()] = k
+    tags = []
+    for w in _FakeIO.written:
+        if (w == w[0, 0, 0]).all():
+            tags.append(["gen", int(w[0, 0, 0])])
+        else:
+            tags.append(["copy", src[w.tobytes()]])
+    return {"log": model.log, "written": tags}
+
+
+def golden_schedule():
+    res = {"traces": {}, "calc_t": {}, "sizes": {}}
+    clip = synth.make_clip(16, 96, 160, seed=5)
+    clip_cut = synth.make_clip(16, 96, 160, seed=5, cut_at=7)
+    clip_cut2 = synth.make_clip(16, 96, 160, seed=5, cut_at=7)
+    clip_cut2[8:] = synth.make_clip(8, 96, 160, seed=99)  # second cut right after the first: both-sides branch
+    for name, (fr, fps, dst, times, sc) in {
+        "t2": (clip, 24.0, 60, 2, False), "t3": (clip, 24.0, 60, 3, False), "t4": (clip, 24.0, 60, 4, False),
+        "t5": (clip, 24.0, 60, 5, False), "fps24_60": (clip, 24.0, 60, -1, False),
+        "fps23976_60": (clip, 24000 / 1001, 60, -1, False), "fps25_60": (clip, 25.0, 60, -1, False),
+        "fps30_60": (clip, 30.0, 60, -1, False), "fps24_60_scdet": (clip_cut, 24.0, 60, -1, True),
+        "t2_scdet": (clip_cut, 24.0, 60, 2, True), "fps24_60_scdet2": (clip_cut2, 24.0, 60, -1, True),
+        "fps24_144": (clip, 24.0, 144, -1, False),
+    }.items():
+        res["traces"][name] = dict(run_ref_driver(fr, fps, dst, times, sc), fps=fps, dst_fps=dst, times=times, scdet=sc)
+        print(name, "calls:", len(res["traces"][name]["log"]), "written:", len(res["traces"][name]["written"]))
+    # long calc_t tables: 1000 steps on 8x8 frames (driver calls inference_ts_drba(ts=calc_t(idx)) every step)
+    tiny = [np.full((8, 8, 3), k % 251, np.uint8) for k in range(1001)]
+    for k in range(len(tiny)):
+        tiny[k][0, 0, 0] = k // 251  # make every frame's checksum unique
+        tiny[k][0, 1, 1] = (k * 7) % 256
+    for name, (fps, dst, times) in {"t2": (24.0, 60, 2), "t3": (24.0, 60, 3), "t4": (24.0, 60, 4), "t5": (24.0, 60, 5),
+                                    "fps24_60": (24.0, 60, -1), "fps23976_60": (24000 / 1001, 60, -1),
+                                    "fps25_60": (25.0, 60, -1), "fps30_60": (30.0, 60, -1)}.items():
+        tr = run_ref_driver(tiny, fps, dst, times, False)
+        res["calc_t"][name] = {"fps": fps, "dst_fps": dst, "times": times,
+                               "ts": [c[4] for c in tr["log"] if c[0] == "drba"], "n_written": len(tr["written"])}
+    for (h, w), scale, div in (((480, 854), 1.0, 64), ((1080, 1920), 1.0, 64), ((1080, 1920), 1.0, 128),
+                               ((2160, 3840), 0.5, 64), ((2160, 3840), 0.5, 128), ((720, 1280), 1.0, 64),
+                               ((1080, 1920), 0.5, 64), ((1080, 1920), 2.0, 64), ((64, 128), 1.0, 64), ((100, 100), 0.25, 64)):
+        r = ref_tools.get_valid_net_inp_size(np.zeros((h, w, 3), np.uint8), scale, div)
+        res["sizes"][f"{h}x{w}@{scale}/{div}"] = [list(r["src_size"]), list(r["dst_size"])]
+    with open(os.path.join(HERE, "schedule.json"), "w") as f:
+        json.dump(res, f)
+    print("wrote schedule.json", os.path.getsize(os.path.join(HERE, "schedule.json")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "drm", "scdet", "schedule", "rife"]
+    for w in which:
+        globals()["golden_" + w]()

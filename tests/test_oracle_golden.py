@@ -1,0 +1,69 @@
+"""CPU: the oracle restatement against the committed reference outputs (tests/golden/*.npz).
+
+The fixtures were produced by the reference itself (tests/golden/make_golden.py asserts
+oracle == reference bit-for-bit in the build container); here the tolerance only absorbs
+CPU-kernel differences between hosts (MKLDNN/ISA dispatch), it is not a numerical budget.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from drba_amd.utils import synth
+from tests import cases
+
+TOL = 2e-5
+
+
+def _run(case_list, z, backend, tol=TOL):
+    worst = 0.0
+    with torch.no_grad():
+        for name, fn in case_list:
+            for key, t in cases.flatten(name, fn(backend)):
+                d = cases.compare_to_fixture(z, key, t)
+                assert d <= tol, f"{key}: max|oracle - reference fixture| = {d}"
+                worst = max(worst, d)
+    return worst
+
+
+def test_ops_against_reference_fixture(oracle_backend, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    for k, v in cases.ops_inputs().items():  # input generator drift check
+        assert abs(float(torch.nan_to_num(v, 0.0, 0.0, 0.0).double().sum()) - float(z[f"_inputs/{k}"])) < 1e-6
+    _run(cases.ops_cases(), z, oracle_backend)
+
+
+def test_drm_against_reference_fixture(oracle_backend, golden_dir):
+    z = np.load(os.path.join(golden_dir, "drm.npz"))
+    _run(cases.drm_cases(), z, oracle_backend)
+
+
+def test_scdet_against_reference_fixture(oracle_backend, golden_dir):
+    z = np.load(os.path.join(golden_dir, "scdet.npz"))
+    T = cases.scdet_frames()
+    for k, (a, b) in enumerate(cases.SCDET_PAIRS):
+        x1 = torch.nn.functional.interpolate(T[a], (32, 32), mode="bilinear", align_corners=False)
+        x2 = torch.nn.functional.interpolate(T[b], (32, 32), mode="bilinear", align_corners=False)
+        assert abs(float(oracle_backend.ssim_matlab(x1, x2)) - float(z["ssim/values"][k])) < 1e-5
+        assert bool(oracle_backend.check_scene(T[a], T[b], 0.3)) == bool(z["ssim/cut"][k])
+
+
+@pytest.mark.parametrize("scale,size", cases.RIFE_CONFIGS)
+def test_rife_end_to_end_against_reference_fixture(oracle_backend, golden_dir, scale, size):
+    z = np.load(os.path.join(golden_dir, "rife.npz"))
+    sd = synth.ifnet_state_dict(seed=0)
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(z["_meta/weights_sum"])) < 1e-6
+    H, W = size
+    assert abs(sum(float(f.double().sum()) for f in cases.rife_frames(H, W)) - float(z[f"_meta/frames_sum_s{scale}"])) < 1e-6
+    out = cases.rife_run(oracle_backend, sd, scale, H, W)
+    for k, t in out.items():
+        d = cases.compare_to_fixture(z, k, t)
+        assert d <= 5e-5, f"{k}: {d}"
+
+
+def test_reference_bf16_noise_floor_recorded(golden_dir):
+    """The as-shipped reference (bf16 CPU autocast) is ~2e-3 from its own fp32 evaluation: above the 1e-3 bar,
+    which is why parity is defined against the fp32 evaluation."""
+    z = np.load(os.path.join(golden_dir, "rife.npz"))
+    assert 1e-3 < float(z["_meta/ref_bf16_vs_fp32_maxabs"]) < 1e-2
