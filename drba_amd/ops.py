@@ -41,6 +41,22 @@ def _p(t):
 
 _ws_cache = {}
 
+# Optional per-launch timing of the conv kernels (bench.py's roofline leg): when set to a list,
+# every drba_conv3x3 / drba_deconv4x4s2 launch appends (key, flops, start_event, end_event), the
+# events being recorded on the stream the kernel is launched on.
+CONV_TIMING = None
+
+
+def _timed(key, flops, launch):
+    if CONV_TIMING is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = launch()
+    e1.record()
+    CONV_TIMING.append((key, flops, e0, e1))
+    return r
+
 
 def _workspace(device, nfloats):
     """Grow-only scratch per (device, stream): kernels on one stream are ordered, so reuse is safe."""
@@ -237,8 +253,11 @@ class Conv3x3:
         if self.beta is not None:
             assert residual is not None
             residual = _f32(residual)
-        _lib.check(lib.drba_conv3x3(_p(x), _p(wp), _p(self.bias), _p(self.beta), _p(residual if self.beta is not None else None),
-                                    _p(out), n, cin, h, w, self.cout, self.stride, self.act, cfg, _stream()), "drba_conv3x3")
+        res = residual if self.beta is not None else None
+        key = ("conv3x3", cfg, cin, self.cout, ho, wo, self.stride)
+        _lib.check(_timed(key, 2.0 * self.cout * cin * 9 * ho * wo * n, lambda: lib.drba_conv3x3(
+            _p(x), _p(wp), _p(self.bias), _p(self.beta), _p(res), _p(out), n, cin, h, w, self.cout, self.stride,
+            self.act, cfg, _stream())), "drba_conv3x3")
         return out
 
 
@@ -273,8 +292,10 @@ class Deconv4x4:
         if out is None:
             shape = (n, self.cout // 4, 4 * h, 4 * w) if self.ps else (n, self.cout, 2 * h, 2 * w)
             out = torch.empty(shape, dtype=torch.float32, device=x.device)
-        _lib.check(lib.drba_deconv4x4s2(_p(x), _p(wp), _p(self.bias), _p(out), n, cin, h, w, self.cout, self.ps, cfg,
-                                        _stream()), "drba_deconv4x4s2")
+        key = ("deconv4x4", cfg, cin, self.cout, h, w, 2)
+        _lib.check(_timed(key, 2.0 * self.cout * cin * 16 * h * w * n, lambda: lib.drba_deconv4x4s2(
+            _p(x), _p(wp), _p(self.bias), _p(out), n, cin, h, w, self.cout, self.ps, cfg, _stream())),
+            "drba_deconv4x4s2")
         return out
 
 

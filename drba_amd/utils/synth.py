@@ -1,7 +1,7 @@
 """Deterministic synthetic weights and frames.
 
 The RIFE 4.26-heavy checkpoint is not shipped with the reference
-(/root/reference/.MISSING_LARGE_BLOBS), and there is no network, so benchmarks and
+(its .MISSING_LARGE_BLOBS lists weights/train_log_rife_426_heavy/flownet.pkl), and there is no network, so benchmarks and
 parity tests run on seeded random weights of the exact architecture and on seeded
 synthetic clips.  Everything here is pure CPU torch/numpy and regenerates bit-identically
 from the seed on any box with the same torch build, so nothing large is committed.

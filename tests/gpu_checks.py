@@ -1,0 +1,176 @@
+"""GPU parity checks shared by the pytest -m gpu tests and the diagnostic report
+(python -m tests.gpu_report).  Each check returns a list of (name, max_abs_err, tolerance, extra)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from drba_amd.utils import synth
+from tests import cases
+
+
+def _diff(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    nan_a, nan_b = a.isnan(), b.isnan()
+    if not torch.equal(nan_a, nan_b):
+        return float("inf")
+    d = (torch.where(nan_a, torch.zeros_like(a), a) - torch.where(nan_b, torch.zeros_like(b), b)).abs()
+    return float(d.max()) if d.numel() else 0.0
+
+
+def _outliers(a, b, tol):
+    d = (a.detach().float().cpu() - b.detach().float().cpu()).abs()
+    return int((d > tol).sum()), d.numel()
+
+
+def check_cases(case_list, hip, ora, tol, fixtures=None):
+    rows = []
+    for name, fn in case_list:
+        try:
+            with torch.no_grad():
+                g, o = fn(hip), fn(ora)
+            for (k, gv), (_, ov) in zip(cases.flatten(name, g), cases.flatten(name, o)):
+                extra = ""
+                if fixtures is not None:
+                    extra = f"vs_fixture={cases.compare_to_fixture(fixtures, k, gv):.2e}"
+                rows.append((k, _diff(gv, ov), tol, extra))
+        except Exception as e:  # noqa: BLE001 - a crashing case is reported, not fatal for the report
+            rows.append((name, float("inf"), tol, f"EXC {type(e).__name__}: {e}"))
+    return rows
+
+
+# ----------------------------------------------------------------------------------------- conv layers
+def conv_layer_shapes():
+    """(name, cin, cout, h, w, stride, kind) covering every conv config the IFNet uses, plus ragged sizes."""
+    shapes = []
+    for (H, W) in ((128, 192),):
+        for i, (c, cin) in enumerate(zip(synth.IFNET_BLOCK_C, synth.IFNET_BLOCK_IN)):
+            s = (16, 8, 4, 2, 1)[i]
+            h, w = H // s, W // s
+            shapes.append((f"b{i}.conv0.0", cin, c // 2, h, w, 2, "conv"))
+            shapes.append((f"b{i}.conv0.1", c // 2, c, h // 2, w // 2, 2, "conv"))
+            shapes.append((f"b{i}.resconv", c, c, h // 4, w // 4, 1, "res"))
+            shapes.append((f"b{i}.lastconv", c, 52, h // 4, w // 4, 1, "deconv_ps"))
+        shapes.append(("enc.cnn0", 3, 16, H, W, 2, "conv"))
+        shapes.append(("enc.cnn1", 16, 16, H // 2, W // 2, 1, "conv"))
+        shapes.append(("enc.cnn3", 16, 16, H // 2, W // 2, 1, "deconv"))
+    # 1080p-like ragged sizes (width 30 / 60 / 120 are not multiples of 16; 17 rows)
+    shapes += [("ragged.res192", 192, 192, 17, 30, 1, "res"), ("ragged.res128", 128, 128, 34, 60, 1, "res"),
+               ("ragged.conv_s2", 39, 96, 68, 120, 2, "conv"), ("ragged.deconv", 192, 52, 17, 30, 1, "deconv_ps"),
+               ("ragged.res96", 96, 96, 9, 13, 1, "res"), ("ragged.conv16", 16, 16, 21, 37, 1, "conv"),
+               ("ragged.conv_s2_odd", 5, 32, 19, 23, 2, "conv"), ("big.res32", 32, 32, 72, 200, 1, "res")]
+    return shapes
+
+
+def check_conv_layers(dev):
+    from drba_amd import ops
+    rows = []
+    g = torch.Generator().manual_seed(123)
+    for name, cin, cout, h, w, stride, kind in conv_layer_shapes():
+        try:
+            x = torch.randn(1, cin, h, w, generator=g)
+            b = torch.randn(cout, generator=g) * 0.1
+            if kind in ("conv", "res"):
+                wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+                if kind == "res":
+                    beta = torch.rand(1, cout, 1, 1, generator=g) + 0.5
+                    ref = F.leaky_relu(F.conv2d(x, wt, b, stride=1, padding=1) * beta + x, 0.2)
+                    got = ops.Conv3x3(wt, b, 1, True, beta, device=dev)(x.to(dev), residual=x.to(dev))
+                else:
+                    ref = F.leaky_relu(F.conv2d(x, wt, b, stride=stride, padding=1), 0.2)
+                    got = ops.Conv3x3(wt, b, stride, True, None, device=dev)(x.to(dev))
+            else:
+                wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+                ref = F.conv_transpose2d(x, wt, b, stride=2, padding=1)
+                ps = kind == "deconv_ps"
+                if ps:
+                    ref = F.pixel_shuffle(ref, 2)
+                got = ops.Deconv4x4(wt, b, ps, device=dev)(x.to(dev))
+            scale = float(ref.abs().max())
+            rows.append((f"{name} [{cin}->{cout} {h}x{w} s{stride}]", _diff(got, ref), 2e-5 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+        except Exception as e:  # noqa: BLE001
+            rows.append((name, float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    return rows
+
+
+# ----------------------------------------------------------------------------------------- glue kernels
+def check_glue(dev):
+    import oracle
+    from drba_amd import ops
+    rows = []
+    g = torch.Generator().manual_seed(7)
+    H, W = 64, 128
+    img0, img1 = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 3, H, W, generator=g)
+    f0, f1 = torch.randn(1, 16, H, W, generator=g), torch.randn(1, 16, H, W, generator=g)
+    tmap = torch.rand(1, 1, H, W, generator=g)
+    flow = torch.randn(1, 4, H, W, generator=g) * 3
+    mask, feat = torch.randn(1, 1, H, W, generator=g), torch.randn(1, 8, H, W, generator=g)
+    D = lambda t: t.to(dev)  # noqa: E731
+    for s in (16.0, 8.0, 4.0, 2.0, 1.0, 32.0):
+        if H / s < 1:
+            continue
+        # first stage (no flow)
+        x = torch.cat((img0, img1, f0, f1, tmap), 1)
+        ref = F.interpolate(x, scale_factor=1.0 / s, mode="bilinear", align_corners=False)
+        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), D(tmap), None, None, None, s)
+        rows.append((f"ifblock_input first s={s}", _diff(got, ref), 1e-5, ""))
+        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), 0.5, None, None, None, s)
+        x = torch.cat((img0, img1, f0, f1, tmap * 0 + 0.5), 1)
+        ref = F.interpolate(x, scale_factor=1.0 / s, mode="bilinear", align_corners=False)
+        rows.append((f"ifblock_input first scalar-t s={s}", _diff(got, ref), 1e-5, ""))
+        # later stage (warped)
+        w0, w1 = oracle.ops.backwarp(img0, flow[:, :2]), oracle.ops.backwarp(img1, flow[:, 2:4])
+        wf0, wf1 = oracle.ops.backwarp(f0, flow[:, :2]), oracle.ops.backwarp(f1, flow[:, 2:4])
+        x = torch.cat((w0, w1, wf0, wf1, tmap, mask, feat), 1)
+        x = F.interpolate(x, scale_factor=1.0 / s, mode="bilinear", align_corners=False)
+        fl = F.interpolate(flow, scale_factor=1.0 / s, mode="bilinear", align_corners=False) * 1.0 / s
+        ref = torch.cat((x, fl), 1)
+        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), D(tmap), D(flow), D(mask), D(feat), s)
+        rows.append((f"ifblock_input warped s={s}", _diff(got, ref), 5e-5, ""))
+        # update
+        h, w = int(H / s), int(W / s)
+        tmp = torch.randn(1, 13, h, w, generator=g)
+        up = F.interpolate(tmp, scale_factor=s, mode="bilinear", align_corners=False)
+        gf, gm, gfe = ops.ifblock_update(D(tmp), D(flow), H, W, s)
+        rows.append((f"ifblock_update flow s={s}", _diff(gf, flow + up[:, :4] * s), 1e-5 * max(1.0, s), ""))
+        rows.append((f"ifblock_update mask/feat s={s}", max(_diff(gm, up[:, 4:5]), _diff(gfe, up[:, 5:])), 1e-5, ""))
+        gf, _, _ = ops.ifblock_update(D(tmp), None, H, W, s)
+        rows.append((f"ifblock_update noflow s={s}", _diff(gf, up[:, :4] * s), 1e-5 * max(1.0, s), ""))
+    m = torch.sigmoid(mask)
+    ref = oracle.ops.backwarp(img0, flow[:, :2]) * m + oracle.ops.backwarp(img1, flow[:, 2:4]) * (1 - m)
+    rows.append(("warp_blend", _diff(ops.warp_blend(D(img0), D(img1), D(flow), D(mask)), ref), 1e-5, ""))
+    # frame conversion round trip (tools.py:33-38)
+    u8 = torch.randint(0, 256, (37, 53, 3), dtype=torch.uint8, generator=g)
+    f = ops.u8hwc_to_f32nchw(D(u8))
+    rows.append(("u8->f32", _diff(f, u8.permute(2, 0, 1).unsqueeze(0).float() / 255.0), 0.0, ""))
+    back = ops.f32nchw_to_u8hwc(f).cpu()
+    ref_u8 = torch.from_numpy(((u8.permute(2, 0, 1).unsqueeze(0).float() / 255.0)[0].numpy().transpose(1, 2, 0) * 255.).astype(np.uint8))
+    rows.append(("f32->u8 (truncation)", float((back.int() - ref_u8.int()).abs().max()), 0.0, ""))
+    return rows
+
+
+def check_scdet(hip, golden):
+    rows = []
+    T = cases.scdet_frames()
+    for k, (a, b) in enumerate(cases.SCDET_PAIRS):
+        from drba_amd import ops
+        v = ops.ssim_thumb32(T[a].to(hip.dev), T[b].to(hip.dev))
+        rows.append((f"ssim pair {a},{b}", abs(v - float(golden["ssim/values"][k])), 1e-5, f"value={v:.6f}"))
+        dec = bool(hip.check_scene(T[a].to(hip.dev), T[b].to(hip.dev), 0.3))
+        rows.append((f"check_scene pair {a},{b}", 0.0 if dec == bool(golden["ssim/cut"][k]) else float("inf"), 0.0, str(dec)))
+    return rows
+
+
+def check_rife(hip, ora, golden, scale, size, tol=1e-3):
+    sd = synth.ifnet_state_dict(seed=0)
+    H, W = size
+    rows = []
+    with torch.no_grad():
+        g = cases.rife_run(hip, sd, scale, H, W)
+        o = cases.rife_run(ora, sd, scale, H, W)
+    for k in o:
+        d = _diff(g[k], o[k])
+        n_out, n = _outliers(g[k], o[k], tol)
+        # flows carry the hole-fill discontinuity (2*max(H,W) where the ones-splat < 0.999): report outliers
+        rows.append((k, d, tol, f"outliers>{tol:g}: {n_out}/{n} vs_fixture={cases.compare_to_fixture(golden, k, g[k]):.2e}"))
+    return rows
