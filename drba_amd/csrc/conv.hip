@@ -6,13 +6,30 @@
 //   M = output pixels : a TH x TW tile, split into 16-pixel row segments (MFMA rows)
 //   N = output channels: NT tiles of 16 (MFMA cols)
 //   K = (tap, cin)    : cin consumed 4 at a time (MFMA k = 4), CK channels staged per LDS chunk
-// MFMA operand fetch: lane l supplies A[pixel l&15][cin l>>4] and B[cin l>>4][cout l&15] with one
-// ds_read_b32 each.  LDS layouts are padded so both reads are bank-conflict free:
-//   input tile  [CK][rows][cols], channel stride == 16 (mod 32) for stride 1, odd for stride 2
-//   weight slab [tap][CK][NTP],  NTP == 16 (mod 32)
+// MFMA operand fetch: lane l supplies A[pixel l&15][cin l>>4] and B[cin l>>4][cout l&15].
+//   A: one ds_read_b32 from the LDS input tile [CK][rows][cols]; channel stride == 16 (mod 32)
+//      for stride 1 and odd for stride 2, which makes the read bank-conflict free.
+//   B: weights are pre-packed on the host in MFMA *fragment order*
+//      ([cout tile][chunk][tap][cg][nt][64 lanes]), so a B operand is one coalesced 256-byte
+//      global load straight into the VGPR the MFMA reads (a layer's weights are 36 KB..1.3 MB:
+//      L1/L2 resident) -- no LDS round trip for weights.
+// Input tiles are double-buffered in LDS with the next chunk's global loads issued before the
+// current chunk's MFMAs (register staging), one workgroup barrier per chunk.
 // Accumulator D: lane holds cout l&15 for pixels 4*(l>>4)..+3 -> one float4 store along x.
+//
+// KS = 1: the 4 waves split the tile's rows (TH = 4*RW) and share the LDS input tile.
+// KS = 4: the 4 waves share the whole tile (TH = RW) and split K: wave w owns chunks q == w
+//         (mod 4), stages them into wave-private LDS (no workgroup barrier in the K loop) and the
+//         partial accumulators are reduced through LDS at the end.  For small maps, where a
+//         serial K loop over all input channels is the latency floor.
+//
+// MODE 0: conv3x3.  MODE 1: one output phase (py,px) of ConvTranspose2d(k=4,s=2,p=1):
+//   out[o, 2j+py, 2i+px] = b[o] + sum_{c, a, b in {0,1}} in[c, j+dy(py,a), i+dx(px,b)] * W[c, o, ky(py,a), kx(px,b)]
+//   with (py=0: (ky,dy) = (1,0),(3,-1); py=1: (0,+1),(2,0)), same along x: a 2x2-tap convolution
+//   over the same haloed input tile; blockIdx.z carries the phase.
 #include "common.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 using namespace drba;
@@ -26,36 +43,53 @@ constexpr int round_up_mod32_16(int v) {  // smallest r >= v with r % 32 == 16
   return r >= v ? r : r + 32;
 }
 
-template <int S_, int RW_, int MW_, int NT_, int CK_>
+template <int MODE_, int S_, int RW_, int MW_, int NT_, int CK_, int KS_>
 struct ConvCfg {
-  static constexpr int S = S_, RW = RW_, MW = MW_, NT = NT_, CK = CK_;
-  static constexpr int TH = 4 * RW, TW = 16 * MW, NTC = 16 * NT;
+  static constexpr int MODE = MODE_, S = S_, RW = RW_, MW = MW_, NT = NT_, CK = CK_, KS = KS_;
+  static constexpr int NTAP = (MODE == 0) ? 9 : 4;
+  static constexpr int TH = (KS == 1 ? 4 : 1) * RW, TW = 16 * MW, NTC = 16 * NT;
   static constexpr int TR = (TH - 1) * S + 3, TC = (TW - 1) * S + 3;
   static constexpr int CHS = (S == 1) ? round_up_mod32_16(TR * TC) : ((TR * TC) | 1);
-  static constexpr int NTP = (NT % 2) ? 16 * NT : 16 * NT + 16;
-  static constexpr int SLAB = 9 * CK * NTP;  // floats per (cout-tile, chunk)
-  static constexpr int LDS_FLOATS = ((CK * CHS + 3) / 4) * 4 + SLAB;
-  static constexpr int W_OFF = ((CK * CHS + 3) / 4) * 4;
+  static constexpr int BUF = ((CK * CHS + 3) / 4) * 4;  // floats per staging buffer
+  static constexpr int NL = (KS == 1) ? 256 : 64;       // threads filling one buffer
+  static constexpr int NSTAGE = (CK * TR * TC + NL - 1) / NL;
+  static constexpr int CG = CK / 4;                      // MFMA k-groups per tap per chunk
+  static constexpr int FRAG = NTAP * CG * NT * 64;       // packed weight floats per (cout tile[, phase], chunk)
+  static constexpr int NTILES = RW * MW * NT;
+  static constexpr int LDS_STAGE = 2 * BUF * (KS == 1 ? 1 : 4);
+  static constexpr int LDS_RED = (KS == 1) ? 0 : 4 * NTILES * 256;
+  static constexpr int LDS_FLOATS = LDS_STAGE > LDS_RED ? LDS_STAGE : LDS_RED;
+  static_assert(MODE == 0 || S == 1, "deconv phases read the input at stride 1");
 };
 
 template <class Cfg>
 __global__ void __launch_bounds__(256)
-conv3x3_mfma(const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ bias,
-             const float *__restrict__ beta, const float *__restrict__ res, float *__restrict__ out, int Cin,
-             int H, int W, int Cout, int Ho, int Wo, int act, int n_ctiles) {
-  constexpr int S = Cfg::S, RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, CK = Cfg::CK;
-  constexpr int TH = Cfg::TH, TW = Cfg::TW, TR = Cfg::TR, TC = Cfg::TC, CHS = Cfg::CHS, NTP = Cfg::NTP;
+conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const float *__restrict__ bias,
+          const float *__restrict__ beta, const float *__restrict__ res, float *__restrict__ out, int Cin, int H,
+          int W, int Cout, int Ho, int Wo, int act, int n_ctiles, int pixel_shuffle) {
+  constexpr int MODE = Cfg::MODE, S = Cfg::S, RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, CK = Cfg::CK, KS = Cfg::KS;
+  constexpr int TH = Cfg::TH, TW = Cfg::TW, TR = Cfg::TR, TC = Cfg::TC, CHS = Cfg::CHS;
+  constexpr int NL = Cfg::NL, NSTAGE = Cfg::NSTAGE, CG = Cfg::CG, NTAP = Cfg::NTAP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *s_in = smem;
-  float *s_w = smem + Cfg::W_OFF;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, kq = lane >> 4;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int cz = blockIdx.z % n_ctiles, n = blockIdx.z / n_ctiles;
+  int zz = blockIdx.z;
+  int phase = 0;
+  if (MODE == 1) {
+    phase = zz & 3;
+    zz >>= 2;
+  }
+  const int cz = zz % n_ctiles, n = zz / n_ctiles;
+  const int py = phase >> 1, px = phase & 1;
   in += (size_t)n * Cin * H * W;
-  out += (size_t)n * Cout * Ho * Wo;
-  if (res) res += (size_t)n * Cout * Ho * Wo;
+  if (MODE == 0) {
+    out += (size_t)n * Cout * Ho * Wo;
+    if (res) res += (size_t)n * Cout * Ho * Wo;
+  } else {
+    out += (size_t)n * Cout * (2 * H) * (2 * W);
+  }
 
   f32x4 acc[RW][MW][NT];
 #pragma unroll
@@ -66,315 +100,311 @@ conv3x3_mfma(const float *__restrict__ in, const float *__restrict__ wpk, const 
       for (int c = 0; c < NT; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = (Cin + CK - 1) / CK;
-  const float *a_base = s_in + kq * CHS + (wave * RW * S) * TC + m * S;
-  const float *b_base = s_w + kq * NTP + m;
+  float *buf0 = smem + (KS == 1 ? 0 : wave * 2 * Cfg::BUF);
+  float *buf1 = buf0 + Cfg::BUF;
+  const int ltid = (KS == 1) ? tid : lane;
+  const int row0 = (KS == 1) ? wave * RW : 0;
+  const int a_off = kq * CHS + (row0 * S) * TC + m * S;
   const int gy0 = y0 * S - 1, gx0 = x0 * S - 1;
+  const int q_first = (KS == 1) ? 0 : wave, q_step = (KS == 1) ? 1 : 4;
+  const float *wf_base =
+      wfrag + ((size_t)(MODE == 0 ? cz : cz * 4 + phase) * nchunks) * Cfg::FRAG + lane;
+  // deconv tap -> tile offsets: tap = 2a+b; row = rw + 1 + dy, py=0: dy={0,-1}; py=1: dy={+1,0}
+  const int dro[2] = {py ? 2 : 1, py ? 1 : 0};
+  const int dco[2] = {px ? 2 : 1, px ? 1 : 0};
 
-  for (int q = 0; q < nchunks; ++q) {
-    __syncthreads();
-    // ---- stage the input tile (zero padding outside the image / beyond Cin)
-    for (int e = tid; e < CK * TR * TC; e += 256) {
+  float st[NSTAGE];
+  auto issue = [&](int q) {  // global -> registers (zero padding outside the image / beyond Cin)
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+      const int e = ltid + i * NL;
       const int c = e / (TR * TC), rem = e - c * (TR * TC);
       const int r = rem / TC, col = rem - r * TC;
       const int gy = gy0 + r, gx = gx0 + col, ci = q * CK + c;
       float v = 0.f;
-      if (ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = in[((size_t)ci * H + gy) * W + gx];
-      s_in[c * CHS + r * TC + col] = v;
+      if (e < CK * TR * TC && ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = in[((size_t)ci * H + gy) * W + gx];
+      st[i] = v;
     }
-    // ---- stage this (cout tile, chunk)'s weight slab: contiguous, pre-padded on the host
-    {
-      const float4 *src = reinterpret_cast<const float4 *>(wpk + ((size_t)cz * nchunks + q) * Cfg::SLAB);
-      float4 *dst = reinterpret_cast<float4 *>(s_w);
-      for (int e = tid; e < Cfg::SLAB / 4; e += 256) dst[e] = src[e];
+  };
+  auto commit = [&](float *buf) {  // registers -> LDS
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+      const int e = ltid + i * NL;
+      const int c = e / (TR * TC), rem = e - c * (TR * TC);
+      const int r = rem / TC, col = rem - r * TC;
+      if (e < CK * TR * TC) buf[c * CHS + r * TC + col] = st[i];
     }
-    __syncthreads();
-    // ---- MFMA over (tap, 4-channel group)
+  };
+  auto sync = [&]() {
+    if (KS == 1) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();  // wave-private buffers: DS ops of one wave execute in order
+  };
+
+  if (q_first < nchunks) {
+    issue(q_first);
+    commit(buf0);
+  }
+  sync();
+  int it = 0;
+  for (int q = q_first; q < nchunks; q += q_step, ++it) {
+    const float *cur = (it & 1) ? buf1 : buf0;
+    float *nxt = (it & 1) ? buf0 : buf1;
+    const int qn = q + q_step;
+    if (qn < nchunks) issue(qn);  // next chunk's loads fly under this chunk's MFMAs
+    const float *ab = cur + a_off;
+    const float *wq = wf_base + (size_t)q * Cfg::FRAG;
+    float bnext[CG][NT];  // B fragments are fetched one tap ahead
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap % 3;
+    for (int cg = 0; cg < CG; ++cg)
 #pragma unroll
-      for (int cg = 0; cg < CK / 4; ++cg) {
-        float bv[NT];
+      for (int nt = 0; nt < NT; ++nt) bnext[cg][nt] = wq[(cg * NT + nt) * 64];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = b_base[(tap * CK + cg * 4) * NTP + nt * 16];
+    for (int tap = 0; tap < NTAP; ++tap) {
+      float bv[CG][NT];
+#pragma unroll
+      for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[cg][nt] = bnext[cg][nt];
+      if (tap + 1 < NTAP) {
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bnext[cg][nt] = wq[(((tap + 1) * CG + cg) * NT + nt) * 64];
+      }
+      const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[tap & 1];
+#pragma unroll
+      for (int cg = 0; cg < CG; ++cg)
 #pragma unroll
         for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw) {
-            const float av = a_base[(cg * 4) * CHS + (rw * S + ky) * TC + mw * 16 * S + kx];
+            const float av = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[rw][mw][nt], 0, 0, 0);
+              acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[cg][nt], acc[rw][mw][nt], 0, 0, 0);
           }
-      }
     }
+    if (qn < nchunks) commit(nxt);
+    sync();
   }
 
-  // ---- epilogue: bias, optional beta*y + residual, optional LeakyReLU(0.2)
+  // ---- epilogue
   const bool vec = (Wo & 3) == 0;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
+  auto store_tile = [&](int rw, int mw, int nt, f32x4 v) {
     const int co = cz * Cfg::NTC + nt * 16 + m;
-    if (co >= Cout) continue;
+    const int y = y0 + row0 + rw;
+    const int xb = x0 + mw * 16 + kq * 4;
+    if (co >= Cout) return;
     const float bs = bias ? bias[co] : 0.f;
-    const float bt = beta ? beta[co] : 0.f;
+    if (MODE == 0) {  // bias, optional beta*y + residual, optional LeakyReLU(0.2)
+      if (y >= Ho || xb >= Wo) return;
+      const float bt = beta ? beta[co] : 0.f;
+      const size_t idx = ((size_t)co * Ho + y) * Wo + xb;
+      if (vec) {
+        f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (beta) r = *reinterpret_cast<const f32x4 *>(res + idx);
 #pragma unroll
-    for (int rw = 0; rw < RW; ++rw) {
-      const int y = y0 + wave * RW + rw;
-      if (y >= Ho) continue;
+        for (int k = 0; k < 4; ++k) {
+          float t = v[k] + bs;
+          if (beta) t = t * bt + r[k];
+          v[k] = act ? lrelu02(t) : t;
+        }
+        *reinterpret_cast<f32x4 *>(out + idx) = v;
+      } else {
 #pragma unroll
-      for (int mw = 0; mw < MW; ++mw) {
-        const int xb = x0 + mw * 16 + kq * 4;
-        if (xb >= Wo) continue;
-        const size_t idx = ((size_t)co * Ho + y) * Wo + xb;
-        f32x4 v = acc[rw][mw][nt];
-        if (vec) {
-          f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (beta) r = *reinterpret_cast<const f32x4 *>(res + idx);
+        for (int k = 0; k < 4; ++k) {
+          if (xb + k >= Wo) continue;
+          float t = v[k] + bs;
+          if (beta) t = t * bt + res[idx + k];
+          out[idx + k] = act ? lrelu02(t) : t;
+        }
+      }
+    } else {  // transposed conv phase: bias, scatter to (2j+py, 2i+px) [+ PixelShuffle(2)]
+      if (y >= H) return;
+      const int Hd = 2 * H, Wd = 2 * W;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float t = v[k] + bs;
-            if (beta) t = t * bt + r[k];
-            v[k] = act ? lrelu02(t) : t;
-          }
-          *reinterpret_cast<f32x4 *>(out + idx) = v;
+      for (int k = 0; k < 4; ++k) {
+        const int i = xb + k;
+        if (i >= W) continue;
+        const int oy = 2 * y + py, ox = 2 * i + px;
+        if (pixel_shuffle) {  // [Cout/4, 2*Hd, 2*Wd]
+          const int c13 = co >> 2, si = (co >> 1) & 1, sj = co & 1;
+          out[((size_t)c13 * (2 * Hd) + (2 * oy + si)) * (2 * Wd) + (2 * ox + sj)] = v[k] + bs;
         } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (xb + k >= Wo) continue;
-            float t = v[k] + bs;
-            if (beta) t = t * bt + res[idx + k];
-            out[idx + k] = act ? lrelu02(t) : t;
-          }
+          out[((size_t)co * Hd + oy) * Wd + ox] = v[k] + bs;
         }
       }
     }
-  }
-}
+  };
 
-// ---------------------------------------------------------------------------------------------
-// ConvTranspose2d(k=4, s=2, p=1): out[o, 2j+py, 2i+px] = b[o] + sum_{c, a, b in {0,1}}
-//   in[c, j+dy(py,a), i+dx(px,b)] * W[c, o, ky(py,a), kx(px,b)]
-// with (py=0: (ky,dy) = (1,0),(3,-1); py=1: (0,+1),(2,0)), same along x.  Each of the 4 output
-// phases is a 2x2-tap convolution over the same haloed input tile; blockIdx.z carries the phase.
-template <int RW_, int MW_, int NT_, int CK_>
-struct DeconvCfg {
-  static constexpr int RW = RW_, MW = MW_, NT = NT_, CK = CK_;
-  static constexpr int TH = 4 * RW, TW = 16 * MW, NTC = 16 * NT;
-  static constexpr int TR = TH + 2, TC = TW + 2;
-  static constexpr int CHS = round_up_mod32_16(TR * TC);
-  static constexpr int NTP = (NT % 2) ? 16 * NT : 16 * NT + 16;
-  static constexpr int SLAB = 4 * CK * NTP;  // floats per (cout-tile, phase, chunk)
-  static constexpr int W_OFF = ((CK * CHS + 3) / 4) * 4;
-  static constexpr int LDS_FLOATS = W_OFF + SLAB;
-};
-
-template <class Cfg>
-__global__ void __launch_bounds__(256)
-deconv4x4_mfma(const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ bias,
-               float *__restrict__ out, int Cin, int H, int W, int Cout, int pixel_shuffle, int n_ctiles) {
-  constexpr int RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, CK = Cfg::CK;
-  constexpr int TH = Cfg::TH, TW = Cfg::TW, TR = Cfg::TR, TC = Cfg::TC, CHS = Cfg::CHS, NTP = Cfg::NTP;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *s_in = smem;
-  float *s_w = smem + Cfg::W_OFF;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, kq = lane >> 4;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int phase = blockIdx.z & 3, cz = (blockIdx.z >> 2) % n_ctiles, n = (blockIdx.z >> 2) / n_ctiles;
-  const int py = phase >> 1, px = phase & 1;
-  in += (size_t)n * Cin * H * W;
-  out += (size_t)n * Cout * (2 * H) * (2 * W);
-
-  f32x4 acc[RW][MW][NT];
+  if (KS == 1) {
 #pragma unroll
-  for (int a = 0; a < RW; ++a)
-#pragma unroll
-    for (int b = 0; b < MW; ++b)
-#pragma unroll
-      for (int c = 0; c < NT; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nchunks = (Cin + CK - 1) / CK;
-  // tile row of tap a: (row + 1 + dy); py=0 -> dy = {0,-1}; py=1 -> dy = {+1, 0}
-  const int ry0 = py ? 2 : 1, ry1 = py ? 1 : 0;
-  const int rx0 = px ? 2 : 1, rx1 = px ? 1 : 0;
-  const float *a_base = s_in + kq * CHS + (wave * RW) * TC + m;
-  const float *b_base = s_w + kq * NTP + m;
-
-  for (int q = 0; q < nchunks; ++q) {
-    __syncthreads();
-    for (int e = tid; e < CK * TR * TC; e += 256) {
-      const int c = e / (TR * TC), rem = e - c * (TR * TC);
-      const int r = rem / TC, col = rem - r * TC;
-      const int gy = y0 - 1 + r, gx = x0 - 1 + col, ci = q * CK + c;
-      float v = 0.f;
-      if (ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = in[((size_t)ci * H + gy) * W + gx];
-      s_in[c * CHS + r * TC + col] = v;
-    }
-    {
-      const float4 *src =
-          reinterpret_cast<const float4 *>(wpk + (((size_t)cz * 4 + phase) * nchunks + q) * Cfg::SLAB);
-      float4 *dst = reinterpret_cast<float4 *>(s_w);
-      for (int e = tid; e < Cfg::SLAB / 4; e += 256) dst[e] = src[e];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int tap = 0; tap < 4; ++tap) {
-      const int ro = (tap >> 1) ? ry1 : ry0, cof = (tap & 1) ? rx1 : rx0;
-      const float *a_tap = a_base + ro * TC + cof;
-#pragma unroll
-      for (int cg = 0; cg < CK / 4; ++cg) {
-        float bv[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = b_base[(tap * CK + cg * 4) * NTP + nt * 16];
-#pragma unroll
-        for (int rw = 0; rw < RW; ++rw)
-#pragma unroll
-          for (int mw = 0; mw < MW; ++mw) {
-            const float av = a_tap[(cg * 4) * CHS + rw * TC + mw * 16];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[rw][mw][nt], 0, 0, 0);
-          }
-      }
-    }
-  }
-
-  const int Ho = 2 * H, Wo = 2 * W;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int co = cz * Cfg::NTC + nt * 16 + m;
-    if (co >= Cout) continue;
-    const float bs = bias ? bias[co] : 0.f;
-#pragma unroll
-    for (int rw = 0; rw < RW; ++rw) {
-      const int j = y0 + wave * RW + rw;
-      if (j >= H) continue;
+    for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int i = x0 + mw * 16 + kq * 4 + k;
-          if (i >= W) continue;
-          const float v = acc[rw][mw][nt][k] + bs;
-          const int oy = 2 * j + py, ox = 2 * i + px;
-          if (pixel_shuffle) {  // PixelShuffle(2): [Cout/4, 2*Ho, 2*Wo]
-            const int c13 = co >> 2, si = (co >> 1) & 1, sj = co & 1;
-            out[((size_t)c13 * (2 * Ho) + (2 * oy + si)) * (2 * Wo) + (2 * ox + sj)] = v;
-          } else {
-            out[((size_t)co * Ho + oy) * Wo + ox] = v;
-          }
+        for (int nt = 0; nt < NT; ++nt) store_tile(rw, mw, nt, acc[rw][mw][nt]);
+  } else {
+    // cross-wave K reduction: partials -> LDS, then wave w finishes tiles t == w (mod 4)
+    constexpr int NTILES = Cfg::NTILES;
+    __syncthreads();  // every wave is done with its staging buffers
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem);
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          red[(wave * NTILES + (rw * MW + mw) * NT + nt) * 64 + lane] = acc[rw][mw][nt];
+    __syncthreads();
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int t = (rw * MW + mw) * NT + nt;
+          if ((t & 3) != wave) continue;
+          f32x4 v = red[(0 * NTILES + t) * 64 + lane];
+          v += red[(1 * NTILES + t) * 64 + lane];
+          v += red[(2 * NTILES + t) * 64 + lane];
+          v += red[(3 * NTILES + t) * 64 + lane];
+          store_tile(rw, mw, nt, v);
         }
-    }
   }
 }
 
 // ------------------------------------------------------------------------------------------ cfg tables
-//                 S  RW MW NT CK
-using C0 = ConvCfg<1, 2, 4, 2, 8>;  // 8x64 px, 32 cout   (block4 ResConv)
-using C1 = ConvCfg<1, 2, 2, 4, 8>;  // 8x32 px, 64 cout   (block3 ResConv)
-using C2 = ConvCfg<1, 1, 2, 6, 8>;  // 4x32 px, 96 cout   (block2 ResConv)
-using C3 = ConvCfg<1, 1, 2, 4, 8>;  // 4x32 px, 64 cout   (block0/1 ResConv, cout split over z)
-using C4 = ConvCfg<1, 2, 4, 1, 8>;  // 8x64 px, 16 cout   (encode.cnn1/2)
-using C5 = ConvCfg<2, 2, 2, 1, 4>;  // 8x32 px, 16 cout   (block4.conv0.0, encode.cnn0)
-using C6 = ConvCfg<2, 2, 2, 2, 4>;  // 8x32 px, 32 cout
-using C7 = ConvCfg<2, 1, 2, 4, 4>;  // 4x32 px, 64 cout
-using C8 = ConvCfg<2, 1, 2, 3, 4>;  // 4x32 px, 48 cout
-constexpr int kNumConvCfg = 9;
+//                 M  S  RW MW NT CK KS
+using C0 = ConvCfg<0, 1, 2, 4, 2, 8, 1>;   // 8x64 px x 32 cout
+using C1 = ConvCfg<0, 1, 1, 4, 2, 8, 1>;   // 4x64 px x 32 cout
+using C2 = ConvCfg<0, 1, 1, 2, 2, 8, 1>;   // 4x32 px x 32 cout
+using C3 = ConvCfg<0, 1, 1, 2, 4, 8, 1>;   // 4x32 px x 64 cout
+using C4 = ConvCfg<0, 1, 2, 4, 1, 8, 1>;   // 8x64 px x 16 cout
+using C5 = ConvCfg<0, 1, 1, 2, 2, 8, 4>;   // 1x32 px x 32 cout, split-K
+using C6 = ConvCfg<0, 1, 2, 2, 2, 8, 4>;   // 2x32 px x 32 cout, split-K
+using C7 = ConvCfg<0, 1, 1, 2, 1, 8, 4>;   // 1x32 px x 16 cout, split-K
+using C8 = ConvCfg<0, 2, 2, 2, 1, 4, 1>;   // 8x32 px x 16 cout, stride 2
+using C9 = ConvCfg<0, 2, 2, 2, 2, 4, 1>;   // 8x32 px x 32 cout, stride 2
+using C10 = ConvCfg<0, 2, 1, 2, 2, 4, 1>;  // 4x32 px x 32 cout, stride 2
+using C11 = ConvCfg<0, 2, 1, 2, 2, 4, 4>;  // 1x32 px x 32 cout, stride 2, split-K
+using C12 = ConvCfg<0, 2, 1, 2, 1, 4, 4>;  // 1x32 px x 16 cout, stride 2, split-K
+using C13 = ConvCfg<0, 2, 2, 2, 2, 4, 4>;  // 2x32 px x 32 cout, stride 2, split-K
+constexpr int kNumConvCfg = 14;
 
-//                   RW MW NT CK
-using D0 = DeconvCfg<2, 2, 4, 8>;  // 8x32 px, 64 cout (52 used)
-using D1 = DeconvCfg<2, 4, 1, 8>;  // 8x64 px, 16 cout (encode.cnn3)
-using D2 = DeconvCfg<1, 2, 4, 8>;  // 4x32 px, 64 cout (small maps)
-constexpr int kNumDeconvCfg = 3;
+using D0 = ConvCfg<1, 1, 2, 2, 4, 8, 1>;  // 8x32 px x 64 cout (52 used)
+using D1 = ConvCfg<1, 1, 2, 4, 1, 8, 1>;  // 8x64 px x 16 cout (encode.cnn3)
+using D2 = ConvCfg<1, 1, 1, 2, 4, 8, 1>;  // 4x32 px x 64 cout
+using D3 = ConvCfg<1, 1, 1, 2, 2, 8, 4>;  // 1x32 px x 32 cout, split-K (small maps)
+using D4 = ConvCfg<1, 1, 2, 2, 2, 8, 4>;  // 2x32 px x 32 cout, split-K
+using D5 = ConvCfg<1, 1, 1, 4, 2, 8, 1>;  // 4x64 px x 32 cout
+constexpr int kNumDeconvCfg = 6;
 
 struct CfgInfo {
-  int S, TH, TW, NTC, NTP, CK, SLAB, lds_bytes;
+  int S, TH, TW, NTC, NT, CK, KS, RW, MW, NTAP, per_chunk, lds_bytes;  // per_chunk: packed floats per (cout tile[, phase], chunk)
 };
 template <class C>
-constexpr CfgInfo conv_info() {
-  return {C::S, C::TH, C::TW, C::NTC, C::NTP, C::CK, C::SLAB, C::LDS_FLOATS * 4};
+constexpr CfgInfo cfg_info() {
+  return {C::S, C::TH, C::TW, C::NTC, C::NT, C::CK, C::KS, C::RW, C::MW, C::NTAP, C::FRAG, C::LDS_FLOATS * 4};
 }
-template <class C>
-constexpr CfgInfo deconv_info() {
-  return {1, C::TH, C::TW, C::NTC, C::NTP, C::CK, C::SLAB, C::LDS_FLOATS * 4};
-}
-const CfgInfo kConv[kNumConvCfg] = {conv_info<C0>(), conv_info<C1>(), conv_info<C2>(), conv_info<C3>(), conv_info<C4>(),
-                                    conv_info<C5>(), conv_info<C6>(), conv_info<C7>(), conv_info<C8>()};
-const CfgInfo kDeconv[kNumDeconvCfg] = {deconv_info<D0>(), deconv_info<D1>(), deconv_info<D2>()};
+const CfgInfo kConv[kNumConvCfg] = {cfg_info<C0>(), cfg_info<C1>(), cfg_info<C2>(), cfg_info<C3>(), cfg_info<C4>(),
+                                    cfg_info<C5>(), cfg_info<C6>(), cfg_info<C7>(), cfg_info<C8>(), cfg_info<C9>(),
+                                    cfg_info<C10>(), cfg_info<C11>(), cfg_info<C12>(), cfg_info<C13>()};
+const CfgInfo kDeconv[kNumDeconvCfg] = {cfg_info<D0>(), cfg_info<D1>(), cfg_info<D2>(),
+                                        cfg_info<D3>(), cfg_info<D4>(), cfg_info<D5>()};
 
 template <class Cfg>
-int launch_conv(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, float *out,
-                int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int act, hipStream_t s) {
+int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, float *out, int N,
+           int Cin, int H, int W, int Cout, int Ho, int Wo, int act, int ps, hipStream_t s) {
   const int n_ct = (Cout + Cfg::NTC - 1) / Cfg::NTC;
-  dim3 g((Wo + Cfg::TW - 1) / Cfg::TW, (Ho + Cfg::TH - 1) / Cfg::TH, N * n_ct);
-  hipLaunchKernelGGL(conv3x3_mfma<Cfg>, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, out,
-                     Cin, H, W, Cout, Ho, Wo, act, n_ct);
+  const int gh = Cfg::MODE == 0 ? Ho : H, gw = Cfg::MODE == 0 ? Wo : W;
+  dim3 g((gw + Cfg::TW - 1) / Cfg::TW, (gh + Cfg::TH - 1) / Cfg::TH, N * n_ct * (Cfg::MODE == 0 ? 1 : 4));
+  hipLaunchKernelGGL(conv_mfma<Cfg>, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, out,
+                     Cin, H, W, Cout, Ho, Wo, act, n_ct, ps);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
-template <class Cfg>
-int launch_deconv(const float *in, const float *wpk, const float *bias, float *out, int N, int Cin, int H, int W,
-                  int Cout, int ps, hipStream_t s) {
-  const int n_ct = (Cout + Cfg::NTC - 1) / Cfg::NTC;
-  dim3 g((W + Cfg::TW - 1) / Cfg::TW, (H + Cfg::TH - 1) / Cfg::TH, N * n_ct * 4);
-  hipLaunchKernelGGL(deconv4x4_mfma<Cfg>, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, out, Cin, H,
-                     W, Cout, ps, n_ct);
-  DRBA_CHECK_LAUNCH();
-  return DRBA_OK;
+// Config choice by a small cost model (cycles): a workgroup's serial time is its MFMA issue time
+// (32 cycles per 16x16x4 fp32 MFMA per SIMD) plus a fixed cost per staged chunk; workgroups run
+// `bpc` per CU over 256 CUs and co-resident workgroups share the CU's MFMA pipes.  Small maps
+// therefore pick the split-K configs, large maps the big-tile ones.
+int pick(const CfgInfo *tab, int ntab, int stride, int Cin, int Cout, int gh, int gw, int zmul) {
+  int best = -1;
+  double best_t = 0;
+  for (int id = 0; id < ntab; ++id) {
+    const CfgInfo &c = tab[id];
+    if (c.S != stride) continue;
+    const int nch = (Cin + c.CK - 1) / c.CK;
+    const double blocks =
+        (double)((gw + c.TW - 1) / c.TW) * ((gh + c.TH - 1) / c.TH) * ((Cout + c.NTC - 1) / c.NTC) * zmul;
+    const double cpw = (c.KS == 1) ? nch : (nch + 3) / 4;  // chunks per wave
+    const double mfma_cyc = c.RW * c.MW * c.NT * (double)c.NTAP * (c.CK / 4) * cpw * 32.0;
+    const double fixed = cpw * 900.0 + (c.KS == 4 ? 1500.0 : 0.0) + 2500.0;
+    int bpc = 160 * 1024 / (c.lds_bytes > 0 ? c.lds_bytes : 1);
+    if (bpc > 3) bpc = 3;
+    if (bpc < 1) bpc = 1;
+    const double slots = 256.0 * bpc;
+    const double rounds = blocks <= slots ? 1.0 : blocks / slots;
+    const double share = blocks <= 256.0 ? 1.0 : (blocks >= slots ? (double)bpc : blocks / 256.0);
+    const double t = rounds * (mfma_cyc * share + fixed);
+    if (best < 0 || t < best_t) {
+      best = id;
+      best_t = t;
+    }
+  }
+  return best < 0 ? DRBA_EUNSUPPORTED : best;
+}
+
+size_t packed_floats(const CfgInfo &c, int Cin, int Cout, int phases) {
+  const size_t n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK;
+  return n_ct * phases * nch * c.per_chunk;
+}
+
+int env_override(const char *name, int ntab) {
+  const char *ov = getenv(name);
+  if (!ov) return -1;
+  const int id = atoi(ov);
+  return (id >= 0 && id < ntab) ? id : -1;
 }
 
 }  // namespace
 
 extern "C" {
 
+// DRBA_CONV_CFG=<id> / DRBA_DECONV_CFG=<id> in the environment override the choice (experiments only).
 int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride) {
-  (void)Cin;
-  if (stride == 1) {
-    if (Cout <= 16) return 4;
-    if (Cout <= 32) return 0;
-    if (Cout <= 64) return ((size_t)Ho * Wo >= 8192) ? 1 : 3;
-    if (Cout == 96) return 2;
-    return 3;
-  }
-  if (stride == 2) {
-    if (Cout <= 16) return 5;
-    if (Cout <= 32) return 6;
-    if (Cout == 48 || Cout == 96) return 8;
-    return 7;
-  }
-  return DRBA_EUNSUPPORTED;
+  if (stride != 1 && stride != 2) return DRBA_EUNSUPPORTED;
+  if (Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0) return DRBA_EINVAL;
+  const int ov = env_override("DRBA_CONV_CFG", kNumConvCfg);
+  if (ov >= 0 && kConv[ov].S == stride) return ov;
+  return pick(kConv, kNumConvCfg, stride, Cin, Cout, Ho, Wo, 1);
 }
 
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
   if (cfg < 0 || cfg >= kNumConvCfg || Cin <= 0 || Cout <= 0) return 0;
-  const CfgInfo &c = kConv[cfg];
-  const size_t n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK;
-  return n_ct * nch * c.SLAB;
+  return packed_floats(kConv[cfg], Cin, Cout, 1);
 }
 
-// packed[(cz*nchunks + q)][tap][c][NTP] = w[cz*NTC + j][q*CK + c][tap], zero outside
+// fragment order: packed[(((cz*nchunks + q)*9 + tap)*CG + cg)*NT + nt][lane] =
+//   w[cz*NTC + nt*16 + (lane&15)][q*CK + cg*4 + (lane>>4)][tap], zero outside Cout/Cin
 int drba_conv3x3_pack(const float *w, float *packed, int Cin, int Cout, int cfg) {
   if (!w || !packed || cfg < 0 || cfg >= kNumConvCfg || Cin <= 0 || Cout <= 0) return DRBA_EINVAL;
   const CfgInfo &c = kConv[cfg];
-  const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK;
-  memset(packed, 0, sizeof(float) * (size_t)n_ct * nch * c.SLAB);
+  const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK, CG = c.CK / 4;
+  memset(packed, 0, sizeof(float) * packed_floats(c, Cin, Cout, 1));
   for (int cz = 0; cz < n_ct; ++cz)
-    for (int q = 0; q < nch; ++q) {
-      float *slab = packed + ((size_t)cz * nch + q) * c.SLAB;
+    for (int q = 0; q < nch; ++q)
       for (int tap = 0; tap < 9; ++tap)
-        for (int cc = 0; cc < c.CK; ++cc) {
-          const int ci = q * c.CK + cc;
-          if (ci >= Cin) continue;
-          for (int j = 0; j < c.NTC; ++j) {
-            const int co = cz * c.NTC + j;
-            if (co >= Cout) break;
-            slab[(tap * c.CK + cc) * c.NTP + j] = w[((size_t)co * Cin + ci) * 9 + tap];
+        for (int cg = 0; cg < CG; ++cg)
+          for (int nt = 0; nt < c.NT; ++nt) {
+            float *frag = packed + (((((size_t)cz * nch + q) * 9 + tap) * CG + cg) * c.NT + nt) * 64;
+            for (int lane = 0; lane < 64; ++lane) {
+              const int co = cz * c.NTC + nt * 16 + (lane & 15), ci = q * c.CK + cg * 4 + (lane >> 4);
+              if (co < Cout && ci < Cin) frag[lane] = w[((size_t)co * Cin + ci) * 9 + tap];
+            }
           }
-        }
-    }
   return DRBA_OK;
 }
 
@@ -385,63 +415,65 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
   if (beta && !residual) return DRBA_EINVAL;
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   hipStream_t s = (hipStream_t)stream;
-#define DRBA_CONV_CASE(ID, T) \
-  case ID:                    \
-    return launch_conv<T>(in, packed_w, bias, beta, residual, out, N, Cin, H, W, Cout, Ho, Wo, act, s);
+#define DRBA_CASE(ID, T) \
+  case ID:               \
+    return launch<T>(in, packed_w, bias, beta, residual, out, N, Cin, H, W, Cout, Ho, Wo, act, 0, s);
   switch (cfg) {
-    DRBA_CONV_CASE(0, C0)
-    DRBA_CONV_CASE(1, C1)
-    DRBA_CONV_CASE(2, C2)
-    DRBA_CONV_CASE(3, C3)
-    DRBA_CONV_CASE(4, C4)
-    DRBA_CONV_CASE(5, C5)
-    DRBA_CONV_CASE(6, C6)
-    DRBA_CONV_CASE(7, C7)
-    DRBA_CONV_CASE(8, C8)
+    DRBA_CASE(0, C0)
+    DRBA_CASE(1, C1)
+    DRBA_CASE(2, C2)
+    DRBA_CASE(3, C3)
+    DRBA_CASE(4, C4)
+    DRBA_CASE(5, C5)
+    DRBA_CASE(6, C6)
+    DRBA_CASE(7, C7)
+    DRBA_CASE(8, C8)
+    DRBA_CASE(9, C9)
+    DRBA_CASE(10, C10)
+    DRBA_CASE(11, C11)
+    DRBA_CASE(12, C12)
+    DRBA_CASE(13, C13)
   }
-#undef DRBA_CONV_CASE
+#undef DRBA_CASE
   return DRBA_EUNSUPPORTED;
 }
 
 int drba_deconv4x4_pick_cfg(int Cin, int Cout, int H, int W) {
-  (void)Cin;
-  if (Cout <= 16) return 1;
-  return ((size_t)H * W >= 4096) ? 0 : 2;
+  if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  const int ov = env_override("DRBA_DECONV_CFG", kNumDeconvCfg);
+  if (ov >= 0) return ov;
+  return pick(kDeconv, kNumDeconvCfg, 1, Cin, Cout, H, W, 4);
 }
 
 size_t drba_deconv4x4_packed_floats(int Cin, int Cout, int cfg) {
   if (cfg < 0 || cfg >= kNumDeconvCfg || Cin <= 0 || Cout <= 0) return 0;
-  const CfgInfo &c = kDeconv[cfg];
-  const size_t n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK;
-  return n_ct * 4 * nch * c.SLAB;
+  return packed_floats(kDeconv[cfg], Cin, Cout, 4);
 }
 
-// w: [Cin, Cout, 4, 4].  packed[((cz*4 + phase)*nchunks + q)][tap = 2a+b][c][NTP]
+// w: [Cin, Cout, 4, 4].  packed[((((cz*4 + phase)*nchunks + q)*4 + tap)*CG + cg)*NT + nt][lane], tap = 2a+b,
+// ky = py ? (a ? 2 : 0) : (a ? 3 : 1), kx likewise from (px, b).
 int drba_deconv4x4_pack(const float *w, float *packed, int Cin, int Cout, int cfg) {
   if (!w || !packed || cfg < 0 || cfg >= kNumDeconvCfg || Cin <= 0 || Cout <= 0) return DRBA_EINVAL;
   const CfgInfo &c = kDeconv[cfg];
-  const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK;
-  memset(packed, 0, sizeof(float) * (size_t)n_ct * 4 * nch * c.SLAB);
+  const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK, CG = c.CK / 4;
+  memset(packed, 0, sizeof(float) * packed_floats(c, Cin, Cout, 4));
   for (int cz = 0; cz < n_ct; ++cz)
     for (int phase = 0; phase < 4; ++phase) {
       const int py = phase >> 1, px = phase & 1;
-      for (int q = 0; q < nch; ++q) {
-        float *slab = packed + (((size_t)cz * 4 + phase) * nch + q) * c.SLAB;
+      for (int q = 0; q < nch; ++q)
         for (int tap = 0; tap < 4; ++tap) {
           const int a = tap >> 1, b = tap & 1;
           const int ky = py ? (a ? 2 : 0) : (a ? 3 : 1);
           const int kx = px ? (b ? 2 : 0) : (b ? 3 : 1);
-          for (int cc = 0; cc < c.CK; ++cc) {
-            const int ci = q * c.CK + cc;
-            if (ci >= Cin) continue;
-            for (int j = 0; j < c.NTC; ++j) {
-              const int co = cz * c.NTC + j;
-              if (co >= Cout) break;
-              slab[(tap * c.CK + cc) * c.NTP + j] = w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+          for (int cg = 0; cg < CG; ++cg)
+            for (int nt = 0; nt < c.NT; ++nt) {
+              float *frag = packed + ((((((size_t)cz * 4 + phase) * nch + q) * 4 + tap) * CG + cg) * c.NT + nt) * 64;
+              for (int lane = 0; lane < 64; ++lane) {
+                const int co = cz * c.NTC + nt * 16 + (lane & 15), ci = q * c.CK + cg * 4 + (lane >> 4);
+                if (co < Cout && ci < Cin) frag[lane] = w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+              }
             }
-          }
         }
-      }
     }
   return DRBA_OK;
 }
@@ -452,11 +484,18 @@ int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, 
   if (cfg < 0 || cfg >= kNumDeconvCfg) return DRBA_EINVAL;
   if (pixel_shuffle && (Cout & 3)) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+#define DRBA_CASE(ID, T) \
+  case ID:               \
+    return launch<T>(in, packed_w, bias, nullptr, nullptr, out, N, Cin, H, W, Cout, 2 * H, 2 * W, 0, pixel_shuffle, s);
   switch (cfg) {
-    case 0: return launch_deconv<D0>(in, packed_w, bias, out, N, Cin, H, W, Cout, pixel_shuffle, s);
-    case 1: return launch_deconv<D1>(in, packed_w, bias, out, N, Cin, H, W, Cout, pixel_shuffle, s);
-    case 2: return launch_deconv<D2>(in, packed_w, bias, out, N, Cin, H, W, Cout, pixel_shuffle, s);
+    DRBA_CASE(0, D0)
+    DRBA_CASE(1, D1)
+    DRBA_CASE(2, D2)
+    DRBA_CASE(3, D3)
+    DRBA_CASE(4, D4)
+    DRBA_CASE(5, D5)
   }
+#undef DRBA_CASE
   return DRBA_EUNSUPPORTED;
 }
 

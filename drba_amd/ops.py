@@ -220,7 +220,8 @@ def ssim_thumb32(x1, x2):
 class Conv3x3:
     """One 3x3 conv layer (pad 1) with fused epilogue; weights are packed per kernel config on first use."""
 
-    def __init__(self, weight, bias, stride=1, act=True, beta=None, device=None):
+    def __init__(self, weight, bias, stride=1, act=True, beta=None, device=None, cfg=None):
+        self.force_cfg = cfg  # tests only: pin a kernel configuration
         self.w_host = weight.detach().float().cpu().contiguous()
         self.cout, self.cin = self.w_host.shape[:2]
         self.device = device
@@ -245,7 +246,7 @@ class Conv3x3:
         assert cin == self.cin, (cin, self.cin)
         ho, wo = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
         lib = _lib.load()
-        cfg = lib.drba_conv3x3_pick_cfg(self.cin, self.cout, ho, wo, self.stride)
+        cfg = self.force_cfg if self.force_cfg is not None else lib.drba_conv3x3_pick_cfg(self.cin, self.cout, ho, wo, self.stride)
         _lib.check(min(cfg, 0), "drba_conv3x3_pick_cfg")
         wp = self._pack(cfg)
         if out is None:
@@ -264,7 +265,8 @@ class Conv3x3:
 class Deconv4x4:
     """ConvTranspose2d(k=4, s=2, p=1), optionally fused with PixelShuffle(2)."""
 
-    def __init__(self, weight, bias, pixel_shuffle=False, device=None):
+    def __init__(self, weight, bias, pixel_shuffle=False, device=None, cfg=None):
+        self.force_cfg = cfg  # tests only
         self.w_host = weight.detach().float().cpu().contiguous()  # [Cin, Cout, 4, 4]
         self.cin, self.cout = self.w_host.shape[:2]
         self.device = device
@@ -287,7 +289,8 @@ class Deconv4x4:
         n, cin, h, w = x.shape
         assert cin == self.cin
         lib = _lib.load()
-        cfg = lib.drba_deconv4x4_pick_cfg(self.cin, self.cout, h, w)
+        cfg = self.force_cfg if self.force_cfg is not None else lib.drba_deconv4x4_pick_cfg(self.cin, self.cout, h, w)
+        _lib.check(min(cfg, 0), "drba_deconv4x4_pick_cfg")
         wp = self._pack(cfg)
         if out is None:
             shape = (n, self.cout // 4, 4 * h, 4 * w) if self.ps else (n, self.cout, 2 * h, 2 * w)

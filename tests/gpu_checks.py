@@ -90,6 +90,34 @@ def check_conv_layers(dev):
             rows.append((f"{name} [{cin}->{cout} {h}x{w} s{stride}]", _diff(got, ref), 2e-5 * max(1.0, scale), f"|ref|max={scale:.2f}"))
         except Exception as e:  # noqa: BLE001
             rows.append((name, float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    # every kernel configuration, pinned explicitly, on ragged shapes (tile-edge masks, split-K reduce, cout padding)
+    S1 = [0, 1, 2, 3, 4, 5, 6, 7]
+    S2 = [8, 9, 10, 11, 12, 13]
+    for cfg in S1 + S2:
+        stride = 1 if cfg in S1 else 2
+        for (cin, cout, h, w) in ((20, 40, 11, 45), (7, 16, 5, 70)):
+            try:
+                x = torch.randn(1, cin, h, w, generator=g)
+                wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+                b = torch.randn(cout, generator=g) * 0.1
+                ref = F.leaky_relu(F.conv2d(x, wt, b, stride=stride, padding=1), 0.2)
+                got = ops.Conv3x3(wt, b, stride, True, None, device=dev, cfg=cfg)(x.to(dev))
+                rows.append((f"conv cfg{cfg} [{cin}->{cout} {h}x{w} s{stride}]", _diff(got, ref), 5e-5, ""))
+            except Exception as e:  # noqa: BLE001
+                rows.append((f"conv cfg{cfg}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    for cfg in range(6):
+        for (cin, cout, h, w, ps) in ((20, 52, 11, 45, True), (9, 16, 6, 70, False)):
+            try:
+                x = torch.randn(1, cin, h, w, generator=g)
+                wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+                b = torch.randn(cout, generator=g) * 0.1
+                ref = F.conv_transpose2d(x, wt, b, stride=2, padding=1)
+                if ps:
+                    ref = F.pixel_shuffle(ref, 2)
+                got = ops.Deconv4x4(wt, b, ps, device=dev, cfg=cfg)(x.to(dev))
+                rows.append((f"deconv cfg{cfg} [{cin}->{cout} {h}x{w} ps={ps}]", _diff(got, ref), 5e-5, ""))
+            except Exception as e:  # noqa: BLE001
+                rows.append((f"deconv cfg{cfg}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     return rows
 
 
