@@ -41,31 +41,23 @@ def _p(t):
 
 _ws_cache = {}
 
-# Optional per-launch timing of the conv kernels (bench.py's roofline leg): when set to a list,
-# every drba_conv3x3 / drba_deconv4x4s2 launch appends (key, flops, start_event, end_event), the
-# events being recorded on the stream the kernel is launched on.
-CONV_TIMING = None
+# Optional per-launch timing (bench.py's roofline leg).  When TIMING is a dict
+# {"want": callable(kind, key) -> bool, "records": []}, each selected launch appends
+# (kind, key, work, unit, start_event, end_event); the events are recorded on the stream the kernel
+# is launched on.  Only a few launches per step are selected so the timed region is not perturbed.
+TIMING = None
 
 
-def _timed(key, flops, launch):
-    if CONV_TIMING is None:
+def _timed(kind, key, work, unit, launch):
+    t = TIMING
+    if t is None or not t["want"](kind, key):
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = launch()
     e1.record()
-    CONV_TIMING.append((key, flops, e0, e1))
+    t["records"].append((kind, key, work, unit, e0, e1))
     return r
-
-
-def _workspace(device, nfloats):
-    """Grow-only scratch per (device, stream): kernels on one stream are ordered, so reuse is safe."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nfloats:
-        buf = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
-        _ws_cache[key] = buf
-    return buf
 
 
 # ----------------------------------------------------------------------------- splat / warp / drm
@@ -255,8 +247,8 @@ class Conv3x3:
             assert residual is not None
             residual = _f32(residual)
         res = residual if self.beta is not None else None
-        key = ("conv3x3", cfg, cin, self.cout, ho, wo, self.stride)
-        _lib.check(_timed(key, 2.0 * self.cout * cin * 9 * ho * wo * n, lambda: lib.drba_conv3x3(
+        key = (cfg, cin, self.cout, ho, wo, self.stride)
+        _lib.check(_timed("conv3x3", key, 2.0 * self.cout * cin * 9 * ho * wo * n, "flop", lambda: lib.drba_conv3x3(
             _p(x), _p(wp), _p(self.bias), _p(self.beta), _p(res), _p(out), n, cin, h, w, self.cout, self.stride,
             self.act, cfg, _stream())), "drba_conv3x3")
         return out
@@ -295,8 +287,8 @@ class Deconv4x4:
         if out is None:
             shape = (n, self.cout // 4, 4 * h, 4 * w) if self.ps else (n, self.cout, 2 * h, 2 * w)
             out = torch.empty(shape, dtype=torch.float32, device=x.device)
-        key = ("deconv4x4", cfg, cin, self.cout, h, w, 2)
-        _lib.check(_timed(key, 2.0 * self.cout * cin * 16 * h * w * n, lambda: lib.drba_deconv4x4s2(
+        key = (cfg, cin, self.cout, h, w, 2)
+        _lib.check(_timed("deconv4x4", key, 2.0 * self.cout * cin * 16 * h * w * n, "flop", lambda: lib.drba_deconv4x4s2(
             _p(x), _p(wp), _p(self.bias), _p(out), n, cin, h, w, self.cout, self.ps, cfg, _stream())),
             "drba_deconv4x4s2")
         return out
@@ -313,9 +305,13 @@ def ifblock_input(img0, img1, f0, f1, timestep, flow, mask, feat, scale):
     out = torch.empty((1, nch, h, w), dtype=torch.float32, device=img0.device)
     if flow is not None:
         flow, mask, feat = _f32(flow), _f32(mask), _f32(feat)
-    _lib.check(_lib.load().drba_ifblock_input(_p(img0), _p(img1), _p(f0), _p(f1), _p(tmap), tsc, _p(flow), _p(mask),
-                                              _p(feat), _p(out), H, W, h, w, float(scale), _stream()),
-               "drba_ifblock_input")
+    # algorithmic bytes: every full-resolution sample point read once per channel + the low-res output written
+    pts = H * W if scale <= 2 else 4 * h * w
+    nbytes = 4.0 * (nch * pts + nch * h * w)
+    lib = _lib.load()
+    _lib.check(_timed("ifblock_input", (nch, H, W, h, w), nbytes, "byte", lambda: lib.drba_ifblock_input(
+        _p(img0), _p(img1), _p(f0), _p(f1), _p(tmap), tsc, _p(flow), _p(mask), _p(feat), _p(out), H, W, h, w,
+        float(scale), _stream())), "drba_ifblock_input")
     return out
 
 
