@@ -35,6 +35,9 @@ SIGNATURES = {
     "drba_f32nchw_to_u8hwc": (_i, [_p, _p, _i, _i, _p]),
     "drba_ssim3d_32": (_i, [_p, _p, _p, _p]),
     "drba_conv3x3_pick_cfg": (_i, [_i, _i, _i, _i, _i]),
+    "drba_conv3x3_num_cfgs": (_i, []),
+    "drba_conv3x3_cfg_stride": (_i, [_i]),
+    "drba_deconv4x4_num_cfgs": (_i, []),
     "drba_conv3x3_packed_floats": (_z, [_i, _i, _i]),
     "drba_conv3x3_pack": (_i, [_p, _p, _i, _i, _i]),
     "drba_conv3x3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -42,9 +45,9 @@ SIGNATURES = {
     "drba_deconv4x4_packed_floats": (_z, [_i, _i, _i]),
     "drba_deconv4x4_pack": (_i, [_p, _p, _i, _i, _i]),
     "drba_deconv4x4s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _i, _i, _i, _i, _f, _p]),
     "drba_ifblock_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
-    "drba_warp_blend": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "drba_warp_blend": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
 }
 
 _lib = None

@@ -10,11 +10,12 @@
 //   A: one ds_read_b32 from the LDS input tile [CK][rows][cols]; channel stride == 16 (mod 32)
 //      for stride 1 and odd for stride 2, which makes the read bank-conflict free.
 //   B: weights are pre-packed on the host in MFMA *fragment order*
-//      ([cout tile][chunk][tap][cg][nt][64 lanes]), so a B operand is one coalesced 256-byte
-//      global load straight into the VGPR the MFMA reads (a layer's weights are 36 KB..1.3 MB:
-//      L1/L2 resident) -- no LDS round trip for weights.
-// Input tiles are double-buffered in LDS with the next chunk's global loads issued before the
-// current chunk's MFMAs (register staging), one workgroup barrier per chunk.
+//      ([cout tile][chunk][tap][cg][nt][64 lanes]): a chunk's block is contiguous, so it is staged
+//      with float4 global loads + ds_write_b128 and a B operand is one conflict-free ds_read_b32
+//      (lane-linear).  (Feeding B straight from L2 was measured first: hipcc sinks the loads next
+//      to their MFMAs and every k-step eats an L1/L2 round trip -- 35 % MFMA utilisation.)
+// Input tile and weight block are double-buffered in LDS with the next chunk's global loads
+// issued before the current chunk's MFMAs (register staging), one workgroup barrier per chunk.
 // Accumulator D: lane holds cout l&15 for pixels 4*(l>>4)..+3 -> one float4 store along x.
 //
 // KS = 1: the 4 waves split the tile's rows (TH = 4*RW) and share the LDS input tile.
@@ -56,7 +57,13 @@ struct ConvCfg {
   static constexpr int CG = CK / 4;                      // MFMA k-groups per tap per chunk
   static constexpr int FRAG = NTAP * CG * NT * 64;       // packed weight floats per (cout tile[, phase], chunk)
   static constexpr int NTILES = RW * MW * NT;
-  static constexpr int LDS_STAGE = 2 * BUF * (KS == 1 ? 1 : 4);
+  // Weight path: KS=1 stages the chunk's fragment block through LDS (shared by the 4 waves);
+  // KS=4 (small maps, wave-private chunks) reads B fragments straight from L2 -- staging them per
+  // wave would quadruple the LDS writes (measured: 40 -> 56 us on the 64-ch 136x240 ResConv).
+  static constexpr bool WLDS = (KS == 1);
+  static constexpr int NWV = WLDS ? (FRAG / 4 + NL - 1) / NL : 1;   // float4 weight loads per thread per chunk
+  static constexpr int BUFALL = BUF + (WLDS ? FRAG : 0);  // input tile (+ weight fragments) of one chunk
+  static constexpr int LDS_STAGE = 2 * BUFALL * (KS == 1 ? 1 : 4);
   static constexpr int LDS_RED = (KS == 1) ? 0 : 4 * NTILES * 256;
   static constexpr int LDS_FLOATS = LDS_STAGE > LDS_RED ? LDS_STAGE : LDS_RED;
   static_assert(MODE == 0 || S == 1, "deconv phases read the input at stride 1");
@@ -100,21 +107,30 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
       for (int c = 0; c < NT; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = (Cin + CK - 1) / CK;
-  float *buf0 = smem + (KS == 1 ? 0 : wave * 2 * Cfg::BUF);
-  float *buf1 = buf0 + Cfg::BUF;
+  float *buf0 = smem + (KS == 1 ? 0 : wave * 2 * Cfg::BUFALL);
+  float *buf1 = buf0 + Cfg::BUFALL;
   const int ltid = (KS == 1) ? tid : lane;
   const int row0 = (KS == 1) ? wave * RW : 0;
   const int a_off = kq * CHS + (row0 * S) * TC + m * S;
   const int gy0 = y0 * S - 1, gx0 = x0 * S - 1;
   const int q_first = (KS == 1) ? 0 : wave, q_step = (KS == 1) ? 1 : 4;
-  const float *wf_base =
-      wfrag + ((size_t)(MODE == 0 ? cz : cz * 4 + phase) * nchunks) * Cfg::FRAG + lane;
+  const float *wf_base = wfrag + ((size_t)(MODE == 0 ? cz : cz * 4 + phase) * nchunks) * Cfg::FRAG;
+  constexpr int NWV = Cfg::NWV;
   // deconv tap -> tile offsets: tap = 2a+b; row = rw + 1 + dy, py=0: dy={0,-1}; py=1: dy={+1,0}
   const int dro[2] = {py ? 2 : 1, py ? 1 : 0};
   const int dco[2] = {px ? 2 : 1, px ? 1 : 0};
 
   float st[NSTAGE];
+  f32x4 wst[NWV];
   auto issue = [&](int q) {  // global -> registers (zero padding outside the image / beyond Cin)
+    if (Cfg::WLDS) {
+      const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wf_base + (size_t)q * Cfg::FRAG);
+#pragma unroll
+      for (int i = 0; i < NWV; ++i) {
+        const int e = ltid + i * NL;
+        wst[i] = (e < Cfg::FRAG / 4) ? wsrc[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
       const int e = ltid + i * NL;
@@ -128,6 +144,14 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
     }
   };
   auto commit = [&](float *buf) {  // registers -> LDS
+    if (Cfg::WLDS) {
+      f32x4 *wdst = reinterpret_cast<f32x4 *>(buf + Cfg::BUF);
+#pragma unroll
+      for (int i = 0; i < NWV; ++i) {
+        const int e = ltid + i * NL;
+        if (e < Cfg::FRAG / 4) wdst[e] = wst[i];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
       const int e = ltid + i * NL;
@@ -153,28 +177,16 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
     const int qn = q + q_step;
     if (qn < nchunks) issue(qn);  // next chunk's loads fly under this chunk's MFMAs
     const float *ab = cur + a_off;
-    const float *wq = wf_base + (size_t)q * Cfg::FRAG;
-    float bnext[CG][NT];  // B fragments are fetched one tap ahead
-#pragma unroll
-    for (int cg = 0; cg < CG; ++cg)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bnext[cg][nt] = wq[(cg * NT + nt) * 64];
+    // this chunk's weight fragments [tap][cg][nt][64 lanes]: LDS copy (KS=1) or L2 (KS=4)
+    const float *wb = Cfg::WLDS ? cur + Cfg::BUF + lane : wf_base + (size_t)q * Cfg::FRAG + lane;
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap) {
-      float bv[CG][NT];
-#pragma unroll
-      for (int cg = 0; cg < CG; ++cg)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[cg][nt] = bnext[cg][nt];
-      if (tap + 1 < NTAP) {
-#pragma unroll
-        for (int cg = 0; cg < CG; ++cg)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bnext[cg][nt] = wq[(((tap + 1) * CG + cg) * NT + nt) * 64];
-      }
       const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[tap & 1];
 #pragma unroll
-      for (int cg = 0; cg < CG; ++cg)
+      for (int cg = 0; cg < CG; ++cg) {
+        float bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[((tap * CG + cg) * NT + nt) * 64];
 #pragma unroll
         for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
@@ -182,8 +194,9 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
             const float av = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[cg][nt], acc[rw][mw][nt], 0, 0, 0);
+              acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[rw][mw][nt], 0, 0, 0);
           }
+      }
     }
     if (qn < nchunks) commit(nxt);
     sync();
@@ -372,6 +385,10 @@ int env_override(const char *name, int ntab) {
 }  // namespace
 
 extern "C" {
+
+int drba_conv3x3_num_cfgs(void) { return kNumConvCfg; }
+int drba_conv3x3_cfg_stride(int cfg) { return (cfg < 0 || cfg >= kNumConvCfg) ? DRBA_EINVAL : kConv[cfg].S; }
+int drba_deconv4x4_num_cfgs(void) { return kNumDeconvCfg; }
 
 // DRBA_CONV_CFG=<id> / DRBA_DECONV_CFG=<id> in the environment override the choice (experiments only).
 int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride) {

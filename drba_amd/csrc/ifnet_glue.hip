@@ -6,6 +6,8 @@
 // plus bilinear resize and the uint8<->fp32 frame conversions used by to_inp/to_out.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 using namespace drba;
 
 namespace {
@@ -57,28 +59,38 @@ __global__ void __launch_bounds__(256) f32_to_u8_kernel(const float *__restrict_
 // One lane per LOW-RES output pixel.  For integer scale s >= 2 the align_corners=False
 // downsample touches only the central 2x2 full-res samples of each s x s cell, so the four
 // warps are evaluated at 4/s^2 of the full-res pixels (all of them only at s <= 2).
-template <bool HAS_FLOW>
-__global__ void __launch_bounds__(256) ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ img1,
-                                     const float *__restrict__ f0, const float *__restrict__ f1,
-                                     const float *__restrict__ tmap, float tscalar,
-                                     const float *__restrict__ flow, const float *__restrict__ mask,
-                                     const float *__restrict__ feat, float *__restrict__ out, int H, int W,
-                                     int h, int w, float scale) {
-  const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
+// mask/feat of the previous stage are NOT read from full-resolution tensors: they are the
+// x s_prev bilinear upsample of the previous head output `tmp_prev` [13, hp, wp]
+// (IFNet_HDv3.py:92-95), evaluated here at the sample points from the (L2-resident) low-res tensor.
+// SINGLE: scale == 1, exactly one sample point per output pixel (keeps the register count low).
+// Variant 0: one lane per OUTPUT pixel holding all (up to 4) sample points.
+template <bool HAS_FLOW, bool SINGLE>
+__global__ void __launch_bounds__(256)
+ifblock_input_pixel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
+                    const float *__restrict__ f1, const float *__restrict__ tmap, float tscalar,
+                    const float *__restrict__ flow, const float *__restrict__ tmp_prev, int hp, int wp,
+                    float inv_prev_scale, float *__restrict__ out, int H, int W, int h, int w, float scale) {
+  constexpr int NS = SINGLE ? 1 : 2;
+  const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
   for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < p_lo; o += (size_t)gridDim.x * blockDim.x) {
     const int oy = (int)(o / w), ox = (int)(o - (size_t)oy * w);
     const Lerp ly = lerp_src(oy, scale, H), lx = lerp_src(ox, scale, W);
-    // zero-weight taps (scale == 1) are skipped: they would contribute exactly +0.
-    const bool use_x1 = lx.w1 != 0.f, use_y1 = ly.w1 != 0.f;
+    // zero-weight taps are skipped: they would contribute exactly +0.
+    const bool use_x1 = !SINGLE && lx.w1 != 0.f, use_y1 = !SINGLE && ly.w1 != 0.f;
     const int Xs[2] = {lx.i0, lx.i1}, Ys[2] = {ly.i0, ly.i1};
-    size_t q[2][2];
-    bool live[2][2];
-    Taps t0[2][2], t1[2][2];
-    float fl[2][2][4];
+    size_t q[NS][NS];
+    bool live[NS][NS];
+    Taps t0[NS][NS], t1[NS][NS];
+    float fl[NS][NS][4];
+    Lerp py_[NS], px_[NS];  // source taps of the previous stage's upsample at each sample row / column
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NS; ++j) {
+      if (HAS_FLOW) {
+        py_[j] = lerp_src(Ys[j], inv_prev_scale, hp);
+        px_[j] = lerp_src(Xs[j], inv_prev_scale, wp);
+      }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NS; ++i) {
         live[j][i] = (i == 0 || use_x1) && (j == 0 || use_y1);
         q[j][i] = (size_t)Ys[j] * W + Xs[i];
         if (HAS_FLOW && live[j][i]) {
@@ -88,18 +100,28 @@ __global__ void __launch_bounds__(256) ifblock_input_kernel(const float *__restr
           t1[j][i] = taps_border(warp_coord(Xs[i], W, fl[j][i][2]), warp_coord(Ys[j], H, fl[j][i][3]), W, H);
         }
       }
+    }
     // separable lerp, innermost axis first: wy0*(wx0*V00 + wx1*V01) + wy1*(wx0*V10 + wx1*V11)
     auto lerp4 = [&](auto &&val) -> float {
+      if (SINGLE) return ly.w0 * (lx.w0 * val(0, 0) + lx.w1 * 0.f) + ly.w1 * 0.f;
       const float v00 = val(0, 0);
-      const float v01 = live[0][1] ? val(0, 1) : 0.f;
+      const float v01 = live[0][NS - 1] ? val(0, NS - 1) : 0.f;
       const float top = lx.w0 * v00 + lx.w1 * v01;
       float bot = 0.f;
       if (use_y1) {
-        const float v10 = val(1, 0);
-        const float v11 = live[1][1] ? val(1, 1) : 0.f;
+        const float v10 = val(NS - 1, 0);
+        const float v11 = live[NS - 1][NS - 1] ? val(NS - 1, NS - 1) : 0.f;
         bot = lx.w0 * v10 + lx.w1 * v11;
       }
       return ly.w0 * top + ly.w1 * bot;
+    };
+    // previous head output channel c, bilinearly upsampled to full-res sample point (j, i)
+    auto prev_up = [&](int c, int j, int i) -> float {
+      const float *tp = tmp_prev + (size_t)c * p_prev;
+      const Lerp &a = py_[j], &b = px_[i];
+      const float top = b.w0 * tp[(size_t)a.i0 * wp + b.i0] + b.w1 * tp[(size_t)a.i0 * wp + b.i1];
+      const float bot = b.w0 * tp[(size_t)a.i1 * wp + b.i0] + b.w1 * tp[(size_t)a.i1 * wp + b.i1];
+      return a.w0 * top + a.w1 * bot;
     };
     float *dst = out + o;
     if (HAS_FLOW) {
@@ -115,11 +137,8 @@ __global__ void __launch_bounds__(256) ifblock_input_kernel(const float *__restr
         dst[(size_t)(22 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl1, W, t1[j][i]); });
       }
       dst[(size_t)38 * p_lo] = lerp4([&](int j, int i) { return tmap ? tmap[q[j][i]] : tscalar; });
-      dst[(size_t)39 * p_lo] = lerp4([&](int j, int i) { return mask[q[j][i]]; });
-      for (int c = 0; c < 8; ++c) {
-        const float *pl = feat + (size_t)c * P;
-        dst[(size_t)(40 + c) * p_lo] = lerp4([&](int j, int i) { return pl[q[j][i]]; });
-      }
+      for (int c = 0; c < 9; ++c)  // mask (tmp[4]) then feat (tmp[5:13])
+        dst[(size_t)(39 + c) * p_lo] = lerp4([&](int j, int i) { return prev_up(4 + c, j, i); });
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float v = lerp4([&](int j, int i) { return fl[j][i][c]; });
@@ -141,18 +160,118 @@ __global__ void __launch_bounds__(256) ifblock_input_kernel(const float *__restr
   }
 }
 
-// IFNet_HDv3.py:92-95 + :160: tmp [13,h,w] -> x`scale` bilinear; flow += tmp[:4]*scale; mask; feat.
-__global__ void __launch_bounds__(256) ifblock_update_kernel(const float *__restrict__ tmp, const float *flow_in, float *flow_out,
-                                      float *__restrict__ mask, float *__restrict__ feat, int h, int w, int H,
-                                      int W, float scale, float inv_scale) {
+// SINGLE (scale == 1): one lane per output pixel, one sample point.
+// otherwise: FOUR lanes per output pixel, one per sample point (j,i) of the 2x2 bilinear footprint;
+// the separable lerp  wy0*(wx0*V00 + wx1*V01) + wy1*(wx0*V10 + wx1*V11)  is formed across the lane
+// quad with two xor-shuffles (fp add is commutative, so every lane gets the reference's exact sum).
+// This keeps the per-lane state at one sample point (86 VGPRs instead of 211) and gives the
+// small low-resolution stages 4x more lanes in flight.
+template <bool HAS_FLOW, bool SINGLE, int UNR>
+__global__ void __launch_bounds__(256)
+ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
+                     const float *__restrict__ f1, const float *__restrict__ tmap, float tscalar,
+                     const float *__restrict__ flow, const float *__restrict__ tmp_prev, int hp, int wp,
+                     float inv_prev_scale, float *__restrict__ out, int H, int W, int h, int w, float scale) {
+  constexpr int LPO = SINGLE ? 1 : 4;  // lanes per output pixel
+  const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
+  const size_t total = ((p_lo * LPO + 63) / 64) * 64;  // whole waves: the shuffles need every lane of a quad
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t o_raw = g / LPO;
+    const bool valid = o_raw < p_lo;
+    const size_t o = valid ? o_raw : p_lo - 1;
+    const int sub = (int)(g % LPO), sj = sub >> 1, si = sub & 1;
+    const int oy = (int)(o / w), ox = (int)(o - (size_t)oy * w);
+    const Lerp ly = lerp_src(oy, scale, H), lx = lerp_src(ox, scale, W);
+    const int X = si ? lx.i1 : lx.i0, Y = sj ? ly.i1 : ly.i0;
+    const float wx = si ? lx.w1 : lx.w0, wy = sj ? ly.w1 : ly.w0;
+    const size_t q = (size_t)Y * W + X;
+    auto comb = [&](float v) -> float {
+      if (SINGLE) return ly.w0 * (lx.w0 * v + lx.w1 * 0.f) + ly.w1 * 0.f;
+      const float a = wx * v;
+      const float row = a + __shfl_xor(a, 1, 64);  // wx0*V_j0 + wx1*V_j1
+      const float b = wy * row;
+      return b + __shfl_xor(b, 2, 64);             // wy0*top + wy1*bot
+    };
+    const bool writer = valid && sub == 0;
+    float *dst = out + o;
+    if (HAS_FLOW) {
+      const float fl0 = flow[q], fl1 = flow[P + q], fl2 = flow[2 * P + q], fl3 = flow[3 * P + q];
+      const Taps t0 = taps_border(warp_coord(X, W, fl0), warp_coord(Y, H, fl1), W, H);
+      const Taps t1 = taps_border(warp_coord(X, W, fl2), warp_coord(Y, H, fl3), W, H);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v0 = comb(sample(img0 + (size_t)c * P, W, t0)), v1 = comb(sample(img1 + (size_t)c * P, W, t1));
+        if (writer) {
+          dst[(size_t)c * p_lo] = v0;
+          dst[(size_t)(3 + c) * p_lo] = v1;
+        }
+      }
+#pragma unroll UNR
+      for (int c = 0; c < 16; ++c) {
+        const float v0 = comb(sample(f0 + (size_t)c * P, W, t0)), v1 = comb(sample(f1 + (size_t)c * P, W, t1));
+        if (writer) {
+          dst[(size_t)(6 + c) * p_lo] = v0;
+          dst[(size_t)(22 + c) * p_lo] = v1;
+        }
+      }
+      {
+        const float v = comb(tmap ? tmap[q] : tscalar);
+        if (writer) dst[(size_t)38 * p_lo] = v;
+      }
+      // mask (tmp[4]) and feat (tmp[5:13]) = x s_prev upsample of the previous head output at (X, Y)
+      const Lerp a = lerp_src(Y, inv_prev_scale, hp), b = lerp_src(X, inv_prev_scale, wp);
+      const size_t o00 = (size_t)a.i0 * wp + b.i0, o01 = (size_t)a.i0 * wp + b.i1;
+      const size_t o10 = (size_t)a.i1 * wp + b.i0, o11 = (size_t)a.i1 * wp + b.i1;
+#pragma unroll UNR
+      for (int c = 0; c < 9; ++c) {
+        const float *tp = tmp_prev + (size_t)(4 + c) * p_prev;
+        const float top = b.w0 * tp[o00] + b.w1 * tp[o01];
+        const float bot = b.w0 * tp[o10] + b.w1 * tp[o11];
+        const float v = comb(a.w0 * top + a.w1 * bot);
+        if (writer) dst[(size_t)(39 + c) * p_lo] = v;
+      }
+      const float fls[4] = {fl0, fl1, fl2, fl3};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float v = comb(fls[c]);
+        if (writer) dst[(size_t)(48 + c) * p_lo] = (v * 1.f) / scale;  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v0 = comb(img0[(size_t)c * P + q]), v1 = comb(img1[(size_t)c * P + q]);
+        if (writer) {
+          dst[(size_t)c * p_lo] = v0;
+          dst[(size_t)(3 + c) * p_lo] = v1;
+        }
+      }
+#pragma unroll UNR
+      for (int c = 0; c < 16; ++c) {
+        const float v0 = comb(f0[(size_t)c * P + q]), v1 = comb(f1[(size_t)c * P + q]);
+        if (writer) {
+          dst[(size_t)(6 + c) * p_lo] = v0;
+          dst[(size_t)(22 + c) * p_lo] = v1;
+        }
+      }
+      const float v = comb(tmap ? tmap[q] : tscalar);
+      if (writer) dst[(size_t)38 * p_lo] = v;
+    }
+  }
+}
+
+// IFNet_HDv3.py:92-95 + :160: tmp [13,h,w] -> x`scale` bilinear; flow_out = flow_in + tmp[:4]*scale.
+// mask / feat are written only when requested (the fused pipeline re-derives them from tmp on the fly).
+__global__ void __launch_bounds__(256)
+ifblock_update_kernel(const float *__restrict__ tmp, const float *flow_in, float *flow_out, float *__restrict__ mask,
+                      float *__restrict__ feat, int h, int w, int H, int W, float scale, float inv_scale) {
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
+  const int nch = (mask || feat) ? 13 : 4;
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
     const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
     const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
     const size_t o00 = (size_t)ly.i0 * w + lx.i0, o01 = (size_t)ly.i0 * w + lx.i1;
     const size_t o10 = (size_t)ly.i1 * w + lx.i0, o11 = (size_t)ly.i1 * w + lx.i1;
-#pragma unroll
-    for (int c = 0; c < 13; ++c) {
+    for (int c = 0; c < nch; ++c) {
       const float *t = tmp + (size_t)c * p_lo;
       const float top = lx.w0 * t[o00] + lx.w1 * t[o01];
       const float bot = lx.w0 * t[o10] + lx.w1 * t[o11];
@@ -161,24 +280,30 @@ __global__ void __launch_bounds__(256) ifblock_update_kernel(const float *__rest
         const float fd = v * scale;
         flow_out[(size_t)c * P + p] = flow_in ? flow_in[(size_t)c * P + p] + fd : fd;
       } else if (c == 4) {
-        mask[p] = v;
-      } else {
+        if (mask) mask[p] = v;
+      } else if (feat) {
         feat[(size_t)(c - 5) * P + p] = v;
       }
     }
   }
 }
 
-// IFNet_HDv3.py:163-167: warped_img0*sigmoid(mask) + warped_img1*(1-sigmoid(mask)).
-__global__ void __launch_bounds__(256) warp_blend_kernel(const float *__restrict__ img0, const float *__restrict__ img1,
-                                  const float *__restrict__ flow, const float *__restrict__ mask,
-                                  float *__restrict__ out, int H, int W) {
+// IFNet_HDv3.py:163-167: warped_img0*sigmoid(mask) + warped_img1*(1-sigmoid(mask)); mask = x`scale`
+// upsample of the last head output's channel 4 (mask_lo, [h, w]).
+__global__ void __launch_bounds__(256)
+warp_blend_kernel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ flow,
+                  const float *__restrict__ mask_lo, int h, int w, float inv_scale, float *__restrict__ out, int H,
+                  int W) {
   const size_t P = (size_t)H * W;
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
     const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
     const Taps t0 = taps_border(warp_coord(x, W, flow[p]), warp_coord(y, H, flow[P + p]), W, H);
     const Taps t1 = taps_border(warp_coord(x, W, flow[2 * P + p]), warp_coord(y, H, flow[3 * P + p]), W, H);
-    const float m = 1.f / (1.f + expf(-mask[p]));
+    const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
+    const float top = lx.w0 * mask_lo[(size_t)ly.i0 * w + lx.i0] + lx.w1 * mask_lo[(size_t)ly.i0 * w + lx.i1];
+    const float bot = lx.w0 * mask_lo[(size_t)ly.i1 * w + lx.i0] + lx.w1 * mask_lo[(size_t)ly.i1 * w + lx.i1];
+    const float mk = ly.w0 * top + ly.w1 * bot;
+    const float m = 1.f / (1.f + expf(-mk));
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float a = sample(img0 + (size_t)c * P, W, t0), b = sample(img1 + (size_t)c * P, W, t1);
@@ -215,35 +340,60 @@ int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *str
 }
 
 int drba_ifblock_input(const float *img0, const float *img1, const float *f0, const float *f1,
-                       const float *timestep_map, float timestep_scalar, const float *flow, const float *mask,
-                       const float *feat, float *out, int H, int W, int h, int w, float scale, void *stream) {
+                       const float *timestep_map, float timestep_scalar, const float *flow, const float *tmp_prev,
+                       int hp, int wp, float prev_scale, float *out, int H, int W, int h, int w, float scale,
+                       void *stream) {
   if (!img0 || !img1 || !f0 || !f1 || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
-  if (flow && (!mask || !feat)) return DRBA_EINVAL;
-  dim3 g(grid_for((size_t)h * w)), b(kBlock);
-  if (flow)
-    hipLaunchKernelGGL(ifblock_input_kernel<true>, g, b, 0, (hipStream_t)stream, img0, img1, f0, f1, timestep_map,
-                       timestep_scalar, flow, mask, feat, out, H, W, h, w, scale);
-  else
-    hipLaunchKernelGGL(ifblock_input_kernel<false>, g, b, 0, (hipStream_t)stream, img0, img1, f0, f1, timestep_map,
-                       timestep_scalar, flow, mask, feat, out, H, W, h, w, scale);
+  if (flow && (!tmp_prev || hp <= 0 || wp <= 0 || !(prev_scale > 0.f))) return DRBA_EINVAL;
+  const bool single = scale == 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  const float ips = flow ? (float)(1.0 / (double)prev_scale) : 1.f;
+  // variant: 0 = lane per output pixel; 1 = lane per sample point; 2 = lane per sample point, channel loops unrolled x4.
+  // DRBA_IFIN_VARIANT overrides the default (A/B experiments only).
+  static const int forced = getenv("DRBA_IFIN_VARIANT") ? atoi(getenv("DRBA_IFIN_VARIANT")) : -1;
+  const int var = forced >= 0 ? forced : (single ? 0 : 1);
+  dim3 b(kBlock);
+#define DRBA_ARGS img0, img1, f0, f1, timestep_map, timestep_scalar, flow, tmp_prev, hp, wp, ips, out, H, W, h, w, scale
+#define DRBA_LAUNCH(HF, SG)                                                                                        \
+  do {                                                                                                             \
+    if (var == 0) {                                                                                                \
+      hipLaunchKernelGGL((ifblock_input_pixel<HF, SG>), dim3(grid_for((size_t)h * w)), b, 0, s, DRBA_ARGS);        \
+    } else if (var == 1) {                                                                                         \
+      hipLaunchKernelGGL((ifblock_input_kernel<HF, SG, 1>), dim3(grid_for((size_t)h * w * (SG ? 1 : 4))), b, 0, s, \
+                         DRBA_ARGS);                                                                               \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL((ifblock_input_kernel<HF, SG, 4>), dim3(grid_for((size_t)h * w * (SG ? 1 : 4))), b, 0, s, \
+                         DRBA_ARGS);                                                                               \
+    }                                                                                                              \
+  } while (0)
+  if (flow) {
+    if (single) DRBA_LAUNCH(true, true);
+    else DRBA_LAUNCH(true, false);
+  } else {
+    if (single) DRBA_LAUNCH(false, true);
+    else DRBA_LAUNCH(false, false);
+  }
+#undef DRBA_ARGS
+#undef DRBA_LAUNCH
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
 int drba_ifblock_update(const float *tmp, const float *flow_in, float *flow_out, float *mask, float *feat, int h,
                         int w, int H, int W, float scale, void *stream) {
-  if (!tmp || !flow_out || !mask || !feat || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
+  if (!tmp || !flow_out || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
   hipLaunchKernelGGL(ifblock_update_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, tmp,
                      flow_in, flow_out, mask, feat, h, w, H, W, scale, (float)(1.0 / (double)scale));
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
-int drba_warp_blend(const float *img0, const float *img1, const float *flow, const float *mask, float *out, int H,
-                    int W, void *stream) {
-  if (!img0 || !img1 || !flow || !mask || !out || H <= 1 || W <= 1) return DRBA_EINVAL;
+int drba_warp_blend(const float *img0, const float *img1, const float *flow, const float *mask_lo, int h, int w,
+                    float scale, float *out, int H, int W, void *stream) {
+  if (!img0 || !img1 || !flow || !mask_lo || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f))
+    return DRBA_EINVAL;
   hipLaunchKernelGGL(warp_blend_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1,
-                     flow, mask, out, H, W);
+                     flow, mask_lo, h, w, (float)(1.0 / (double)scale), out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -155,69 +155,136 @@ __device__ __forceinline__ void scatter_avg(float *__restrict__ acc, int x, int 
   }
 }
 
-// rife.py:59-60 + :62-64: splat (fx, fy, 1) along the flow itself.
-__global__ void __launch_bounds__(256) flow_reverse_scatter(const float *__restrict__ flow, float *__restrict__ acc, int H, int W) {
-  const int n = blockIdx.y;
-  const size_t P = (size_t)H * W;
-  flow += (size_t)n * 2 * P;
-  acc += (size_t)n * P * 3;
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
-    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
-    const float v[2] = {flow[p], flow[P + p]};
-    scatter_avg<2>(acc, x, y, v[0], v[1], v, H, W);
+// ------------------------------------------------------------------------------------------
+// Fused avg-splat pipelines of the RIFE path, LDS-tiled.
+//   MODE 0 (rife.py:59-73)  : value = (fx, fy), splat flow = the flow itself;
+//                             out = 2 * (hole ? max(H,W) : -avg)
+//   MODE 1 (drm.py:65-107)  : value = u = d_other/(d_self+d_other)*t*2, splat flow = self*u;
+//                             out = hole ? u : avg
+// A workgroup owns a TX x TY output tile whose accumulators live in LDS.  It visits every source
+// pixel within R of the tile and adds the corners that land inside the tile with ds_add_f32 --
+// no global atomics for "short" flows (all four corners within R of the source).  The rare
+// "long" pixels are scattered by a pre-pass with global atomics into `gacc` (zeroed), which the
+// finish step adds in.  Each (source, corner) pair is accumulated exactly once either way.
+constexpr int kTX = 64, kTY = 32, kR = 16;
+
+template <int MODE>
+struct SplatSrc {
+  float v[2];
+  float fx, fy;
+  bool finite, is_short;
+};
+
+template <int MODE>
+__device__ __forceinline__ SplatSrc<MODE> splat_source(const float *__restrict__ fs, const float *__restrict__ fo,
+                                                       size_t P, size_t p, int x, int y, float t, float eps) {
+  SplatSrc<MODE> s;
+  const float su = fs[p], sv = fs[P + p];
+  if (MODE == 0) {
+    s.v[0] = su;
+    s.v[1] = sv;
+    s.fx = su;
+    s.fy = sv;
+  } else {
+    const float ou = fo[p], ov = fo[P + p];
+    const float ds = sqrtf(su * su + sv * sv) + eps, d_o = sqrtf(ou * ou + ov * ov) + eps;
+    const float u = (d_o / (ds + d_o)) * t * 2.f;
+    s.v[0] = u;
+    s.v[1] = 0.f;
+    s.fx = su * u;
+    s.fy = sv * u;
   }
+  const float X = (float)x + s.fx, Y = (float)y + s.fy;
+  s.finite = isfinite(X) && isfinite(Y);
+  // all four corners within kR of the source <=> floor(f) >= -kR and floor(f)+1 <= kR
+  s.is_short = s.fx >= -(float)kR && s.fx < (float)(kR - 1) && s.fy >= -(float)kR && s.fy < (float)(kR - 1);
+  return s;
 }
 
-// rife.py:59-73: flow05 = -avg; holes (ones-splat n/(n+1e-7) < 0.999) -> max(H,W); then *2.
-__global__ void __launch_bounds__(256) flow_reverse_finish(const float *__restrict__ acc, float *__restrict__ out, int H, int W) {
-  const int n = blockIdx.y;
-  const size_t P = (size_t)H * W;
-  acc += (size_t)n * P * 3;
-  out += (size_t)n * 2 * P;
-  const float fill = (float)max(H, W);
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
-    const float s = acc[p * 3 + 2];
-    const float nrm = s + 0.0000001f;
-    const bool gap = (s / nrm) < 0.999f;
-    const float u = gap ? fill : -1.f * (acc[p * 3 + 0] / nrm);
-    const float v = gap ? fill : -1.f * (acc[p * 3 + 1] / nrm);
-    out[p] = u * 2.f;
-    out[P + p] = v * 2.f;
-  }
-}
-
-// drm.py:67-76 (linear) + :89/:94 scatter: u = d_other/(d_self+d_other)*t*2, splat (u, 1) along self*u.
-// `unaligned` keeps u for the hole fill.
-__global__ void __launch_bounds__(256) drm_scatter(const float *__restrict__ fs, const float *__restrict__ fo, float t, float eps,
-                            float *__restrict__ unaligned, float *__restrict__ acc, int H, int W) {
+// pre-pass: long (but finite) pixels -> global atomics into gacc [P][NV+1]
+template <int MODE>
+__global__ void __launch_bounds__(256) splat_long_prepass(const float *__restrict__ fs, const float *__restrict__ fo,
+                                                          float t, float eps, float *__restrict__ gacc, int H, int W) {
+  constexpr int NV = MODE == 0 ? 2 : 1;
   const int n = blockIdx.y;
   const size_t P = (size_t)H * W;
   fs += (size_t)n * 2 * P;
-  fo += (size_t)n * 2 * P;
-  unaligned += (size_t)n * P;
-  acc += (size_t)n * P * 2;
+  if (fo) fo += (size_t)n * 2 * P;
+  gacc += (size_t)n * P * (NV + 1);
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
     const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
-    const float su = fs[p], sv = fs[P + p], ou = fo[p], ov = fo[P + p];
-    const float ds = sqrtf(su * su + sv * sv) + eps, d_o = sqrtf(ou * ou + ov * ov) + eps;
-    const float u = (d_o / (ds + d_o)) * t * 2.f;  // same operand order as d10+d12 / d12+d10 (commutative)
-    unaligned[p] = u;
-    const float v[1] = {u};
-    scatter_avg<1>(acc, x, y, su * u, sv * u, v, H, W);
+    const SplatSrc<MODE> s = splat_source<MODE>(fs, fo, P, p, x, y, t, eps);
+    if (!s.finite || s.is_short) continue;
+    if (MODE == 0) {
+      const float v[2] = {s.v[0], s.v[1]};
+      scatter_avg<2>(gacc, x, y, s.fx, s.fy, v, H, W);
+    } else {
+      const float v[1] = {s.v[0]};
+      scatter_avg<1>(gacc, x, y, s.fx, s.fy, v, H, W);
+    }
   }
 }
 
-// `unaligned` and `out` may alias (same index read-then-written by the same lane).
-__global__ void __launch_bounds__(256) drm_finish(const float *__restrict__ acc, const float *unaligned, float *out, int H, int W) {
-  const int n = blockIdx.y;
+template <int MODE>
+__global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs, const float *__restrict__ fo, float t,
+                                                   float eps, const float *__restrict__ gacc, float *__restrict__ out,
+                                                   int H, int W) {
+  constexpr int NV = MODE == 0 ? 2 : 1;
+  __shared__ float acc[NV + 1][kTY * kTX];
+  const int n = blockIdx.z;
   const size_t P = (size_t)H * W;
-  acc += (size_t)n * P * 2;
-  unaligned += (size_t)n * P;
-  out += (size_t)n * P;
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
-    const float s = acc[p * 2 + 1];
-    const float nrm = s + 0.0000001f;
-    out[p] = ((s / nrm) < 0.999f) ? unaligned[p] : acc[p * 2] / nrm;
+  fs += (size_t)n * 2 * P;
+  if (fo) fo += (size_t)n * 2 * P;
+  gacc += (size_t)n * P * (NV + 1);
+  out += (size_t)n * (MODE == 0 ? 2 : 1) * P;
+  const int tx0 = blockIdx.x * kTX, ty0 = blockIdx.y * kTY;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (NV + 1) * kTY * kTX; i += 256) (&acc[0][0])[i] = 0.f;
+  __syncthreads();
+  constexpr int SW = kTX + 2 * kR, SH = kTY + 2 * kR;
+  for (int e = tid; e < SW * SH; e += 256) {
+    const int ry = e / SW, rx = e - ry * SW;
+    const int y = ty0 - kR + ry, x = tx0 - kR + rx;
+    if (x < 0 || x >= W || y < 0 || y >= H) continue;
+    const SplatSrc<MODE> s = splat_source<MODE>(fs, fo, P, (size_t)y * W + x, x, y, t, eps);
+    if (!s.finite || !s.is_short) continue;
+    const float X = (float)x + s.fx, Y = (float)y + s.fy;
+    const float fxf = floorf(X), fyf = floorf(Y);
+    const int x0 = (int)fxf, y0 = (int)fyf;
+    const float wx0 = (fxf + 1.f) - X, wx1 = X - fxf, wy0 = (fyf + 1.f) - Y, wy1 = Y - fyf;
+    const float wgt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+      if (cx < 0 || cx >= W || cy < 0 || cy >= H) continue;        // corner outside the image: dropped
+      const int lx = cx - tx0, ly = cy - ty0;
+      if (lx < 0 || lx >= kTX || ly < 0 || ly >= kTY) continue;    // corner belongs to another tile
+      const int li = ly * kTX + lx;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) atomicAdd(&acc[c][li], s.v[c] * wgt[k]);
+      atomicAdd(&acc[NV][li], wgt[k]);
+    }
+  }
+  __syncthreads();
+  const float fill = (float)max(H, W);
+  for (int i = tid; i < kTY * kTX; i += 256) {
+    const int ly = i / kTX, lx = i - ly * kTX;
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (x >= W || y >= H) continue;
+    const size_t p = (size_t)y * W + x;
+    const float *g = gacc + p * (NV + 1);
+    const float sw = acc[NV][i] + g[NV];
+    const float nrm = sw + 0.0000001f;
+    const bool gap = (sw / nrm) < 0.999f;
+    if (MODE == 0) {
+      const float a0 = acc[0][i] + g[0], a1 = acc[1][i] + g[1];
+      out[p] = (gap ? fill : -1.f * (a0 / nrm)) * 2.f;
+      out[P + p] = (gap ? fill : -1.f * (a1 / nrm)) * 2.f;
+    } else {
+      const float a0 = acc[0][i] + g[0];
+      const SplatSrc<MODE> s = splat_source<MODE>(fs, fo, P, p, x, y, t, eps);  // the unaligned value for holes
+      out[p] = gap ? s.v[0] : a0 / nrm;
+    }
   }
 }
 
@@ -339,9 +406,10 @@ int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, in
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
   if (hipMemsetAsync(ws, 0, (size_t)N * P * 3 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
-  dim3 g(grid_for(P), N);
-  hipLaunchKernelGGL(flow_reverse_scatter, g, dim3(kBlock), 0, s, flow, ws, H, W);
-  hipLaunchKernelGGL(flow_reverse_finish, g, dim3(kBlock), 0, s, ws, out, H, W);
+  hipLaunchKernelGGL(splat_long_prepass<0>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f,
+                     0.f, ws, H, W);
+  dim3 g((W + kTX - 1) / kTX, (H + kTY - 1) / kTY, N);
+  hipLaunchKernelGGL(splat_tiled<0>, g, dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f, 0.f, ws, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -351,11 +419,11 @@ int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float 
   if (!flow_self || !flow_other || !out || !ws || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
-  // ws layout: [N*P*2] accumulator (value, weight)  — `out` doubles as the unaligned map until the finish pass
   if (hipMemsetAsync(ws, 0, (size_t)N * P * 2 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
-  dim3 g(grid_for(P), N);
-  hipLaunchKernelGGL(drm_scatter, g, dim3(kBlock), 0, s, flow_self, flow_other, t, eps, out, ws, H, W);
-  hipLaunchKernelGGL(drm_finish, g, dim3(kBlock), 0, s, ws, out, out, H, W);
+  hipLaunchKernelGGL(splat_long_prepass<1>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow_self, flow_other, t, eps, ws,
+                     H, W);
+  dim3 g((W + kTX - 1) / kTX, (H + kTY - 1) / kTY, N);
+  hipLaunchKernelGGL(splat_tiled<1>, g, dim3(kBlock), 0, s, flow_self, flow_other, t, eps, ws, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -57,8 +57,8 @@ class RIFE:
         f0 = self.ifnet.encode(a) if f0 is None else f0
         f1 = self.ifnet.encode(b) if f1 is None else f1
         s = self.scale_list[0]
-        xin = _ops.ifblock_input(a, b, f0, f1, 0.5, None, None, None, s)
-        flow, _, _ = _ops.ifblock_update(self.ifnet.block[0].core(xin), None, H, W, s)
+        xin = _ops.ifblock_input(a, b, f0, f1, 0.5, None, None, 1.0, s)
+        flow = _ops.ifblock_update(self.ifnet.block[0].core(xin), None, H, W, s)
         flow01 = _ops.flow_reverse(flow[:, :2])   # 2 * (-splat_avg(flow50)), holes -> 2*max(H, W)
         flow10 = _ops.flow_reverse(flow[:, 2:])
         return flow01, flow10, f0, f1

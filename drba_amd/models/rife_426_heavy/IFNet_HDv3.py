@@ -7,7 +7,8 @@ libdrba_hip.so.  What the reference does with cat / interpolate / grid_sample be
 convolutions is fused into three glue kernels (drba_amd/csrc/ifnet_glue.hip):
 
     stage input  = warp x4 + concat + 1/s bilinear downsample   (drba_ifblock_input)
-    stage output = PixelShuffle + x s bilinear upsample + flow accumulate (deconv epilogue + drba_ifblock_update)
+    stage output = PixelShuffle (deconv epilogue) + x s upsample + flow accumulate (drba_ifblock_update);
+                   mask/feat are re-derived from the low-res head output by the next stage's input kernel
     synthesis    = warp x2 + sigmoid blend                       (drba_warp_blend)
 """
 import torch
@@ -64,7 +65,7 @@ class IFBlock:
             fl = _ops.affine(_ops.resize_bilinear_scale(flow, (h, w), scale), 1.0 / scale, 0.0)
             x = torch.cat((x, fl), 1)
         tmp = self.core(x)
-        return _ops.ifblock_update(tmp, None, H, W, scale)
+        return _ops.ifblock_update(tmp, None, H, W, scale, want_mask_feat=True)
 
     forward = __call__
 
@@ -97,15 +98,17 @@ class IFNet:
         _, _, H, W = img0.shape
         f0 = self.encode(img0) if f0 is None else f0
         f1 = self.encode(img1) if f1 is None else f1
-        flow = mask = feat = None
+        flow = tmp = None
+        s_prev = 1.0
         flow_list = []
         for i in range(5):
             s = scale_list[i]
-            xin = _ops.ifblock_input(img0, img1, f0, f1, timestep, flow, mask, feat, s)
-            tmp = self.block[i].core(xin)
-            flow, mask, feat = _ops.ifblock_update(tmp, flow, H, W, s)
+            xin = _ops.ifblock_input(img0, img1, f0, f1, timestep, flow, tmp, s_prev, s)
+            tmp = self.block[i].core(xin)  # [1,13,H/s,W/s]: flow delta (4), mask (1), feat (8)
+            flow = _ops.ifblock_update(tmp, flow, H, W, s)  # only the running flow exists at full resolution
             flow_list.append(flow)
-        return _ops.warp_blend(img0, img1, flow, mask), flow_list
+            s_prev = s
+        return _ops.warp_blend(img0, img1, flow, tmp, s_prev), flow_list
 
     def __call__(self, x, timestep=0.5, scale_list=(8, 4, 2, 1), training=False, fastmode=True, ensemble=False,
                  f0=None, f1=None):

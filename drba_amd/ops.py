@@ -41,6 +41,17 @@ def _p(t):
 
 _ws_cache = {}
 
+
+def _workspace(device, nfloats):
+    """Grow-only scratch per (device, stream): kernels on one stream are ordered, so reuse is safe."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
 # Optional per-launch timing (bench.py's roofline leg).  When TIMING is a dict
 # {"want": callable(kind, key) -> bool, "records": []}, each selected launch appends
 # (kind, key, work, unit, start_event, end_event); the events are recorded on the stream the kernel
@@ -209,6 +220,32 @@ def ssim_thumb32(x1, x2):
 
 
 # ----------------------------------------------------------------------------- convolutions
+# Kernel-configuration choice.  The library's cost model gives a default; with AUTOTUNE on (default) the
+# first call for a new layer shape times every configuration built for that stride once on the device
+# and keeps the fastest ("measure, don't guess").  Results are shared by all layers of the same shape.
+AUTOTUNE = True
+_tuned = {}
+
+
+def _tune(shape_key, candidates, run, reps=3):
+    if shape_key in _tuned:
+        return _tuned[shape_key]
+    best, best_ms = None, None
+    for cfg in candidates:
+        run(cfg)  # warm: packs weights, faults pages
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run(cfg)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if best_ms is None or ms < best_ms:
+            best, best_ms = cfg, ms
+    _tuned[shape_key] = best
+    return best
+
+
 class Conv3x3:
     """One 3x3 conv layer (pad 1) with fused epilogue; weights are packed per kernel config on first use."""
 
@@ -238,15 +275,25 @@ class Conv3x3:
         assert cin == self.cin, (cin, self.cin)
         ho, wo = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
         lib = _lib.load()
-        cfg = self.force_cfg if self.force_cfg is not None else lib.drba_conv3x3_pick_cfg(self.cin, self.cout, ho, wo, self.stride)
-        _lib.check(min(cfg, 0), "drba_conv3x3_pick_cfg")
-        wp = self._pack(cfg)
         if out is None:
             out = torch.empty((n, self.cout, ho, wo), dtype=torch.float32, device=x.device)
         if self.beta is not None:
             assert residual is not None
             residual = _f32(residual)
         res = residual if self.beta is not None else None
+        if self.force_cfg is not None:
+            cfg = self.force_cfg
+        elif AUTOTUNE and x.is_cuda:
+            cands = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_stride(c) == self.stride]
+            cfg = _tune(("conv3x3", n, cin, self.cout, h, w, self.stride), cands, lambda c: lib.drba_conv3x3(
+                _p(x), _p(self._pack(c)), _p(self.bias), _p(self.beta), _p(res), _p(out), n, cin, h, w, self.cout,
+                self.stride, self.act, c, _stream()))
+            for c in [c for c in self._packed if c != cfg]:
+                del self._packed[c]  # keep only the winner's packed weights
+        else:
+            cfg = lib.drba_conv3x3_pick_cfg(self.cin, self.cout, ho, wo, self.stride)
+        _lib.check(min(cfg, 0), "drba_conv3x3_pick_cfg")
+        wp = self._pack(cfg)
         key = (cfg, cin, self.cout, ho, wo, self.stride)
         _lib.check(_timed("conv3x3", key, 2.0 * self.cout * cin * 9 * ho * wo * n, "flop", lambda: lib.drba_conv3x3(
             _p(x), _p(wp), _p(self.bias), _p(self.beta), _p(res), _p(out), n, cin, h, w, self.cout, self.stride,
@@ -281,12 +328,21 @@ class Deconv4x4:
         n, cin, h, w = x.shape
         assert cin == self.cin
         lib = _lib.load()
-        cfg = self.force_cfg if self.force_cfg is not None else lib.drba_deconv4x4_pick_cfg(self.cin, self.cout, h, w)
-        _lib.check(min(cfg, 0), "drba_deconv4x4_pick_cfg")
-        wp = self._pack(cfg)
         if out is None:
             shape = (n, self.cout // 4, 4 * h, 4 * w) if self.ps else (n, self.cout, 2 * h, 2 * w)
             out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        if self.force_cfg is not None:
+            cfg = self.force_cfg
+        elif AUTOTUNE and x.is_cuda:
+            cfg = _tune(("deconv4x4", n, cin, self.cout, h, w, self.ps), list(range(lib.drba_deconv4x4_num_cfgs())),
+                        lambda c: lib.drba_deconv4x4s2(_p(x), _p(self._pack(c)), _p(self.bias), _p(out), n, cin, h, w,
+                                                       self.cout, self.ps, c, _stream()))
+            for c in [c for c in self._packed if c != cfg]:
+                del self._packed[c]
+        else:
+            cfg = lib.drba_deconv4x4_pick_cfg(self.cin, self.cout, h, w)
+        _lib.check(min(cfg, 0), "drba_deconv4x4_pick_cfg")
+        wp = self._pack(cfg)
         key = (cfg, cin, self.cout, h, w, 2)
         _lib.check(_timed("deconv4x4", key, 2.0 * self.cout * cin * 16 * h * w * n, "flop", lambda: lib.drba_deconv4x4s2(
             _p(x), _p(wp), _p(self.bias), _p(out), n, cin, h, w, self.cout, self.ps, cfg, _stream())),
@@ -295,46 +351,55 @@ class Deconv4x4:
 
 
 # ----------------------------------------------------------------------------- IFNet glue
-def ifblock_input(img0, img1, f0, f1, timestep, flow, mask, feat, scale):
-    """Stage input at 1/scale resolution (52 ch with flow, 39 without).  `timestep`: float or [1,1,H,W] map."""
+def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scale):
+    """Stage input at 1/scale resolution (52 ch with flow, 39 without).  `timestep`: float or [1,1,H,W] map;
+    `tmp_prev`: the previous stage's [1,13,hp,wp] head output (mask/feat are its x prev_scale upsample)."""
     img0, img1, f0, f1 = _f32(img0), _f32(img1), _f32(f0), _f32(f1)
     _, _, H, W = img0.shape
     h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
     tmap, tsc = (None, float(timestep)) if not torch.is_tensor(timestep) else (_f32(timestep), 0.0)
     nch = 52 if flow is not None else 39
     out = torch.empty((1, nch, h, w), dtype=torch.float32, device=img0.device)
+    hp = wp = 0
+    ps = 1.0
     if flow is not None:
-        flow, mask, feat = _f32(flow), _f32(mask), _f32(feat)
-    # algorithmic bytes: every full-resolution sample point read once per channel + the low-res output written
+        flow, tmp_prev = _f32(flow), _f32(tmp_prev)
+        hp, wp, ps = tmp_prev.shape[2], tmp_prev.shape[3], float(prev_scale)
+    # algorithmic bytes: every full-resolution sample point read once per full-res channel + the output written
     pts = H * W if scale <= 2 else 4 * h * w
-    nbytes = 4.0 * (nch * pts + nch * h * w)
+    nbytes = 4.0 * ((nch - (9 if flow is not None else 0)) * pts + nch * h * w)
     lib = _lib.load()
     _lib.check(_timed("ifblock_input", (nch, H, W, h, w), nbytes, "byte", lambda: lib.drba_ifblock_input(
-        _p(img0), _p(img1), _p(f0), _p(f1), _p(tmap), tsc, _p(flow), _p(mask), _p(feat), _p(out), H, W, h, w,
+        _p(img0), _p(img1), _p(f0), _p(f1), _p(tmap), tsc, _p(flow), _p(tmp_prev), hp, wp, ps, _p(out), H, W, h, w,
         float(scale), _stream())), "drba_ifblock_input")
     return out
 
 
-def ifblock_update(tmp, flow_in, H, W, scale):
-    """(flow, mask, feat) at full resolution from the 13-channel head output at 1/scale."""
+def ifblock_update(tmp, flow_in, H, W, scale, want_mask_feat=False):
+    """flow (and optionally mask, feat) at full resolution from the 13-channel head output at 1/scale."""
     tmp = _f32(tmp)
     _, c, h, w = tmp.shape
     assert c == 13
     dev = tmp.device
     flow = torch.empty((1, 4, H, W), dtype=torch.float32, device=dev)
-    mask = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
-    feat = torch.empty((1, 8, H, W), dtype=torch.float32, device=dev)
+    mask = feat = None
+    if want_mask_feat:
+        mask = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
+        feat = torch.empty((1, 8, H, W), dtype=torch.float32, device=dev)
     if flow_in is not None:
         flow_in = _f32(flow_in)
     _lib.check(_lib.load().drba_ifblock_update(_p(tmp), _p(flow_in), _p(flow), _p(mask), _p(feat), h, w, H, W,
                                                float(scale), _stream()), "drba_ifblock_update")
-    return flow, mask, feat
+    return (flow, mask, feat) if want_mask_feat else flow
 
 
-def warp_blend(img0, img1, flow, mask):
-    img0, img1, flow, mask = _f32(img0), _f32(img1), _f32(flow), _f32(mask)
+def warp_blend(img0, img1, flow, tmp_last, scale):
+    """Final frame from the two inputs, the accumulated flow and the last head output (mask = channel 4)."""
+    img0, img1, flow, tmp_last = _f32(img0), _f32(img1), _f32(flow), _f32(tmp_last)
     _, _, H, W = img0.shape
+    h, w = tmp_last.shape[2], tmp_last.shape[3]
+    mask_lo = tmp_last[:, 4:5]  # contiguous plane of the [1,13,h,w] tensor
     out = torch.empty((1, 3, H, W), dtype=torch.float32, device=img0.device)
-    _lib.check(_lib.load().drba_warp_blend(_p(img0), _p(img1), _p(flow), _p(mask), _p(out), H, W, _stream()),
-               "drba_warp_blend")
+    _lib.check(_lib.load().drba_warp_blend(_p(img0), _p(img1), _p(flow), C.c_void_p(mask_lo.data_ptr()), h, w,
+                                           float(scale), _p(out), H, W, _stream()), "drba_warp_blend")
     return out

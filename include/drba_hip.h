@@ -90,7 +90,9 @@ int drba_ssim3d_32(const float *x1, const float *x2, float *out, void *stream);
  * fp32 implicit GEMM on v_mfma_f32_16x16x4_f32.  Weights must be pre-packed by the matching
  * drba_pack_* call for the same `cfg`; cfg is chosen by drba_conv3x3_pick_cfg.
  * epilogue: y = acc + bias; if (beta) y = y*beta[c] + residual; if (act) y = lrelu_0.2(y). */
-int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride);
+int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride); /* cost-model default */
+int drba_conv3x3_num_cfgs(void);         /* configs are 0..num-1; a host may time them and keep the fastest */
+int drba_conv3x3_cfg_stride(int cfg);    /* the stride (1 or 2) a config was built for */
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg);
 int drba_conv3x3_pack(const float *w /*[Cout,Cin,3,3] host or device-visible*/, float *packed,
                       int Cin, int Cout, int cfg);  /* HOST function: both pointers are host memory */
@@ -101,6 +103,7 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
 /* ConvTranspose2d(k=4, s=2, p=1) as four 2x2 phase convolutions; pixel_shuffle=1 writes
  * PixelShuffle(2) of the result directly (IFNet_HDv3.py:79-82), else plain [Cout,2H,2W]. */
 int drba_deconv4x4_pick_cfg(int Cin, int Cout, int H, int W);
+int drba_deconv4x4_num_cfgs(void);
 size_t drba_deconv4x4_packed_floats(int Cin, int Cout, int cfg);
 int drba_deconv4x4_pack(const float *w /*[Cin,Cout,4,4] host*/, float *packed, int Cin, int Cout, int cfg);
 int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, float *out,
@@ -110,19 +113,23 @@ int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, 
  * Build one IFBlock's input at 1/scale resolution without materialising the full-resolution
  * concat: channels [warp(img0,flow[:2]) 3, warp(img1,flow[2:4]) 3, warp(f0) 16, warp(f1) 16,
  * timestep 1, (mask 1, feat 8, flow/scale 4 when flow != NULL)], bilinear-downsampled
- * (align_corners=False, src = scale*(dst+0.5)-0.5).  flow == NULL: first stage, no warp, 39 ch.
- * timestep_map may be NULL -> timestep_scalar. */
+ * (align_corners=False, src = scale*(dst+0.5)-0.5).  mask/feat are evaluated on the fly as the
+ * x prev_scale bilinear upsample of the previous stage's 13-channel head output tmp_prev [13,hp,wp]
+ * (channels 4 and 5..12), so they never exist at full resolution.
+ * flow == NULL: first stage, no warp, 39 ch.  timestep_map may be NULL -> timestep_scalar. */
 int drba_ifblock_input(const float *img0, const float *img1, const float *f0, const float *f1,
                        const float *timestep_map, float timestep_scalar, const float *flow,
-                       const float *mask, const float *feat, float *out, int H, int W, int h, int w,
-                       float scale, void *stream);
-/* Upsample the 13-channel head output by `scale` and fold it into the running state:
- * flow_out = (flow_in ? flow_in : 0) + up(tmp[0:4])*scale; mask = up(tmp[4]); feat = up(tmp[5:13]). */
+                       const float *tmp_prev, int hp, int wp, float prev_scale, float *out,
+                       int H, int W, int h, int w, float scale, void *stream);
+/* Upsample the 13-channel head output by `scale` and fold it into the running flow:
+ * flow_out = (flow_in ? flow_in : 0) + up(tmp[0:4])*scale.  mask / feat (full resolution,
+ * = up(tmp[4]), up(tmp[5:13])) are written only when non-NULL. */
 int drba_ifblock_update(const float *tmp, const float *flow_in, float *flow_out, float *mask,
                         float *feat, int h, int w, int H, int W, float scale, void *stream);
-/* Final synthesis: out = warp(img0,flow[:2])*sigmoid(mask) + warp(img1,flow[2:4])*(1-sigmoid(mask)) */
-int drba_warp_blend(const float *img0, const float *img1, const float *flow, const float *mask,
-                    float *out, int H, int W, void *stream);
+/* Final synthesis: out = warp(img0,flow[:2])*sigmoid(m) + warp(img1,flow[2:4])*(1-sigmoid(m)),
+ * m = x scale bilinear upsample of mask_lo [h, w] (channel 4 of the last head output). */
+int drba_warp_blend(const float *img0, const float *img1, const float *flow, const float *mask_lo,
+                    int h, int w, float scale, float *out, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

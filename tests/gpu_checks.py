@@ -140,33 +140,39 @@ def check_glue(dev):
         # first stage (no flow)
         x = torch.cat((img0, img1, f0, f1, tmap), 1)
         ref = F.interpolate(x, scale_factor=1.0 / s, mode="bilinear", align_corners=False)
-        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), D(tmap), None, None, None, s)
+        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), D(tmap), None, None, 1.0, s)
         rows.append((f"ifblock_input first s={s}", _diff(got, ref), 1e-5, ""))
-        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), 0.5, None, None, None, s)
+        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), 0.5, None, None, 1.0, s)
         x = torch.cat((img0, img1, f0, f1, tmap * 0 + 0.5), 1)
         ref = F.interpolate(x, scale_factor=1.0 / s, mode="bilinear", align_corners=False)
         rows.append((f"ifblock_input first scalar-t s={s}", _diff(got, ref), 1e-5, ""))
-        # later stage (warped)
+        # later stage (warped); mask/feat come from the previous stage's low-res head output (scale sp = 2s)
+        sp = 2.0 * s
+        tprev = torch.randn(1, 13, max(int(H / sp), 1), max(int(W / sp), 1), generator=g)
+        upp = F.interpolate(tprev, scale_factor=sp, mode="bilinear", align_corners=False)
+        mask, feat = upp[:, 4:5], upp[:, 5:]
         w0, w1 = oracle.ops.backwarp(img0, flow[:, :2]), oracle.ops.backwarp(img1, flow[:, 2:4])
         wf0, wf1 = oracle.ops.backwarp(f0, flow[:, :2]), oracle.ops.backwarp(f1, flow[:, 2:4])
         x = torch.cat((w0, w1, wf0, wf1, tmap, mask, feat), 1)
         x = F.interpolate(x, scale_factor=1.0 / s, mode="bilinear", align_corners=False)
         fl = F.interpolate(flow, scale_factor=1.0 / s, mode="bilinear", align_corners=False) * 1.0 / s
         ref = torch.cat((x, fl), 1)
-        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), D(tmap), D(flow), D(mask), D(feat), s)
+        got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), D(tmap), D(flow), D(tprev), sp, s)
         rows.append((f"ifblock_input warped s={s}", _diff(got, ref), 5e-5, ""))
         # update
         h, w = int(H / s), int(W / s)
         tmp = torch.randn(1, 13, h, w, generator=g)
         up = F.interpolate(tmp, scale_factor=s, mode="bilinear", align_corners=False)
-        gf, gm, gfe = ops.ifblock_update(D(tmp), D(flow), H, W, s)
+        gf, gm, gfe = ops.ifblock_update(D(tmp), D(flow), H, W, s, want_mask_feat=True)
         rows.append((f"ifblock_update flow s={s}", _diff(gf, flow + up[:, :4] * s), 1e-5 * max(1.0, s), ""))
         rows.append((f"ifblock_update mask/feat s={s}", max(_diff(gm, up[:, 4:5]), _diff(gfe, up[:, 5:])), 1e-5, ""))
-        gf, _, _ = ops.ifblock_update(D(tmp), None, H, W, s)
+        gf = ops.ifblock_update(D(tmp), None, H, W, s)
         rows.append((f"ifblock_update noflow s={s}", _diff(gf, up[:, :4] * s), 1e-5 * max(1.0, s), ""))
-    m = torch.sigmoid(mask)
-    ref = oracle.ops.backwarp(img0, flow[:, :2]) * m + oracle.ops.backwarp(img1, flow[:, 2:4]) * (1 - m)
-    rows.append(("warp_blend", _diff(ops.warp_blend(D(img0), D(img1), D(flow), D(mask)), ref), 1e-5, ""))
+    for sl in (1.0, 2.0):
+        tl = torch.randn(1, 13, int(H / sl), int(W / sl), generator=g)
+        m = torch.sigmoid(F.interpolate(tl, scale_factor=sl, mode="bilinear", align_corners=False)[:, 4:5])
+        ref = oracle.ops.backwarp(img0, flow[:, :2]) * m + oracle.ops.backwarp(img1, flow[:, 2:4]) * (1 - m)
+        rows.append((f"warp_blend s={sl}", _diff(ops.warp_blend(D(img0), D(img1), D(flow), D(tl), sl), ref), 1e-5, ""))
     # frame conversion round trip (tools.py:33-38)
     u8 = torch.randint(0, 256, (37, 53, 3), dtype=torch.uint8, generator=g)
     f = ops.u8hwc_to_f32nchw(D(u8))

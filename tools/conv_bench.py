@@ -10,13 +10,22 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drba_amd import _lib, ops  # noqa: E402
 
-H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1088, 1920)
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("H", nargs="?", type=int, default=1088)
+ap.add_argument("W", nargs="?", type=int, default=1920)
+ap.add_argument("--only", default=None, help="comma list of layer names (e.g. b4.res,b3.res)")
+ap.add_argument("--cfg", type=int, default=None, help="run only this config id")
+ap.add_argument("--reps", type=int, default=20)
+args = ap.parse_args()
+H, W = args.H, args.W
 dev = torch.device("cuda:0")
 lib = _lib.load()
 S1, S2, NDC = list(range(0, 8)), list(range(8, 14)), 6
 
 
-def timeit(fn, reps=20):
+def timeit(fn, reps=None):
+    reps = reps or args.reps
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -42,7 +51,10 @@ layers += [("enc.cnn0", "conv", 3, 16, H, W, 2), ("enc.cnn1", "conv", 16, 16, H 
            ("enc.cnn3", "deconv16", 16, 16, H // 2, W // 2, 1)]
 
 g = torch.Generator().manual_seed(0)
+only = set(args.only.split(",")) if args.only else None
 for name, kind, cin, cout, h, w, stride in layers:
+    if only and name not in only:
+        continue
     x = torch.randn(1, cin, h, w, generator=g).to(dev)
     b = torch.zeros(cout)
     if kind in ("conv", "res"):
@@ -51,7 +63,7 @@ for name, kind, cin, cout, h, w, stride in layers:
         flops = 2.0 * cout * cin * 9 * ho * wo
         picked = lib.drba_conv3x3_pick_cfg(cin, cout, ho, wo, stride)
         res = []
-        for cfg in (S1 if stride == 1 else S2):
+        for cfg in ([args.cfg] if args.cfg is not None else (S1 if stride == 1 else S2)):
             beta = torch.ones(1, cout, 1, 1) if kind == "res" else None
             layer = ops.Conv3x3(wt, b, stride, True, beta, device=dev, cfg=cfg)
             out = torch.empty((1, cout, ho, wo), device=dev)
@@ -62,12 +74,12 @@ for name, kind, cin, cout, h, w, stride in layers:
         flops = 2.0 * cout * cin * 16 * h * w
         picked = lib.drba_deconv4x4_pick_cfg(cin, cout, h, w)
         res = []
-        for cfg in range(NDC):
+        for cfg in ([args.cfg] if args.cfg is not None else range(NDC)):
             layer = ops.Deconv4x4(wt, b, kind == "deconv", device=dev, cfg=cfg)
             us = timeit(lambda: layer(x))
             res.append((cfg, us))
     best = min(res, key=lambda r: r[1])
     line = " ".join(f"{'*' if c == picked else ''}c{c}:{us:.0f}us" for c, us in res)
-    pk = dict(res)[picked]
+    pk = dict(res).get(picked, best[1])
     print(f"{name:12s} {cin:3d}->{cout:3d} {h}x{w} s{stride} {flops / 1e9:6.2f}GF picked c{picked} {pk:.0f}us {flops / pk / 1e6:6.1f}TF/s"
           f" | best c{best[0]} {best[1]:.0f}us {flops / best[1] / 1e6:6.1f}TF/s | {line}")
