@@ -24,7 +24,7 @@ SIGNATURES = {
     "drba_backwarp": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "drba_flow_distance": (_i, [_p, _p, _i, _i, _i, _p]),
     "drba_flow_reverse": (_i, [_p, _p, _p, _i, _i, _i, _p]),
-    "drba_drm_rife_linear": (_i, [_p, _p, _f, _f, _p, _p, _i, _i, _i, _p]),
+    "drba_drm_rife_linear": (_i, [_p, _p, _f, _p, _f, _p, _p, _i, _i, _i, _p]),
     "drba_drm_ratio": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _p]),
     "drba_affine": (_i, [_p, _f, _f, _p, _z, _p]),
     "drba_mul_map": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

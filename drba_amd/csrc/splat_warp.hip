@@ -204,8 +204,10 @@ __device__ __forceinline__ SplatSrc<MODE> splat_source(const float *__restrict__
 // pre-pass: long (but finite) pixels -> global atomics into gacc [P][NV+1]
 template <int MODE>
 __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restrict__ fs, const float *__restrict__ fo,
-                                                          float t, float eps, float *__restrict__ gacc, int H, int W) {
+                                                          float t, const float *__restrict__ t_dev, float eps,
+                                                          float *__restrict__ gacc, int H, int W) {
   constexpr int NV = MODE == 0 ? 2 : 1;
+  if (t_dev) t = *t_dev;  // timestep from device memory: lets one captured HIP graph serve every t
   const int n = blockIdx.y;
   const size_t P = (size_t)H * W;
   fs += (size_t)n * 2 * P;
@@ -227,9 +229,11 @@ __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restric
 
 template <int MODE>
 __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs, const float *__restrict__ fo, float t,
-                                                   float eps, const float *__restrict__ gacc, float *__restrict__ out,
-                                                   int H, int W) {
+                                                   const float *__restrict__ t_dev, float eps,
+                                                   const float *__restrict__ gacc, float *__restrict__ out, int H,
+                                                   int W) {
   constexpr int NV = MODE == 0 ? 2 : 1;
+  if (t_dev) t = *t_dev;
   __shared__ float acc[NV + 1][kTY * kTX];
   const int n = blockIdx.z;
   const size_t P = (size_t)H * W;
@@ -407,23 +411,24 @@ int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, in
   const size_t P = (size_t)H * W;
   if (hipMemsetAsync(ws, 0, (size_t)N * P * 3 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
   hipLaunchKernelGGL(splat_long_prepass<0>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f,
-                     0.f, ws, H, W);
+                     (const float *)nullptr, 0.f, ws, H, W);
   dim3 g((W + kTX - 1) / kTX, (H + kTY - 1) / kTY, N);
-  hipLaunchKernelGGL(splat_tiled<0>, g, dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f, 0.f, ws, out, H, W);
+  hipLaunchKernelGGL(splat_tiled<0>, g, dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f, (const float *)nullptr,
+                     0.f, ws, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
-int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float t, float eps, float *out, float *ws,
-                         int N, int H, int W, void *stream) {
+int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float t, const float *t_dev, float eps,
+                         float *out, float *ws, int N, int H, int W, void *stream) {
   if (!flow_self || !flow_other || !out || !ws || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
   if (hipMemsetAsync(ws, 0, (size_t)N * P * 2 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
-  hipLaunchKernelGGL(splat_long_prepass<1>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow_self, flow_other, t, eps, ws,
-                     H, W);
+  hipLaunchKernelGGL(splat_long_prepass<1>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev,
+                     eps, ws, H, W);
   dim3 g((W + kTX - 1) / kTX, (H + kTY - 1) / kTY, N);
-  hipLaunchKernelGGL(splat_tiled<1>, g, dim3(kBlock), 0, s, flow_self, flow_other, t, eps, ws, out, H, W);
+  hipLaunchKernelGGL(splat_tiled<1>, g, dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev, eps, ws, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -117,13 +117,14 @@ def flow_reverse(flow):
     return out
 
 
-def drm_rife_linear(flow_self, flow_other, t, eps=1e-4):
+def drm_rife_linear(flow_self, flow_other, t, eps=1e-4, t_dev=None):
+    """`t_dev`: optional 1-element CUDA float tensor holding t (used instead of `t`; for graph replay)."""
     a, b = _f32(flow_self, "flow_self"), _f32(flow_other, "flow_other")
     n, _, h, w = a.shape
     out = torch.empty((n, 1, h, w), dtype=torch.float32, device=a.device)
     ws = _workspace(a.device, n * h * w * 2)
-    _lib.check(_lib.load().drba_drm_rife_linear(_p(a), _p(b), float(t), float(eps), _p(out), _p(ws), n, h, w,
-                                                _stream()), "drba_drm_rife_linear")
+    _lib.check(_lib.load().drba_drm_rife_linear(_p(a), _p(b), float(t), _p(t_dev), float(eps), _p(out), _p(ws), n, h,
+                                                w, _stream()), "drba_drm_rife_linear")
     return out
 
 

@@ -56,9 +56,10 @@ int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, in
 /* ---- fused linear DRM, one direction: models/drm.py:65-107 with linear=True
  * u = d_other/(d_self+d_other) * t * 2 with d = |flow| + eps; out = splat_avg(u, self*u) with
  * uncovered pixels (ones-splat < 0.999) keeping u.  drm_t1_t01 = (self=flow10, other=flow12),
- * drm_t1_t12 = (self=flow12, other=flow10).  ws: N*H*W*2 floats. */
-int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float t, float eps,
-                         float *out, float *ws, int N, int H, int W, void *stream);
+ * drm_t1_t12 = (self=flow12, other=flow10).  ws: N*H*W*2 floats.  If t_dev != NULL the timestep
+ * is read from that device float instead of `t` (so a captured HIP graph can be replayed for any t). */
+int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float t, const float *t_dev,
+                         float eps, float *out, float *ws, int N, int H, int W, void *stream);
 
 /* ---- DRM building blocks for the non-fused variants (drm.py:110-195, :10-62) */
 /* ratio maps: a = d10/(d10+d12), b = d12/(d10+d12), d = |flow| + eps; either output may be NULL */
