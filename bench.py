@@ -144,13 +144,23 @@ def gpu_leg(args, rank, world):
     if timing and timing["records"]:
         agg = {}
         for kind, key, work, unit, e0, e1 in timing["records"]:
-            a = agg.setdefault((kind, key), [0.0, 0, work, unit])
-            a[0] += e0.elapsed_time(e1)
+            a = agg.setdefault((kind, key), [0.0, 0, work, unit, []])
+            d = e0.elapsed_time(e1)
+            a[0] += d
             a[1] += 1
+            a[4].append(d)
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath))
 
         def entry(k, v):
-            ms, cnt, work, unit = v
-            avg_s = ms / cnt / 1e3
+            ms, cnt, work, unit, durs = v
+            # average launch duration; a launch whose event pair straddled a host stall (GPU idle between the two
+            # records) is an outlier, so the mean is taken over the launches within 1.5x of the median
+            med = sorted(durs)[len(durs) // 2]
+            good = [d for d in durs if d <= 1.5 * med] or durs
+            avg_s = sum(good) / len(good) / 1e3
             if unit == "flop":
                 ach, peak, u, bound = work / avg_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
                 name = f"conv_mfma cfg{k[1][0]} {k[1][1]}->{k[1][2]}ch {k[1][3]}x{k[1][4]} s{k[1][5]} (ResConv)"
@@ -158,7 +168,7 @@ def gpu_leg(args, rank, world):
                 ach, peak, u, bound = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
                 name = f"ifblock_input_kernel<true> {k[1][0]}ch {k[1][1]}x{k[1][2]} -> {k[1][3]}x{k[1][4]}"
             return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
-                    "traffic": None, "kernel": name, "launches": cnt, "avg_us": round(avg_s * 1e6, 2),
+                    "traffic": traffic.get(name), "kernel": name, "launches": cnt, "avg_us": round(avg_s * 1e6, 2),
                     "algorithmic_per_launch": work, "ms_per_step": round(ms / args.steps, 3)}
 
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])
