@@ -72,8 +72,10 @@ ifblock_input_pixel(const float *__restrict__ img0, const float *__restrict__ im
                     float inv_prev_scale, float *__restrict__ out, int H, int W, int h, int w, float scale) {
   constexpr int NS = SINGLE ? 1 : 2;
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
-  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < p_lo; o += (size_t)gridDim.x * blockDim.x) {
-    const int oy = (int)(o / w), ox = (int)(o - (size_t)oy * w);
+  const Tile2D tp_ = tile_pixel(w, h);  // 32 x 8 output tile per workgroup, XCD-banded
+  if (tp_.valid) {
+    const int oy = tp_.y, ox = tp_.x;
+    const size_t o = (size_t)oy * w + ox;
     const Lerp ly = lerp_src(oy, scale, H), lx = lerp_src(ox, scale, W);
     // zero-weight taps are skipped: they would contribute exactly +0.
     const bool use_x1 = !SINGLE && lx.w1 != 0.f, use_y1 = !SINGLE && ly.w1 != 0.f;
@@ -174,13 +176,19 @@ ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ i
                      float inv_prev_scale, float *__restrict__ out, int H, int W, int h, int w, float scale) {
   constexpr int LPO = SINGLE ? 1 : 4;  // lanes per output pixel
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
-  const size_t total = ((p_lo * LPO + 63) / 64) * 64;  // whole waves: the shuffles need every lane of a quad
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t o_raw = g / LPO;
-    const bool valid = o_raw < p_lo;
-    const size_t o = valid ? o_raw : p_lo - 1;
-    const int sub = (int)(g % LPO), sj = sub >> 1, si = sub & 1;
-    const int oy = (int)(o / w), ox = (int)(o - (size_t)oy * w);
+  // workgroup = XCD-banded output tile: 32 x 8 px (SINGLE) or 16 x 4 px x 4 sample lanes; every lane runs
+  // (the shuffles need whole quads), out-of-image lanes are clamped and do not store
+  constexpr int TWo = SINGLE ? 32 : 16, THo = SINGLE ? 8 : 4;
+  {
+    const int tiles_x = (w + TWo - 1) / TWo;
+    const int t = xcd_band(blockIdx.x, gridDim.x);
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int lo = threadIdx.x / LPO;
+    const int ox_raw = tx * TWo + (lo % TWo), oy_raw = ty * THo + (lo / TWo);
+    const bool valid = ox_raw < w && oy_raw < h;
+    const int ox = min(ox_raw, w - 1), oy = min(oy_raw, h - 1);
+    const size_t o = (size_t)oy * w + ox;
+    const int sub = (int)(threadIdx.x % LPO), sj = sub >> 1, si = sub & 1;
     const Lerp ly = lerp_src(oy, scale, H), lx = lerp_src(ox, scale, W);
     const int X = si ? lx.i1 : lx.i0, Y = sj ? ly.i1 : ly.i0;
     const float wx = si ? lx.w1 : lx.w0, wy = sj ? ly.w1 : ly.w0;
@@ -266,8 +274,10 @@ ifblock_update_kernel(const float *__restrict__ tmp, const float *flow_in, float
                       float *__restrict__ feat, int h, int w, int H, int W, float scale, float inv_scale) {
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
   const int nch = (mask || feat) ? 13 : 4;
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
-    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+  const Tile2D tp_ = tile_pixel(W, H);
+  if (tp_.valid) {
+    const int y = tp_.y, x = tp_.x;
+    const size_t p = (size_t)y * W + x;
     const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
     const size_t o00 = (size_t)ly.i0 * w + lx.i0, o01 = (size_t)ly.i0 * w + lx.i1;
     const size_t o10 = (size_t)ly.i1 * w + lx.i0, o11 = (size_t)ly.i1 * w + lx.i1;
@@ -295,8 +305,10 @@ warp_blend_kernel(const float *__restrict__ img0, const float *__restrict__ img1
                   const float *__restrict__ mask_lo, int h, int w, float inv_scale, float *__restrict__ out, int H,
                   int W) {
   const size_t P = (size_t)H * W;
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
-    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+  const Tile2D tp_ = tile_pixel(W, H);
+  if (tp_.valid) {
+    const int y = tp_.y, x = tp_.x;
+    const size_t p = (size_t)y * W + x;
     const Taps t0 = taps_border(warp_coord(x, W, flow[p]), warp_coord(y, H, flow[P + p]), W, H);
     const Taps t1 = taps_border(warp_coord(x, W, flow[2 * P + p]), warp_coord(y, H, flow[3 * P + p]), W, H);
     const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
@@ -353,17 +365,16 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
   static const int forced = getenv("DRBA_IFIN_VARIANT") ? atoi(getenv("DRBA_IFIN_VARIANT")) : -1;
   const int var = forced >= 0 ? forced : (single ? 0 : 1);
   dim3 b(kBlock);
+  const int quad_tiles = single ? tiles_for(w, h) : ((w + 15) / 16) * ((h + 3) / 4);
 #define DRBA_ARGS img0, img1, f0, f1, timestep_map, timestep_scalar, flow, tmp_prev, hp, wp, ips, out, H, W, h, w, scale
 #define DRBA_LAUNCH(HF, SG)                                                                                        \
   do {                                                                                                             \
     if (var == 0) {                                                                                                \
-      hipLaunchKernelGGL((ifblock_input_pixel<HF, SG>), dim3(grid_for((size_t)h * w)), b, 0, s, DRBA_ARGS);        \
+      hipLaunchKernelGGL((ifblock_input_pixel<HF, SG>), dim3(tiles_for(w, h)), b, 0, s, DRBA_ARGS);                \
     } else if (var == 1) {                                                                                         \
-      hipLaunchKernelGGL((ifblock_input_kernel<HF, SG, 1>), dim3(grid_for((size_t)h * w * (SG ? 1 : 4))), b, 0, s, \
-                         DRBA_ARGS);                                                                               \
+      hipLaunchKernelGGL((ifblock_input_kernel<HF, SG, 1>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                 \
     } else {                                                                                                       \
-      hipLaunchKernelGGL((ifblock_input_kernel<HF, SG, 4>), dim3(grid_for((size_t)h * w * (SG ? 1 : 4))), b, 0, s, \
-                         DRBA_ARGS);                                                                               \
+      hipLaunchKernelGGL((ifblock_input_kernel<HF, SG, 4>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                 \
     }                                                                                                              \
   } while (0)
   if (flow) {
@@ -382,7 +393,7 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
 int drba_ifblock_update(const float *tmp, const float *flow_in, float *flow_out, float *mask, float *feat, int h,
                         int w, int H, int W, float scale, void *stream) {
   if (!tmp || !flow_out || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
-  hipLaunchKernelGGL(ifblock_update_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, tmp,
+  hipLaunchKernelGGL(ifblock_update_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, tmp,
                      flow_in, flow_out, mask, feat, h, w, H, W, scale, (float)(1.0 / (double)scale));
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -392,7 +403,7 @@ int drba_warp_blend(const float *img0, const float *img1, const float *flow, con
                     float scale, float *out, int H, int W, void *stream) {
   if (!img0 || !img1 || !flow || !mask_lo || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f))
     return DRBA_EINVAL;
-  hipLaunchKernelGGL(warp_blend_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1,
+  hipLaunchKernelGGL(warp_blend_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1,
                      flow, mask_lo, h, w, (float)(1.0 / (double)scale), out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
