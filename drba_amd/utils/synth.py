@@ -80,6 +80,146 @@ def ifnet_state_dict(seed=0):
     return sd
 
 
+def gmflow_shapes():
+    """Ordered {key: shape} of GMFlow().state_dict() (124 tensors, 4 716 720 params; models/gmflow/gmflow.py:13-44)."""
+    sh = {"backbone.conv1.weight": (64, 3, 7, 7)}
+    cin = 64
+    for name, c in (("layer1", 64), ("layer2", 96), ("layer3", 128)):
+        for b in (0, 1):
+            ci = cin if b == 0 else c
+            sh[f"backbone.{name}.{b}.conv1.weight"] = (c, ci, 3, 3)
+            sh[f"backbone.{name}.{b}.conv2.weight"] = (c, c, 3, 3)
+            if b == 0 and ci != c:
+                sh[f"backbone.{name}.{b}.downsample.0.weight"] = (c, ci, 1, 1)
+                sh[f"backbone.{name}.{b}.downsample.0.bias"] = (c,)
+        cin = c
+    sh["backbone.conv2.weight"] = (128, 128, 1, 1)
+    sh["backbone.conv2.bias"] = (128,)
+    sh["backbone.trident_conv.weight"] = (128, 128, 3, 3)
+    for i in range(6):
+        for part, ffn in (("self_attn", False), ("cross_attn_ffn", True)):
+            p = f"transformer.layers.{i}.{part}."
+            for n in ("q_proj", "k_proj", "v_proj", "merge"):
+                sh[p + n + ".weight"] = (128, 128)
+            sh[p + "norm1.weight"] = (128,)
+            sh[p + "norm1.bias"] = (128,)
+            if ffn:
+                sh[p + "mlp.0.weight"] = (1024, 256)
+                sh[p + "mlp.2.weight"] = (128, 1024)
+                sh[p + "norm2.weight"] = (128,)
+                sh[p + "norm2.bias"] = (128,)
+    for n in ("q_proj", "k_proj"):
+        sh[f"feature_flow_attn.{n}.weight"] = (128, 128)
+        sh[f"feature_flow_attn.{n}.bias"] = (128,)
+    sh["upsampler.0.weight"] = (256, 130, 3, 3)
+    sh["upsampler.0.bias"] = (256,)
+    sh["upsampler.2.weight"] = (144, 256, 1, 1)
+    sh["upsampler.2.bias"] = (144,)
+    return sh
+
+
+def metricnet_shapes():
+    """MetricNet (model_gmfss_union/MetricNet.py:23-43): 14 tensors, 120 070 params."""
+    sh = {"metric_in.weight": (64, 14, 3, 3), "metric_in.bias": (64,)}
+    for k in (1, 2, 3):
+        sh[f"metric_net{k}.0.weight"] = (1,)
+        sh[f"metric_net{k}.1.weight"] = (64, 64, 3, 3)
+        sh[f"metric_net{k}.1.bias"] = (64,)
+    sh["metric_out.0.weight"] = (1,)
+    sh["metric_out.1.weight"] = (2, 64, 3, 3)
+    sh["metric_out.1.bias"] = (2,)
+    return sh
+
+
+def featurenet_shapes():
+    """FeatureNet (FeatureNet.py:9-27): 18 tensors, 813 510 params."""
+    sh = {}
+    cin = 3
+    for b, c in ((1, 64), (2, 128), (3, 192)):
+        sh[f"block{b}.0.weight"] = (1,)
+        sh[f"block{b}.1.weight"] = (c, cin, 3, 3)
+        sh[f"block{b}.1.bias"] = (c,)
+        sh[f"block{b}.2.weight"] = (1,)
+        sh[f"block{b}.3.weight"] = (c, c, 3, 3)
+        sh[f"block{b}.3.bias"] = (c,)
+        cin = c
+    return sh
+
+
+def gridnet_shapes(in_channels=9, head0="head0"):
+    """GridNet(in, 128, 256, 384, 3) (FusionNet.py:55-104); union: in=9, key 'head0'; gmfss: in=12, key 'head'."""
+    sh = {}
+
+    def two(name, ci, co, deconv=False):
+        p = name + "."
+        sh[p + "0.weight"] = (1,)
+        sh[p + "1.weight"] = (ci, co, 4, 4) if deconv else (co, ci, 3, 3)
+        sh[p + "1.bias"] = (co,)
+        sh[p + "2.weight"] = (1,)
+        sh[p + "3.weight"] = (co, co, 3, 3)
+        sh[p + "3.bias"] = (co,)
+
+    two("residual_model_" + head0, in_channels, 64)
+    two("residual_model_head1", 128, 64)
+    two("residual_model_head2", 256, 128)
+    two("residual_model_head3", 384, 192)
+    for n in ("01", "04", "05"):
+        two("residual_model_" + n, 64, 64)
+    sh["residual_model_tail.conv_before_upsample.0.weight"] = (64, 64, 3, 3)
+    sh["residual_model_tail.conv_before_upsample.0.bias"] = (64,)
+    sh["residual_model_tail.conv_before_upsample.1.weight"] = (1,)
+    sh["residual_model_tail.upsample.0.weight"] = (256, 64, 3, 3)
+    sh["residual_model_tail.upsample.0.bias"] = (256,)
+    sh["residual_model_tail.conv_last.weight"] = (3, 64, 3, 3)
+    sh["residual_model_tail.conv_last.bias"] = (3,)
+    for n in ("11", "14", "15"):
+        two("residual_model_" + n, 128, 128)
+    for n in ("21", "24", "25"):
+        two("residual_model_" + n, 192, 192)
+    two("downsample_model_10", 64, 128)
+    two("downsample_model_20", 128, 192)
+    two("downsample_model_11", 64, 128)
+    two("downsample_model_21", 128, 192)
+    two("upsample_model_04", 128, 64, deconv=True)
+    two("upsample_model_14", 192, 128, deconv=True)
+    two("upsample_model_05", 128, 64, deconv=True)
+    two("upsample_model_15", 192, 128, deconv=True)
+    return sh
+
+
+def seeded_state_dict(shapes, seed=0, tag=""):
+    """Generic seeded weights: conv/linear ~ N(0, (g/sqrt(fan_in))^2), PReLU slopes ~ U(0.1, 0.4), norm weights ~ 1, biases small."""
+    sd = {}
+    for key, shape in shapes.items():
+        g = _gen(tag + key, seed)
+        if len(shape) == 1 and shape[0] == 1:  # nn.PReLU() slope
+            t = torch.rand(shape, generator=g) * 0.3 + 0.1
+        elif key.endswith("bias"):
+            t = torch.randn(shape, generator=g) * 0.02
+        elif len(shape) == 1:  # LayerNorm weight
+            t = 1.0 + torch.randn(shape, generator=g) * 0.05
+        else:
+            if len(shape) == 4 and shape[2] == 4:  # ConvTranspose2d [Cin, Cout, 4, 4]: 2x2 taps per output
+                fan_in = shape[0] * 4
+            elif len(shape) == 4:
+                fan_in = shape[1] * shape[2] * shape[3]
+            else:
+                fan_in = shape[1]
+            gain = 0.7 if ("residual_model" in key or "metric_net" in key) else 1.0
+            t = torch.randn(shape, generator=g) * (gain / fan_in ** 0.5)
+        sd[key] = t.contiguous()
+    return sd
+
+
+def gmfss_union_state_dicts(seed=0):
+    """flownet (GMFlow), metric, feat, fusion (GridNet in=9) and the auxiliary RIFE for GMFSS_UNION."""
+    return {"flownet": seeded_state_dict(gmflow_shapes(), seed, "gmflow."),
+            "metric": seeded_state_dict(metricnet_shapes(), seed, "metric."),
+            "feat": seeded_state_dict(featurenet_shapes(), seed, "feat."),
+            "fusion": seeded_state_dict(gridnet_shapes(9, "head0"), seed, "grid."),
+            "rife": ifnet_state_dict(seed + 1)}
+
+
 def _smooth_field(c, h, w, seed, cell=16):
     """Smooth random texture in [0,1]: bicubic upsample of a coarse uniform grid."""
     g = torch.Generator(device="cpu")

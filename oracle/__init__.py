@@ -21,4 +21,4 @@ Third-party arithmetic: torch (reference requirements.txt:2 `torch>=2.5.1`, unpi
 upper bound); the concrete oracle version is this image's torch 2.10.0 CPU kernels for
 conv2d / conv_transpose2d / interpolate / grid_sample / index_add_.
 """
-from . import ops, drm, ifnet, rife, scdet  # noqa: F401
+from . import ops, drm, ifnet, rife, scdet, gmflow, gmfss  # noqa: F401

@@ -48,7 +48,7 @@ def splat_sum(src, flow):
     out = torch.zeros(n * h * w, c, dtype=dt)
     ok = torch.isfinite(tx) & torch.isfinite(ty)
     if not bool(ok.any()):
-        return out.view(n, h, w, c).permute(0, 3, 1, 2)
+        return out.view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
     vals = src.permute(0, 2, 3, 1)[ok]  # [M, C]
     bidx = torch.arange(n).view(n, 1, 1).expand(n, h, w)[ok]
     tx, ty = tx[ok], ty[ok]
@@ -64,7 +64,9 @@ def splat_sum(src, flow):
             continue
         lin = bidx[inb] * h * w + cy[inb] * w + cx[inb]
         out.index_add_(0, lin, vals[inb] * wgt[inb].unsqueeze(1))
-    return out.view(n, h, w, c).permute(0, 3, 1, 2)
+    # NCHW-contiguous result: that is the layout the reference's softsplat_func.apply hands back (observed), and
+    # oneDNN convolutions downstream (GridNet) round differently for channels-last inputs
+    return out.view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
 
 
 def softsplat(src, flow, metric, mode):

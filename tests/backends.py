@@ -24,6 +24,9 @@ class OracleBackend:
     def make_rife(self, sd, scale):
         return self._o.rife.RifeOracle(sd, scale)
 
+    def make_gmfss_union(self, sds, scale):
+        return self._o.gmfss.GmfssUnionOracle(sds["flownet"], sds["metric"], sds["feat"], sds["fusion"], sds["rife"], scale)
+
 
 class HipBackend:
     """The product: drba_amd's reference-named call surface running on the HIP library."""

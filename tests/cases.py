@@ -167,6 +167,42 @@ def rife_run(b, sd, scale, H, W):
     return out
 
 
+# ------------------------------------------------------------------------------------------ gmfss_union end to end
+GMFSS_CONFIGS = ((1.0, (128, 256)), (0.5, (256, 512)))
+
+
+def gmfss_frames(H, W):
+    clip = synth.make_clip(4, H, W, seed=4321)
+    return [torch.from_numpy(f.transpose(2, 0, 1)).unsqueeze(0).float().div(255.0) for f in clip]
+
+
+def gmfss_union_run(b, sds, scale, H, W):
+    """End-to-end GMFSS_UNION outputs for one (scale, size): inference_ts, cold + warm inference_ts_drba, reuse parts."""
+    m = b.make_gmfss_union(sds, scale)
+    I0, I1, I2, I3 = [f.to(b.dev) for f in gmfss_frames(H, W)]
+    tag = f"s{scale}"
+    out = {}
+    r = m.inference_ts(I0, I1, np.array([0.0, 0.5, 1.0]))
+    assert r[0] is I0 and r[2] is I1
+    out[f"ts_{tag}"] = r[1]
+    for ts_name, ts in (("t2", np.array([0.75, 1.25])), ("f3", np.array([0.6, 1.0, 1.4]))):
+        r, reuse = m.inference_ts_drba(I0, I1, I2, ts, None, True)
+        for k in range(len(ts)):
+            if ts[k] != 1.0:
+                out[f"drba_cold_{tag}_{ts_name}_{k}"] = r[k]
+        if ts_name == "t2":
+            for k, nm in enumerate(("flow21", "flow12", "metric2", "metric1")):
+                out[f"reuse_{tag}_{nm}"] = reuse[k]
+            out[f"reuse_{tag}_feat2_0"], out[f"reuse_{tag}_feat2_2"] = reuse[4][0], reuse[4][2]
+            r2, _ = m.inference_ts_drba(I1, I2, I3, ts, reuse, True)
+            for k in range(len(ts)):
+                out[f"drba_warm_{tag}_{ts_name}_{k}"] = r2[k]
+    if scale == 1.0:
+        r, _ = m.inference_ts_drba(I0, I1, I2, np.array([1.3]), None, False)  # non-linear DRM
+        out["drba_nonlinear"] = r[0]
+    return out
+
+
 # ------------------------------------------------------------------------------------------ fixture packing
 MAX_FULL = 1 << 15
 

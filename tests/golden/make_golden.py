@@ -26,10 +26,13 @@ REF = "/root/reference"
 for name in ("cv2", "torchvision", "torchvision.transforms"):  # absent here; only video IO/debug use them
     sys.modules.setdefault(name, types.ModuleType(name))
 sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
-sys.path = [REF] + [p for p in sys.path if p not in ("", ROOT, HERE)] + [ROOT]
+# The repo ships a regular `models/` shim package; the reference's `models/` is a namespace package and would
+# lose to it, so the reference modules are imported FIRST with the repo root off sys.path.
+sys.path = [REF] + [p for p in sys.path if p not in ("", ROOT, HERE)]
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+import torch.nn.functional as F_  # noqa: E402
 
 import models.drm as ref_drm  # noqa: E402  (reference)
 import models.rife as ref_rife  # noqa: E402
@@ -39,6 +42,15 @@ from models.rife_426_heavy.IFNet_HDv3 import IFNet as RefIFNet  # noqa: E402
 from models.rife_426_heavy.warplayer import warp as ref_warp  # noqa: E402
 from models.pytorch_msssim import ssim_matlab as ref_ssim  # noqa: E402
 
+import infer as ref_infer_module  # noqa: E402,F401  (reference infer.py, before the repo root joins sys.path)
+from models.gmflow.gmflow import GMFlow as RefGMFlow  # noqa: E402
+from models.model_gmfss_union.MetricNet import MetricNet as RefMetricNet  # noqa: E402
+from models.model_gmfss_union.FeatureNet import FeatureNet as RefFeatureNet  # noqa: E402
+from models.model_gmfss_union.FusionNet import GridNet as RefGridNet  # noqa: E402
+import models.model_gmfss_union.GMFSS as ref_union_model  # noqa: E402
+import models.gmfss_union as ref_gmfss_union  # noqa: E402
+
+sys.path.append(ROOT)
 import oracle  # noqa: E402  (repo)
 from drba_amd.utils import synth  # noqa: E402
 
@@ -87,6 +99,28 @@ class ReferenceBackend:
     make_rife = staticmethod(_RefRife)
 
 
+class _RefGmfssUnion:
+    """The reference GMFSS_UNION evaluated in fp32 (decorators stripped)."""
+
+    def __init__(self, sds, scale):
+        d = tempfile.mkdtemp()
+        torch.save(sds["flownet"], os.path.join(d, "flownet.pkl"))
+        torch.save(sds["metric"], os.path.join(d, "metric.pkl"))
+        torch.save(sds["feat"], os.path.join(d, "feat.pkl"))
+        torch.save(sds["fusion"], os.path.join(d, "fusionnet.pkl"))
+        torch.save({"module." + k: v for k, v in sds["rife"].items()}, os.path.join(d, "rife.pkl"))
+        self.m = ref_gmfss_union.GMFSS_UNION(weights=d, scale=scale, device=torch.device("cpu"))
+        self._ts = ref_gmfss_union.GMFSS_UNION.inference_ts.__wrapped__.__wrapped__
+        self._drba = ref_gmfss_union.GMFSS_UNION.inference_ts_drba.__wrapped__.__wrapped__
+
+    def inference_ts(self, I0, I1, ts):
+        return self._ts(self.m, I0, I1, ts)
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False):
+        return self._drba(self.m, I0, I1, I2, ts, reuse, linear)
+
+
+ReferenceBackend.make_gmfss_union = staticmethod(_RefGmfssUnion)
 REFB, ORAB = ReferenceBackend(), OracleBackend()
 
 
@@ -168,6 +202,55 @@ def golden_rife():
     print("reference bf16-autocast vs its own fp32 evaluation, max-abs:", meta["ref_bf16_vs_fp32_maxabs"])
 
 
+def golden_gmfss():
+    sds = synth.gmfss_union_state_dicts(seed=0)
+    for nm, mod, key in (("gmflow", RefGMFlow(), "flownet"), ("metric", RefMetricNet(), "metric"),
+                         ("feat", RefFeatureNet(), "feat"), ("grid", RefGridNet(9, 128, 256, 384, 3), "fusion")):
+        ref = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        assert ref == {k: tuple(v.shape) for k, v in sds[key].items()} and list(ref) == list(sds[key]), nm
+    out = {}
+    meta = {"weights_sum": float(sum(v.double().sum() for d in sds.values() for v in d.values()))}
+    # per-network pins at 128x256
+    H, W = 128, 256
+    I0, I1 = cases.gmfss_frames(H, W)[:2]
+    with torch.inference_mode():
+        def load(mod, sd):
+            mod.load_state_dict(sd)
+            return mod.eval()
+        h0 = F_.interpolate(I0, scale_factor=0.5, mode="bilinear", align_corners=False)
+        h1 = F_.interpolate(I1, scale_factor=0.5, mode="bilinear", align_corners=False)
+        rflow = load(RefGMFlow(), sds["flownet"])(h0, h1)
+        same(oracle.gmflow.gmflow(sds["flownet"], h0, h1), rflow, "gmflow")
+        out["gmflow_01"] = cases.pack(rflow)
+        rflow10 = load(RefGMFlow(), sds["flownet"])(h1, h0)
+        rf = load(RefFeatureNet(), sds["feat"])(I0)
+        of = oracle.gmfss.featurenet(sds["feat"], I0)
+        for k in range(3):
+            same(of[k], rf[k], f"featurenet {k}")
+            out[f"featurenet_{k}"] = cases.pack(rf[k])
+        rm = load(RefMetricNet(), sds["metric"])(h0, h1, rflow, rflow10)
+        om = oracle.gmfss.metricnet(sds["metric"], h0, h1, rflow, rflow10)
+        for k in range(2):
+            same(om[k], rm[k], f"metricnet {k}")
+            out[f"metricnet_{k}"] = cases.pack(rm[k])
+        g = torch.Generator().manual_seed(9)
+        gx = [torch.randn(1, c, H // s, W // s, generator=g) for c, s in ((9, 2), (128, 2), (256, 4), (384, 8))]
+        rg = load(RefGridNet(9, 128, 256, 384, 3), sds["fusion"])(*gx)
+        same(oracle.gmfss.gridnet(sds["fusion"], *gx), rg, "gridnet")
+        out["gridnet"] = cases.pack(rg)
+    for scale, (H, W) in cases.GMFSS_CONFIGS:
+        meta[f"frames_sum_s{scale}"] = float(sum(f.double().sum() for f in cases.gmfss_frames(H, W)))
+        with torch.inference_mode():
+            r = cases.gmfss_union_run(REFB, sds, scale, H, W)
+            o = cases.gmfss_union_run(ORAB, sds, scale, H, W)
+        assert list(r) == list(o)
+        for k in r:
+            same(o[k], r[k], k)
+            out[k] = cases.pack(r[k])
+    out["_meta"] = {k: np.float64(v) for k, v in meta.items()}
+    save("gmfss_union.npz", out)
+
+
 def golden_scdet():
     T = cases.scdet_frames()
     vals, dec = [], []
@@ -231,7 +314,7 @@ class _FakeModel:
 
 
 def run_ref_driver(frames, fps, dst_fps, times, scdet, thr=0.3):
-    import infer as ref_infer  # reference infer.py
+    ref_infer = ref_infer_module  # reference infer.py
     keys = {}
     for k, f in enumerate(frames):
         keys[ref_tools.to_inp(f, ref_tools.get_valid_net_inp_size(f, 1.0, 64)["dst_size"]).numpy().tobytes()] = k
@@ -296,6 +379,6 @@ def golden_schedule():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "drm", "scdet", "schedule", "rife"]
+    which = sys.argv[1:] or ["ops", "drm", "scdet", "schedule", "rife", "gmfss"]
     for w in which:
         globals()["golden_" + w]()

@@ -67,3 +67,39 @@ def test_reference_bf16_noise_floor_recorded(golden_dir):
     which is why parity is defined against the fp32 evaluation."""
     z = np.load(os.path.join(golden_dir, "rife.npz"))
     assert 1e-3 < float(z["_meta/ref_bf16_vs_fp32_maxabs"]) < 1e-2
+
+
+@pytest.mark.parametrize("scale,size", cases.GMFSS_CONFIGS)
+def test_gmfss_union_end_to_end_against_reference_fixture(oracle_backend, golden_dir, scale, size):
+    """GMFSS_UNION (GMFlow + MetricNet + FeatureNet + GridNet + auxiliary RIFE): oracle vs reference outputs."""
+    z = np.load(os.path.join(golden_dir, "gmfss_union.npz"))
+    sds = synth.gmfss_union_state_dicts(seed=0)
+    assert abs(sum(float(v.double().sum()) for d in sds.values() for v in d.values()) - float(z["_meta/weights_sum"])) < 1e-5
+    H, W = size
+    with torch.no_grad():
+        out = cases.gmfss_union_run(oracle_backend, sds, scale, H, W)
+    for k, t in out.items():
+        d = cases.compare_to_fixture(z, k, t)
+        assert d <= 2e-4, f"{k}: {d}"  # flows are O(10) px: relative fp32 noise between hosts
+
+
+def test_gmfss_subnet_pins(golden_dir):
+    """GMFlow, FeatureNet, MetricNet and GridNet individually (fixtures written from the reference modules)."""
+    import oracle
+    import torch.nn.functional as F
+    z = np.load(os.path.join(golden_dir, "gmfss_union.npz"))
+    sds = synth.gmfss_union_state_dicts(seed=0)
+    I0, I1 = cases.gmfss_frames(128, 256)[:2]
+    with torch.no_grad():
+        h0 = F.interpolate(I0, scale_factor=0.5, mode="bilinear", align_corners=False)
+        h1 = F.interpolate(I1, scale_factor=0.5, mode="bilinear", align_corners=False)
+        f01 = oracle.gmflow.gmflow(sds["flownet"], h0, h1)
+        assert cases.compare_to_fixture(z, "gmflow_01", f01) < 2e-4
+        f10 = oracle.gmflow.gmflow(sds["flownet"], h1, h0)
+        for k, t in enumerate(oracle.gmfss.featurenet(sds["feat"], I0)):
+            assert cases.compare_to_fixture(z, f"featurenet_{k}", t) < 2e-5
+        for k, t in enumerate(oracle.gmfss.metricnet(sds["metric"], h0, h1, f01, f10)):
+            assert cases.compare_to_fixture(z, f"metricnet_{k}", t) < 2e-4
+        g = torch.Generator().manual_seed(9)
+        gx = [torch.randn(1, c, 128 // s, 256 // s, generator=g) for c, s in ((9, 2), (128, 2), (256, 4), (384, 8))]
+        assert cases.compare_to_fixture(z, "gridnet", oracle.gmfss.gridnet(sds["fusion"], *gx)) < 5e-5
