@@ -55,6 +55,11 @@ import oracle  # noqa: E402  (repo)
 from drba_amd.utils import synth  # noqa: E402
 
 torch.set_num_threads(8)
+# Importing the reference's softsplat_torch sets torch.set_float32_matmul_precision("medium") process-wide
+# (softsplat_torch.py:13).  On bf16-capable CPUs that silently runs GMFlow's fp32 matmuls through bf16 oneDNN
+# kernels (measured: 2.5e-2 max-abs on the final frame).  Like the autocast decorators, this is undone here: the
+# parity target is the reference's functions evaluated in true fp32.
+torch.set_float32_matmul_precision("highest")
 
 from tests import cases  # noqa: E402
 from tests.backends import OracleBackend  # noqa: E402
