@@ -40,13 +40,31 @@ SIGNATURES = {
     "drba_deconv4x4_num_cfgs": (_i, []),
     "drba_conv3x3_packed_floats": (_z, [_i, _i, _i]),
     "drba_conv3x3_pack": (_i, [_p, _p, _i, _i, _i]),
-    "drba_conv3x3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_conv3x3": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p]),
     "drba_deconv4x4_pick_cfg": (_i, [_i, _i, _i, _i]),
     "drba_deconv4x4_packed_floats": (_z, [_i, _i, _i]),
     "drba_deconv4x4_pack": (_i, [_p, _p, _i, _i, _i]),
-    "drba_deconv4x4s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_deconv4x4s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _i, _i, _i, _i, _f, _p]),
     "drba_ifblock_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_metric_input": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "drba_pixel_shuffle2": (_i, [_p, _p, _i, _i, _i, _p]),
+    "drba_timestep_fix": (_i, [_p, _p, _p, _p, _p, _p, _z, _p]),
+    "drba_swap_select": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "drba_clamp": (_i, [_p, _p, _f, _f, _z, _p]),
+    "drba_conv_direct": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_instance_norm": (_i, [_p, _p, _i, _z, _f, _i, _p]),
+    "drba_add_act": (_i, [_p, _p, _p, _z, _i, _p]),
+    "drba_channel_normalize3": (_i, [_p, _p, _i, _z, _p, _p, _p]),
+    "drba_layernorm": (_i, [_p, _p, _p, _p, _p, _z, _i, _f, _p]),
+    "drba_gelu": (_i, [_p, _p, _z, _p]),
+    "drba_softmax_rows": (_i, [_p, _p, _z, _i, _i, _i, _f, _p]),
+    "drba_softmax_expect2": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
+    "drba_local_corr_flow": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "drba_local_attn_flow": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "drba_convex_upsample": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "drba_flow_warp": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "drba_resize_bilinear_ac": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "drba_warp_blend": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
 }
 

@@ -72,8 +72,9 @@ struct ConvCfg {
 template <class Cfg>
 __global__ void __launch_bounds__(256)
 conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const float *__restrict__ bias,
-          const float *__restrict__ beta, const float *__restrict__ res, float *__restrict__ out, int Cin, int H,
-          int W, int Cout, int Ho, int Wo, int act, int n_ctiles, int pixel_shuffle) {
+          const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
+          float *__restrict__ out, int Cin, int H, int W, int Cout, int Ho, int Wo, int act, float post_slope,
+          int pre_act, float pre_slope, int n_ctiles, int pixel_shuffle) {
   constexpr int MODE = Cfg::MODE, S = Cfg::S, RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, CK = Cfg::CK, KS = Cfg::KS;
   constexpr int TH = Cfg::TH, TW = Cfg::TW, TR = Cfg::TR, TC = Cfg::TC, CHS = Cfg::CHS;
   constexpr int NL = Cfg::NL, NSTAGE = Cfg::NSTAGE, CG = Cfg::CG, NTAP = Cfg::NTAP;
@@ -94,6 +95,7 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
   if (MODE == 0) {
     out += (size_t)n * Cout * Ho * Wo;
     if (res) res += (size_t)n * Cout * Ho * Wo;
+    if (res2) res2 += (size_t)n * Cout * Ho * Wo;
   } else {
     out += (size_t)n * Cout * (2 * H) * (2 * W);
   }
@@ -140,6 +142,7 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
       float v = 0.f;
       if (e < CK * TR * TC && ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
         v = in[((size_t)ci * H + gy) * W + gx];
+      if (pre_act) v = v > 0.f ? v : pre_slope * v;  // PReLU (one shared slope) fused into the loader; prelu(0) = 0 keeps the padding
       st[i] = v;
     }
   };
@@ -210,18 +213,34 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
     const int xb = x0 + mw * 16 + kq * 4;
     if (co >= Cout) return;
     const float bs = bias ? bias[co] : 0.f;
-    if (MODE == 0) {  // bias, optional beta*y + residual, optional LeakyReLU(0.2)
+    if (MODE == 0) {
+      // y = acc + bias; ResConv: y = y*beta + res; otherwise y += res (+ res2); then the post activation:
+      // act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10
       if (y >= Ho || xb >= Wo) return;
       const float bt = beta ? beta[co] : 0.f;
       const size_t idx = ((size_t)co * Ho + y) * Wo + xb;
+      auto post = [&](float t) -> float {
+        switch (act) {
+          case 1: return lrelu02(t);
+          case 2: return t > 0.f ? t : post_slope * t;
+          case 3: return fmaxf(t, 0.f);
+          case 4: return tanhf(t) * 10.f;
+        }
+        return t;
+      };
       if (vec) {
-        f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (beta) r = *reinterpret_cast<const f32x4 *>(res + idx);
+        f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (res) r = *reinterpret_cast<const f32x4 *>(res + idx);
+        if (res2) r2 = *reinterpret_cast<const f32x4 *>(res2 + idx);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float t = v[k] + bs;
           if (beta) t = t * bt + r[k];
-          v[k] = act ? lrelu02(t) : t;
+          else {
+            if (res) t = t + r[k];
+            if (res2) t = t + r2[k];
+          }
+          v[k] = post(t);
         }
         *reinterpret_cast<f32x4 *>(out + idx) = v;
       } else {
@@ -230,7 +249,11 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
           if (xb + k >= Wo) continue;
           float t = v[k] + bs;
           if (beta) t = t * bt + res[idx + k];
-          out[idx + k] = act ? lrelu02(t) : t;
+          else {
+            if (res) t = t + res[idx + k];
+            if (res2) t = t + res2[idx + k];
+          }
+          out[idx + k] = post(t);
         }
       }
     } else {  // transposed conv phase: bias, scatter to (2j+py, 2i+px) [+ PixelShuffle(2)]
@@ -328,13 +351,14 @@ const CfgInfo kDeconv[kNumDeconvCfg] = {cfg_info<D0>(), cfg_info<D1>(), cfg_info
                                         cfg_info<D3>(), cfg_info<D4>(), cfg_info<D5>()};
 
 template <class Cfg>
-int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, float *out, int N,
-           int Cin, int H, int W, int Cout, int Ho, int Wo, int act, int ps, hipStream_t s) {
+int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, const float *res2,
+           float *out, int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int act, float post_slope, int pre_act,
+           float pre_slope, int ps, hipStream_t s) {
   const int n_ct = (Cout + Cfg::NTC - 1) / Cfg::NTC;
   const int gh = Cfg::MODE == 0 ? Ho : H, gw = Cfg::MODE == 0 ? Wo : W;
   dim3 g((gw + Cfg::TW - 1) / Cfg::TW, (gh + Cfg::TH - 1) / Cfg::TH, N * n_ct * (Cfg::MODE == 0 ? 1 : 4));
-  hipLaunchKernelGGL(conv_mfma<Cfg>, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, out,
-                     Cin, H, W, Cout, Ho, Wo, act, n_ct, ps);
+  hipLaunchKernelGGL(conv_mfma<Cfg>, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2,
+                     out, Cin, H, W, Cout, Ho, Wo, act, post_slope, pre_act, pre_slope, n_ct, ps);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -426,15 +450,19 @@ int drba_conv3x3_pack(const float *w, float *packed, int Cin, int Cout, int cfg)
 }
 
 int drba_conv3x3(const float *in, const float *packed_w, const float *bias, const float *beta, const float *residual,
-                 float *out, int N, int Cin, int H, int W, int Cout, int stride, int act, int cfg, void *stream) {
+                 const float *residual2, float *out, int N, int Cin, int H, int W, int Cout, int stride, int act,
+                 float post_slope, int pre_act, float pre_slope, int cfg, void *stream) {
   if (!in || !packed_w || !out || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   if (cfg < 0 || cfg >= kNumConvCfg || kConv[cfg].S != stride) return DRBA_EINVAL;
   if (beta && !residual) return DRBA_EINVAL;
+  if (residual2 && !residual) return DRBA_EINVAL;
+  if (act < 0 || act > 4) return DRBA_EINVAL;
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   hipStream_t s = (hipStream_t)stream;
 #define DRBA_CASE(ID, T) \
   case ID:               \
-    return launch<T>(in, packed_w, bias, beta, residual, out, N, Cin, H, W, Cout, Ho, Wo, act, 0, s);
+    return launch<T>(in, packed_w, bias, beta, residual, residual2, out, N, Cin, H, W, Cout, Ho, Wo, act, post_slope, \
+                     pre_act, pre_slope, 0, s);
   switch (cfg) {
     DRBA_CASE(0, C0)
     DRBA_CASE(1, C1)
@@ -496,14 +524,15 @@ int drba_deconv4x4_pack(const float *w, float *packed, int Cin, int Cout, int cf
 }
 
 int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, float *out, int N, int Cin, int H,
-                     int W, int Cout, int pixel_shuffle, int cfg, void *stream) {
+                     int W, int Cout, int pixel_shuffle, int pre_act, float pre_slope, int cfg, void *stream) {
   if (!in || !packed_w || !out || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   if (cfg < 0 || cfg >= kNumDeconvCfg) return DRBA_EINVAL;
   if (pixel_shuffle && (Cout & 3)) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
 #define DRBA_CASE(ID, T) \
   case ID:               \
-    return launch<T>(in, packed_w, bias, nullptr, nullptr, out, N, Cin, H, W, Cout, 2 * H, 2 * W, 0, pixel_shuffle, s);
+    return launch<T>(in, packed_w, bias, nullptr, nullptr, nullptr, out, N, Cin, H, W, Cout, 2 * H, 2 * W, 0, 0.f,     \
+                     pre_act, pre_slope, pixel_shuffle, s);
   switch (cfg) {
     DRBA_CASE(0, D0)
     DRBA_CASE(1, D1)

@@ -1,0 +1,477 @@
+// GMFlow operators that are not plain GEMMs (models/gmflow/*): direct k x k convolution for the 7x7 / 1x1
+// layers, InstanceNorm, LayerNorm, GELU, masked row softmax, the fused correlation-softmax -> flow
+// expectations (global, local), local-window flow propagation, convex upsampling, flow_warp and the
+// align_corners=True resize.  The q/k/v/merge/MLP projections and the QK^T / PV products are plain GEMMs and go
+// through the vendor BLAS from the host (allowed for plain library GEMMs); everything around them is here.
+#include "common.hpp"
+
+using namespace drba;
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+  return v;
+}
+// block-wide reductions over 256 threads (4 waves); result broadcast to all threads
+__device__ __forceinline__ float block_sum256(float v, float *red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max256(float v, float *red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------------ direct conv
+// out[n,co,y,x] = b[co] + sum_{ci,ky,kx} in[n,ci,y*s-p+ky,x*s-p+kx] * w[co,ci,ky,kx]   (zero padding)
+// One lane per output element; used for the 7x7 stem and the 1x1 projections (small share of GMFlow's FLOPs).
+__global__ void __launch_bounds__(256)
+conv_direct_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                   float *__restrict__ out, int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int K, int S, int P) {
+  const size_t total = (size_t)N * Cout * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+    const int co = (int)((i / ((size_t)Wo * Ho)) % Cout), n = (int)(i / ((size_t)Wo * Ho * Cout));
+    float acc = bias ? bias[co] : 0.f;
+    const float *ip = in + (size_t)n * Cin * H * W;
+    const float *wp = w + (size_t)co * Cin * K * K;
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int ky = 0; ky < K; ++ky) {
+        const int gy = y * S - P + ky;
+        if (gy < 0 || gy >= H) continue;
+        for (int kx = 0; kx < K; ++kx) {
+          const int gx = x * S - P + kx;
+          if (gx < 0 || gx >= W) continue;
+          acc += ip[((size_t)ci * H + gy) * W + gx] * wp[(ci * K + ky) * K + kx];
+        }
+      }
+    out[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ norms / pointwise
+// nn.InstanceNorm2d (eps 1e-5, no affine): one workgroup per (n, c) plane, three passes (mean, biased var, write)
+__global__ void __launch_bounds__(256)
+instance_norm_kernel(const float *__restrict__ in, float *__restrict__ out, size_t HW, float eps, int relu) {
+  __shared__ float red[4];
+  const float *p = in + (size_t)blockIdx.x * HW;
+  float *o = out + (size_t)blockIdx.x * HW;
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < HW; i += 256) s += p[i];
+  const float mean = block_sum256(s, red) / (float)HW;
+  float v = 0.f;
+  for (size_t i = threadIdx.x; i < HW; i += 256) {
+    const float d = p[i] - mean;
+    v += d * d;
+  }
+  const float var = block_sum256(v, red) / (float)HW;
+  const float inv = 1.f / sqrtf(var + eps);
+  for (size_t i = threadIdx.x; i < HW; i += 256) {
+    const float y = (p[i] - mean) * inv;
+    o[i] = relu ? fmaxf(y, 0.f) : y;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+add_act_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, size_t n, int relu) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = a[i] + b[i];
+    out[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+// (x - mean[c]) / std[c] over [N, C, HW]
+__global__ void __launch_bounds__(256)
+channel_affine_kernel(const float *__restrict__ in, float *__restrict__ out, int C, size_t HW, float m0, float m1,
+                      float m2, float s0, float s1, float s2, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    const float m = c == 0 ? m0 : c == 1 ? m1 : m2, s = c == 0 ? s0 : c == 1 ? s1 : s2;
+    out[i] = (in[i] - m) / s;
+  }
+}
+
+// nn.LayerNorm(cols) per row, optional residual: out = (res ? res : 0) + LN(x)*w + b.  One wave per row.
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                 const float *__restrict__ res, float *__restrict__ out, size_t rows, int cols, float eps) {
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float *p = x + row * cols;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += p[c];
+  s = wave_sum(s);
+  const float mean = __shfl(s, 0, 64) / (float)cols;
+  float v = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float d = p[c] - mean;
+    v += d * d;
+  }
+  v = wave_sum(v);
+  const float inv = 1.f / sqrtf(__shfl(v, 0, 64) / (float)cols + eps);
+  for (int c = lane; c < cols; c += 64) {
+    const float y = (p[c] - mean) * inv * w[c] + b[c];
+    out[row * cols + c] = res ? res[row * cols + c] + y : y;
+  }
+}
+
+__global__ void __launch_bounds__(256) gelu_kernel(const float *__restrict__ x, float *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    out[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // nn.GELU() (erf form)
+  }
+}
+
+// in-place softmax over each row of x*scale (+ mask[(row / rows_per_mat) % n_masks][row % rows_per_mat][:]); one block per row
+__global__ void __launch_bounds__(256)
+softmax_rows_kernel(float *__restrict__ x, const float *__restrict__ mask, int cols, int rows_per_mat, int n_masks,
+                    float scale) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.x;
+  float *p = x + row * cols;
+  const float *m = mask ? mask + (((row / rows_per_mat) % n_masks) * (size_t)rows_per_mat + (row % rows_per_mat)) * cols : nullptr;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float v = p[c] / scale;  // scores / sqrt(c): the reference divides
+    if (m) v += m[c];
+    p[c] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max256(mx, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float e = expf(p[c] - mx);
+    p[c] = e;
+    s += e;
+  }
+  s = block_sum256(s, red);
+  for (int c = threadIdx.x; c < cols; c += 256) p[c] = p[c] / s;
+}
+
+// Row softmax of scores/scale followed by the expectation of a 2-vector per column, fused:
+//   vals == NULL: column j carries its pixel coordinate (j % w, j / w) and the row's own coordinate is
+//                 subtracted -> global correlation flow (matching.py:7-38)
+//   vals != NULL: [2][cols] planar values (the flow) -> global self-attention propagation (transformer.py:355-372)
+__global__ void __launch_bounds__(256)
+softmax_expect2_kernel(const float *__restrict__ scores, const float *__restrict__ vals, float *__restrict__ out,
+                       int rows, int cols, int w, float scale) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const float *p = scores + (size_t)row * cols;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, p[c] / scale);
+  mx = block_max256(mx, red);
+  float s = 0.f, ax = 0.f, ay = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float e = expf(p[c] / scale - mx);
+    s += e;
+    const float vx = vals ? vals[c] : (float)(c % w), vy = vals ? vals[cols + c] : (float)(c / w);
+    ax += e * vx;
+    ay += e * vy;
+  }
+  s = block_sum256(s, red);
+  ax = block_sum256(ax, red);
+  ay = block_sum256(ay, red);
+  if (threadIdx.x == 0) {
+    float ox = ax / s, oy = ay / s;
+    if (!vals) {
+      ox -= (float)(row % w);
+      oy -= (float)(row / w);
+    }
+    out[row] = ox;
+    out[rows + row] = oy;
+  }
+}
+
+// matching.py:41-89 with local_radius r: for every pixel, correlation of feature0 with feature1 at the (2r+1)^2
+// integer offsets (zeros outside the image, those taps get -1e4), softmax, expected offset.  One wave per pixel:
+// lanes split the channels of each dot product.
+__global__ void __launch_bounds__(256)
+local_corr_flow_kernel(const float *__restrict__ f0, const float *__restrict__ f1, float *__restrict__ out, int C, int H,
+                       int W, int r, float scale) {
+  const size_t P = (size_t)H * W;
+  const size_t p = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const int lane = threadIdx.x & 63, y = (int)(p / W), x = (int)(p % W);
+  const int n = 2 * r + 1;
+  float mx = -INFINITY, s = 0.f, ax = 0.f, ay = 0.f;
+  // online softmax over the (2r+1)^2 taps (all lanes hold the same running values)
+  for (int dy = -r; dy <= r; ++dy)
+    for (int dx = -r; dx <= r; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      float corr;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
+        corr = -1e4f;
+      } else {
+        float d = 0.f;
+        for (int c = lane; c < C; c += 64) d += f0[(size_t)c * P + p] * f1[(size_t)c * P + (size_t)yy * W + xx];
+        d = wave_sum(d);
+        corr = __shfl(d, 0, 64) / scale;
+      }
+      const float nm = fmaxf(mx, corr);
+      const float f = expf(mx - nm), e = expf(corr - nm);
+      s = s * f + e;
+      ax = ax * f + e * (float)(xx);
+      ay = ay * f + e * (float)(yy);
+      mx = nm;
+    }
+  (void)n;
+  if (lane == 0) {
+    out[p] = ax / s - (float)x;
+    out[P + p] = ay / s - (float)y;
+  }
+}
+
+// transformer.py:374-409 (local_window_radius r): q . k over the (2r+1)^2 zero-padded window (out-of-image keys are
+// zero vectors: score 0, NOT masked), softmax, weighted sum of the zero-padded flow window.
+__global__ void __launch_bounds__(256)
+local_attn_flow_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ flow,
+                       float *__restrict__ out, int C, int H, int W, int r, float scale) {
+  const size_t P = (size_t)H * W;
+  const size_t p = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const int lane = threadIdx.x & 63, y = (int)(p / W), x = (int)(p % W);
+  float mx = -INFINITY, s = 0.f, ax = 0.f, ay = 0.f;
+  for (int dy = -r; dy <= r; ++dy)
+    for (int dx = -r; dx <= r; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      float sc = 0.f, fx = 0.f, fy = 0.f;
+      if (in) {
+        const size_t pq = (size_t)yy * W + xx;
+        float d = 0.f;
+        for (int c = lane; c < C; c += 64) d += q[p * C + c] * k[pq * C + c];  // token-major [P, C]
+        d = wave_sum(d);
+        sc = __shfl(d, 0, 64) / scale;
+        fx = flow[pq];
+        fy = flow[P + pq];
+      }
+      const float nm = fmaxf(mx, sc);
+      const float f = expf(mx - nm), e = expf(sc - nm);
+      s = s * f + e;
+      ax = ax * f + e * fx;
+      ay = ay * f + e * fy;
+      mx = nm;
+    }
+  if (lane == 0) {
+    out[p] = ax / s;
+    out[P + p] = ay / s;
+  }
+}
+
+// gmflow.py:76-89 (upsample_factor K): mask [9*K*K, h, w] -> softmax over the 9 taps; up[c, K*y+i, K*x+j] =
+// sum_t softmax_t * (K * flow[c, y+ty-1, x+tx-1]) with zero padding.
+__global__ void __launch_bounds__(256)
+convex_upsample_kernel(const float *__restrict__ mask, const float *__restrict__ flow, float *__restrict__ out, int h,
+                       int w, int K) {
+  const size_t P = (size_t)h * w;
+  const int HW_o = K * w;
+  const size_t total = P * K * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int X = (int)(i % HW_o), Y = (int)(i / HW_o);
+    const int x = X / K, jj = X % K, y = Y / K, ii = Y % K;
+    const size_t p = (size_t)y * w + x;
+    float m[9], mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      m[t] = mask[((size_t)(t * K + ii) * K + jj) * P + p];
+      mx = fmaxf(mx, m[t]);
+    }
+    float s = 0.f, ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float e = expf(m[t] - mx);
+      s += e;
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+        ax += e * ((float)K * flow[(size_t)yy * w + xx]);
+        ay += e * ((float)K * flow[P + (size_t)yy * w + xx]);
+      }
+    }
+    out[i] = ax / s;
+    out[total + i] = ay / s;
+  }
+}
+
+// geometry.py:53-84 flow_warp: bilinear, zeros padding, coords normalised 2c/(size-1)-1
+__device__ __forceinline__ float fw_coord(int c, float f, int n) {
+  const float g = 2.f * ((float)c + f) / (float)(n - 1) - 1.f;
+  return (g + 1.f) * (((float)n - 1.f) / 2.f);
+}
+__global__ void __launch_bounds__(256)
+flow_warp_kernel(const float *__restrict__ in, const float *__restrict__ flow, float *__restrict__ out, int C, int H,
+                 int W) {
+  const size_t P = (size_t)H * W;
+  const Tile2D tp = tile_pixel(W, H);
+  if (!tp.valid) return;
+  const size_t p = (size_t)tp.y * W + tp.x;
+  const float sx = fw_coord(tp.x, flow[p], W), sy = fw_coord(tp.y, flow[P + p], H);
+  const bool fin = isfinite(sx) && isfinite(sy);
+  const float fx = floorf(sx), fy = floorf(sy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = sx - fx, wy1 = sy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+  for (int c = 0; c < C; ++c) {
+    const float *pl = in + (size_t)c * P;
+    float v = 0.f;
+    if (fin) {
+      if (okx0 && oky0) v += pl[(size_t)y0 * W + x0] * (wx0 * wy0);
+      if (okx1 && oky0) v += pl[(size_t)y0 * W + x0 + 1] * (wx1 * wy0);
+      if (okx0 && oky1) v += pl[(size_t)(y0 + 1) * W + x0] * (wx0 * wy1);
+      if (okx1 && oky1) v += pl[(size_t)(y0 + 1) * W + x0 + 1] * (wx1 * wy1);
+    }
+    out[(size_t)c * P + p] = v;
+  }
+}
+
+// F.interpolate(bilinear, align_corners=True): src = dst * (in-1)/(out-1)
+__global__ void __launch_bounds__(256)
+resize_ac_kernel(const float *__restrict__ in, float *__restrict__ out, int NC, int Hin, int Win, int Hout, int Wout,
+                 float mul) {
+  const size_t total = (size_t)NC * Hout * Wout;
+  const float ry = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+  const float rx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wout), oy = (int)((i / Wout) % Hout), c = (int)(i / ((size_t)Wout * Hout));
+    const float sy = ry * (float)oy, sx = rx * (float)ox;
+    const int y0 = min((int)sy, Hin - 1), x0 = min((int)sx, Win - 1);
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float *p = in + (size_t)c * Hin * Win;
+    const float top = (1.f - lx) * p[(size_t)y0 * Win + x0] + lx * p[(size_t)y0 * Win + x1];
+    const float bot = (1.f - lx) * p[(size_t)y1 * Win + x0] + lx * p[(size_t)y1 * Win + x1];
+    out[i] = ((1.f - ly) * top + ly * bot) * mul;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int drba_conv_direct(const float *in, const float *w, const float *bias, float *out, int N, int Cin, int H, int W,
+                     int Cout, int K, int stride, int pad, void *stream) {
+  if (!in || !w || !out || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || K <= 0 || stride <= 0 || pad < 0)
+    return DRBA_EINVAL;
+  const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+  hipLaunchKernelGGL(conv_direct_kernel, dim3(grid_for((size_t)N * Cout * Ho * Wo)), dim3(kBlock), 0, (hipStream_t)stream,
+                     in, w, bias, out, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_instance_norm(const float *in, float *out, int planes, size_t HW, float eps, int relu, void *stream) {
+  if (!in || !out || planes <= 0 || HW == 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(instance_norm_kernel, dim3(planes), dim3(kBlock), 0, (hipStream_t)stream, in, out, HW, eps, relu);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_add_act(const float *a, const float *b, float *out, size_t n, int relu, void *stream) {
+  if (!a || !b || !out || n == 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(add_act_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, a, b, out, n, relu);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_channel_normalize3(const float *in, float *out, int N, size_t HW, const float *mean3, const float *std3,
+                            void *stream) {
+  if (!in || !out || !mean3 || !std3 || N <= 0 || HW == 0) return DRBA_EINVAL;
+  const size_t n = (size_t)N * 3 * HW;
+  hipLaunchKernelGGL(channel_affine_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, in, out, 3, HW,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], n);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_layernorm(const float *x, const float *w, const float *b, const float *residual, float *out, size_t rows,
+                   int cols, float eps, void *stream) {
+  if (!x || !w || !b || !out || rows == 0 || cols <= 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, w, b,
+                     residual, out, rows, cols, eps);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_gelu(const float *x, float *out, size_t n, void *stream) {
+  if (!x || !out || n == 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(gelu_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, out, n);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks, float scale,
+                      void *stream) {
+  if (!x || rows == 0 || cols <= 0 || rows_per_mat <= 0 || !(scale > 0.f) || (mask && n_masks <= 0)) return DRBA_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, mask, cols,
+                     rows_per_mat, mask ? n_masks : 1, scale);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_softmax_expect2(const float *scores, const float *vals, float *out, int rows, int cols, int w, float scale,
+                         void *stream) {
+  if (!scores || !out || rows <= 0 || cols <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
+  hipLaunchKernelGGL(softmax_expect2_kernel, dim3(rows), dim3(kBlock), 0, (hipStream_t)stream, scores, vals, out, rows,
+                     cols, w, scale);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_local_corr_flow(const float *f0, const float *f1, float *out, int C, int H, int W, int radius, void *stream) {
+  if (!f0 || !f1 || !out || C <= 0 || H <= 0 || W <= 0 || radius <= 0) return DRBA_EINVAL;
+  const size_t P = (size_t)H * W;
+  hipLaunchKernelGGL(local_corr_flow_kernel, dim3((unsigned)((P + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, f0, f1,
+                     out, C, H, W, radius, sqrtf((float)C));
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_local_attn_flow(const float *q_tok, const float *k_tok, const float *flow, float *out, int C, int H, int W,
+                         int radius, void *stream) {
+  if (!q_tok || !k_tok || !flow || !out || C <= 0 || H <= 0 || W <= 0 || radius <= 0) return DRBA_EINVAL;
+  const size_t P = (size_t)H * W;
+  hipLaunchKernelGGL(local_attn_flow_kernel, dim3((unsigned)((P + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, q_tok,
+                     k_tok, flow, out, C, H, W, radius, sqrtf((float)C));
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_convex_upsample(const float *mask, const float *flow, float *out, int h, int w, int factor, void *stream) {
+  if (!mask || !flow || !out || h <= 0 || w <= 0 || factor <= 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3(grid_for((size_t)h * w * factor * factor)), dim3(kBlock), 0,
+                     (hipStream_t)stream, mask, flow, out, h, w, factor);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_flow_warp(const float *in, const float *flow, float *out, int C, int H, int W, void *stream) {
+  if (!in || !flow || !out || C <= 0 || H <= 1 || W <= 1) return DRBA_EINVAL;
+  hipLaunchKernelGGL(flow_warp_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H,
+                     W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_resize_bilinear_ac(const float *in, float *out, int NC, int Hin, int Win, int Hout, int Wout, float mul,
+                            void *stream) {
+  if (!in || !out || NC <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
+  hipLaunchKernelGGL(resize_ac_kernel, dim3(grid_for((size_t)NC * Hout * Wout)), dim3(kBlock), 0, (hipStream_t)stream, in,
+                     out, NC, Hin, Win, Hout, Wout, mul);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+}  // extern "C"

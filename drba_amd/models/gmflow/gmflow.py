@@ -1,0 +1,242 @@
+"""GMFlow on the MI355X (reference models/gmflow/{gmflow,backbone,trident_conv,transformer,matching,geometry,utils,
+position}.py, same state-dict keys; configuration used by DRBA: 2 scales, swin attention, 6 layers, 1 head).
+
+Division of labour: the 3x3 convolutions run on the fp32-MFMA implicit-GEMM kernel; the 7x7 / 1x1 convolutions, the
+norms, GELU, masked softmax, correlation-softmax -> flow expectations, local-window propagation, convex upsampling
+and warps are hand-written HIP kernels (drba_amd/csrc/gmflow.hip); the plain GEMMs (linear projections, QK^T, PV)
+go to the vendor BLAS through torch.matmul, and window split / merge / roll are pure data movement done with torch
+views.  No arithmetic other than those GEMMs happens in torch.
+"""
+import math
+
+import torch
+
+from drba_amd import ops as _ops
+
+C = 128
+_MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def _linear(x, w, b=None):
+    y = torch.matmul(x, w.t())
+    return y if b is None else torch.add(y, b)  # bias add of the two flow-attention projections (128 floats)
+
+
+class _ResBlock:
+    """backbone.py:5-36."""
+
+    def __init__(self, sd, p, stride, device):
+        self.c1 = _ops.Conv3x3(sd[p + "conv1.weight"], None, stride=stride, act=None, device=device)
+        self.c2 = _ops.Conv3x3(sd[p + "conv2.weight"], None, stride=1, act=None, device=device)
+        self.stride = stride
+        self.down = None
+        if (p + "downsample.0.weight") in sd:
+            self.down = (sd[p + "downsample.0.weight"].float().to(device).contiguous(),
+                         sd[p + "downsample.0.bias"].float().to(device).contiguous())
+
+    def __call__(self, x):
+        y = _ops.instance_norm(self.c1(x), relu=True)
+        y = _ops.instance_norm(self.c2(y), relu=True)
+        if self.down is not None:
+            x = _ops.instance_norm(_ops.conv_direct(x, self.down[0], self.down[1], self.stride, 0), relu=False)
+        return _ops.add_act(x, y, relu=True)
+
+
+class GMFlow:
+    def __init__(self, sd=None, device=None):
+        self.device = device
+        if sd is not None:
+            self.load_state_dict(sd)
+
+    def to(self, device):
+        self.device = device
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        dev = self.device if self.device is not None else _ops.default_device()
+        self.device = dev
+        g = lambda k: sd[k].detach().float().to(dev).contiguous()  # noqa: E731
+        self.conv1_w = g("backbone.conv1.weight")
+        self.blocks = []
+        for name, stride in (("layer1", 1), ("layer2", 2), ("layer3", 1)):
+            self.blocks.append(_ResBlock(sd, f"backbone.{name}.0.", stride, dev))
+            self.blocks.append(_ResBlock(sd, f"backbone.{name}.1.", 1, dev))
+        self.conv2 = (g("backbone.conv2.weight"), g("backbone.conv2.bias"))
+        self.trident = [_ops.Conv3x3(sd["backbone.trident_conv.weight"], None, stride=s, act=None, device=dev) for s in (1, 2)]
+        self.layers = []
+        for i in range(6):
+            lay = {}
+            for part, ffn in (("self_attn", False), ("cross_attn_ffn", True)):
+                p = f"transformer.layers.{i}.{part}."
+                d = {n: g(p + n + ".weight") for n in ("q_proj", "k_proj", "v_proj", "merge")}
+                d["n1w"], d["n1b"] = g(p + "norm1.weight"), g(p + "norm1.bias")
+                if ffn:
+                    d["mlp0"], d["mlp2"] = g(p + "mlp.0.weight"), g(p + "mlp.2.weight")
+                    d["n2w"], d["n2b"] = g(p + "norm2.weight"), g(p + "norm2.bias")
+                lay[part] = d
+            self.layers.append(lay)
+        self.ffa = {k: g(f"feature_flow_attn.{k}") for k in ("q_proj.weight", "q_proj.bias", "k_proj.weight", "k_proj.bias")}
+        self.up0 = _ops.Conv3x3(sd["upsampler.0.weight"], sd["upsampler.0.bias"], stride=1, act="relu", device=dev)
+        self.up2 = (g("upsampler.2.weight").view(144, 256), g("upsampler.2.bias"))
+        self._pos, self._mask = {}, {}
+        return self
+
+    # ---------------------------------------------------------------- encoder (backbone.py:39-117)
+    def encoder(self, x):
+        x = _ops.instance_norm(_ops.conv_direct(x, self.conv1_w, None, 2, 3), relu=True)
+        for b in self.blocks:
+            x = b(x)
+        x = _ops.conv_direct(x, self.conv2[0], self.conv2[1], 1, 0)
+        return [self.trident[0](x), self.trident[1](x)]  # [1/4-res, 1/8-res]
+
+    # ---------------------------------------------------------------- host-side tables
+    def _position(self, b, h, w):
+        """PositionEmbeddingSine (position.py:13-54), data independent: built once per size on the host."""
+        key = (b, h, w)
+        if key not in self._pos:
+            npf, temp, scale, eps = C // 2, 10000, 2 * math.pi, 1e-6
+            ones = torch.ones((b, h, w), dtype=torch.float32)
+            ye, xe = ones.cumsum(1), ones.cumsum(2)
+            ye = ye / (ye[:, -1:, :] + eps) * scale
+            xe = xe / (xe[:, :, -1:] + eps) * scale
+            dim_t = torch.arange(npf, dtype=torch.float32)
+            dim_t = temp ** (2 * (dim_t // 2) / npf)
+            px, py = xe[:, :, :, None] / dim_t, ye[:, :, :, None] / dim_t
+            px = torch.stack((px[:, :, :, 0::2].sin(), px[:, :, :, 1::2].cos()), dim=4).flatten(3)
+            py = torch.stack((py[:, :, :, 0::2].sin(), py[:, :, :, 1::2].cos()), dim=4).flatten(3)
+            self._pos[key] = torch.cat((py, px), dim=3).permute(0, 3, 1, 2).contiguous().to(self.device)
+        return self._pos[key]
+
+    def _shift_mask(self, h, w, k):
+        """generate_shift_window_attn_mask (transformer.py:19-43): host table, [k*k, L, L]."""
+        key = (h, w, k)
+        if key not in self._mask:
+            wh, ww = h // k, w // k
+            sh, sw = wh // 2, ww // 2
+            img = torch.zeros((1, h, w, 1))
+            cnt = 0
+            for hs in (slice(0, -wh), slice(-wh, -sh), slice(-sh, None)):
+                for ws in (slice(0, -ww), slice(-ww, -sw), slice(-sw, None)):
+                    img[:, hs, ws, :] = cnt
+                    cnt += 1
+            mw = _split(img, k, True).view(-1, wh * ww)
+            m = mw.unsqueeze(1) - mw.unsqueeze(2)
+            m = m.masked_fill(m != 0, float(-100.0)).masked_fill(m == 0, float(0.0))
+            self._mask[key] = m.contiguous().to(self.device)
+        return self._mask[key]
+
+    # ---------------------------------------------------------------- transformer (transformer.py)
+    def _attention(self, q, k, v, h, w, splits, shift):
+        b, _, c = q.shape
+        scale = c ** 0.5
+        if splits <= 1:
+            scores = torch.matmul(q, k.transpose(1, 2)).contiguous()
+            _ops.softmax_rows_(scores, scale)
+            return torch.matmul(scores, v)
+        bn, wh, ww = b * splits * splits, h // splits, w // splits
+        q, k, v = q.view(b, h, w, c), k.view(b, h, w, c), v.view(b, h, w, c)
+        if shift:
+            sh, sw = wh // 2, ww // 2
+            q, k, v = [torch.roll(t, shifts=(-sh, -sw), dims=(1, 2)) for t in (q, k, v)]
+        q, k, v = [_split(t, splits, True).reshape(bn, -1, c) for t in (q, k, v)]
+        scores = torch.matmul(q, k.transpose(1, 2)).contiguous()
+        _ops.softmax_rows_(scores, scale, self._shift_mask(h, w, splits) if shift else None)
+        out = _merge(torch.matmul(scores, v).view(bn, wh, ww, c), splits, True)
+        if shift:
+            out = torch.roll(out, shifts=(sh, sw), dims=(1, 2))
+        return out.reshape(b, -1, c)
+
+    def _layer(self, d, source, target, h, w, splits, shift, ffn):
+        q, k, v = _linear(source, d["q_proj"]), _linear(target, d["k_proj"]), _linear(target, d["v_proj"])
+        msg = _linear(self._attention(q, k, v, h, w, splits, shift), d["merge"])
+        if not ffn:
+            return _ops.layernorm(msg, d["n1w"], d["n1b"], residual=source)
+        msg = _ops.layernorm(msg, d["n1w"], d["n1b"])
+        hid = _ops.gelu(_linear(torch.cat([source, msg], dim=-1), d["mlp0"]))
+        return _ops.layernorm(_linear(hid, d["mlp2"]), d["n2w"], d["n2b"], residual=source)
+
+    def transformer(self, f0, f1, splits):
+        b, c, h, w = f0.shape
+        t0 = f0.flatten(-2).permute(0, 2, 1)
+        t1 = f1.flatten(-2).permute(0, 2, 1)
+        c0, c1 = torch.cat((t0, t1), 0).contiguous(), torch.cat((t1, t0), 0).contiguous()
+        for i, lay in enumerate(self.layers):
+            shift = (i % 2 == 1) and splits > 1
+            c0 = self._layer(lay["self_attn"], c0, c0, h, w, splits, shift, False)
+            c0 = self._layer(lay["cross_attn_ffn"], c0, c1, h, w, splits, shift, True)
+            c1 = torch.cat(c0.chunk(2, 0)[::-1], 0).contiguous()
+        t0, t1 = c0.chunk(2, 0)
+        return (t0.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous(),
+                t1.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous())
+
+    def _add_position(self, f0, f1, splits):
+        if splits > 1:
+            s0, s1 = _split(f0, splits, False), _split(f1, splits, False)
+            pos = self._position(*[s0.shape[0], s0.shape[2], s0.shape[3]])
+            return (_merge(_ops.add_act(s0.contiguous(), pos), splits, False),
+                    _merge(_ops.add_act(s1.contiguous(), pos), splits, False))
+        pos = self._position(f0.shape[0], f0.shape[2], f0.shape[3])
+        return _ops.add_act(f0, pos), _ops.add_act(f1, pos)
+
+    def _propagate(self, f0, flow, local, radius):
+        """FeatureFlowAttention (transformer.py:325-409)."""
+        b, c, h, w = f0.shape
+        tok = f0.view(b, c, h * w).permute(0, 2, 1).contiguous()
+        q = _linear(tok, self.ffa["q_proj.weight"], self.ffa["q_proj.bias"])
+        if not local:
+            k = _linear(q, self.ffa["k_proj.weight"], self.ffa["k_proj.bias"])  # key from the projected query, as written
+            scores = torch.matmul(q[0], k[0].t()).contiguous()
+            return _ops.softmax_expect2(scores, flow.view(2, h * w), w, c ** 0.5).view(1, 2, h, w)
+        k = _linear(tok, self.ffa["k_proj.weight"], self.ffa["k_proj.bias"])
+        return _ops.local_attn_flow(q[0].contiguous(), k[0].contiguous(), flow, radius)
+
+    # ---------------------------------------------------------------- forward (gmflow.py:92-185)
+    def __call__(self, img0, img1, attn_splits_list=(2, 8), corr_radius_list=(-1, 4), prop_radius_list=(-1, 1), **kw):
+        x = _ops.channel_normalize3(torch.cat((img0, img1), 0).contiguous(), _MEAN, _STD)
+        feats = self.encoder(x)[::-1]  # low -> high resolution
+        flow = None
+        for idx, (splits, corr_r, prop_r) in enumerate(zip(attn_splits_list, corr_radius_list, prop_radius_list)):
+            f0, f1 = feats[idx][0:1].contiguous(), feats[idx][1:2].contiguous()
+            _, c, h, w = f0.shape
+            if idx > 0:
+                flow = _ops.resize_bilinear_ac(flow, (h, w), 2.0)  # x2 bilinear (align_corners=True), * 2
+                f1 = _ops.flow_warp(f1, flow)
+            f0, f1 = self._add_position(f0, f1, splits)
+            f0, f1 = self.transformer(f0, f1, splits)
+            if corr_r == -1:
+                scores = torch.matmul(f0.view(c, h * w).t(), f1.view(c, h * w)).contiguous()
+                pred = _ops.softmax_expect2(scores, None, w, c ** 0.5).view(1, 2, h, w)
+            else:
+                pred = _ops.local_corr_flow(f0, f1, corr_r)
+            flow = pred if flow is None else _ops.add_act(flow, pred)
+            flow = self._propagate(f0, flow, local=prop_r > 0, radius=prop_r)
+        # learned convex upsampling x4 (gmflow.py:67-90)
+        m = self.up0(torch.cat((flow, f0), 1))
+        _, _, h, w = flow.shape
+        m = torch.add(torch.matmul(self.up2[0], m.view(256, h * w)), self.up2[1].view(144, 1))  # 1x1 conv = plain GEMM
+        return _ops.convex_upsample(m.view(1, 144, h, w), flow, 4)
+
+    forward = __call__
+
+
+def _split(f, k, channel_last):
+    """utils.py:5-31 (data movement only)."""
+    if channel_last:
+        b, h, w, c = f.shape
+        return f.reshape(b, k, h // k, k, w // k, c).permute(0, 1, 3, 2, 4, 5).reshape(b * k * k, h // k, w // k, c)
+    b, c, h, w = f.shape
+    return f.reshape(b, c, k, h // k, k, w // k).permute(0, 2, 4, 1, 3, 5).reshape(b * k * k, c, h // k, w // k)
+
+
+def _merge(s, k, channel_last):
+    """utils.py:34-54 (data movement only)."""
+    if channel_last:
+        b, h, w, c = s.shape
+        nb = b // k // k
+        return s.reshape(nb, k, k, h, w, c).permute(0, 1, 3, 2, 4, 5).contiguous().view(nb, k * h, k * w, c)
+    b, c, h, w = s.shape
+    nb = b // k // k
+    return s.reshape(nb, k, k, c, h, w).permute(0, 3, 1, 4, 2, 5).contiguous().view(nb, c, k * h, k * w)

@@ -1,0 +1,75 @@
+"""GMFSS_UNION wrapper with the DRBA call surface (reference models/gmfss_union.py:10-100), HIP path, fp32."""
+import os
+
+import torch
+
+from drba_amd import ops as _ops
+from drba_amd.models.drm import calc_drm_gmfss, calc_drm_rife_auxiliary
+from drba_amd.models.model_gmfss_union.GMFSS import Model, _half
+from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
+from drba_amd.models.utils.tools import convert, resize
+
+
+class GMFSS_UNION:
+    def __init__(self, weights="weights/train_log_gmfss_union", scale=1.0, device=None):
+        device = _ops.default_device() if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("drba_amd GMFSS_UNION runs on the MI355X HIP path only; there is no CPU fallback")
+        self.model = Model(union=True)
+        if isinstance(weights, dict):  # already-loaded state dicts: flownet, metric, feat, fusion, rife
+            self.model.load_state_dicts(weights["flownet"], weights["metric"], weights["feat"], weights["fusion"], device)
+            rife_sd = weights["rife"]
+        else:
+            self.model.load_model(weights, -1, device)
+            rife_sd = convert(torch.load(os.path.join(weights, "rife.pkl"), map_location="cpu"))
+        self.ifnet = IFNet().to(device).eval()
+        self.ifnet.load_state_dict(rife_sd, strict=False)
+        self.scale = scale
+        self.scale_list = [16 / scale, 8 / scale, 4 / scale, 2 / scale, 1 / scale]
+        self.pad_size = 128
+
+    def inference_ts(self, I0, I1, ts):
+        reuse = self.model.reuse(I0, I1, self.scale)
+        output = []
+        I0s = I1s = None
+        for t in ts:
+            if t == 0:
+                output.append(I0)
+            elif t == 1:
+                output.append(I1)
+            else:
+                if I0s is None:
+                    I0s, I1s = _half(I0), _half(I1)
+                rife = self.ifnet.forward_pair(I0s, I1s, float(t), self.scale_list)[0]
+                output.append(self.model.inference(I0, I1, reuse, timestep0=float(t), timestep1=float(1 - t), rife=rife))
+        return output
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False):
+        reuseI1I0 = self.model.reuse(I1, I0, self.scale) if reuse is None else reuse
+        reuseI1I2 = self.model.reuse(I1, I2, self.scale)
+        flow10, metric10 = reuseI1I0[0], reuseI1I0[2]
+        flow12, metric12 = reuseI1I2[0], reuseI1I2[2]
+        I0s, I1s, I2s = _half(I0), _half(I1), _half(I2)
+        output = []
+        for t in ts:
+            if t == 0:
+                output.append(I0)
+            elif t == 1:
+                output.append(I1)
+            elif t == 2:
+                output.append(I2)
+            elif 0 < t < 1 or 1 < t < 2:
+                left = t < 1
+                tt = 1 - t if left else t - 1
+                dg = calc_drm_gmfss(tt, flow10, flow12, metric10, metric12, linear)
+                dr = calc_drm_rife_auxiliary(tt, flow10, flow12, metric10, metric12, linear)
+                dr = {k: resize(v, I0s.shape[2:]) for k, v in dr.items()}
+                if left:
+                    rife = self.ifnet.forward_pair(I1s, I0s, dr["drm_t1_t01"], self.scale_list)[0]
+                    output.append(self.model.inference(I1, I0, reuseI1I0, dg["drm1t_t01"], dg["drm0t_t01"], rife))
+                else:
+                    rife = self.ifnet.forward_pair(I1s, I2s, dr["drm_t1_t12"], self.scale_list)[0]
+                    output.append(self.model.inference(I1, I2, reuseI1I2, dg["drm1t_t12"], dg["drm2t_t12"], rife))
+        # next step's (I1, I0) state = this step's (I1, I2) state with the roles swapped (gmfss_union.py:95-98)
+        new_reuse = [v for pair in zip(reuseI1I2[1::2], reuseI1I2[0::2]) for v in pair]
+        return output, new_reuse

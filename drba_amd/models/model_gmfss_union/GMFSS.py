@@ -1,0 +1,94 @@
+"""GMFSS(_UNION) Model on the HIP path (reference models/model_gmfss_union/GMFSS.py:19-155; model_gmfss/GMFSS.py for
+union=False): FeatureNet x2, GMFlow both directions, MetricNet (`reuse`), then softmax-splatting of the half-res
+frames and the 3-level feature pyramid, timestep-map swap masks and GridNet fusion (`inference`)."""
+import torch
+
+from drba_amd import ops as _ops
+from drba_amd.models.gmflow.gmflow import GMFlow
+from drba_amd.models.model_gmfss_union.FeatureNet import FeatureNet
+from drba_amd.models.model_gmfss_union.FusionNet import GridNet
+from drba_amd.models.model_gmfss_union.MetricNet import MetricNet
+from drba_amd.models.softsplat.softsplat import softsplat as warp
+
+
+def _half(x, s=0.5):
+    """F.interpolate(x, scale_factor=s, bilinear, align_corners=False)."""
+    _, _, h, w = x.shape
+    return _ops.resize_bilinear_scale(x, (int(h * s), int(w * s)), 1.0 / s)
+
+
+def _times(t, x):
+    """timestep * x for a scalar or a [1,1,H,W] map (GMFSS.py:86-90)."""
+    return _ops.mul_map(x, t) if torch.is_tensor(t) else _ops.affine(x, float(t), 0.0)
+
+
+class Model:
+    def __init__(self, union=True):
+        self.union = union
+        self.flownet = self.metricnet = self.feat_ext = self.fusionnet = None
+        self._device = None
+        self.version = 3.9
+
+    def eval(self):
+        return self
+
+    def device(self, device=None):
+        self._device = device
+
+    def load_state_dicts(self, flownet, metric, feat, fusion, device):
+        self._device = device
+        self.flownet = GMFlow(flownet, device)
+        self.metricnet = MetricNet(metric, device, tanh10=self.union)
+        self.feat_ext = FeatureNet(feat, device)
+        self.fusionnet = GridNet(fusion, device)
+
+    def load_model(self, path, rank=-1, device=None):
+        """flownet.pkl / metric.pkl / feat.pkl / fusionnet.pkl (GMFSS.py:42-53); CUDA-tagged pickles load via map_location."""
+        device = device or self._device or _ops.default_device()
+        ld = lambda n: torch.load(f"{path}/{n}.pkl", map_location="cpu")  # noqa: E731
+        self.load_state_dicts(ld("flownet"), ld("metric"), ld("feat"), ld("fusionnet"), device)
+
+    def reuse(self, img0, img1, scale):
+        feat0, feat1 = self.feat_ext(img0), self.feat_ext(img1)
+        img0, img1 = _half(img0), _half(img1)
+        if scale != 1.0:
+            if0, if1 = _half(img0, scale), _half(img1, scale)
+        else:
+            if0, if1 = img0, img1
+        flow01 = self.flownet(if0, if1)
+        flow10 = self.flownet(if1, if0)
+        if scale != 1.0:
+            _, _, h, w = img0.shape
+            up = lambda f: _ops.affine(_ops.resize_bilinear_scale(f, (h, w), scale), 1.0 / scale, 0.0)  # noqa: E731
+            flow01, flow10 = up(flow01), up(flow10)
+        metric0, metric1 = self.metricnet(img0, img1, flow01, flow10)
+        return flow01, flow10, metric0, metric1, feat0, feat1
+
+    def inference(self, img0, img1, reuse_things, timestep0, timestep1, rife=None):
+        flow01, flow10, metric0, metric1, (f11, f12, f13), (f21, f22, f23) = reuse_things
+        F1t, F2t = _times(timestep0, flow01), _times(timestep1, flow10)
+        Z1t, Z2t = _times(timestep0, metric0), _times(timestep1, metric1)
+        img0, img1 = _half(img0), _half(img1)
+        I1t, I2t = warp(img0, F1t, Z1t, "soft"), warp(img1, F2t, Z2t, "soft")
+        a1, b1 = warp(f11, F1t, Z1t, "soft"), warp(f21, F2t, Z2t, "soft")
+
+        def down(flow, z, s):
+            return _ops.affine(_half(flow, s), s, 0.0), _half(z, s)
+
+        a2 = warp(f12, *down(F1t, Z1t, 0.5), "soft")
+        b2 = warp(f22, *down(F2t, Z2t, 0.5), "soft")
+        a3 = warp(f13, *down(F1t, Z1t, 0.25), "soft")
+        b3 = warp(f23, *down(F2t, Z2t, 0.25), "soft")
+        if self.union and torch.is_tensor(timestep0):
+            t0 = warp(timestep0, F1t, Z1t, "soft")
+            t1 = warp(timestep1, F2t, Z2t, "soft")
+            cov0 = warp(_ops.affine(t0, 0.0, 1.0), F1t, Z1t, "soft")  # t.clone()*0+1 splatted (GMFSS.py:116-117)
+            cov1 = warp(_ops.affine(t1, 0.0, 1.0), F2t, Z2t, "soft")
+            t0, t1 = _ops.timestep_fix(t0, t1, cov0, cov1)
+            I1t, I2t = _ops.swap_select(I1t, I2t, t0, t1, 25.0)
+            a1, b1 = _ops.swap_select(a1, b1, t0, t1, 25.0)
+            a2, b2 = _ops.swap_select(a2, b2, _half(t0, 0.5), _half(t1, 0.5), 25.0)
+            a3, b3 = _ops.swap_select(a3, b3, _half(t0, 0.25), _half(t1, 0.25), 25.0)
+        x = torch.cat([I1t, rife, I2t], 1) if self.union else torch.cat([img0, I1t, I2t, img1], 1)
+        out = self.fusionnet(x, torch.cat([a1, b1], 1), torch.cat([a2, b2], 1), torch.cat([a3, b3], 1))
+        return _ops.clamp(out, 0.0, 1.0)

@@ -250,14 +250,21 @@ def _tune(shape_key, candidates, run, reps=3):
 class Conv3x3:
     """One 3x3 conv layer (pad 1) with fused epilogue; weights are packed per kernel config on first use."""
 
-    def __init__(self, weight, bias, stride=1, act=True, beta=None, device=None, cfg=None):
+    ACTS = {None: 0, False: 0, "none": 0, True: 1, "lrelu": 1, "prelu": 2, "relu": 3, "tanh10": 4}
+
+    def __init__(self, weight, bias, stride=1, act=True, beta=None, device=None, cfg=None, pre_slope=None,
+                 post_slope=0.0):
+        """act: True/'lrelu' LeakyReLU(0.2), 'prelu' (post_slope), 'relu', 'tanh10', None.  pre_slope: a float applies
+        PReLU with that shared slope to the input inside the loader."""
         self.force_cfg = cfg  # tests only: pin a kernel configuration
+        self.pre_slope = None if pre_slope is None else float(pre_slope)
+        self.post_slope = float(post_slope)
         self.w_host = weight.detach().float().cpu().contiguous()
         self.cout, self.cin = self.w_host.shape[:2]
         self.device = device
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
         self.beta = None if beta is None else beta.detach().float().reshape(-1).to(device).contiguous()
-        self.stride, self.act = int(stride), 1 if act else 0
+        self.stride, self.act = int(stride), self.ACTS[act]
         self._packed = {}
 
     def _pack(self, cfg):
@@ -270,7 +277,7 @@ class Conv3x3:
             self._packed[cfg] = buf.to(self.device)
         return self._packed[cfg]
 
-    def __call__(self, x, residual=None, out=None):
+    def __call__(self, x, residual=None, out=None, residual2=None):
         x = _f32(x)
         n, cin, h, w = x.shape
         assert cin == self.cin, (cin, self.cin)
@@ -280,15 +287,16 @@ class Conv3x3:
             out = torch.empty((n, self.cout, ho, wo), dtype=torch.float32, device=x.device)
         if self.beta is not None:
             assert residual is not None
-            residual = _f32(residual)
-        res = residual if self.beta is not None else None
+        res = None if residual is None else _f32(residual)
+        res2 = None if residual2 is None else _f32(residual2)
+        pre, ps = (0, 0.0) if self.pre_slope is None else (1, self.pre_slope)
         if self.force_cfg is not None:
             cfg = self.force_cfg
         elif AUTOTUNE and x.is_cuda:
             cands = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_stride(c) == self.stride]
             cfg = _tune(("conv3x3", n, cin, self.cout, h, w, self.stride), cands, lambda c: lib.drba_conv3x3(
-                _p(x), _p(self._pack(c)), _p(self.bias), _p(self.beta), _p(res), _p(out), n, cin, h, w, self.cout,
-                self.stride, self.act, c, _stream()))
+                _p(x), _p(self._pack(c)), _p(self.bias), _p(self.beta), _p(res), _p(res2), _p(out), n, cin, h, w,
+                self.cout, self.stride, self.act, self.post_slope, pre, ps, c, _stream()))
             for c in [c for c in self._packed if c != cfg]:
                 del self._packed[c]  # keep only the winner's packed weights
         else:
@@ -297,16 +305,17 @@ class Conv3x3:
         wp = self._pack(cfg)
         key = (cfg, cin, self.cout, ho, wo, self.stride)
         _lib.check(_timed("conv3x3", key, 2.0 * self.cout * cin * 9 * ho * wo * n, "flop", lambda: lib.drba_conv3x3(
-            _p(x), _p(wp), _p(self.bias), _p(self.beta), _p(res), _p(out), n, cin, h, w, self.cout, self.stride,
-            self.act, cfg, _stream())), "drba_conv3x3")
+            _p(x), _p(wp), _p(self.bias), _p(self.beta), _p(res), _p(res2), _p(out), n, cin, h, w, self.cout,
+            self.stride, self.act, self.post_slope, pre, ps, cfg, _stream())), "drba_conv3x3")
         return out
 
 
 class Deconv4x4:
     """ConvTranspose2d(k=4, s=2, p=1), optionally fused with PixelShuffle(2)."""
 
-    def __init__(self, weight, bias, pixel_shuffle=False, device=None, cfg=None):
+    def __init__(self, weight, bias, pixel_shuffle=False, device=None, cfg=None, pre_slope=None):
         self.force_cfg = cfg  # tests only
+        self.pre_slope = None if pre_slope is None else float(pre_slope)
         self.w_host = weight.detach().float().cpu().contiguous()  # [Cin, Cout, 4, 4]
         self.cin, self.cout = self.w_host.shape[:2]
         self.device = device
@@ -332,12 +341,13 @@ class Deconv4x4:
         if out is None:
             shape = (n, self.cout // 4, 4 * h, 4 * w) if self.ps else (n, self.cout, 2 * h, 2 * w)
             out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        pre, ps_ = (0, 0.0) if self.pre_slope is None else (1, self.pre_slope)
         if self.force_cfg is not None:
             cfg = self.force_cfg
         elif AUTOTUNE and x.is_cuda:
             cfg = _tune(("deconv4x4", n, cin, self.cout, h, w, self.ps), list(range(lib.drba_deconv4x4_num_cfgs())),
                         lambda c: lib.drba_deconv4x4s2(_p(x), _p(self._pack(c)), _p(self.bias), _p(out), n, cin, h, w,
-                                                       self.cout, self.ps, c, _stream()))
+                                                       self.cout, self.ps, pre, ps_, c, _stream()))
             for c in [c for c in self._packed if c != cfg]:
                 del self._packed[c]
         else:
@@ -346,7 +356,7 @@ class Deconv4x4:
         wp = self._pack(cfg)
         key = (cfg, cin, self.cout, h, w, 2)
         _lib.check(_timed("deconv4x4", key, 2.0 * self.cout * cin * 16 * h * w * n, "flop", lambda: lib.drba_deconv4x4s2(
-            _p(x), _p(wp), _p(self.bias), _p(out), n, cin, h, w, self.cout, self.ps, cfg, _stream())),
+            _p(x), _p(wp), _p(self.bias), _p(out), n, cin, h, w, self.cout, self.ps, pre, ps_, cfg, _stream())),
             "drba_deconv4x4s2")
         return out
 
@@ -403,4 +413,179 @@ def warp_blend(img0, img1, flow, tmp_last, scale):
     out = torch.empty((1, 3, H, W), dtype=torch.float32, device=img0.device)
     _lib.check(_lib.load().drba_warp_blend(_p(img0), _p(img1), _p(flow), C.c_void_p(mask_lo.data_ptr()), h, w,
                                            float(scale), _p(out), H, W, _stream()), "drba_warp_blend")
+    return out
+
+
+# ----------------------------------------------------------------------------- GMFSS glue
+def metric_input(img0, img1, flow01, flow10):
+    img0, img1, flow01, flow10 = _f32(img0), _f32(img1), _f32(flow01), _f32(flow10)
+    _, _, h, w = img0.shape
+    out = torch.empty((1, 14, h, w), dtype=torch.float32, device=img0.device)
+    _lib.check(_lib.load().drba_metric_input(_p(img0), _p(img1), _p(flow01), _p(flow10), _p(out), h, w, _stream()),
+               "drba_metric_input")
+    return out
+
+
+def pixel_shuffle2(x):
+    x = _f32(x)
+    n, c4, h, w = x.shape
+    assert n == 1 and c4 % 4 == 0
+    out = torch.empty((1, c4 // 4, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().drba_pixel_shuffle2(_p(x), _p(out), c4 // 4, h, w, _stream()), "drba_pixel_shuffle2")
+    return out
+
+
+def timestep_fix(t0, t1, cover0, cover1):
+    t0, t1, cover0, cover1 = _f32(t0), _f32(t1), _f32(cover0), _f32(cover1)
+    o0, o1 = torch.empty_like(t0), torch.empty_like(t1)
+    _lib.check(_lib.load().drba_timestep_fix(_p(t0), _p(t1), _p(cover0), _p(cover1), _p(o0), _p(o1), t0.numel(),
+                                             _stream()), "drba_timestep_fix")
+    return o0, o1
+
+
+def swap_select(x, y, t0, t1, thr=25.0):
+    x, y, t0, t1 = _f32(x), _f32(y), _f32(t0), _f32(t1)
+    n, c, h, w = x.shape
+    assert n == 1 and t0.shape[2:] == x.shape[2:]
+    ox, oy = torch.empty_like(x), torch.empty_like(y)
+    _lib.check(_lib.load().drba_swap_select(_p(x), _p(y), _p(t0), _p(t1), _p(ox), _p(oy), c, h, w, float(thr),
+                                            _stream()), "drba_swap_select")
+    return ox, oy
+
+
+def clamp(x, lo, hi):
+    x = _f32(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().drba_clamp(_p(x), _p(out), float(lo), float(hi), x.numel(), _stream()), "drba_clamp")
+    return out
+
+
+# ----------------------------------------------------------------------------- GMFlow operators
+def conv_direct(x, w, bias, stride, pad):
+    x, w = _f32(x), _f32(w)
+    n, cin, h, wd = x.shape
+    cout, _, k, _ = w.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().drba_conv_direct(_p(x), _p(w), _p(bias), _p(out), n, cin, h, wd, cout, k, stride, pad,
+                                            _stream()), "drba_conv_direct")
+    return out
+
+
+def instance_norm(x, relu=False, eps=1e-5):
+    x = _f32(x)
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().drba_instance_norm(_p(x), _p(out), n * c, h * w, float(eps), 1 if relu else 0, _stream()),
+               "drba_instance_norm")
+    return out
+
+
+def add_act(a, b, relu=False):
+    a, b = _f32(a), _f32(b)
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().drba_add_act(_p(a), _p(b), _p(out), a.numel(), 1 if relu else 0, _stream()), "drba_add_act")
+    return out
+
+
+def channel_normalize3(x, mean, std):
+    x = _f32(x)
+    n, c, h, w = x.shape
+    assert c == 3
+    out = torch.empty_like(x)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _lib.check(_lib.load().drba_channel_normalize3(_p(x), _p(out), n, h * w, C.cast(m, C.c_void_p), C.cast(s, C.c_void_p),
+                                                   _stream()), "drba_channel_normalize3")
+    return out
+
+
+def layernorm(x, w, b, residual=None, eps=1e-5):
+    x = _f32(x)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    out = torch.empty_like(x)
+    res = None if residual is None else _f32(residual)
+    _lib.check(_lib.load().drba_layernorm(_p(x), _p(w), _p(b), _p(res), _p(out), rows, cols, float(eps), _stream()),
+               "drba_layernorm")
+    return out
+
+
+def gelu(x):
+    x = _f32(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().drba_gelu(_p(x), _p(out), x.numel(), _stream()), "drba_gelu")
+    return out
+
+
+def softmax_rows_(scores, scale, mask=None):
+    """In-place softmax over the last dim of scores [M, L, cols] / scale (+ mask [n_masks, L, cols] cycled over M)."""
+    assert scores.is_contiguous() and scores.dtype == torch.float32
+    cols = scores.shape[-1]
+    rows_per_mat = scores.shape[-2]
+    rows = scores.numel() // cols
+    n_masks = 1
+    if mask is not None:
+        mask = _f32(mask)
+        n_masks = mask.shape[0]
+    _lib.check(_lib.load().drba_softmax_rows(_p(scores), _p(mask), rows, cols, rows_per_mat, n_masks, float(scale),
+                                             _stream()), "drba_softmax_rows")
+    return scores
+
+
+def softmax_expect2(scores, vals, w, scale):
+    """scores [rows, cols]; vals None (pixel coordinates, own coordinate subtracted) or [2, cols] -> [2, rows]."""
+    scores = _f32(scores)
+    rows, cols = scores.shape
+    out = torch.empty((2, rows), dtype=torch.float32, device=scores.device)
+    v = None if vals is None else _f32(vals)
+    _lib.check(_lib.load().drba_softmax_expect2(_p(scores), _p(v), _p(out), rows, cols, int(w), float(scale), _stream()),
+               "drba_softmax_expect2")
+    return out
+
+
+def local_corr_flow(f0, f1, radius):
+    f0, f1 = _f32(f0), _f32(f1)
+    n, c, h, w = f0.shape
+    assert n == 1
+    out = torch.empty((1, 2, h, w), dtype=torch.float32, device=f0.device)
+    _lib.check(_lib.load().drba_local_corr_flow(_p(f0), _p(f1), _p(out), c, h, w, int(radius), _stream()),
+               "drba_local_corr_flow")
+    return out
+
+
+def local_attn_flow(q_tok, k_tok, flow, radius):
+    q_tok, k_tok, flow = _f32(q_tok), _f32(k_tok), _f32(flow)
+    _, _, h, w = flow.shape
+    c = q_tok.shape[-1]
+    out = torch.empty_like(flow)
+    _lib.check(_lib.load().drba_local_attn_flow(_p(q_tok), _p(k_tok), _p(flow), _p(out), c, h, w, int(radius), _stream()),
+               "drba_local_attn_flow")
+    return out
+
+
+def convex_upsample(mask, flow, factor):
+    mask, flow = _f32(mask), _f32(flow)
+    _, _, h, w = flow.shape
+    out = torch.empty((1, 2, factor * h, factor * w), dtype=torch.float32, device=flow.device)
+    _lib.check(_lib.load().drba_convex_upsample(_p(mask), _p(flow), _p(out), h, w, int(factor), _stream()),
+               "drba_convex_upsample")
+    return out
+
+
+def flow_warp(x, flow):
+    x, flow = _f32(x), _f32(flow)
+    n, c, h, w = x.shape
+    assert n == 1
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().drba_flow_warp(_p(x), _p(flow), _p(out), c, h, w, _stream()), "drba_flow_warp")
+    return out
+
+
+def resize_bilinear_ac(x, size, mul=1.0):
+    x = _f32(x)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().drba_resize_bilinear_ac(_p(x), _p(out), n * c, h, w, int(size[0]), int(size[1]), float(mul),
+                                                   _stream()), "drba_resize_bilinear_ac")
     return out

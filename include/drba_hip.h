@@ -90,7 +90,10 @@ int drba_ssim3d_32(const float *x1, const float *x2, float *out, void *stream);
 /* ---- convolutions (models/rife_426_heavy/IFNet_HDv3.py:11-16, :28-47, :50-59, :65-82) ------
  * fp32 implicit GEMM on v_mfma_f32_16x16x4_f32.  Weights must be pre-packed by the matching
  * drba_pack_* call for the same `cfg`; cfg is chosen by drba_conv3x3_pick_cfg.
- * epilogue: y = acc + bias; if (beta) y = y*beta[c] + residual; if (act) y = lrelu_0.2(y). */
+ * loader:   pre_act != 0 applies PReLU with one shared slope (nn.PReLU()) to the input as it is staged
+ *           (FeatureNet.py:9-27, FusionNet.py:6-31: PReLU precedes every conv).
+ * epilogue: y = acc + bias; if (beta) y = y*beta[c] + residual (ResConv) else y += residual (+ residual2);
+ *           act: 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10 (MetricNet.py:41-42,63). */
 int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride); /* cost-model default */
 int drba_conv3x3_num_cfgs(void);         /* configs are 0..num-1; a host may time them and keep the fastest */
 int drba_conv3x3_cfg_stride(int cfg);    /* the stride (1 or 2) a config was built for */
@@ -98,8 +101,9 @@ size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg);
 int drba_conv3x3_pack(const float *w /*[Cout,Cin,3,3] host or device-visible*/, float *packed,
                       int Cin, int Cout, int cfg);  /* HOST function: both pointers are host memory */
 int drba_conv3x3(const float *in, const float *packed_w, const float *bias, const float *beta,
-                 const float *residual, float *out, int N, int Cin, int H, int W, int Cout,
-                 int stride, int act, int cfg, void *stream);
+                 const float *residual, const float *residual2, float *out, int N, int Cin, int H, int W,
+                 int Cout, int stride, int act, float post_slope, int pre_act, float pre_slope, int cfg,
+                 void *stream);
 
 /* ConvTranspose2d(k=4, s=2, p=1) as four 2x2 phase convolutions; pixel_shuffle=1 writes
  * PixelShuffle(2) of the result directly (IFNet_HDv3.py:79-82), else plain [Cout,2H,2W]. */
@@ -108,7 +112,8 @@ int drba_deconv4x4_num_cfgs(void);
 size_t drba_deconv4x4_packed_floats(int Cin, int Cout, int cfg);
 int drba_deconv4x4_pack(const float *w /*[Cin,Cout,4,4] host*/, float *packed, int Cin, int Cout, int cfg);
 int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, float *out,
-                     int N, int Cin, int H, int W, int Cout, int pixel_shuffle, int cfg, void *stream);
+                     int N, int Cin, int H, int W, int Cout, int pixel_shuffle, int pre_act, float pre_slope,
+                     int cfg, void *stream);
 
 /* ---- IFNet glue (IFNet_HDv3.py:84-96, :126-177) -------------------------------------------
  * Build one IFBlock's input at 1/scale resolution without materialising the full-resolution
@@ -131,6 +136,60 @@ int drba_ifblock_update(const float *tmp, const float *flow_in, float *flow_out,
  * m = x scale bilinear upsample of mask_lo [h, w] (channel 4 of the last head output). */
 int drba_warp_blend(const float *img0, const float *img1, const float *flow, const float *mask_lo,
                     int h, int w, float scale, float *out, int H, int W, void *stream);
+
+/* ---- GMFSS / GMFSS_UNION glue (models/model_gmfss_union: MetricNet.py, FusionNet.py, GMFSS.py) ---
+ * MetricNet.forward input (MetricNet.py:45-60, geometry.py:87-108), 14 channels at the half-res size:
+ * [img0 3, img1 3, -mean_c|img0 - backwarp0(img1,f01)|, -mean_c|img1 - backwarp0(img0,f10)|,
+ *  f01/((W-1)/2,(H-1)/2), f10/(..), fwd_occ, bwd_occ] with occ = |f + flow_warp(b,f)| > 0.01(|f|+|b|)+0.5 */
+int drba_metric_input(const float *img0, const float *img1, const float *flow01, const float *flow10,
+                      float *out, int H, int W, void *stream);
+/* nn.PixelShuffle(2): in [4C,H,W] -> out [C,2H,2W] (FusionNet.py:41-44) */
+int drba_pixel_shuffle2(const float *in, float *out, int C, int H, int W, void *stream);
+/* GMFSS.py:116-122: out_k = (cover0 < 0.999 || cover1 < 0.999) ? 1 : t_k */
+int drba_timestep_fix(const float *t0, const float *t1, const float *cover0, const float *cover1,
+                      float *out0, float *out1, size_t n, void *stream);
+/* GMFSS.py:125-150: out_x = (t0/t1 > thr) ? y : x; out_y = (t1/t0 > thr) ? x : y; t maps [H,W] broadcast over C */
+int drba_swap_select(const float *x, const float *y, const float *t0, const float *t1, float *out_x,
+                     float *out_y, int C, int H, int W, float thr, void *stream);
+/* torch.clamp(x, lo, hi) (GMFSS.py:155) */
+int drba_clamp(const float *in, float *out, float lo, float hi, size_t n, void *stream);
+
+/* ---- GMFlow operators that are not plain GEMMs (models/gmflow) ---------------------------------
+ * The q/k/v/merge/MLP projections and the QK^T / PV products are plain GEMMs issued by the host through the
+ * vendor BLAS; these entry points are everything around them. */
+/* generic direct convolution, zero padding (backbone.py:46 7x7 s2 stem, :63 / :24 1x1 projections) */
+int drba_conv_direct(const float *in, const float *w /*[Cout,Cin,K,K]*/, const float *bias, float *out,
+                     int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, void *stream);
+/* nn.InstanceNorm2d(eps, no affine) over `planes` = N*C planes of HW elements, optional ReLU (backbone.py:27-36) */
+int drba_instance_norm(const float *in, float *out, int planes, size_t HW, float eps, int relu, void *stream);
+int drba_add_act(const float *a, const float *b, float *out, size_t n, int relu, void *stream); /* a + b [, ReLU] */
+/* utils.py:57-69 normalize_img: (x - mean[c]) / std[c]; mean3/std3 are HOST arrays of 3 floats */
+int drba_channel_normalize3(const float *in, float *out, int N, size_t HW, const float *mean3, const float *std3,
+                            void *stream);
+/* nn.LayerNorm(cols): out = (residual ? residual : 0) + LN(x)*w + b  (transformer.py:178-185) */
+int drba_layernorm(const float *x, const float *w, const float *b, const float *residual, float *out,
+                   size_t rows, int cols, float eps, void *stream);
+int drba_gelu(const float *x, float *out, size_t n, void *stream); /* nn.GELU(), erf form */
+/* in-place row softmax of x/scale + mask[(row/rows_per_mat) % n_masks][row % rows_per_mat] (transformer.py:91-96) */
+int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks,
+                      float scale, void *stream);
+/* fused softmax(scores/scale) . values per row -> out [2, rows].  vals NULL: global-correlation flow
+ * (matching.py:7-38; column j = pixel (j % w, j / w), own coordinate subtracted); else vals [2, cols]
+ * (global flow propagation, transformer.py:355-372) */
+int drba_softmax_expect2(const float *scores, const float *vals, float *out, int rows, int cols, int w,
+                         float scale, void *stream);
+/* matching.py:41-89: local correlation softmax flow, radius r, features NCHW */
+int drba_local_corr_flow(const float *f0, const float *f1, float *out, int C, int H, int W, int radius, void *stream);
+/* transformer.py:374-409: local-window flow propagation; q_tok / k_tok token-major [H*W, C], flow [2,H,W] */
+int drba_local_attn_flow(const float *q_tok, const float *k_tok, const float *flow, float *out, int C, int H,
+                         int W, int radius, void *stream);
+/* gmflow.py:76-89: convex upsampling, mask [9*factor^2, h, w], flow [2,h,w] -> out [2, factor*h, factor*w] */
+int drba_convex_upsample(const float *mask, const float *flow, float *out, int h, int w, int factor, void *stream);
+/* geometry.py:53-84 flow_warp: bilinear, zeros padding */
+int drba_flow_warp(const float *in, const float *flow, float *out, int C, int H, int W, void *stream);
+/* F.interpolate(bilinear, align_corners=True) * mul (gmflow.py:118) */
+int drba_resize_bilinear_ac(const float *in, float *out, int NC, int Hin, int Win, int Hout, int Wout, float mul,
+                            void *stream);
 
 #ifdef __cplusplus
 }

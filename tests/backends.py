@@ -52,3 +52,7 @@ class HipBackend:
 
     def make_rife(self, sd, scale):
         return self._RIFE(weights=sd, scale=scale, device=self.dev)
+
+    def make_gmfss_union(self, sds, scale):
+        from drba_amd.models.gmfss_union import GMFSS_UNION
+        return GMFSS_UNION(weights=sds, scale=scale, device=self.dev)

@@ -208,3 +208,84 @@ def check_rife(hip, ora, golden, scale, size, tol=1e-3):
         # flows carry the hole-fill discontinuity (2*max(H,W) where the ones-splat < 0.999): report outliers
         rows.append((k, d, tol, f"outliers>{tol:g}: {n_out}/{n} vs_fixture={cases.compare_to_fixture(golden, k, g[k]):.2e}"))
     return rows
+
+
+# ----------------------------------------------------------------------------------------- GMFSS_UNION
+def check_gmfss_parts(dev, size=(128, 256)):
+    """FeatureNet / MetricNet / GridNet / GMFlow (and its stages) on the HIP path against the oracle, same seeded
+    weights and inputs.  Returns rows like the other checks."""
+    from drba_amd.models.gmflow.gmflow import GMFlow
+    from drba_amd.models.model_gmfss_union.FeatureNet import FeatureNet
+    from drba_amd.models.model_gmfss_union.FusionNet import GridNet
+    from drba_amd.models.model_gmfss_union.MetricNet import MetricNet
+    from oracle import gmflow as ogm
+    from oracle import gmfss as ogs
+    sds = synth.gmfss_union_state_dicts(seed=0)
+    H, W = size
+    I0, I1 = cases.gmfss_frames(H, W)[:2]
+    h0 = F.interpolate(I0, scale_factor=0.5, mode="bilinear", align_corners=False)
+    h1 = F.interpolate(I1, scale_factor=0.5, mode="bilinear", align_corners=False)
+    rows = []
+
+    def row(name, g, o, tol):
+        rows.append((name, _diff(g, o), tol, f"ref_absmax={float(o.abs().max()):.3g}"))
+
+    with torch.no_grad():
+        # FeatureNet
+        of = ogs.featurenet(sds["feat"], I0)
+        gf = FeatureNet(sds["feat"], dev)(I0.to(dev))
+        for k in range(3):
+            row(f"featurenet level{k}", gf[k], of[k], 2e-5 * max(1.0, float(of[k].abs().max())))
+        # GMFlow stages
+        net = GMFlow(sds["flownet"], dev)
+        x = torch.cat((h0, h1), 0)
+        mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        oe = ogm.encoder(sds["flownet"], (x - mean) / std)
+        from drba_amd import ops
+        ge = net.encoder(ops.channel_normalize3(x.to(dev), (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)))
+        for k in range(2):
+            row(f"gmflow encoder out{k}", ge[k], oe[k], 1e-4 * max(1.0, float(oe[k].abs().max())))
+        for k, splits in ((1, 2), (0, 8)):
+            a, b = oe[k][0:1], oe[k][1:2]
+            oa, ob = ogm.feature_add_position(a, b, splits)
+            ga, gb = net._add_position(a.to(dev).contiguous(), b.to(dev).contiguous(), splits)
+            row(f"gmflow add_position splits{splits}", ga, oa, 1e-5)
+            ot = ogm.feature_transformer(sds["flownet"], oa, ob, splits)
+            gt = net.transformer(oa.to(dev).contiguous(), ob.to(dev).contiguous(), splits)
+            row(f"gmflow transformer splits{splits} f0", gt[0], ot[0], 1e-4 * max(1.0, float(ot[0].abs().max())))
+            row(f"gmflow transformer splits{splits} f1", gt[1], ot[1], 1e-4 * max(1.0, float(ot[1].abs().max())))
+        oflow = ogm.gmflow(sds["flownet"], h0, h1)
+        gflow = net(h0.to(dev), h1.to(dev))
+        row("gmflow flow01", gflow, oflow, 1e-3)
+        oflow_b = ogm.gmflow(sds["flownet"], h1, h0)
+        # MetricNet (on the oracle's flows, so the check isolates the subnet)
+        om = ogs.metricnet(sds["metric"], h0, h1, oflow, oflow_b, True)
+        gm = MetricNet(sds["metric"], dev, tanh10=True)(h0.to(dev), h1.to(dev), oflow.to(dev), oflow_b.to(dev))
+        row("metricnet m0", gm[0], om[0], 1e-4)
+        row("metricnet m1", gm[1], om[1], 1e-4)
+        om2 = ogs.metricnet(sds["metric"], h0, h1, oflow, oflow_b, False)
+        gm2 = MetricNet(sds["metric"], dev, tanh10=False)(h0.to(dev), h1.to(dev), oflow.to(dev), oflow_b.to(dev))
+        row("metricnet (no tanh) m0", gm2[0], om2[0], 1e-4 * max(1.0, float(om2[0].abs().max())))
+        # GridNet on seeded random pyramids
+        hh, hw = H // 2, W // 2
+        xin = cases.rnd((1, 9, hh, hw), 31, 0.5)
+        p1, p2, p3 = cases.rnd((1, 128, hh, hw), 32, 0.5), cases.rnd((1, 256, hh // 2, hw // 2), 33, 0.5), cases.rnd((1, 384, hh // 4, hw // 4), 34, 0.5)
+        og = ogs.gridnet(sds["fusion"], xin, p1, p2, p3)
+        gg = GridNet(sds["fusion"], dev)(xin.to(dev), p1.to(dev), p2.to(dev), p3.to(dev))
+        row("gridnet", gg, og, 1e-4 * max(1.0, float(og.abs().max())))
+    return rows
+
+
+def check_gmfss_union(hip, ora, golden, scale, size, tol=1e-3):
+    sds = synth.gmfss_union_state_dicts(seed=0)
+    H, W = size
+    rows = []
+    with torch.no_grad():
+        g = cases.gmfss_union_run(hip, sds, scale, H, W)
+        o = cases.gmfss_union_run(ora, sds, scale, H, W)
+    for k in o:
+        d = _diff(g[k], o[k])
+        n_out, n = _outliers(g[k], o[k], tol)
+        rows.append((k, d, tol, f"outliers>{tol:g}: {n_out}/{n} vs_fixture={cases.compare_to_fixture(golden, k, g[k]):.2e}"))
+    return rows

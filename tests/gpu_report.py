@@ -31,6 +31,21 @@ def main():
             import traceback
             traceback.print_exc()
             sections.append((f"rife s={scale}", [("EXC", float("inf"), 0.0, repr(e))]))
+    if os.environ.get("DRBA_REPORT_GMFSS", "1") == "1":
+        try:
+            sections.append(("gmfss parts", gpu_checks.check_gmfss_parts(hip.dev)))
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            sections.append(("gmfss parts", [("EXC", float("inf"), 0.0, repr(e))]))
+        gold = np.load(os.path.join(GOLD, "gmfss_union.npz"))
+        for scale, size in cases.GMFSS_CONFIGS:
+            try:
+                sections.append((f"gmfss_union s={scale} {size}", gpu_checks.check_gmfss_union(hip, ora, gold, scale, size)))
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                sections.append((f"gmfss_union s={scale}", [("EXC", float("inf"), 0.0, repr(e))]))
     torch.cuda.synchronize()
     bad = 0
     out = {}

@@ -34,7 +34,7 @@ def test_header_symbols_all_exported_and_bound():
 def test_argument_validation_without_gpu():
     lib = _lib.load()
     assert lib.drba_softsplat(None, None, None, None, None, 1, 1, 4, 4, 1, 0, None) == -1
-    assert lib.drba_conv3x3(None, None, None, None, None, None, 1, 3, 8, 8, 16, 1, 1, 0, None) == -1
+    assert lib.drba_conv3x3(None, None, None, None, None, None, None, 1, 3, 8, 8, 16, 1, 1, 0.0, 0, 0.0, 0, None) == -1
     assert lib.drba_conv3x3_pick_cfg(3, 16, 8, 8, 3) == -2
 
 

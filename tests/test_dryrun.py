@@ -93,3 +93,50 @@ def test_operator_surface_plumbing(dry):
     blk = IFBlock(synth.ifnet_state_dict(0), "block1.", torch.device("cpu"))
     fl, mk, ft = blk(torch.rand(1, 48, 64, 64), torch.rand(1, 4, 64, 64), scale=2)
     assert fl.shape == (1, 4, 64, 64) and mk.shape == (1, 1, 64, 64) and ft.shape == (1, 8, 64, 64)
+
+
+@pytest.mark.parametrize("scale,size", ((1.0, (128, 256)), (0.5, (256, 512))))
+def test_gmfss_union_pipeline_plumbing(dry, monkeypatch, scale, size):
+    """GMFSS_UNION + GMFlow + GridNet plumbing: argument lists, shapes, window bookkeeping (no arithmetic)."""
+    from drba_amd.models import gmfss_union as gu
+    from drba_amd.models.model_gmfss_union.GMFSS import Model
+    from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
+    sds = synth.gmfss_union_state_dicts(0)
+    cpu = torch.device("cpu")
+    m = gu.GMFSS_UNION.__new__(gu.GMFSS_UNION)
+    m.model = Model(union=True)
+    m.model.load_state_dicts(sds["flownet"], sds["metric"], sds["feat"], sds["fusion"], cpu)
+    m.ifnet = IFNet().to(cpu).eval()
+    m.ifnet.load_state_dict(sds["rife"])
+    m.scale, m.pad_size = scale, 128
+    m.scale_list = [16 / scale, 8 / scale, 4 / scale, 2 / scale, 1 / scale]
+    H, W = size
+    I = [torch.rand(1, 3, H, W) for _ in range(3)]
+    out, reuse = m.inference_ts_drba(I[0], I[1], I[2], np.array([0.75, 1.0, 1.25]), None, True)
+    assert out[1] is I[1] and out[0].shape == (1, 3, H, W) and out[2].shape == (1, 3, H, W)
+    assert reuse[0].shape == (1, 2, H // 2, W // 2) and reuse[2].shape == (1, 1, H // 2, W // 2)
+    assert [f.shape[1:] for f in reuse[4]] == [(64, H // 2, W // 2), (128, H // 4, W // 4), (192, H // 8, W // 8)]
+    out2, _ = m.inference_ts_drba(I[0], I[1], I[2], np.array([1.4]), reuse, False)
+    assert out2[0].shape == (1, 3, H, W)
+    r = m.inference_ts(I[0], I[1], np.array([0.0, 0.5, 1.0]))
+    assert r[0] is I[0] and r[2] is I[1] and r[1].shape == (1, 3, H, W)
+    for k in ("drba_conv_direct", "drba_instance_norm", "drba_layernorm", "drba_gelu", "drba_softmax_rows",
+              "drba_softmax_expect2", "drba_local_corr_flow", "drba_local_attn_flow", "drba_convex_upsample",
+              "drba_flow_warp", "drba_resize_bilinear_ac", "drba_metric_input", "drba_pixel_shuffle2",
+              "drba_timestep_fix", "drba_swap_select", "drba_clamp", "drba_channel_normalize3", "drba_add_act"):
+        assert dry.calls.get(k, 0) > 0, k
+
+
+def test_gmfss_pipeline_plumbing(dry):
+    from drba_amd.models import gmfss as g
+    from drba_amd.models.model_gmfss_union.GMFSS import Model
+    sds = synth.gmfss_union_state_dicts(0)
+    fusion = synth.seeded_state_dict(synth.gridnet_shapes(12, "head"), 0, "grid.")
+    m = g.GMFSS.__new__(g.GMFSS)
+    m.model = Model(union=False)
+    m.model.load_state_dicts(sds["flownet"], sds["metric"], sds["feat"], fusion, torch.device("cpu"))
+    m.scale, m.pad_size = 1.0, 64
+    I = [torch.rand(1, 3, 128, 256) for _ in range(3)]
+    out, reuse = m.inference_ts_drba(I[0], I[1], I[2], np.array([0.75, 1.25]), None, True)
+    assert out[0].shape == (1, 3, 128, 256) and len(reuse) == 6
+    assert m.inference_ts(I[0], I[1], np.array([0.5]))[0].shape == (1, 3, 128, 256)
