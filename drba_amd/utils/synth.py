@@ -198,6 +198,11 @@ def seeded_state_dict(shapes, seed=0, tag=""):
             t = torch.randn(shape, generator=g) * 0.02
         elif len(shape) == 1:  # LayerNorm weight
             t = 1.0 + torch.randn(shape, generator=g) * 0.05
+            if key.startswith("transformer."):
+                # damped attention / FFN messages keep the matching features close to the CNN features, so the
+                # correlation softmax is peaked as in a trained network; with unit gains the random transformer
+                # makes it diffuse and a 1-ulp input change moves the reference's own flow by > 1e-2
+                t = t * 0.1
         else:
             if len(shape) == 4 and shape[2] == 4:  # ConvTranspose2d [Cin, Cout, 4, 4]: 2x2 taps per output
                 fan_in = shape[0] * 4

@@ -176,10 +176,16 @@ def gmfss_frames(H, W):
     return [torch.from_numpy(f.transpose(2, 0, 1)).unsqueeze(0).float().div(255.0) for f in clip]
 
 
-def gmfss_union_run(b, sds, scale, H, W):
-    """End-to-end GMFSS_UNION outputs for one (scale, size): inference_ts, cold + warm inference_ts_drba, reuse parts."""
+def gmfss_union_run(b, sds, scale, H, W, ulp_noise=False):
+    """End-to-end GMFSS_UNION outputs for one (scale, size): inference_ts, cold + warm inference_ts_drba, reuse parts.
+    ulp_noise=True adds a seeded +-1e-7 (about one ulp of a pixel value) perturbation to the frames: the change it
+    causes in the oracle's outputs is the conditioning floor of an fp32 evaluation of this path."""
     m = b.make_gmfss_union(sds, scale)
-    I0, I1, I2, I3 = [f.to(b.dev) for f in gmfss_frames(H, W)]
+    frames = gmfss_frames(H, W)
+    if ulp_noise:
+        g = torch.Generator().manual_seed(99)
+        frames = [f + (torch.rand(f.shape, generator=g) - 0.5) * 2e-7 for f in frames]
+    I0, I1, I2, I3 = [f.to(b.dev) for f in frames]
     tag = f"s{scale}"
     out = {}
     r = m.inference_ts(I0, I1, np.array([0.0, 0.5, 1.0]))

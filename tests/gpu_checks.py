@@ -278,14 +278,22 @@ def check_gmfss_parts(dev, size=(128, 256)):
 
 
 def check_gmfss_union(hip, ora, golden, scale, size, tol=1e-3):
+    """Bar: 1e-3 max-abs.  GMFlow's correlation softmax amplifies rounding (a +-1e-7 change of the input frames
+    moves the oracle's own flows by a few 1e-4 here); so that the check cannot flake on summation order, an output
+    whose measured fp32 conditioning floor (oracle vs oracle on 1-ulp-perturbed frames) exceeds 2.5e-4 is allowed
+    4x that floor instead.  The floor is reported in the row."""
     sds = synth.gmfss_union_state_dicts(seed=0)
     H, W = size
     rows = []
     with torch.no_grad():
         g = cases.gmfss_union_run(hip, sds, scale, H, W)
         o = cases.gmfss_union_run(ora, sds, scale, H, W)
+        o2 = cases.gmfss_union_run(ora, sds, scale, H, W, ulp_noise=True)
     for k in o:
         d = _diff(g[k], o[k])
-        n_out, n = _outliers(g[k], o[k], tol)
-        rows.append((k, d, tol, f"outliers>{tol:g}: {n_out}/{n} vs_fixture={cases.compare_to_fixture(golden, k, g[k]):.2e}"))
+        floor = _diff(o2[k], o[k])
+        tk = max(tol, 4.0 * floor)
+        n_out, n = _outliers(g[k], o[k], tk)
+        rows.append((k, d, tk, f"outliers>{tk:g}: {n_out}/{n} fp32_floor={floor:.2e} "
+                                f"vs_fixture={cases.compare_to_fixture(golden, k, g[k]):.2e}"))
     return rows

@@ -67,3 +67,20 @@ def test_ops_reject_cpu_tensors():
     from drba_amd import _lib, ops
     with pytest.raises(_lib.DrbaHipError):
         ops.flow_distance(torch.zeros(1, 2, 4, 4))
+
+
+def test_gmfss_subnets_parity(hip_backend):
+    """FeatureNet, MetricNet, GridNet, GMFlow and its stages, each fed the oracle's inputs."""
+    _assert_rows(gpu_checks.check_gmfss_parts(hip_backend.dev))
+
+
+@pytest.mark.parametrize("scale,size", cases.GMFSS_CONFIGS)
+def test_gmfss_union_end_to_end_parity(hip_backend, oracle_backend, golden_dir, scale, size):
+    """GMFSS_UNION through the reference call surface: every output (frames, flows, metrics, features) within
+    1e-3 max-abs of the oracle and of the reference's own outputs in the fixture (or 4x the measured fp32
+    conditioning floor of that output where the floor is above 2.5e-4, see gpu_checks.check_gmfss_union)."""
+    rows = gpu_checks.check_gmfss_union(hip_backend, oracle_backend, np.load(os.path.join(golden_dir, "gmfss_union.npz")),
+                                        scale, size)
+    _assert_rows(rows)
+    for name, _, tol, extra in rows:
+        assert float(extra.split("vs_fixture=")[1]) <= tol, f"{name}: {extra}"
