@@ -27,6 +27,9 @@ class OracleBackend:
     def make_gmfss_union(self, sds, scale):
         return self._o.gmfss.GmfssUnionOracle(sds["flownet"], sds["metric"], sds["feat"], sds["fusion"], sds["rife"], scale)
 
+    def make_gmfss(self, sds, scale):
+        return self._o.gmfss.GmfssOracle(sds["flownet"], sds["metric"], sds["feat"], sds["fusion"], scale)
+
 
 class HipBackend:
     """The product: drba_amd's reference-named call surface running on the HIP library."""
@@ -56,3 +59,7 @@ class HipBackend:
     def make_gmfss_union(self, sds, scale):
         from drba_amd.models.gmfss_union import GMFSS_UNION
         return GMFSS_UNION(weights=sds, scale=scale, device=self.dev)
+
+    def make_gmfss(self, sds, scale):
+        from drba_amd.models.gmfss import GMFSS
+        return GMFSS(weights=sds, scale=scale, device=self.dev)

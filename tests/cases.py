@@ -209,6 +209,30 @@ def gmfss_union_run(b, sds, scale, H, W, ulp_noise=False):
     return out
 
 
+def gmfss_state_dicts(seed=0):
+    """Non-union GMFSS: same GMFlow / MetricNet (no tanh) / FeatureNet weights, GridNet with 12 input channels."""
+    sds = synth.gmfss_union_state_dicts(seed)
+    return {"flownet": sds["flownet"], "metric": sds["metric"], "feat": sds["feat"],
+            "fusion": synth.seeded_state_dict(synth.gridnet_shapes(12, "head"), seed, "grid12.")}
+
+
+def gmfss_run(b, sds, scale, H, W):
+    """End-to-end GMFSS (models/gmfss.py) outputs: inference_ts, cold + warm inference_ts_drba."""
+    m = b.make_gmfss(sds, scale)
+    I0, I1, I2, I3 = [f.to(b.dev) for f in gmfss_frames(H, W)]
+    out = {}
+    r = m.inference_ts(I0, I1, np.array([0.0, 0.4, 1.0]))
+    assert r[0] is I0 and r[2] is I1
+    out["ts"] = r[1]
+    ts = np.array([0.75, 1.25])
+    r, reuse = m.inference_ts_drba(I0, I1, I2, ts, None, True)
+    out["drba_cold_0"], out["drba_cold_1"] = r
+    out["reuse_metric2"] = reuse[2]
+    r2, _ = m.inference_ts_drba(I1, I2, I3, ts, reuse, False)
+    out["drba_warm_nl_0"], out["drba_warm_nl_1"] = r2
+    return out
+
+
 # ------------------------------------------------------------------------------------------ fixture packing
 MAX_FULL = 1 << 15
 

@@ -49,6 +49,7 @@ from models.model_gmfss_union.FeatureNet import FeatureNet as RefFeatureNet  # n
 from models.model_gmfss_union.FusionNet import GridNet as RefGridNet  # noqa: E402
 import models.model_gmfss_union.GMFSS as ref_union_model  # noqa: E402
 import models.gmfss_union as ref_gmfss_union  # noqa: E402
+import models.gmfss as ref_gmfss  # noqa: E402
 
 sys.path.append(ROOT)
 import oracle  # noqa: E402  (repo)
@@ -125,7 +126,26 @@ class _RefGmfssUnion:
         return self._drba(self.m, I0, I1, I2, ts, reuse, linear)
 
 
+class _RefGmfss:
+    """The reference GMFSS (non-union) evaluated in fp32 (decorators stripped)."""
+
+    def __init__(self, sds, scale):
+        d = tempfile.mkdtemp()
+        for key, fn in (("flownet", "flownet"), ("metric", "metric"), ("feat", "feat"), ("fusion", "fusionnet")):
+            torch.save(sds[key], os.path.join(d, fn + ".pkl"))
+        self.m = ref_gmfss.GMFSS(weights=d, scale=scale, device=torch.device("cpu"))
+        self._ts = ref_gmfss.GMFSS.inference_ts.__wrapped__.__wrapped__
+        self._drba = ref_gmfss.GMFSS.inference_ts_drba.__wrapped__.__wrapped__
+
+    def inference_ts(self, I0, I1, ts):
+        return self._ts(self.m, I0, I1, ts)
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False):
+        return self._drba(self.m, I0, I1, I2, ts, reuse, linear)
+
+
 ReferenceBackend.make_gmfss_union = staticmethod(_RefGmfssUnion)
+ReferenceBackend.make_gmfss = staticmethod(_RefGmfss)
 REFB, ORAB = ReferenceBackend(), OracleBackend()
 
 
@@ -383,7 +403,23 @@ def golden_schedule():
     print("wrote schedule.json", os.path.getsize(os.path.join(HERE, "schedule.json")) // 1024, "KiB")
 
 
+def golden_gmfss_plain():
+    """models/gmfss.py (non-union): 128x256, scale 1."""
+    sds = cases.gmfss_state_dicts(seed=0)
+    H, W = 128, 256
+    with torch.inference_mode():
+        r = cases.gmfss_run(REFB, sds, 1.0, H, W)
+        o = cases.gmfss_run(ORAB, sds, 1.0, H, W)
+    assert list(r) == list(o)
+    out = {}
+    for k in r:
+        same(o[k], r[k], k)
+        out[k] = cases.pack(r[k])
+    out["_meta"] = {"weights_sum": np.float64(sum(v.double().sum() for d in sds.values() for v in d.values()))}
+    save("gmfss.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "drm", "scdet", "schedule", "rife", "gmfss"]
+    which = sys.argv[1:] or ["ops", "drm", "scdet", "schedule", "rife", "gmfss", "gmfss_plain"]
     for w in which:
         globals()["golden_" + w]()

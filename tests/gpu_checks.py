@@ -297,3 +297,14 @@ def check_gmfss_union(hip, ora, golden, scale, size, tol=1e-3):
         rows.append((k, d, tk, f"outliers>{tk:g}: {n_out}/{n} fp32_floor={floor:.2e} "
                                 f"vs_fixture={cases.compare_to_fixture(golden, k, g[k]):.2e}"))
     return rows
+
+
+def check_gmfss_plain(hip, ora, golden, tol=1e-3):
+    sds = cases.gmfss_state_dicts(seed=0)
+    rows = []
+    with torch.no_grad():
+        g = cases.gmfss_run(hip, sds, 1.0, 128, 256)
+        o = cases.gmfss_run(ora, sds, 1.0, 128, 256)
+    for k in o:
+        rows.append((k, _diff(g[k], o[k]), tol, f"vs_fixture={cases.compare_to_fixture(golden, k, g[k]):.2e}"))
+    return rows

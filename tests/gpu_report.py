@@ -46,6 +46,12 @@ def main():
                 import traceback
                 traceback.print_exc()
                 sections.append((f"gmfss_union s={scale}", [("EXC", float("inf"), 0.0, repr(e))]))
+        try:
+            sections.append(("gmfss (non-union)", gpu_checks.check_gmfss_plain(hip, ora, np.load(os.path.join(GOLD, "gmfss.npz")))))
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            sections.append(("gmfss (non-union)", [("EXC", float("inf"), 0.0, repr(e))]))
     torch.cuda.synchronize()
     bad = 0
     out = {}

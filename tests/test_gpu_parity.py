@@ -84,3 +84,10 @@ def test_gmfss_union_end_to_end_parity(hip_backend, oracle_backend, golden_dir, 
     _assert_rows(rows)
     for name, _, tol, extra in rows:
         assert float(extra.split("vs_fixture=")[1]) <= tol, f"{name}: {extra}"
+
+
+def test_gmfss_plain_end_to_end_parity(hip_backend, oracle_backend, golden_dir):
+    rows = gpu_checks.check_gmfss_plain(hip_backend, oracle_backend, np.load(os.path.join(golden_dir, "gmfss.npz")))
+    _assert_rows(rows)
+    for name, _, tol, extra in rows:
+        assert float(extra.split("vs_fixture=")[1]) <= tol, f"{name}: {extra}"

@@ -103,3 +103,15 @@ def test_gmfss_subnet_pins(golden_dir):
         g = torch.Generator().manual_seed(9)
         gx = [torch.randn(1, c, 128 // s, 256 // s, generator=g) for c, s in ((9, 2), (128, 2), (256, 4), (384, 8))]
         assert cases.compare_to_fixture(z, "gridnet", oracle.gmfss.gridnet(sds["fusion"], *gx)) < 5e-5
+
+
+def test_gmfss_plain_end_to_end_against_reference_fixture(oracle_backend, golden_dir):
+    """models/gmfss.py (no auxiliary RIFE frame, no swap masks, MetricNet without tanh): oracle vs reference outputs."""
+    z = np.load(os.path.join(golden_dir, "gmfss.npz"))
+    sds = cases.gmfss_state_dicts(seed=0)
+    assert abs(sum(float(v.double().sum()) for d in sds.values() for v in d.values()) - float(z["_meta/weights_sum"])) < 1e-5
+    with torch.no_grad():
+        out = cases.gmfss_run(oracle_backend, sds, 1.0, 128, 256)
+    for k, t in out.items():
+        d = cases.compare_to_fixture(z, k, t)
+        assert d <= 2e-4, f"{k}: {d}"
