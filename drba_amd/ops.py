@@ -84,8 +84,8 @@ def softsplat(tenIn, tenFlow, tenMetric, strMode):
     m = None if tenMetric is None else _f32(tenMetric, "tenMetric")
     n, c, h, w = x.shape
     out = torch.empty_like(x)
-    ws = _workspace(x.device, n * h * w * (c + 1))
     lib = _lib.load()
+    ws = _workspace(x.device, lib.drba_softsplat_ws_floats(n, c, h, w))
     _lib.check(lib.drba_softsplat(_p(x), _p(f), _p(m), _p(out), _p(ws), n, c, h, w, _MODES[main], _EPS.get(sub, 0),
                                   _stream()), "drba_softsplat")
     return out

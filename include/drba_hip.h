@@ -34,7 +34,7 @@ const char *drba_error_string(int code);
  * replaces: models/softsplat/softsplat.py:248-293 (softsplat) + :306-367 (kernel softsplat_out)
  *           == models/softsplat/softsplat_torch.py:19-179.
  * mode: 0 sum, 1 avg, 2 linear, 3 soft.  eps: 0 addeps(+1e-7, default), 1 zeroeps, 2 clipeps.
- * metric: [N,1,H,W] or NULL (required for linear/soft).  ws: N*H*W*(C+1) floats. */
+ * metric: [N,1,H,W] or NULL (required for linear/soft).  ws: drba_softsplat_ws_floats(N,C,H,W) floats. */
 int drba_softsplat(const float *in, const float *flow, const float *metric, float *out, float *ws,
                    int N, int C, int H, int W, int mode, int eps, void *stream);
 size_t drba_softsplat_ws_floats(int N, int C, int H, int W);

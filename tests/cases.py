@@ -31,6 +31,10 @@ def ops_inputs():
         "flow_big": rnd((1, 2, H, W), 4, 30.0),  # mostly out of bounds: border clamp / dropped corners
         "metric": rnd((1, 1, H, W), 5, 2.0),
     }
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    # zoom-out by 4 about the centre: ~25 sources land on every output pixel near the centre (list overflow path of
+    # the gather splat); the outer columns exceed the 16-pixel tile halo (long-flow path)
+    d["flow_converge"] = torch.stack([-0.75 * (xs - W / 2 + 0.3), -0.75 * (ys - H / 2 + 0.2)]).unsqueeze(0).contiguous()
     fn = d["flow"].clone()
     fn[0, 0, 5, 7] = float("nan")
     fn[0, 1, 9, 11] = float("inf")
@@ -71,6 +75,12 @@ def ops_cases():
         ("splat_soft_zeroeps", splat("x3", "flow_big", "metric", "soft-zeroeps")),
         ("splat_soft_clipeps", splat("x3", "flow_big", "metric", "soft-clipeps")),
         ("splat_avg_addeps", splat("x3", "flow", None, "avg-addeps")),
+        ("splat_soft16_big", splat("x16", "flow_big", "metric", "soft")),
+        ("splat_soft16_nan", splat("x16", "flow_nan", "metric", "soft")),
+        ("splat_soft16_converge", splat("x16", "flow_converge", "metric", "soft")),
+        ("splat_sum16_converge", splat("x16", "flow_converge", None, "sum")),
+        ("splat_linear16_zeroeps", splat("x16", "flow_big", "metric", "linear-zeroeps", mabs=True)),
+        ("splat_avg3_converge", splat("x3", "flow_converge", None, "avg")),
         ("distance", lambda b: b.distance(*on(b, "flow"))),
         ("resize_up", lambda b: b.resize(on(b, "x3")[0], (64, 96))),
         ("resize_down", lambda b: b.resize(on(b, "x3")[0], (30, 50))),
