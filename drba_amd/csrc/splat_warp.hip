@@ -1,7 +1,8 @@
 // Forward splat (softsplat), backward warp, flow distance and the fused RIFE/DRM splat
-// pipelines.  All HBM-bound.  The splats are LDS-tiled: a workgroup owns an output tile, gathers
-// the contributions of the source pixels around it with ds_add_f32 and stores the normalised
-// result; only sources with flows longer than the tile halo use global fp32 atomics.
+// pipelines.  All HBM-bound.  The generic splat is a counting sort by target pixel followed by a
+// gather (no float atomics); the fused 1-2 channel RIFE splats are LDS-tiled: a workgroup owns an
+// output tile, accumulates the source pixels around it with ds_add_f32 and stores the normalised
+// result, and only flows longer than the tile halo use global fp32 atomics.
 #include "common.hpp"
 
 using namespace drba;
@@ -222,180 +223,6 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
 
 
 // ------------------------------------------------------------------------------------------
-// Generic softsplat (softsplat.py:248-367 == softsplat_torch.py:19-179; mode 0 sum, 1 avg, 2 linear, 3 soft),
-// LDS-tiled with the same ownership scheme as splat_tiled above, any channel count:
-// a workgroup owns a kTX x kTY tile of the OUTPUT and a group of SG channels (+ the normaliser), visits the source
-// pixels within kR of the tile, accumulates the corners that land inside with ds_add_f32 and writes the normalised
-// result with plain stores -- no global atomics, no zero-fill and no separate normalise pass for short flows.
-// Sources whose flow is longer than kR (rare in real footage) go through global atomics into a planar `gacc`
-// [C+1][P]; a device-side flag keeps that path (zero-fill, scatter, read-back) dormant when there are none.
-constexpr int SG = 6;  // data channels per workgroup: (SG+1) * 8 KB of LDS -> two workgroups per CU
-
-__device__ __forceinline__ bool flow_is_short(float fx, float fy) {
-  return fx >= -(float)kR && fx < (float)(kR - 1) && fy >= -(float)kR && fy < (float)(kR - 1);
-}
-
-__global__ void __launch_bounds__(256) softsplat_long_flag(const float *__restrict__ flow, int *__restrict__ flag, size_t P,
-                                                           int N) {
-  bool any = false;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P * N; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t n = i / P, p = i - n * P;
-    const float fx = flow[n * 2 * P + p], fy = flow[n * 2 * P + P + p];
-    any |= isfinite(fx) && isfinite(fy) && !flow_is_short(fx, fy);
-  }
-  if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-}
-
-__global__ void __launch_bounds__(256) softsplat_long_zero(float *__restrict__ gacc, const int *__restrict__ flag, size_t n) {
-  if (*flag == 0) return;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) gacc[i] = 0.f;
-}
-
-__global__ void __launch_bounds__(256) softsplat_long_scatter(const float *__restrict__ in, const float *__restrict__ flow,
-                                                              const float *__restrict__ metric, float *__restrict__ gacc,
-                                                              const int *__restrict__ flag, int C, int H, int W, int mode) {
-  if (*flag == 0) return;
-  const int n = blockIdx.y;
-  const size_t P = (size_t)H * W;
-  const int CP = (mode == 0) ? C : C + 1;
-  in += (size_t)n * C * P;
-  flow += (size_t)n * 2 * P;
-  if (metric) metric += (size_t)n * P;
-  gacc += (size_t)n * P * CP;
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
-    const float fx_ = flow[p], fy_ = flow[P + p];
-    if (flow_is_short(fx_, fy_)) continue;
-    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
-    const float X = (float)x + fx_, Y = (float)y + fy_;
-    if (!(isfinite(X) && isfinite(Y))) continue;
-    const float fx = floorf(X), fy = floorf(Y);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const float wx0 = (fx + 1.f) - X, wx1 = X - fx, wy0 = (fy + 1.f) - Y, wy1 = Y - fy;
-    const float wgt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
-    float m = 1.f;
-    if (mode == 2) m = metric[p];
-    if (mode == 3) m = expf(metric[p]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
-      if (cx < 0 || cx >= W || cy < 0 || cy >= H) continue;
-      float *d = gacc + (size_t)cy * W + cx;
-      for (int c = 0; c < C; ++c) {
-        const float v = (mode >= 2) ? in[(size_t)c * P + p] * m : in[(size_t)c * P + p];
-        atomic_add_f32(d + (size_t)c * P, v * wgt[k]);
-      }
-      if (mode != 0) atomic_add_f32(d + (size_t)C * P, m * wgt[k]);
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256, 2)
-softsplat_tiled(const float *__restrict__ in, const float *__restrict__ flow, const float *__restrict__ metric,
-                const float *__restrict__ gacc, const int *__restrict__ flag, float *__restrict__ out, int C, int H, int W,
-                int mode, int eps, int groups) {
-  __shared__ float acc[SG + 1][kTY * kTX];
-  const int n = blockIdx.z / groups, grp = blockIdx.z - n * groups;
-  const int c0 = grp * SG, gc = min(SG, C - c0);
-  const size_t P = (size_t)H * W;
-  const int CP = (mode == 0) ? C : C + 1;
-  in += ((size_t)n * C + c0) * P;
-  flow += (size_t)n * 2 * P;
-  if (metric) metric += (size_t)n * P;
-  gacc += (size_t)n * P * CP;
-  out += ((size_t)n * C + c0) * P;
-  const int tx0 = blockIdx.x * kTX, ty0 = blockIdx.y * kTY;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < (SG + 1) * kTY * kTX; i += 256) (&acc[0][0])[i] = 0.f;
-  __syncthreads();
-  // The window scan is latency-bound (flow -> metric/values -> ds_add), so U window pixels per lane are processed
-  // together with their loads issued back to back: U*2 flow loads, then U*(SG+1) value loads in flight per lane.
-  constexpr int SW = kTX + 2 * kR, SH = kTY + 2 * kR, U = 8;
-  static_assert((SW * SH) % (256 * U) == 0, "window must split evenly");
-  for (int e0 = tid; e0 < SW * SH; e0 += 256 * U) {
-    size_t p[U];
-    int xs[U], ys[U];
-    float fx_[U], fy_[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = e0 + u * 256;
-      const int ry = e / SW, rx = e - ry * SW;
-      ys[u] = ty0 - kR + ry;
-      xs[u] = tx0 - kR + rx;
-      const bool inb = xs[u] >= 0 && xs[u] < W && ys[u] >= 0 && ys[u] < H;
-      p[u] = inb ? (size_t)ys[u] * W + xs[u] : 0;
-      fx_[u] = flow[p[u]];
-      fy_[u] = flow[P + p[u]];
-      if (!inb) fx_[u] = __builtin_nanf("");
-    }
-    int li[U][4];
-    float wgt[U][4];
-    bool land[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      land[u] = flow_is_short(fx_[u], fy_[u]);  // false for NaN (and for window pixels outside the image)
-      const float X = (float)xs[u] + fx_[u], Y = (float)ys[u] + fy_[u];
-      const float fxf = floorf(X), fyf = floorf(Y);
-      const int lx0 = land[u] ? (int)fxf - tx0 : -8, ly0 = land[u] ? (int)fyf - ty0 : -8;
-      land[u] = land[u] && !(lx0 < -1 || lx0 >= kTX || ly0 < -1 || ly0 >= kTY);  // some corner inside this tile
-      const float wx0 = (fxf + 1.f) - X, wx1 = X - fxf, wy0 = (fyf + 1.f) - Y, wy1 = Y - fyf;
-      wgt[u][0] = wx0 * wy0;
-      wgt[u][1] = wx1 * wy0;
-      wgt[u][2] = wx0 * wy1;
-      wgt[u][3] = wx1 * wy1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int lx = lx0 + (k & 1), ly = ly0 + (k >> 1);
-        const bool ok = land[u] && lx >= 0 && lx < kTX && ly >= 0 && ly < kTY && tx0 + lx < W && ty0 + ly < H;
-        li[u][k] = ok ? ly * kTX + lx : -1;
-      }
-    }
-    float m[U], v[U][SG];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      m[u] = 1.f;
-      if (land[u]) {
-        if (mode >= 2) m[u] = metric[p[u]];
-#pragma unroll
-        for (int c = 0; c < SG; ++c) v[u][c] = c < gc ? in[(size_t)c * P + p[u]] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!land[u]) continue;
-      if (mode == 3) m[u] = expf(m[u]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (li[u][k] < 0) continue;
-#pragma unroll
-        for (int c = 0; c < SG; ++c)
-          if (c < gc) atomicAdd(&acc[c][li[u][k]], (mode >= 2 ? v[u][c] * m[u] : v[u][c]) * wgt[u][k]);
-        if (mode != 0) atomicAdd(&acc[SG][li[u][k]], m[u] * wgt[u][k]);
-      }
-    }
-  }
-  __syncthreads();
-  const bool has_long = *flag != 0;
-  for (int i = tid; i < kTY * kTX; i += 256) {
-    const int ly = i / kTX, lx = i - ly * kTX;
-    const int y = ty0 + ly, x = tx0 + lx;
-    if (x >= W || y >= H) continue;
-    const size_t p = (size_t)y * W + x;
-    float nrm = 1.f;
-    if (mode != 0) {
-      nrm = acc[SG][i] + (has_long ? gacc[(size_t)C * P + p] : 0.f);
-      if (eps == 0) nrm = nrm + 0.0000001f;
-      else if (eps == 1) nrm = (nrm == 0.f) ? 1.f : nrm;
-      else nrm = fmaxf(nrm, 0.0000001f) + (nrm != nrm ? nrm : 0.f);  // clip(min=1e-7); NaN stays NaN
-    }
-    for (int c = 0; c < gc; ++c) {
-      const float a = acc[c][i] + (has_long ? gacc[(size_t)(c0 + c) * P + p] : 0.f);
-      out[(size_t)c * P + p] = mode == 0 ? a : a / nrm;
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------
 // Generic softsplat for many channels (C >= gather_min_c()): sort once, gather per channel -- no float atomics.
 // ds_add_f32 sustains only ~0.25 lane-adds per clock per CU (measured: run time ~ number of adds) and L2 float
 // atomics far less, so with 4*(C+1) adds per source pixel the kernels above are add-bound for the 64..192-channel
@@ -405,14 +232,6 @@ softsplat_tiled(const float *__restrict__ in, const float *__restrict__ flow, co
 // plain coalesced loads and stores, cost independent of the flow length, no halo limit, no overflow case.
 // Keys live on a (W+1) x (H+1) grid because a footprint may start one pixel outside the image.
 constexpr int kChunk = 16, kScanPerBlock = 4096;
-// channel count from which the sorted gather beats the LDS-atomic tiles (DRBA_SPLAT_GATHER_MIN_C overrides, for A/B runs)
-static int gather_min_c() {
-  static const int v = [] {
-    const char *e = getenv("DRBA_SPLAT_GATHER_MIN_C");
-    return e ? atoi(e) : 3;
-  }();
-  return v;
-}
 
 struct __attribute__((aligned(16))) SplatRec {
   int src;      // source pixel index within the image
@@ -645,11 +464,9 @@ extern "C" {
 static size_t sort_keys(int N, int H, int W) { return (size_t)N * (H + 1) * (W + 1); }
 
 size_t drba_softsplat_ws_floats(int N, int C, int H, int W) {
-  if (C >= gather_min_c()) {  // [cnt: L][start: L + 1][block sums][rec: 4 * N*P]
-    const size_t L = sort_keys(N, H, W);
-    return 2 * L + 8 + (L + kScanPerBlock - 1) / kScanPerBlock + 8 + 4 * (size_t)N * H * W;
-  }
-  return (size_t)N * H * W * (C + 1) + 64;  // [flag][gacc]
+  (void)C;  // [cnt: L][start: L + 1][block sums][rec: 4 * N*P]
+  const size_t L = sort_keys(N, H, W);
+  return 2 * L + 8 + (L + kScanPerBlock - 1) / kScanPerBlock + 8 + 4 * (size_t)N * H * W;
 }
 
 int drba_softsplat(const float *in, const float *flow, const float *metric, float *out, float *ws, int N, int C,
@@ -657,39 +474,24 @@ int drba_softsplat(const float *in, const float *flow, const float *metric, floa
   if (!in || !flow || !out || !ws || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   if (mode < 0 || mode > 3 || eps < 0 || eps > 2) return DRBA_EINVAL;
   if (mode >= 2 && !metric) return DRBA_EINVAL;
-  if ((size_t)N * H * W >= (1u << 31)) return DRBA_EINVAL;
+  if ((size_t)N * (H + 1) * (W + 1) >= (1u << 31)) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
-  if (C >= gather_min_c()) {
-    const size_t L = sort_keys(N, H, W);
-    const int nb = (int)((L + kScanPerBlock - 1) / kScanPerBlock);
-    int *cnt = (int *)ws;
-    int *start = cnt + L;                                // L + 1 entries
-    int *bsum = start + ((L + 1 + 3) & ~(size_t)3);      // nb entries
-    SplatRec *rec = (SplatRec *)(((uintptr_t)(bsum + nb) + 15) & ~(uintptr_t)15);
-    if (hipMemsetAsync(cnt, 0, L * sizeof(int), s) != hipSuccess) return DRBA_ELAUNCH;
-    hipLaunchKernelGGL(splat_sort_count, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, cnt, H, W);
-    hipLaunchKernelGGL(scan_block, dim3(nb), dim3(kBlock), 0, s, cnt, start, bsum, L);
-    hipLaunchKernelGGL(scan_sums, dim3(1), dim3(kBlock), 0, s, bsum, nb, start + L);
-    hipLaunchKernelGGL(scan_add, dim3((unsigned)((L + 255) / 256)), dim3(kBlock), 0, s, start, bsum, L);
-    hipLaunchKernelGGL(splat_sort_fill, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, metric, start, cnt, rec, H, W, mode);
-    const int chunks = (C + kChunk - 1) / kChunk;
-    hipLaunchKernelGGL(splat_sorted_gather, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, in, start, rec, out, C, H,
-                       W, mode, eps, chunks);
-    DRBA_CHECK_LAUNCH();
-    return DRBA_OK;
-  }
-  const int CP = mode == 0 ? C : C + 1;
-  int *flag = (int *)ws;  // ws = [64 floats: long-flow flag][gacc: N * CP * P]
-  float *gacc = ws + 64;
-  if (hipMemsetAsync(flag, 0, 64 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
-  hipLaunchKernelGGL(softsplat_long_flag, dim3(grid_for(P * N)), dim3(kBlock), 0, s, flow, flag, P, N);
-  hipLaunchKernelGGL(softsplat_long_zero, dim3(grid_for((size_t)N * P * CP)), dim3(kBlock), 0, s, gacc, flag, (size_t)N * P * CP);
-  hipLaunchKernelGGL(softsplat_long_scatter, dim3(grid_for(P), N), dim3(kBlock), 0, s, in, flow, metric, gacc, flag, C, H, W,
-                     mode);
-  const int groups = (C + SG - 1) / SG;
-  dim3 g((W + kTX - 1) / kTX, (H + kTY - 1) / kTY, N * groups);
-  hipLaunchKernelGGL(softsplat_tiled, g, dim3(kBlock), 0, s, in, flow, metric, gacc, flag, out, C, H, W, mode, eps, groups);
+  const size_t L = sort_keys(N, H, W);
+  const int nb = (int)((L + kScanPerBlock - 1) / kScanPerBlock);
+  int *cnt = (int *)ws;
+  int *start = cnt + L;                                // L + 1 entries
+  int *bsum = start + ((L + 1 + 3) & ~(size_t)3);      // nb entries
+  SplatRec *rec = (SplatRec *)(((uintptr_t)(bsum + nb) + 15) & ~(uintptr_t)15);
+  if (hipMemsetAsync(cnt, 0, L * sizeof(int), s) != hipSuccess) return DRBA_ELAUNCH;
+  hipLaunchKernelGGL(splat_sort_count, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, cnt, H, W);
+  hipLaunchKernelGGL(scan_block, dim3(nb), dim3(kBlock), 0, s, cnt, start, bsum, L);
+  hipLaunchKernelGGL(scan_sums, dim3(1), dim3(kBlock), 0, s, bsum, nb, start + L);
+  hipLaunchKernelGGL(scan_add, dim3((unsigned)((L + 255) / 256)), dim3(kBlock), 0, s, start, bsum, L);
+  hipLaunchKernelGGL(splat_sort_fill, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, metric, start, cnt, rec, H, W, mode);
+  const int chunks = (C + kChunk - 1) / kChunk;
+  hipLaunchKernelGGL(splat_sorted_gather, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, in, start, rec, out, C, H,
+                     W, mode, eps, chunks);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -73,7 +73,7 @@ class RIFE:
 
     def inference_ts(self, I0, I1, ts):
         """t == 0 / t == 1 return the input tensor objects themselves (reference rife.py:30-33)."""
-        output = []
+        output, items = [], []
         f0 = f1 = None
         for t in ts:
             if t == 0:
@@ -83,7 +83,15 @@ class RIFE:
             else:
                 if f0 is None:  # encode once per call, not once per t (same values)
                     f0, f1 = self.ifnet.encode(I0), self.ifnet.encode(I1)
-                output.append(self.ifnet.forward_pair(I0, I1, float(t), self.scale_list, f0, f1)[0])
+                output.append(len(items))  # placeholder: index into the batched pass below
+                items.append((I0, I1, float(t), f0, f1))
+        return self._fill(output, items)
+
+    def _fill(self, output, items):
+        """Run the queued interpolations as one stacked IFNet pass and put the frames where their indices are."""
+        if items:
+            frames = self.ifnet.forward_pairs(items, self.scale_list)
+            output = [frames[o] if isinstance(o, int) else o for o in output]
         return output
 
     def calc_flow(self, a, b, f0=None, f1=None):
@@ -102,17 +110,19 @@ class RIFE:
     def _warm_step(self, I0, I1, I2, flow10, f1, f0, kinds, t_dev):
         """The steady-state body of inference_ts_drba with linear DRM; timesteps come from device memory."""
         flow12, flow21, f1, f2 = self.calc_flow(I1, I2, f0=f1)
-        outs = []
+        outs, items = [], []
         for k, kind in enumerate(kinds):
             if kind == "L":
                 drm = _ops.drm_rife_linear(flow10, flow12, 0.0, 1e-4, t_dev=t_dev[k:k + 1])
-                outs.append(self.ifnet.forward_pair(I1, I0, drm, self.scale_list, f1, f0)[0])
+                outs.append(len(items))
+                items.append((I1, I0, drm, f1, f0))
             elif kind == "R":
                 drm = _ops.drm_rife_linear(flow12, flow10, 0.0, 1e-4, t_dev=t_dev[k:k + 1])
-                outs.append(self.ifnet.forward_pair(I1, I2, drm, self.scale_list, f1, f2)[0])
+                outs.append(len(items))
+                items.append((I1, I2, drm, f1, f2))
             else:
                 outs.append(None)
-        return outs, (flow21, flow12, f2, f1)
+        return self._fill(outs, items), (flow21, flow12, f2, f1)
 
     def _graphed_step(self, I0, I1, I2, ts, reuse):
         kinds, tvals = [], []
@@ -147,7 +157,7 @@ class RIFE:
             flow12, flow21, f1, f2 = self.calc_flow(I1, I2)
         else:
             flow12, flow21, f1, f2 = self.calc_flow(I1, I2, f0=reuse[2])
-        output = []
+        output, items = [], []
         for t in ts:
             if t == 0:
                 output.append(I0)
@@ -160,10 +170,12 @@ class RIFE:
                 # only the map this frame consumes is computed (the reference builds both, drm.py:89-96)
                 drm = (_ops.drm_rife_linear(flow10, flow12, t, 1e-4) if linear
                        else calc_drm_rife(t, flow10, flow12, False)["drm_t1_t01"])
-                output.append(self.ifnet.forward_pair(I1, I0, drm, self.scale_list, f1, f0)[0])
+                output.append(len(items))
+                items.append((I1, I0, drm, f1, f0))
             elif 1 < t < 2:
                 t = t - 1
                 drm = (_ops.drm_rife_linear(flow12, flow10, t, 1e-4) if linear
                        else calc_drm_rife(t, flow10, flow12, False)["drm_t1_t12"])
-                output.append(self.ifnet.forward_pair(I1, I2, drm, self.scale_list, f1, f2)[0])
-        return output, (flow21, flow12, f2, f1)
+                output.append(len(items))
+                items.append((I1, I2, drm, f1, f2))
+        return self._fill(output, items), (flow21, flow12, f2, f1)

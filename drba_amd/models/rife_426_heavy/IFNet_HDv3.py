@@ -11,6 +11,7 @@ convolutions is fused into three glue kernels (drba_amd/csrc/ifnet_glue.hip):
                    mask/feat are re-derived from the low-res head output by the next stage's input kernel
     synthesis    = warp x2 + sigmoid blend                       (drba_warp_blend)
 """
+import numpy as np
 import torch
 
 from drba_amd import ops as _ops
@@ -109,6 +110,31 @@ class IFNet:
             flow_list.append(flow)
             s_prev = s
         return _ops.warp_blend(img0, img1, flow, tmp, s_prev), flow_list
+
+    def forward_pairs(self, items, scale_list=(8, 4, 2, 1)):
+        """Several interpolations of one frame size in one pass: items = [(img0, img1, timestep, f0, f1), ...].
+        The samples are independent (IFNet_HDv3.py:126-177 applied to each); stacking them makes every
+        convolution of a stage one launch over the batch, which fills the 256 CUs better than the 1/16..1/64
+        resolution maps of a single 1080p frame do and halves the launch count of a `-t 2` step."""
+        B = len(items)
+        if B == 1:
+            img0, img1, t, f0, f1 = items[0]
+            return [self.forward_pair(img0, img1, t, scale_list, f0, f1)[0]]
+        _, _, H, W = items[0][0].shape
+        flows, tmp = [None] * B, None
+        s_prev = 1.0
+        for i in range(5):
+            s = scale_list[i]
+            h, w = int(np.floor(H * (1.0 / s))), int(np.floor(W * (1.0 / s)))
+            xin = torch.empty((B, 52 if i else 39, h, w), dtype=torch.float32, device=items[0][0].device)
+            for k, (img0, img1, t, f0, f1) in enumerate(items):
+                _ops.ifblock_input(img0, img1, f0, f1, t, flows[k], None if tmp is None else tmp[k:k + 1], s_prev, s,
+                                   out=xin[k:k + 1])
+            tmp = self.block[i].core(xin)  # [B,13,H/s,W/s]
+            for k in range(B):
+                flows[k] = _ops.ifblock_update(tmp[k:k + 1], flows[k], H, W, s)
+            s_prev = s
+        return [_ops.warp_blend(it[0], it[1], flows[k], tmp[k:k + 1], s_prev) for k, it in enumerate(items)]
 
     def __call__(self, x, timestep=0.5, scale_list=(8, 4, 2, 1), training=False, fastmode=True, ensemble=False,
                  f0=None, f1=None):

@@ -303,7 +303,7 @@ class Conv3x3:
             cfg = lib.drba_conv3x3_pick_cfg(self.cin, self.cout, ho, wo, self.stride)
         _lib.check(min(cfg, 0), "drba_conv3x3_pick_cfg")
         wp = self._pack(cfg)
-        key = (cfg, cin, self.cout, ho, wo, self.stride)
+        key = (cfg, cin, self.cout, ho, wo, self.stride, n)
         _lib.check(_timed("conv3x3", key, 2.0 * self.cout * cin * 9 * ho * wo * n, "flop", lambda: lib.drba_conv3x3(
             _p(x), _p(wp), _p(self.bias), _p(self.beta), _p(res), _p(res2), _p(out), n, cin, h, w, self.cout,
             self.stride, self.act, self.post_slope, pre, ps, cfg, _stream())), "drba_conv3x3")
@@ -362,15 +362,19 @@ class Deconv4x4:
 
 
 # ----------------------------------------------------------------------------- IFNet glue
-def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scale):
+def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scale, out=None):
     """Stage input at 1/scale resolution (52 ch with flow, 39 without).  `timestep`: float or [1,1,H,W] map;
-    `tmp_prev`: the previous stage's [1,13,hp,wp] head output (mask/feat are its x prev_scale upsample)."""
+    `tmp_prev`: the previous stage's [1,13,hp,wp] head output (mask/feat are its x prev_scale upsample).
+    `out`: optional [1,nch,h,w] destination (one sample of a stacked stage batch)."""
     img0, img1, f0, f1 = _f32(img0), _f32(img1), _f32(f0), _f32(f1)
     _, _, H, W = img0.shape
     h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
     tmap, tsc = (None, float(timestep)) if not torch.is_tensor(timestep) else (_f32(timestep), 0.0)
     nch = 52 if flow is not None else 39
-    out = torch.empty((1, nch, h, w), dtype=torch.float32, device=img0.device)
+    if out is None:
+        out = torch.empty((1, nch, h, w), dtype=torch.float32, device=img0.device)
+    elif tuple(out.shape) != (1, nch, h, w) or not out.is_contiguous():
+        raise _lib.DrbaHipError(f"ifblock_input: out must be a contiguous [1,{nch},{h},{w}] tensor")
     hp = wp = 0
     ps = 1.0
     if flow is not None:
