@@ -36,8 +36,9 @@
 using namespace drba;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_ptr;
 
-namespace {
+namespace drba_conv {
 
 constexpr int round_up_mod32_16(int v) {  // smallest r >= v with r % 32 == 16
   int r = v - (v % 32) + 16;
@@ -50,19 +51,21 @@ struct ConvCfg {
   static constexpr int NTAP = (MODE == 0) ? 9 : 4;
   static constexpr int TH = (KS == 1 ? 4 : 1) * RW, TW = 16 * MW, NTC = 16 * NT;
   static constexpr int TR = (TH - 1) * S + 3, TC = (TW - 1) * S + 3;
-  static constexpr int CHS = (S == 1) ? round_up_mod32_16(TR * TC) : ((TR * TC) | 1);
+  static constexpr int NL = (KS == 1) ? 256 : 64;       // lanes filling one buffer (the workgroup, or one wave)
+  // Staging is LDS-direct (buffer_load ... lds): lane l of a load writes LDS dword base + l, so a channel's
+  // TR x TC window is fetched by SPC loads of NL consecutive elements and its LDS slot holds SPC * NL dwords.
+  static constexpr int SPC = (TR * TC + NL - 1) / NL;
+  static constexpr int CHS = (S == 1) ? round_up_mod32_16(SPC * NL) : ((SPC * NL) | 1);
   static constexpr int BUF = ((CK * CHS + 3) / 4) * 4;  // floats per staging buffer
-  static constexpr int NL = (KS == 1) ? 256 : 64;       // threads filling one buffer
-  static constexpr int NSTAGE = (CK * TR * TC + NL - 1) / NL;
   static constexpr int CG = CK / 4;                      // MFMA k-groups per tap per chunk
   static constexpr int FRAG = NTAP * CG * NT * 64;       // packed weight floats per (cout tile[, phase], chunk)
   static constexpr int NTILES = RW * MW * NT;
-  // Weight path: KS=1 stages the chunk's fragment block through LDS (shared by the 4 waves);
-  // KS=4 (small maps, wave-private chunks) reads B fragments straight from L2 -- staging them per
+  // Weight path: KS=1 stages the chunk's fragment block through LDS (shared by the 4 waves, 16-byte LDS-direct
+  // loads); KS=4 (small maps, wave-private chunks) reads B fragments straight from L2 -- staging them per
   // wave would quadruple the LDS writes (measured: 40 -> 56 us on the 64-ch 136x240 ResConv).
   static constexpr bool WLDS = (KS == 1);
-  static constexpr int NWV = WLDS ? (FRAG / 4 + NL - 1) / NL : 1;   // float4 weight loads per thread per chunk
-  static constexpr int BUFALL = BUF + (WLDS ? FRAG : 0);  // input tile (+ weight fragments) of one chunk
+  static constexpr int SPW = WLDS ? (FRAG / 4 + NL - 1) / NL : 0;   // 16-byte weight loads per lane per chunk
+  static constexpr int BUFALL = BUF + SPW * NL * 4;      // input tile (+ weight fragments) of one chunk
   static constexpr int LDS_STAGE = 2 * BUFALL * (KS == 1 ? 1 : 4);
   static constexpr int LDS_RED = (KS == 1) ? 0 : 4 * NTILES * 256;
   static constexpr int LDS_FLOATS = LDS_STAGE > LDS_RED ? LDS_STAGE : LDS_RED;
@@ -75,9 +78,10 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
           const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
           float *__restrict__ out, int Cin, int H, int W, int Cout, int Ho, int Wo, int act, float post_slope,
           int pre_act, float pre_slope, int n_ctiles, int pixel_shuffle) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types/builtins (buffer resources, LDS-direct loads); the host pass only needs the launch stub
   constexpr int MODE = Cfg::MODE, S = Cfg::S, RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, CK = Cfg::CK, KS = Cfg::KS;
   constexpr int TH = Cfg::TH, TW = Cfg::TW, TR = Cfg::TR, TC = Cfg::TC, CHS = Cfg::CHS;
-  constexpr int NL = Cfg::NL, NSTAGE = Cfg::NSTAGE, CG = Cfg::CG, NTAP = Cfg::NTAP;
+  constexpr int NL = Cfg::NL, SPC = Cfg::SPC, SPW = Cfg::SPW, CG = Cfg::CG, NTAP = Cfg::NTAP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,68 +121,58 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
   const int gy0 = y0 * S - 1, gx0 = x0 * S - 1;
   const int q_first = (KS == 1) ? 0 : wave, q_step = (KS == 1) ? 1 : 4;
   const float *wf_base = wfrag + ((size_t)(MODE == 0 ? cz : cz * 4 + phase) * nchunks) * Cfg::FRAG;
-  constexpr int NWV = Cfg::NWV;
   // deconv tap -> tile offsets: tap = 2a+b; row = rw + 1 + dy, py=0: dy={0,-1}; py=1: dy={+1,0}
   const int dro[2] = {py ? 2 : 1, py ? 1 : 0};
   const int dco[2] = {px ? 2 : 1, px ? 1 : 0};
 
-  float st[NSTAGE];
-  f32x4 wst[NWV];
-  auto issue = [&](int q) {  // global -> registers (zero padding outside the image / beyond Cin)
-    if (Cfg::WLDS) {
-      const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wf_base + (size_t)q * Cfg::FRAG);
+  // ---- staging: global -> LDS without passing through registers.  Each lane owns the same (row, col) of the
+  // window for every channel, so its byte offset inside a channel plane is computed once; the channel / chunk
+  // offset rides in the scalar soffset.  Out-of-image taps, window padding lanes and channels >= Cin read as
+  // zero through the buffer range check (an out-of-range lane still writes its 0 to LDS).
+  constexpr unsigned kOOB = 0x7FFFFFF0u;
+  const unsigned plane_bytes = (unsigned)H * (unsigned)W * 4u;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, Cin * (int)plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void *)wf_base, 0, nchunks * Cfg::FRAG * 4, 0x00020000);
+  unsigned voff[SPC];
 #pragma unroll
-      for (int i = 0; i < NWV; ++i) {
-        const int e = ltid + i * NL;
-        wst[i] = (e < Cfg::FRAG / 4) ? wsrc[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+  for (int i = 0; i < SPC; ++i) {
+    const int e = ltid + i * NL;
+    const int r = e / TC, col = e - r * TC;
+    const int gy = gy0 + r, gx = gx0 + col;
+    const bool ok = e < TR * TC && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    voff[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
+  }
+  const int wslot = (KS == 1) ? wave * 64 : 0;  // first LDS dword this wave's lanes write within a load
+  auto issue = [&](int q, float *buf) {
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const unsigned soff = (unsigned)min(q * CK + c, Cin) * plane_bytes;  // == num_records for ci >= Cin: all lanes zero
+#pragma unroll
+      for (int i = 0; i < SPC; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(buf + c * CHS + i * NL + wslot), 4, voff[i], soff, 0, 0);
     }
+    if (Cfg::WLDS) {
 #pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-      const int e = ltid + i * NL;
-      const int c = e / (TR * TC), rem = e - c * (TR * TC);
-      const int r = rem / TC, col = rem - r * TC;
-      const int gy = gy0 + r, gx = gx0 + col, ci = q * CK + c;
-      float v = 0.f;
-      if (e < CK * TR * TC && ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
-        v = in[((size_t)ci * H + gy) * W + gx];
-      if (pre_act) v = v > 0.f ? v : pre_slope * v;  // PReLU (one shared slope) fused into the loader; prelu(0) = 0 keeps the padding
-      st[i] = v;
+      for (int i = 0; i < SPW; ++i)  // lanes past the fragment block fetch the next chunk's head into LDS padding
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(buf + Cfg::BUF + (i * NL + wslot) * 4), 16,
+                                                 (unsigned)(i * NL + ltid) * 16u, (unsigned)q * (Cfg::FRAG * 4), 0, 0);
     }
   };
-  auto commit = [&](float *buf) {  // registers -> LDS
-    if (Cfg::WLDS) {
-      f32x4 *wdst = reinterpret_cast<f32x4 *>(buf + Cfg::BUF);
-#pragma unroll
-      for (int i = 0; i < NWV; ++i) {
-        const int e = ltid + i * NL;
-        if (e < Cfg::FRAG / 4) wdst[e] = wst[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-      const int e = ltid + i * NL;
-      const int c = e / (TR * TC), rem = e - c * (TR * TC);
-      const int r = rem / TC, col = rem - r * TC;
-      if (e < CK * TR * TC) buf[c * CHS + r * TC + col] = st[i];
-    }
-  };
-  auto sync = [&]() {
+  auto sync = [&]() {  // the chunk just requested has landed and everybody is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (KS == 1) __syncthreads();
-    else __builtin_amdgcn_wave_barrier();  // wave-private buffers: DS ops of one wave execute in order
+    else __builtin_amdgcn_wave_barrier();  // wave-private buffers
   };
 
-  if (q_first < nchunks) {
-    issue(q_first);
-    commit(buf0);
-  }
+  if (q_first < nchunks) issue(q_first, buf0);
   sync();
   int it = 0;
   for (int q = q_first; q < nchunks; q += q_step, ++it) {
     const float *cur = (it & 1) ? buf1 : buf0;
     float *nxt = (it & 1) ? buf0 : buf1;
     const int qn = q + q_step;
-    if (qn < nchunks) issue(qn);  // next chunk's loads fly under this chunk's MFMAs
+    if (qn < nchunks) issue(qn, nxt);  // next chunk's loads fly under this chunk's MFMAs
     const float *ab = cur + a_off;
     // this chunk's weight fragments [tap][cg][nt][64 lanes]: LDS copy (KS=1) or L2 (KS=4)
     const float *wb = Cfg::WLDS ? cur + Cfg::BUF + lane : wf_base + (size_t)q * Cfg::FRAG + lane;
@@ -194,14 +188,16 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
         for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw) {
-            const float av = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
+            float av = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
+            // PReLU (one shared slope) of pre-activated convolutions, applied on the way into the MFMA
+            // (the staged data never passes through registers); prelu(0) = 0 keeps the zero padding
+            if (pre_act) av = av > 0.f ? av : pre_slope * av;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
               acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[rw][mw][nt], 0, 0, 0);
           }
       }
     }
-    if (qn < nchunks) commit(nxt);
     sync();
   }
 
@@ -309,7 +305,14 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
           store_tile(rw, mw, nt, v);
         }
   }
+#endif
 }
+
+}  // namespace drba_conv
+
+using namespace drba_conv;
+
+namespace {
 
 // ------------------------------------------------------------------------------------------ cfg tables
 //                 M  S  RW MW NT CK KS
@@ -357,6 +360,13 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   const int n_ct = (Cout + Cfg::NTC - 1) / Cfg::NTC;
   const int gh = Cfg::MODE == 0 ? Ho : H, gw = Cfg::MODE == 0 ? Wo : W;
   dim3 g((gw + Cfg::TW - 1) / Cfg::TW, (gh + Cfg::TH - 1) / Cfg::TH, N * n_ct * (Cfg::MODE == 0 ? 1 : 4));
+  if (Cfg::LDS_FLOATS * sizeof(float) > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KB per CU)
+    auto kernel = conv_mfma<Cfg>;
+    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         Cfg::LDS_FLOATS * (int)sizeof(float));
+    if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
+  }
   hipLaunchKernelGGL(conv_mfma<Cfg>, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2,
                      out, Cin, H, W, Cout, Ho, Wo, act, post_slope, pre_act, pre_slope, n_ct, ps);
   DRBA_CHECK_LAUNCH();
