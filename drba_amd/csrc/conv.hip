@@ -72,19 +72,20 @@ struct ConvCfg {
   static_assert(MODE == 0 || S == 1, "deconv phases read the input at stride 1");
 };
 
-template <class Cfg>
+template <class Cfg, bool PRE>
 __global__ void __launch_bounds__(256)
 conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const float *__restrict__ bias,
           const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
           float *__restrict__ out, int Cin, int H, int W, int Cout, int Ho, int Wo, int act, float post_slope,
-          int pre_act, float pre_slope, int n_ctiles, int pixel_shuffle) {
+          float pre_slope, int n_ctiles, int pixel_shuffle) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types/builtins (buffer resources, LDS-direct loads); the host pass only needs the launch stub
   constexpr int MODE = Cfg::MODE, S = Cfg::S, RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, CK = Cfg::CK, KS = Cfg::KS;
   constexpr int TH = Cfg::TH, TW = Cfg::TW, TR = Cfg::TR, TC = Cfg::TC, CHS = Cfg::CHS;
   constexpr int NL = Cfg::NL, SPC = Cfg::SPC, SPW = Cfg::SPW, CG = Cfg::CG, NTAP = Cfg::NTAP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: keeps chunk indices and LDS bases in SGPRs
   const int m = lane & 15, kq = lane >> 4;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   int zz = blockIdx.z;
@@ -176,26 +177,65 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
     const float *ab = cur + a_off;
     // this chunk's weight fragments [tap][cg][nt][64 lanes]: LDS copy (KS=1) or L2 (KS=4)
     const float *wb = Cfg::WLDS ? cur + Cfg::BUF + lane : wf_base + (size_t)q * Cfg::FRAG + lane;
+    if constexpr (Cfg::WLDS) {
+      // Software-pipelined over the (tap, k-group) steps: the A/B fragments of step j+1 are read from LDS while the
+      // MFMAs of step j issue, so a wave waits for LDS once per chunk instead of once per step (left to the
+      // compiler, the reads sit directly in front of the MFMAs that consume them: MFMA pipe 55-65 % busy).
+      constexpr int NSTEP = NTAP * CG;
+      float av[2][RW][MW], bv[2][NT];
+      auto fetch = [&](int j, int slot) {
+        const int tap = j / CG, cg = j - tap * CG;
+        const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[tap & 1];
 #pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap) {
-      const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[tap & 1];
+        for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = wb[((tap * CG + cg) * NT + nt) * 64];
 #pragma unroll
-      for (int cg = 0; cg < CG; ++cg) {
-        float bv[NT];
+        for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[((tap * CG + cg) * NT + nt) * 64];
+          for (int mw = 0; mw < MW; ++mw) av[slot][rw][mw] = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int j = 0; j < NSTEP; ++j) {
+        const int slot = j & 1;
+        if (j + 1 < NSTEP) fetch(j + 1, slot ^ 1);
 #pragma unroll
         for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw) {
-            float av = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
+            float a = av[slot][rw][mw];
             // PReLU (one shared slope) of pre-activated convolutions, applied on the way into the MFMA
             // (the staged data never passes through registers); prelu(0) = 0 keeps the zero padding
-            if (pre_act) av = av > 0.f ? av : pre_slope * av;
+            if (PRE) a = a > 0.f ? a : pre_slope * a;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[rw][mw][nt], 0, 0, 0);
+              acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[slot][nt], acc[rw][mw][nt], 0, 0, 0);
           }
+        // keep the issue order: the LDS reads of step j+1, then the MFMAs of step j
+        __builtin_amdgcn_sched_group_barrier(0x100, RW * MW + NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, RW * MW * NT, 0);
+      }
+    } else {
+      // split-K: the B fragments come from L2 (global loads); the compiler hoists them across the taps on its own,
+      // and pinning an LDS-style pipeline here serialises one L2 round trip per step (measured 21 -> 48 us)
+#pragma unroll
+      for (int tap = 0; tap < NTAP; ++tap) {
+        const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[tap & 1];
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+          float bv[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[((tap * CG + cg) * NT + nt) * 64];
+#pragma unroll
+          for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+            for (int mw = 0; mw < MW; ++mw) {
+              float a = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
+              if (PRE) a = a > 0.f ? a : pre_slope * a;
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[rw][mw][nt], 0, 0, 0);
+            }
+        }
       }
     }
     sync();
@@ -360,15 +400,20 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   const int n_ct = (Cout + Cfg::NTC - 1) / Cfg::NTC;
   const int gh = Cfg::MODE == 0 ? Ho : H, gw = Cfg::MODE == 0 ? Wo : W;
   dim3 g((gw + Cfg::TW - 1) / Cfg::TW, (gh + Cfg::TH - 1) / Cfg::TH, N * n_ct * (Cfg::MODE == 0 ? 1 : 4));
-  if (Cfg::LDS_FLOATS * sizeof(float) > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KB per CU)
-    auto kernel = conv_mfma<Cfg>;
-    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         Cfg::LDS_FLOATS * (int)sizeof(float));
-    if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
-  }
-  hipLaunchKernelGGL(conv_mfma<Cfg>, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2,
-                     out, Cin, H, W, Cout, Ho, Wo, act, post_slope, pre_act, pre_slope, n_ct, ps);
+  // PRE: PReLU pre-activation compiled into the MFMA loop (FeatureNet / MetricNet / GridNet convolutions)
+  auto go = [&](auto kernel) -> int {
+    if (Cfg::LDS_FLOATS * sizeof(float) > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950: 160 KB per CU)
+      static const hipError_t lds_ok =  // once per kernel (one static per instantiation of this generic lambda)
+          hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              Cfg::LDS_FLOATS * (int)sizeof(float));
+      if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kernel, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2, out, Cin, H,
+                       W, Cout, Ho, Wo, act, post_slope, pre_slope, n_ct, ps);
+    return DRBA_OK;
+  };
+  const int rc = pre_act ? go(conv_mfma<Cfg, true>) : go(conv_mfma<Cfg, false>);
+  if (rc != DRBA_OK) return rc;
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -265,7 +265,7 @@ class Conv3x3:
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
         self.beta = None if beta is None else beta.detach().float().reshape(-1).to(device).contiguous()
         self.stride, self.act = int(stride), self.ACTS[act]
-        self._packed = {}
+        self._packed, self._keep = {}, set()
 
     def _pack(self, cfg):
         if cfg not in self._packed:
@@ -297,8 +297,9 @@ class Conv3x3:
             cfg = _tune(("conv3x3", n, cin, self.cout, h, w, self.stride), cands, lambda c: lib.drba_conv3x3(
                 _p(x), _p(self._pack(c)), _p(self.bias), _p(self.beta), _p(res), _p(res2), _p(out), n, cin, h, w,
                 self.cout, self.stride, self.act, self.post_slope, pre, ps, c, _stream()))
-            for c in [c for c in self._packed if c != cfg]:
-                del self._packed[c]  # keep only the winner's packed weights
+            self._keep.add(cfg)  # a layer can have one winner per batch size (block0: N=1 in calc_flow, N=2 stacked)
+            for c in [c for c in self._packed if c not in self._keep]:
+                del self._packed[c]  # drop the packings of the losing candidates
         else:
             cfg = lib.drba_conv3x3_pick_cfg(self.cin, self.cout, ho, wo, self.stride)
         _lib.check(min(cfg, 0), "drba_conv3x3_pick_cfg")
@@ -321,7 +322,7 @@ class Deconv4x4:
         self.device = device
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
         self.ps = 1 if pixel_shuffle else 0
-        self._packed = {}
+        self._packed, self._keep = {}, set()
 
     def _pack(self, cfg):
         if cfg not in self._packed:
@@ -348,7 +349,8 @@ class Deconv4x4:
             cfg = _tune(("deconv4x4", n, cin, self.cout, h, w, self.ps), list(range(lib.drba_deconv4x4_num_cfgs())),
                         lambda c: lib.drba_deconv4x4s2(_p(x), _p(self._pack(c)), _p(self.bias), _p(out), n, cin, h, w,
                                                        self.cout, self.ps, pre, ps_, c, _stream()))
-            for c in [c for c in self._packed if c != cfg]:
+            self._keep.add(cfg)
+            for c in [c for c in self._packed if c not in self._keep]:
                 del self._packed[c]
         else:
             cfg = lib.drba_deconv4x4_pick_cfg(self.cin, self.cout, h, w)
