@@ -98,9 +98,17 @@ __device__ __forceinline__ Taps taps_border(float x, float y, int W, int H) {
   return t;
 }
 
+// The two taps of a row are adjacent (x1 == x0 + 1, or x1 == x0 == W-1 at the right border), so each row is one
+// 8-byte load instead of two 4-byte ones: the gather kernels are bound by the texture-address unit (TA busy 86-98 %,
+// ~20 cycles per wave-level gather instruction measured), i.e. by the NUMBER of vector-memory instructions.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ float sample(const float *__restrict__ p, int W, const Taps &t) {
-  const float *r0 = p + (size_t)t.y0 * W, *r1 = p + (size_t)t.y1 * W;
-  return r0[t.x0] * t.wnw + r0[t.x1] * t.wne + r1[t.x0] * t.wsw + r1[t.x1] * t.wse;
+  const int xb = min(t.x0, W - 2);  // W >= 2; xb != x0 only when x0 == x1 == W-1
+  const f32x2u a = *reinterpret_cast<const f32x2u *>(p + (size_t)t.y0 * W + xb);
+  const f32x2u b = *reinterpret_cast<const f32x2u *>(p + (size_t)t.y1 * W + xb);
+  const bool edge = t.x0 != xb;
+  const float a0 = edge ? a.y : a.x, b0 = edge ? b.y : b.x;
+  return a0 * t.wnw + a.y * t.wne + b0 * t.wsw + b.y * t.wse;
 }
 
 // Source taps of F.interpolate(bilinear, align_corners=False) along one axis.
