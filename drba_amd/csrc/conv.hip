@@ -52,11 +52,12 @@ struct ConvCfg {
   static constexpr int TH = (KS == 1 ? 4 : 1) * RW, TW = 16 * MW, NTC = 16 * NT;
   static constexpr int TR = (TH - 1) * S + 3, TC = (TW - 1) * S + 3;
   static constexpr int NL = (KS == 1) ? 256 : 64;       // lanes filling one buffer (the workgroup, or one wave)
-  // Staging is LDS-direct (buffer_load ... lds): lane l of a load writes LDS dword base + l, so a channel's
-  // TR x TC window is fetched by SPC loads of NL consecutive elements and its LDS slot holds SPC * NL dwords.
-  static constexpr int SPC = (TR * TC + NL - 1) / NL;
-  static constexpr int CHS = (S == 1) ? round_up_mod32_16(SPC * NL) : ((SPC * NL) | 1);
-  static constexpr int BUF = ((CK * CHS + 3) / 4) * 4;  // floats per staging buffer
+  // Staging is LDS-direct (buffer_load ... lds): lane l of a load writes LDS dword base + l.  The chunk's CK channel
+  // windows are laid out back to back ([CK][CHS], CHS = window + bank padding) and fetched as one linear run of
+  // SPB loads of NL lanes: a lane's source (channel-in-chunk, row, col) is fixed for the whole kernel.
+  static constexpr int CHS = (S == 1) ? round_up_mod32_16(TR * TC) : ((TR * TC) | 1);
+  static constexpr int BUF = ((CK * CHS + 63) / 64) * 64;  // floats per staging buffer: whole 64-lane loads, 16-byte aligned end
+  static constexpr int SPB = (CK * CHS + NL - 1) / NL;
   static constexpr int CG = CK / 4;                      // MFMA k-groups per tap per chunk
   static constexpr int FRAG = NTAP * CG * NT * 64;       // packed weight floats per (cout tile[, phase], chunk)
   static constexpr int NTILES = RW * MW * NT;
@@ -65,7 +66,8 @@ struct ConvCfg {
   // wave would quadruple the LDS writes (measured: 40 -> 56 us on the 64-ch 136x240 ResConv).
   static constexpr bool WLDS = (KS == 1);
   static constexpr int SPW = WLDS ? (FRAG / 4 + NL - 1) / NL : 0;   // 16-byte weight loads per lane per chunk
-  static constexpr int BUFALL = BUF + SPW * NL * 4;      // input tile (+ weight fragments) of one chunk
+  static constexpr int FPAD = WLDS ? ((FRAG / 4 + 63) / 64) * 256 : 0;  // fragment block rounded up to whole wave loads
+  static constexpr int BUFALL = BUF + FPAD;              // input tile (+ weight fragments) of one chunk
   static constexpr int LDS_STAGE = 2 * BUFALL * (KS == 1 ? 1 : 4);
   static constexpr int LDS_RED = (KS == 1) ? 0 : 4 * NTILES * 256;
   static constexpr int LDS_FLOATS = LDS_STAGE > LDS_RED ? LDS_STAGE : LDS_RED;
@@ -81,7 +83,7 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types/builtins (buffer resources, LDS-direct loads); the host pass only needs the launch stub
   constexpr int MODE = Cfg::MODE, S = Cfg::S, RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, CK = Cfg::CK, KS = Cfg::KS;
   constexpr int TH = Cfg::TH, TW = Cfg::TW, TR = Cfg::TR, TC = Cfg::TC, CHS = Cfg::CHS;
-  constexpr int NL = Cfg::NL, SPC = Cfg::SPC, SPW = Cfg::SPW, CG = Cfg::CG, NTAP = Cfg::NTAP;
+  constexpr int NL = Cfg::NL, SPB = Cfg::SPB, SPW = Cfg::SPW, CG = Cfg::CG, NTAP = Cfg::NTAP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -135,28 +137,28 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, Cin * (int)plane_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w =
       __builtin_amdgcn_make_buffer_rsrc((void *)wf_base, 0, nchunks * Cfg::FRAG * 4, 0x00020000);
-  unsigned voff[SPC];
+  unsigned voff[SPB];
 #pragma unroll
-  for (int i = 0; i < SPC; ++i) {
-    const int e = ltid + i * NL;
+  for (int i = 0; i < SPB; ++i) {
+    const int L = ltid + i * NL;             // LDS dword within the buffer
+    const int c = L / CHS, e = L - c * CHS;  // channel within the chunk, element of its window (or bank padding)
     const int r = e / TC, col = e - r * TC;
     const int gy = gy0 + r, gx = gx0 + col;
-    const bool ok = e < TR * TC && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    voff[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
+    const bool ok = c < CK && e < TR * TC && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    voff[i] = ok ? (unsigned)c * plane_bytes + (unsigned)(gy * W + gx) * 4u : kOOB;
   }
   const int wslot = (KS == 1) ? wave * 64 : 0;  // first LDS dword this wave's lanes write within a load
   auto issue = [&](int q, float *buf) {
+    const unsigned soff = (unsigned)(q * CK) * plane_bytes;  // channels >= Cin fall past num_records: zeros
 #pragma unroll
-    for (int c = 0; c < CK; ++c) {
-      const unsigned soff = (unsigned)min(q * CK + c, Cin) * plane_bytes;  // == num_records for ci >= Cin: all lanes zero
-#pragma unroll
-      for (int i = 0; i < SPC; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(buf + c * CHS + i * NL + wslot), 4, voff[i], soff, 0, 0);
-    }
+    for (int i = 0; i < SPB; ++i)
+      if (i * NL + wslot < CK * CHS)  // wave-uniform: waves wholly past the buffer skip the load
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(buf + i * NL + wslot), 4, voff[i], soff, 0, 0);
     if (Cfg::WLDS) {
 #pragma unroll
       for (int i = 0; i < SPW; ++i)  // lanes past the fragment block fetch the next chunk's head into LDS padding
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(buf + Cfg::BUF + (i * NL + wslot) * 4), 16,
+        if (i * NL + wslot < Cfg::FRAG / 4)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(buf + Cfg::BUF + (i * NL + wslot) * 4), 16,
                                                  (unsigned)(i * NL + ltid) * 16u, (unsigned)q * (Cfg::FRAG * 4), 0, 0);
     }
   };
