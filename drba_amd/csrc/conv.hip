@@ -89,14 +89,23 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: keeps chunk indices and LDS bases in SGPRs
   const int m = lane & 15, kq = lane >> 4;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  int zz = blockIdx.z;
+  // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with a private
+  // L2.  Remap so that an XCD owns a contiguous run of tiles in (image, tile row, tile column, cout tile[, phase])
+  // order with the innermost indices sharing their input window: the halo rows/columns neighbouring tiles share and
+  // the window every cout tile / deconv phase re-reads then hit that XCD's L2 instead of being fetched by up to 8.
+  const int nbx = gridDim.x, nby = gridDim.y;
+  int t = xcd_band((int)(blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z)), (int)(nbx * nby * gridDim.z));
   int phase = 0;
   if (MODE == 1) {
-    phase = zz & 3;
-    zz >>= 2;
+    phase = t & 3;
+    t >>= 2;
   }
-  const int cz = zz % n_ctiles, n = zz / n_ctiles;
+  const int cz = t % n_ctiles;
+  t /= n_ctiles;
+  const int bx = t % nbx;
+  t /= nbx;
+  const int by = t % nby, n = t / nby;
+  const int x0 = bx * TW, y0 = by * TH;
   const int py = phase >> 1, px = phase & 1;
   in += (size_t)n * Cin * H * W;
   if (MODE == 0) {
