@@ -45,7 +45,8 @@ SIGNATURES = {
     "drba_deconv4x4_packed_floats": (_z, [_i, _i, _i]),
     "drba_deconv4x4_pack": (_i, [_p, _p, _i, _i, _i]),
     "drba_deconv4x4s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
-    "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_pair_interleave": (_i, [_p, _p, _i, _i, _i, _p]),
     "drba_ifblock_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "drba_metric_input": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "drba_pixel_shuffle2": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -111,6 +111,20 @@ __device__ __forceinline__ float sample(const float *__restrict__ p, int W, cons
   return a0 * t.wnw + a.y * t.wne + b0 * t.wsw + b.y * t.wse;
 }
 
+// Same for two channels stored pair-interleaved ([C/2][H][W][2]): the 2 x 2 taps of BOTH channels of a pair are two
+// 16-byte loads, i.e. half the gather instructions per channel again.  pp points at the pair's plane.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ void sample_pair(const float *__restrict__ pp, int W, const Taps &t, float &v0, float &v1) {
+  const int xb = min(t.x0, W - 2);
+  const f32x4u a = *reinterpret_cast<const f32x4u *>(pp + ((size_t)t.y0 * W + xb) * 2);
+  const f32x4u b = *reinterpret_cast<const f32x4u *>(pp + ((size_t)t.y1 * W + xb) * 2);
+  const bool edge = t.x0 != xb;
+  const float a00 = edge ? a.z : a.x, b00 = edge ? b.z : b.x;
+  const float a01 = edge ? a.w : a.y, b01 = edge ? b.w : b.y;
+  v0 = a00 * t.wnw + a.z * t.wne + b00 * t.wsw + b.z * t.wse;
+  v1 = a01 * t.wnw + a.w * t.wne + b01 * t.wsw + b.w * t.wse;
+}
+
 // Source taps of F.interpolate(bilinear, align_corners=False) along one axis.
 struct Lerp {
   int i0, i1;

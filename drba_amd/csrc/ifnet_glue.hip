@@ -54,6 +54,18 @@ __global__ void __launch_bounds__(256) f32_to_u8_kernel(const float *__restrict_
   }
 }
 
+// [C, H, W] -> [C/2, H, W, 2]: the layout the stage-input gathers read the encoder features in (see sample_pair)
+__global__ void __launch_bounds__(256) pair_interleave_kernel(const float *__restrict__ in, float *__restrict__ out, int C2, size_t P) {
+  const size_t total = (size_t)C2 * P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t c2 = i / P, p = i - c2 * P;
+    float2 v;
+    v.x = in[(2 * c2) * P + p];
+    v.y = in[(2 * c2 + 1) * P + p];
+    reinterpret_cast<float2 *>(out)[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // IFNet_HDv3.py:146 / :151-156 + IFBlock.forward :85-88.
 // One lane per LOW-RES output pixel.  For integer scale s >= 2 the align_corners=False
@@ -67,7 +79,8 @@ __global__ void __launch_bounds__(256) f32_to_u8_kernel(const float *__restrict_
 template <bool HAS_FLOW, bool SINGLE>
 __global__ void __launch_bounds__(256)
 ifblock_input_pixel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
-                    const float *__restrict__ f1, const float *__restrict__ tmap, float tscalar,
+                    const float *__restrict__ f1, const float *__restrict__ f0p, const float *__restrict__ f1p,
+                    const float *__restrict__ tmap, float tscalar,
                     const float *__restrict__ flow, const float *__restrict__ tmp_prev, int hp, int wp,
                     float inv_prev_scale, float *__restrict__ out, int H, int W, int h, int w, float scale) {
   constexpr int NS = SINGLE ? 1 : 2;
@@ -133,10 +146,22 @@ ifblock_input_pixel(const float *__restrict__ img0, const float *__restrict__ im
         dst[(size_t)c * p_lo] = lerp4([&](int j, int i) { return sample(pl0, W, t0[j][i]); });
         dst[(size_t)(3 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl1, W, t1[j][i]); });
       }
-      for (int c = 0; c < 16; ++c) {
-        const float *pl0 = f0 + (size_t)c * P, *pl1 = f1 + (size_t)c * P;
-        dst[(size_t)(6 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl0, W, t0[j][i]); });
-        dst[(size_t)(22 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl1, W, t1[j][i]); });
+      if (SINGLE && f0p) {  // pair-interleaved feature planes: both channels of a pair from two 16-byte loads
+        for (int c2 = 0; c2 < 8; ++c2) {
+          float a0, a1, b0, b1;
+          sample_pair(f0p + (size_t)c2 * 2 * P, W, t0[0][0], a0, a1);
+          sample_pair(f1p + (size_t)c2 * 2 * P, W, t1[0][0], b0, b1);
+          dst[(size_t)(6 + 2 * c2) * p_lo] = lerp4([&](int, int) { return a0; });
+          dst[(size_t)(7 + 2 * c2) * p_lo] = lerp4([&](int, int) { return a1; });
+          dst[(size_t)(22 + 2 * c2) * p_lo] = lerp4([&](int, int) { return b0; });
+          dst[(size_t)(23 + 2 * c2) * p_lo] = lerp4([&](int, int) { return b1; });
+        }
+      } else {
+        for (int c = 0; c < 16; ++c) {
+          const float *pl0 = f0 + (size_t)c * P, *pl1 = f1 + (size_t)c * P;
+          dst[(size_t)(6 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl0, W, t0[j][i]); });
+          dst[(size_t)(22 + c) * p_lo] = lerp4([&](int j, int i) { return sample(pl1, W, t1[j][i]); });
+        }
       }
       dst[(size_t)38 * p_lo] = lerp4([&](int j, int i) { return tmap ? tmap[q[j][i]] : tscalar; });
       for (int c = 0; c < 9; ++c)  // mask (tmp[4]) then feat (tmp[5:13])
@@ -171,7 +196,8 @@ ifblock_input_pixel(const float *__restrict__ img0, const float *__restrict__ im
 template <bool HAS_FLOW, bool SINGLE, int UNR>
 __global__ void __launch_bounds__(256)
 ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
-                     const float *__restrict__ f1, const float *__restrict__ tmap, float tscalar,
+                     const float *__restrict__ f1, const float *__restrict__ f0p, const float *__restrict__ f1p,
+                     const float *__restrict__ tmap, float tscalar,
                      const float *__restrict__ flow, const float *__restrict__ tmp_prev, int hp, int wp,
                      float inv_prev_scale, float *__restrict__ out, int H, int W, int h, int w, float scale) {
   constexpr int LPO = SINGLE ? 1 : 4;  // lanes per output pixel
@@ -214,12 +240,31 @@ ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ i
           dst[(size_t)(3 + c) * p_lo] = v1;
         }
       }
+      if (f0p) {  // pair-interleaved feature planes: both channels of a pair from two 16-byte loads
 #pragma unroll UNR
-      for (int c = 0; c < 16; ++c) {
-        const float v0 = comb(sample(f0 + (size_t)c * P, W, t0)), v1 = comb(sample(f1 + (size_t)c * P, W, t1));
-        if (writer) {
-          dst[(size_t)(6 + c) * p_lo] = v0;
-          dst[(size_t)(22 + c) * p_lo] = v1;
+        for (int c2 = 0; c2 < 8; ++c2) {
+          float a0, a1, b0, b1;
+          sample_pair(f0p + (size_t)c2 * 2 * P, W, t0, a0, a1);
+          sample_pair(f1p + (size_t)c2 * 2 * P, W, t1, b0, b1);
+          a0 = comb(a0);
+          a1 = comb(a1);
+          b0 = comb(b0);
+          b1 = comb(b1);
+          if (writer) {
+            dst[(size_t)(6 + 2 * c2) * p_lo] = a0;
+            dst[(size_t)(7 + 2 * c2) * p_lo] = a1;
+            dst[(size_t)(22 + 2 * c2) * p_lo] = b0;
+            dst[(size_t)(23 + 2 * c2) * p_lo] = b1;
+          }
+        }
+      } else {
+#pragma unroll UNR
+        for (int c = 0; c < 16; ++c) {
+          const float v0 = comb(sample(f0 + (size_t)c * P, W, t0)), v1 = comb(sample(f1 + (size_t)c * P, W, t1));
+          if (writer) {
+            dst[(size_t)(6 + c) * p_lo] = v0;
+            dst[(size_t)(22 + c) * p_lo] = v1;
+          }
         }
       }
       {
@@ -337,6 +382,15 @@ int drba_resize_bilinear(const float *in, float *out, int NC, int Hin, int Win, 
   return DRBA_OK;
 }
 
+int drba_pair_interleave(const float *in, float *out, int C, int H, int W, void *stream) {
+  if (!in || !out || C <= 0 || (C & 1) || H <= 0 || W <= 0) return DRBA_EINVAL;
+  const size_t P = (size_t)H * W;
+  hipLaunchKernelGGL(pair_interleave_kernel, dim3(grid_for((size_t)(C / 2) * P)), dim3(kBlock), 0, (hipStream_t)stream, in,
+                     out, C / 2, P);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
 int drba_u8hwc_to_f32nchw(const uint8_t *in, float *out, int H, int W, void *stream) {
   if (!in || !out || H <= 0 || W <= 0) return DRBA_EINVAL;
   hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, in, out, H, W);
@@ -351,12 +405,14 @@ int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *str
   return DRBA_OK;
 }
 
-int drba_ifblock_input(const float *img0, const float *img1, const float *f0, const float *f1,
-                       const float *timestep_map, float timestep_scalar, const float *flow, const float *tmp_prev,
+int drba_ifblock_input(const float *img0, const float *img1, const float *f0, const float *f1, const float *f0_pair,
+                       const float *f1_pair, const float *timestep_map, float timestep_scalar, const float *flow,
+                       const float *tmp_prev,
                        int hp, int wp, float prev_scale, float *out, int H, int W, int h, int w, float scale,
                        void *stream) {
   if (!img0 || !img1 || !f0 || !f1 || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
   if (flow && (!tmp_prev || hp <= 0 || wp <= 0 || !(prev_scale > 0.f))) return DRBA_EINVAL;
+  if ((f0_pair == nullptr) != (f1_pair == nullptr)) return DRBA_EINVAL;
   const bool single = scale == 1.f;
   hipStream_t s = (hipStream_t)stream;
   const float ips = flow ? (float)(1.0 / (double)prev_scale) : 1.f;
@@ -366,7 +422,8 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
   const int var = forced >= 0 ? forced : (single ? 0 : 1);
   dim3 b(kBlock);
   const int quad_tiles = single ? tiles_for(w, h) : ((w + 15) / 16) * ((h + 3) / 4);
-#define DRBA_ARGS img0, img1, f0, f1, timestep_map, timestep_scalar, flow, tmp_prev, hp, wp, ips, out, H, W, h, w, scale
+#define DRBA_ARGS \
+  img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, timestep_scalar, flow, tmp_prev, hp, wp, ips, out, H, W, h, w, scale
 #define DRBA_LAUNCH(HF, SG)                                                                                        \
   do {                                                                                                             \
     if (var == 0) {                                                                                                \

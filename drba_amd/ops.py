@@ -364,6 +364,20 @@ class Deconv4x4:
 
 
 # ----------------------------------------------------------------------------- IFNet glue
+PAIR_FEATURES = True  # warped stages read the encoder features from a pair-interleaved copy (half the gather instructions)
+
+
+def pair_interleaved(f):
+    """[1,C,H,W] -> the [C/2,H,W,2] copy the stage-input gathers read; made once per feature tensor and kept on it."""
+    fp = getattr(f, "_drba_pair", None)
+    if fp is None:
+        n, c, h, w = f.shape
+        fp = torch.empty((c // 2, h, w, 2), dtype=torch.float32, device=f.device)
+        _lib.check(_lib.load().drba_pair_interleave(_p(f), _p(fp), c, h, w, _stream()), "drba_pair_interleave")
+        f._drba_pair = fp
+    return fp
+
+
 def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scale, out=None):
     """Stage input at 1/scale resolution (52 ch with flow, 39 without).  `timestep`: float or [1,1,H,W] map;
     `tmp_prev`: the previous stage's [1,13,hp,wp] head output (mask/feat are its x prev_scale upsample).
@@ -386,8 +400,11 @@ def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scal
     pts = H * W if scale <= 2 else 4 * h * w
     nbytes = 4.0 * ((nch - (9 if flow is not None else 0)) * pts + nch * h * w)
     lib = _lib.load()
+    f0p = f1p = None
+    if flow is not None and PAIR_FEATURES and f0.shape[1] == 16:
+        f0p, f1p = pair_interleaved(f0), pair_interleaved(f1)
     _lib.check(_timed("ifblock_input", (nch, H, W, h, w), nbytes, "byte", lambda: lib.drba_ifblock_input(
-        _p(img0), _p(img1), _p(f0), _p(f1), _p(tmap), tsc, _p(flow), _p(tmp_prev), hp, wp, ps, _p(out), H, W, h, w,
+        _p(img0), _p(img1), _p(f0), _p(f1), _p(f0p), _p(f1p), _p(tmap), tsc, _p(flow), _p(tmp_prev), hp, wp, ps, _p(out), H, W, h, w,
         float(scale), _stream())), "drba_ifblock_input")
     return out
 

@@ -122,11 +122,16 @@ int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, 
  * (align_corners=False, src = scale*(dst+0.5)-0.5).  mask/feat are evaluated on the fly as the
  * x prev_scale bilinear upsample of the previous stage's 13-channel head output tmp_prev [13,hp,wp]
  * (channels 4 and 5..12), so they never exist at full resolution.
- * flow == NULL: first stage, no warp, 39 ch.  timestep_map may be NULL -> timestep_scalar. */
+ * flow == NULL: first stage, no warp, 39 ch.  timestep_map may be NULL -> timestep_scalar.
+ * f0_pair / f1_pair: optional copies of f0 / f1 in the pair-interleaved layout [8][H][W][2] written by
+ * drba_pair_interleave (both or neither); the warped stages then fetch two channels per 16-byte load. */
 int drba_ifblock_input(const float *img0, const float *img1, const float *f0, const float *f1,
+                       const float *f0_pair, const float *f1_pair,
                        const float *timestep_map, float timestep_scalar, const float *flow,
                        const float *tmp_prev, int hp, int wp, float prev_scale, float *out,
                        int H, int W, int h, int w, float scale, void *stream);
+/* [C,H,W] -> [C/2,H,W,2] (C even): channel pairs interleaved per pixel. */
+int drba_pair_interleave(const float *in, float *out, int C, int H, int W, void *stream);
 /* Upsample the 13-channel head output by `scale` and fold it into the running flow:
  * flow_out = (flow_in ? flow_in : 0) + up(tmp[0:4])*scale.  mask / feat (full resolution,
  * = up(tmp[4]), up(tmp[5:13])) are written only when non-NULL. */
