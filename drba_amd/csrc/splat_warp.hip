@@ -95,7 +95,7 @@ __device__ __forceinline__ void scatter_avg(float *__restrict__ acc, int x, int 
 // no global atomics for "short" flows (all four corners within R of the source).  The rare
 // "long" pixels are scattered by a pre-pass with global atomics into `gacc` (zeroed), which the
 // finish step adds in.  Each (source, corner) pair is accumulated exactly once either way.
-constexpr int kTX = 64, kTY = 32, kR = 16;
+constexpr int kR = 16;  // tile halo: sources with longer flows take the global-atomic pre-pass
 
 template <int MODE>
 struct SplatSrc {
@@ -104,18 +104,17 @@ struct SplatSrc {
   bool finite, is_short;
 };
 
+// value and splat flow of a source from its raw flow vectors (su, sv) [and (ou, ov) of the other direction]
 template <int MODE>
-__device__ __forceinline__ SplatSrc<MODE> splat_source(const float *__restrict__ fs, const float *__restrict__ fo,
-                                                       size_t P, size_t p, int x, int y, float t, float eps) {
+__device__ __forceinline__ SplatSrc<MODE> splat_source_from(float su, float sv, float ou, float ov, int x, int y, float t,
+                                                            float eps) {
   SplatSrc<MODE> s;
-  const float su = fs[p], sv = fs[P + p];
   if (MODE == 0) {
     s.v[0] = su;
     s.v[1] = sv;
     s.fx = su;
     s.fy = sv;
   } else {
-    const float ou = fo[p], ov = fo[P + p];
     const float ds = sqrtf(su * su + sv * sv) + eps, d_o = sqrtf(ou * ou + ov * ov) + eps;
     const float u = (d_o / (ds + d_o)) * t * 2.f;
     s.v[0] = u;
@@ -128,6 +127,18 @@ __device__ __forceinline__ SplatSrc<MODE> splat_source(const float *__restrict__
   // all four corners within kR of the source <=> floor(f) >= -kR and floor(f)+1 <= kR
   s.is_short = s.fx >= -(float)kR && s.fx < (float)(kR - 1) && s.fy >= -(float)kR && s.fy < (float)(kR - 1);
   return s;
+}
+
+template <int MODE>
+__device__ __forceinline__ SplatSrc<MODE> splat_source(const float *__restrict__ fs, const float *__restrict__ fo,
+                                                       size_t P, size_t p, int x, int y, float t, float eps) {
+  const float su = fs[p], sv = fs[P + p];
+  float ou = 0.f, ov = 0.f;
+  if (MODE != 0) {
+    ou = fo[p];
+    ov = fo[P + p];
+  }
+  return splat_source_from<MODE>(su, sv, ou, ov, x, y, t, eps);
 }
 
 // pre-pass: long (but finite) pixels -> global atomics into gacc [P][NV+1]
@@ -156,77 +167,183 @@ __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restric
   }
 }
 
+// Tile kernel.  On gfx950 ds_add_f32 retires ~0.33 lane-adds per clock per CU while integer LDS atomics retire ~13
+// (tools/exp/lds_atomic_rate.hip), so the tile does not accumulate floats atomically: it counting-sorts the sources
+// that touch it by the output pixel their 2x2 footprint starts at (one ds_add_rtn_u32 per source gives the rank, a
+// block scan the segment starts), stores their records in LDS, and every output pixel then sums its four segments
+// with plain LDS reads.  Sources beyond the LDS record capacity (strong local convergence) fall back to the same
+// global-atomic accumulator the long-flow pre-pass uses.
+constexpr int kSX = 32, kSY = 16;                       // output tile of the sorted kernel
+constexpr int kKX = kSX + 1, kKY = kSY + 1;             // key grid: footprint origins (-1..kSX-1) x (-1..kSY-1)
+constexpr int kNKEY = kKX * kKY;
+constexpr int kSWX = kSX + 2 * kR, kSWY = kSY + 2 * kR; // source window
+constexpr int kSPT = (kSWX * kSWY + 255) / 256;         // window sources per thread
+constexpr int kCAP = 1536;                              // records held in LDS (3 per output pixel)
+
 template <int MODE>
 __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs, const float *__restrict__ fo, float t,
-                                                   const float *__restrict__ t_dev, float eps,
-                                                   const float *__restrict__ gacc, float *__restrict__ out, int H,
-                                                   int W) {
+                                                   const float *__restrict__ t_dev, float eps, float *gacc,
+                                                   float *__restrict__ out, int H, int W) {
   constexpr int NV = MODE == 0 ? 2 : 1;
   if (t_dev) t = *t_dev;
-  __shared__ float acc[NV + 1][kTY * kTX];
+  __shared__ int cnt[kNKEY + 1];   // per key: count, then (after the scan) segment start; [kNKEY] = total
+  __shared__ int wsum[4];
+  __shared__ float4 rec[kCAP];     // (v0, v1, X - tx0, Y - ty0) of a source, grouped by key
   const int n = blockIdx.z;
   const size_t P = (size_t)H * W;
   fs += (size_t)n * 2 * P;
   if (fo) fo += (size_t)n * 2 * P;
   gacc += (size_t)n * P * (NV + 1);
   out += (size_t)n * (MODE == 0 ? 2 : 1) * P;
-  const int tx0 = blockIdx.x * kTX, ty0 = blockIdx.y * kTY;
+  const int tx0 = blockIdx.x * kSX, ty0 = blockIdx.y * kSY;
   const int tid = threadIdx.x;
-  for (int i = tid; i < (NV + 1) * kTY * kTX; i += 256) (&acc[0][0])[i] = 0.f;
+  for (int i = tid; i <= kNKEY; i += 256) cnt[i] = 0;
   __syncthreads();
-  constexpr int SW = kTX + 2 * kR, SH = kTY + 2 * kR;
-  for (int e = tid; e < SW * SH; e += 256) {
-    const int ry = e / SW, rx = e - ry * SW;
-    const int y = ty0 - kR + ry, x = tx0 - kR + rx;
-    if (x < 0 || x >= W || y < 0 || y >= H) continue;
-    const SplatSrc<MODE> s = splat_source<MODE>(fs, fo, P, (size_t)y * W + x, x, y, t, eps);
-    if (!s.finite || !s.is_short) continue;
-    const float X = (float)x + s.fx, Y = (float)y + s.fy;
-    const float fxf = floorf(X), fyf = floorf(Y);
-    const int x0 = (int)fxf, y0 = (int)fyf;
-    const float wx0 = (fxf + 1.f) - X, wx1 = X - fxf, wy0 = (fyf + 1.f) - Y, wy1 = Y - fyf;
-    const float wgt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+
+  // pass 1: all of this thread's window sources are loaded first (independent loads, issued back to back), then
+  // each gets its key and, from one ds_add_rtn_u32, its rank within the key
+  float raw[kSPT][MODE == 0 ? 2 : 4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
-      if (cx < 0 || cx >= W || cy < 0 || cy >= H) continue;        // corner outside the image: dropped
-      const int lx = cx - tx0, ly = cy - ty0;
-      if (lx < 0 || lx >= kTX || ly < 0 || ly >= kTY) continue;    // corner belongs to another tile
-      const int li = ly * kTX + lx;
-#pragma unroll
-      for (int c = 0; c < NV; ++c) atomicAdd(&acc[c][li], s.v[c] * wgt[k]);
-      atomicAdd(&acc[NV][li], wgt[k]);
+  for (int i = 0; i < kSPT; ++i) {
+    const int e = min(tid + i * 256, kSWX * kSWY - 1);
+    const int ry = e / kSWX, rx = e - ry * kSWX;
+    const int y = min(max(ty0 - kR + ry, 0), H - 1), x = min(max(tx0 - kR + rx, 0), W - 1);  // clamped: always loadable
+    const size_t p = (size_t)y * W + x;
+    raw[i][0] = fs[p];
+    raw[i][1] = fs[P + p];
+    if (MODE != 0) {
+      raw[i][2] = fo[p];
+      raw[i][3] = fo[P + p];
     }
   }
+  int kr[kSPT];  // key << 16 | rank, or -1
+  float4 val[kSPT];
+#pragma unroll
+  for (int i = 0; i < kSPT; ++i) {
+    kr[i] = -1;
+    const int e = tid + i * 256;
+    const int ry = e / kSWX, rx = e - ry * kSWX;
+    const int y = ty0 - kR + ry, x = tx0 - kR + rx;
+    if (e >= kSWX * kSWY || x < 0 || x >= W || y < 0 || y >= H) continue;
+    const SplatSrc<MODE> sp = splat_source_from<MODE>(raw[i][0], raw[i][1], MODE == 0 ? 0.f : raw[i][2],
+                                                      MODE == 0 ? 0.f : raw[i][3], x, y, t, eps);
+    if (!sp.finite || !sp.is_short) continue;
+    const float X = (float)x + sp.fx, Y = (float)y + sp.fy;
+    const int kx = (int)floorf(X) - tx0 + 1, ky = (int)floorf(Y) - ty0 + 1;
+    if (kx < 0 || kx >= kKX || ky < 0 || ky >= kKY) continue;
+    const int key = ky * kKX + kx;
+    kr[i] = (key << 16) | (atomicAdd(&cnt[key], 1) & 0xFFFF);
+    val[i] = make_float4(sp.v[0], sp.v[1], X - (float)tx0, Y - (float)ty0);
+  }
   __syncthreads();
+
+  // exclusive scan of cnt[0..kNKEY) in place (3 keys per thread), total -> cnt[kNKEY]
+  {
+    constexpr int PER = (kNKEY + 255) / 256;
+    int v[PER], tot = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int k = tid * PER + j;
+      v[j] = k < kNKEY ? cnt[k] : 0;
+      tot += v[j];
+    }
+    int inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if ((tid & 63) >= d) inc += o;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    int run = inc - tot;
+    for (int w = 0; w < (tid >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int k = tid * PER + j;
+      if (k < kNKEY) cnt[k] = run;
+      run += v[j];
+    }
+    if (tid == 255) cnt[kNKEY] = run;
+  }
+  __syncthreads();
+
+  // pass 2: place the records
+#pragma unroll
+  for (int i = 0; i < kSPT; ++i) {
+    if (kr[i] < 0) continue;
+    const int slot = cnt[kr[i] >> 16] + (kr[i] & 0xFFFF);
+    if (slot < kCAP) {
+      rec[slot] = val[i];
+    } else {  // LDS record space exhausted: the corners of this source that lie in THIS tile go through the global
+              // accumulator (a neighbouring tile handles its own corners of the same source)
+      const float X = val[i].z + (float)tx0, Y = val[i].w + (float)ty0;
+      const float fl_x = floorf(X), fl_y = floorf(Y);
+      const int x0 = (int)fl_x, y0 = (int)fl_y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+        if (cx < tx0 || cx >= tx0 + kSX || cy < ty0 || cy >= ty0 + kSY || cx >= W || cy >= H) continue;
+        const float w = ((k & 1) ? X - fl_x : (fl_x + 1.f) - X) * ((k >> 1) ? Y - fl_y : (fl_y + 1.f) - Y);
+        float *d = gacc + ((size_t)cy * W + cx) * (NV + 1);
+        atomic_add_f32(d, val[i].x * w);
+        if (NV == 2) atomic_add_f32(d + 1, val[i].y * w);
+        atomic_add_f32(d + NV, w);
+      }
+    }
+  }
+  // overflow adds (L2 atomics) complete before this tile reads its accumulator entries back; a workgroup-scope fence
+  // is enough (same CU, lines not yet in L1) -- an agent-scope fence writes the XCD's L2 back from every workgroup
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __syncthreads();
+
+  // gather: output pixel (lx, ly) takes, for dy in {0,1}, the segments of keys (lx, ly-dy+1) [dx = 1] and (lx+1, ly-dy+1) [dx = 0]
   const float fill = (float)max(H, W);
-  for (int i = tid; i < kTY * kTX; i += 256) {
-    const int ly = i / kTX, lx = i - ly * kTX;
+  for (int i = tid; i < kSX * kSY; i += 256) {
+    const int ly = i / kSX, lx = i - ly * kSX;
     const int y = ty0 + ly, x = tx0 + lx;
     if (x >= W || y >= H) continue;
+    float a0 = 0.f, a1 = 0.f, sw = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int k1 = (ly - dy + 1) * kKX + lx;
+      const int s0 = cnt[k1], s1 = cnt[k1 + 1], s2 = min(cnt[k1 + 2], kCAP);
+      for (int s_ = s0; s_ < s2; ++s_) {
+        const float4 r = rec[s_];
+        const int dx = s_ < s1 ? 1 : 0;
+        const float X = r.z, Y = r.w;  // tile-relative target: floor and fraction are shift-invariant (tx0, ty0 integers)
+        const float fl_x = floorf(X), fl_y = floorf(Y);
+        const float wx = dx ? X - fl_x : (fl_x + 1.f) - X;
+        const float wy = dy ? Y - fl_y : (fl_y + 1.f) - Y;
+        const float w = wx * wy;
+        a0 += r.x * w;
+        if (NV == 2) a1 += r.y * w;
+        sw += w;
+      }
+    }
     const size_t p = (size_t)y * W + x;
     const float *g = gacc + p * (NV + 1);
-    const float sw = acc[NV][i] + g[NV];
+    sw += g[NV];
     const float nrm = sw + 0.0000001f;
     const bool gap = (sw / nrm) < 0.999f;
     if (MODE == 0) {
-      const float a0 = acc[0][i] + g[0], a1 = acc[1][i] + g[1];
+      a0 += g[0];
+      a1 += g[1];
       out[p] = (gap ? fill : -1.f * (a0 / nrm)) * 2.f;
       out[P + p] = (gap ? fill : -1.f * (a1 / nrm)) * 2.f;
     } else {
-      const float a0 = acc[0][i] + g[0];
-      const SplatSrc<MODE> s = splat_source<MODE>(fs, fo, P, p, x, y, t, eps);  // the unaligned value for holes
-      out[p] = gap ? s.v[0] : a0 / nrm;
+      a0 += g[0];
+      const SplatSrc<MODE> sp = splat_source<MODE>(fs, fo, P, p, x, y, t, eps);  // the unaligned value for holes
+      out[p] = gap ? sp.v[0] : a0 / nrm;
     }
   }
 }
 
 
 // ------------------------------------------------------------------------------------------
-// Generic softsplat for many channels (C >= gather_min_c()): sort once, gather per channel -- no float atomics.
-// ds_add_f32 sustains only ~0.25 lane-adds per clock per CU (measured: run time ~ number of adds) and L2 float
-// atomics far less, so with 4*(C+1) adds per source pixel the kernels above are add-bound for the 64..192-channel
-// GMFSS feature pyramids.  Here the sources are counting-sorted by the pixel their footprint starts at
+// Generic softsplat (softsplat.py:248-367 == softsplat_torch.py:19-179; mode 0 sum, 1 avg, 2 linear, 3 soft):
+// sort once, gather per channel -- no float atomics.
+// ds_add_f32 sustains only ~0.3 lane-adds per clock per CU and L2 float atomics far less, so a scatter with
+// 4*(C+1) adds per source pixel is add-bound for the 64..192-channel GMFSS feature pyramids.  Here the sources are counting-sorted by the pixel their footprint starts at
 // (key = floor(target), one int atomic per source for the histogram and one for the slot), and every OUTPUT pixel
 // then reads the four key segments whose 2x2 footprint covers it and sums weight * value over a chunk of channels:
 // plain coalesced loads and stores, cost independent of the flow length, no halo limit, no overflow case.
@@ -523,7 +640,7 @@ int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, in
   if (hipMemsetAsync(ws, 0, (size_t)N * P * 3 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
   hipLaunchKernelGGL(splat_long_prepass<0>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f,
                      (const float *)nullptr, 0.f, ws, H, W);
-  dim3 g((W + kTX - 1) / kTX, (H + kTY - 1) / kTY, N);
+  dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);
   hipLaunchKernelGGL(splat_tiled<0>, g, dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f, (const float *)nullptr,
                      0.f, ws, out, H, W);
   DRBA_CHECK_LAUNCH();
@@ -538,7 +655,7 @@ int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float 
   if (hipMemsetAsync(ws, 0, (size_t)N * P * 2 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
   hipLaunchKernelGGL(splat_long_prepass<1>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev,
                      eps, ws, H, W);
-  dim3 g((W + kTX - 1) / kTX, (H + kTY - 1) / kTY, N);
+  dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);
   hipLaunchKernelGGL(splat_tiled<1>, g, dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev, eps, ws, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
