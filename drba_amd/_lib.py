@@ -54,7 +54,8 @@ SIGNATURES = {
     "drba_swap_select": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "drba_clamp": (_i, [_p, _p, _f, _f, _z, _p]),
     "drba_conv_direct": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "drba_instance_norm": (_i, [_p, _p, _i, _z, _f, _i, _p]),
+    "drba_instance_norm": (_i, [_p, _p, _p, _i, _z, _f, _i, _p]),
+    "drba_instance_norm_ws_floats": (_z, [_i]),
     "drba_add_act": (_i, [_p, _p, _p, _z, _i, _p]),
     "drba_channel_normalize3": (_i, [_p, _p, _i, _z, _p, _p, _p]),
     "drba_layernorm": (_i, [_p, _p, _p, _p, _p, _z, _i, _f, _p]),

@@ -71,23 +71,55 @@ conv_direct_kernel(const float *__restrict__ in, const float *__restrict__ w, co
 }
 
 // ------------------------------------------------------------------------------------------ norms / pointwise
-// nn.InstanceNorm2d (eps 1e-5, no affine): one workgroup per (n, c) plane, three passes (mean, biased var, write)
+// nn.InstanceNorm2d (eps 1e-5, no affine).  A plane is split into kInChunks chunks so that the whole chip works on
+// it: pass 1 reduces every chunk to (mean, M2) with the two-pass formula inside the chunk, pass 2 merges the chunk
+// statistics of its plane (Chan's parallel update, exact mean/variance algebra) and normalises its chunk.
+// Two reads + one write of the tensor instead of three reads by one workgroup per plane.
+constexpr int kInChunks = 32;
 __global__ void __launch_bounds__(256)
-instance_norm_kernel(const float *__restrict__ in, float *__restrict__ out, size_t HW, float eps, int relu) {
+instance_norm_stats_kernel(const float *__restrict__ in, float *__restrict__ part, size_t HW) {
   __shared__ float red[4];
-  const float *p = in + (size_t)blockIdx.x * HW;
-  float *o = out + (size_t)blockIdx.x * HW;
+  const size_t clen = (HW + kInChunks - 1) / kInChunks;
+  const size_t lo = (size_t)blockIdx.x * clen, hi = min(lo + clen, HW);
+  const float *p = in + (size_t)blockIdx.y * HW;
   float s = 0.f;
-  for (size_t i = threadIdx.x; i < HW; i += 256) s += p[i];
-  const float mean = block_sum256(s, red) / (float)HW;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+  const float cntf = hi > lo ? (float)(hi - lo) : 0.f;
+  const float mean = cntf > 0.f ? block_sum256(s, red) / cntf : 0.f;
   float v = 0.f;
-  for (size_t i = threadIdx.x; i < HW; i += 256) {
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
     const float d = p[i] - mean;
     v += d * d;
   }
-  const float var = block_sum256(v, red) / (float)HW;
-  const float inv = 1.f / sqrtf(var + eps);
-  for (size_t i = threadIdx.x; i < HW; i += 256) {
+  const float m2 = block_sum256(v, red);
+  if (threadIdx.x == 0) {
+    float *o = part + ((size_t)blockIdx.y * kInChunks + blockIdx.x) * 2;
+    o[0] = mean;
+    o[1] = m2;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+instance_norm_apply_kernel(const float *__restrict__ in, const float *__restrict__ part, float *__restrict__ out, size_t HW,
+                           float eps, int relu) {
+  const size_t clen = (HW + kInChunks - 1) / kInChunks;
+  // merge the plane's chunk statistics (every thread does the same 32-step merge: cheaper than a reduction + barrier)
+  const float *pp = part + (size_t)blockIdx.y * kInChunks * 2;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int c = 0; c < kInChunks; ++c) {
+    const size_t lo_c = (size_t)c * clen, hi_c = min(lo_c + clen, HW);
+    if (hi_c <= lo_c) break;
+    const float nb = (float)(hi_c - lo_c), mb = pp[2 * c], m2b = pp[2 * c + 1];
+    const float d = mb - mean, nn = n + nb;
+    mean += d * (nb / nn);
+    m2 += m2b + d * d * (n * nb / nn);
+    n = nn;
+  }
+  const float inv = 1.f / sqrtf(m2 / (float)HW + eps);
+  const size_t lo = (size_t)blockIdx.x * clen, hi = min(lo + clen, HW);
+  const float *p = in + (size_t)blockIdx.y * HW;
+  float *o = out + (size_t)blockIdx.y * HW;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
     const float y = (p[i] - mean) * inv;
     o[i] = relu ? fmaxf(y, 0.f) : y;
   }
@@ -401,9 +433,13 @@ int drba_conv_direct(const float *in, const float *w, const float *bias, float *
   return DRBA_OK;
 }
 
-int drba_instance_norm(const float *in, float *out, int planes, size_t HW, float eps, int relu, void *stream) {
-  if (!in || !out || planes <= 0 || HW == 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(instance_norm_kernel, dim3(planes), dim3(kBlock), 0, (hipStream_t)stream, in, out, HW, eps, relu);
+size_t drba_instance_norm_ws_floats(int planes) { return (size_t)(planes > 0 ? planes : 0) * kInChunks * 2; }
+
+int drba_instance_norm(const float *in, float *out, float *ws, int planes, size_t HW, float eps, int relu, void *stream) {
+  if (!in || !out || !ws || planes <= 0 || HW == 0) return DRBA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(instance_norm_stats_kernel, dim3(kInChunks, planes), dim3(kBlock), 0, s, in, ws, HW);
+  hipLaunchKernelGGL(instance_norm_apply_kernel, dim3(kInChunks, planes), dim3(kBlock), 0, s, in, ws, out, HW, eps, relu);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -499,7 +499,9 @@ def instance_norm(x, relu=False, eps=1e-5):
     x = _f32(x)
     n, c, h, w = x.shape
     out = torch.empty_like(x)
-    _lib.check(_lib.load().drba_instance_norm(_p(x), _p(out), n * c, h * w, float(eps), 1 if relu else 0, _stream()),
+    lib = _lib.load()
+    ws = _workspace(x.device, lib.drba_instance_norm_ws_floats(n * c))
+    _lib.check(lib.drba_instance_norm(_p(x), _p(out), _p(ws), n * c, h * w, float(eps), 1 if relu else 0, _stream()),
                "drba_instance_norm")
     return out
 

@@ -166,7 +166,9 @@ int drba_clamp(const float *in, float *out, float lo, float hi, size_t n, void *
 int drba_conv_direct(const float *in, const float *w /*[Cout,Cin,K,K]*/, const float *bias, float *out,
                      int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, void *stream);
 /* nn.InstanceNorm2d(eps, no affine) over `planes` = N*C planes of HW elements, optional ReLU (backbone.py:27-36) */
-int drba_instance_norm(const float *in, float *out, int planes, size_t HW, float eps, int relu, void *stream);
+int drba_instance_norm(const float *in, float *out, float *ws, int planes, size_t HW, float eps, int relu,
+                       void *stream); /* ws: drba_instance_norm_ws_floats(planes) floats */
+size_t drba_instance_norm_ws_floats(int planes);
 int drba_add_act(const float *a, const float *b, float *out, size_t n, int relu, void *stream); /* a + b [, ReLU] */
 /* utils.py:57-69 normalize_img: (x - mean[c]) / std[c]; mean3/std3 are HOST arrays of 3 floats */
 int drba_channel_normalize3(const float *in, float *out, int N, size_t HW, const float *mean3, const float *std3,
