@@ -17,7 +17,8 @@ inside the timed region.
 Extra objects on the JSON line:
   roofline     the kernel with the largest total time among those that dominate the rocprof trace
                (profiles/): algorithmic bytes (or FLOPs) per launch / average launch duration from HIP
-               events recorded on the launch stream during the timed region; peaks from
+               events attached to those launches' dispatch packets on the launch stream during the timed
+               region (the kernel's own execution time, as rocprofv3's kernel trace reports it); peaks from
                MI355X_MICROARCH.md (HBM 8 TB/s; dense fp32 MFMA 157.3 TFLOP/s).  `others` lists the next ones.
   cpu_baseline the fp32 CPU oracle (a port validated against the reference) on the same workload,
                bounded sample, host cores stated.
@@ -119,9 +120,8 @@ def gpu_leg(args, rank, world):
     timing = None
     if not args.no_roofline:
         # time only the kernels that dominate the rocprof trace: the stage-input gather (HBM-bound) and the large
-        # ResConv layers (MFMA-bound), and only in every `roof_every`-th step of the timed region: an event pair
-        # drains the queue before and after the launch it brackets, so instrumenting every step would slow the
-        # region it measures (measured: +1.4 ms on a 5.9 ms step when all 24 such launches of every step are timed)
+        # ResConv layers (MFMA-bound).  The event pair of a timed launch is attached to the launch's own dispatch
+        # packet inside the library (no barrier packets around it), and only every `roof_every`-th step is timed
         def want(kind, key):
             if kind == "ifblock_input":
                 return key[0] == 52
@@ -148,9 +148,9 @@ def gpu_leg(args, rank, world):
     roof = None
     if timing and timing["records"]:
         agg = {}
-        for kind, key, work, unit, e0, e1 in timing["records"]:
+        for kind, key, work, unit, slot in timing["records"]:
             a = agg.setdefault((kind, key), [0.0, 0, work, unit, []])
-            d = e0.elapsed_time(e1)
+            d = ops.timing_ms(slot)
             a[0] += d
             a[1] += 1
             a[4].append(d)
@@ -161,8 +161,7 @@ def gpu_leg(args, rank, world):
 
         def entry(k, v):
             ms, cnt, work, unit, durs = v
-            # average launch duration; a launch whose event pair straddled a host stall (GPU idle between the two
-            # records) is an outlier, so the mean is taken over the launches within 1.5x of the median
+            # average launch duration over the launches within 1.5x of the median (guards against a preempted launch)
             med = sorted(durs)[len(durs) // 2]
             good = [d for d in durs if d <= 1.5 * med] or durs
             avg_s = sum(good) / len(good) / 1e3

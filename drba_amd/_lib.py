@@ -18,6 +18,9 @@ _z = C.c_size_t
 # name -> (restype, argtypes); mirrors include/drba_hip.h one to one
 SIGNATURES = {
     "drba_abi_version": (_i, []),
+    "drba_timing_slots": (_i, []),
+    "drba_timing_arm": (_i, [_i]),
+    "drba_timing_elapsed_ms": (_i, [_i, C.POINTER(C.c_float)]),
     "drba_error_string": (C.c_char_p, [_i]),
     "drba_softsplat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "drba_softsplat_ws_floats": (_z, [_i, _i, _i, _i]),

@@ -2,6 +2,7 @@
 // 256 CUs in 8 XCDs, fp32 hardware atomics to device (coarse-grained) memory.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/drba_hip.h"
@@ -12,6 +13,22 @@
   } while (0)
 
 namespace drba {
+
+// Per-launch kernel timing for bench.py's roofline object: drba_timing_arm(slot) makes the NEXT timed launch attach
+// the slot's event pair to its own dispatch packet (hipExtLaunchKernelGGL), so the pair brackets exactly the kernel
+// -- the duration rocprofv3's kernel trace reports -- without the barrier packets an event recorded on the stream
+// adds before and after the launch.  Defined in api_misc.hip.
+struct TimedLaunch {
+  hipEvent_t start, stop;  // both null when not armed
+};
+TimedLaunch take_armed_timing();
+
+#define DRBA_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                              \
+  do {                                                                                                        \
+    const drba::TimedLaunch tl_ = drba::take_armed_timing();                                                  \
+    if (tl_.start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tl_.start, tl_.stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                   \
+  } while (0)
 
 constexpr int kBlock = 256;      // 4 waves: one per SIMD of a CU
 constexpr int kMaxBlocks = 2048; // 256 CUs x 8: grid-stride beyond this (guide G11)

@@ -419,8 +419,8 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
                               Cfg::LDS_FLOATS * (int)sizeof(float));
       if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     }
-    hipLaunchKernelGGL(kernel, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2, out, Cin, H,
-                       W, Cout, Ho, Wo, act, post_slope, pre_slope, n_ct, ps);
+    DRBA_LAUNCH_TIMED(kernel, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2, out, Cin, H,
+                      W, Cout, Ho, Wo, act, post_slope, pre_slope, n_ct, ps);
     return DRBA_OK;
   };
   const int rc = pre_act ? go(conv_mfma<Cfg, true>) : go(conv_mfma<Cfg, false>);

@@ -427,11 +427,11 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
 #define DRBA_LAUNCH(HF, SG)                                                                                        \
   do {                                                                                                             \
     if (var == 0) {                                                                                                \
-      hipLaunchKernelGGL((ifblock_input_pixel<HF, SG>), dim3(tiles_for(w, h)), b, 0, s, DRBA_ARGS);                \
+      DRBA_LAUNCH_TIMED((ifblock_input_pixel<HF, SG>), dim3(tiles_for(w, h)), b, 0, s, DRBA_ARGS);                 \
     } else if (var == 1) {                                                                                         \
-      hipLaunchKernelGGL((ifblock_input_kernel<HF, SG, 1>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                 \
+      DRBA_LAUNCH_TIMED((ifblock_input_kernel<HF, SG, 1>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                  \
     } else {                                                                                                       \
-      hipLaunchKernelGGL((ifblock_input_kernel<HF, SG, 4>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                 \
+      DRBA_LAUNCH_TIMED((ifblock_input_kernel<HF, SG, 4>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                  \
     }                                                                                                              \
   } while (0)
   if (flow) {

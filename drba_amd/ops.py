@@ -53,9 +53,11 @@ def _workspace(device, nfloats):
 
 
 # Optional per-launch timing (bench.py's roofline leg).  When TIMING is a dict
-# {"want": callable(kind, key) -> bool, "records": []}, each selected launch appends
-# (kind, key, work, unit, start_event, end_event); the events are recorded on the stream the kernel
-# is launched on.  Only a few launches per step are selected so the timed region is not perturbed.
+# {"want": callable(kind, key) -> bool, "records": []}: each selected launch appends (kind, key, work, unit, slot).
+# `slot` names an event pair inside libdrba_hip.so that is attached to the launch's own dispatch packet
+# (drba_timing_arm -> hipExtLaunchKernelGGL), so the pair brackets exactly the kernel's execution, as rocprofv3's
+# kernel trace does; an event recorded on the stream before/after a launch adds a barrier packet each side and reads
+# ~10 us long.  bench.py turns the slots into durations with timing_ms() after the timed region.
 TIMING = None
 
 
@@ -63,12 +65,20 @@ def _timed(kind, key, work, unit, launch):
     t = TIMING
     if t is None or not t["want"](kind, key):
         return launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    lib = _lib.load()
+    slot = len(t["records"])
+    if slot >= lib.drba_timing_slots():
+        return launch()
+    _lib.check(lib.drba_timing_arm(slot), "drba_timing_arm")
     r = launch()
-    e1.record()
-    t["records"].append((kind, key, work, unit, e0, e1))
+    t["records"].append((kind, key, work, unit, slot))
     return r
+
+
+def timing_ms(slot):
+    ms = C.c_float(0.0)
+    _lib.check(_lib.load().drba_timing_elapsed_ms(int(slot), C.byref(ms)), "drba_timing_elapsed_ms")
+    return float(ms.value)
 
 
 # ----------------------------------------------------------------------------- splat / warp / drm

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Steady-state per-step kernel table from a rocprofv3 kernel_trace.csv of bench.py.
-    python tools/trace_steady.py kernel_trace.csv K [out.csv]
+    python tools/trace_steady.py kernel_trace.csv K [out.csv [rows]] [--by-grid]
 Uses only the dispatches of the last K bench steps (a step ends with its 2nd f32_to_u8_kernel),
 so one-time work (autotuning, warm-up, weight packing) is excluded."""
 import csv
 import re
 import sys
 
+BY_GRID = "--by-grid" in sys.argv
+if BY_GRID:
+    sys.argv.remove("--by-grid")
 rows = list(csv.DictReader(open(sys.argv[1])))
 K = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -20,6 +23,8 @@ agg = {}
 for r in sel:
     nm = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
     nm = re.sub(r"\((float|unsigned) const.*", "", nm).replace("void ", "")
+    if BY_GRID:  # one row per launch geometry: separates the layers that share a kernel instantiation
+        nm += f" grid {r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']}"
     a = agg.setdefault(nm, [0, 0])
     a[0] += 1
     a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
