@@ -168,6 +168,33 @@ def check_glue(dev):
         rows.append((f"ifblock_update mask/feat s={s}", max(_diff(gm, up[:, 4:5]), _diff(gfe, up[:, 5:])), 1e-5, ""))
         gf = ops.ifblock_update(D(tmp), None, H, W, s)
         rows.append((f"ifblock_update noflow s={s}", _diff(gf, up[:, :4] * s), 1e-5 * max(1.0, s), ""))
+    # fused splat pipelines (flow reversal, linear DRM) on flows that exercise every path of the sorted tile kernel:
+    # smooth, longer than the 16-px tile halo, NaN/inf, and a 4x zoom-out that overflows the tile's LDS record space
+    Hs, Ws = 70, 150
+    ys, xs = torch.meshgrid(torch.arange(Hs, dtype=torch.float32), torch.arange(Ws, dtype=torch.float32), indexing="ij")
+    smooth = F.interpolate(torch.randn(1, 2, 5, 9, generator=g) * 5, size=(Hs, Ws), mode="bilinear")
+    longf = smooth * 6
+    nanf = smooth.clone()
+    nanf[0, 0, 7, 9] = float("nan")
+    nanf[0, 1, 30, 100] = float("inf")
+    conv = torch.stack([-0.75 * (xs - Ws / 2 + 0.3), -0.75 * (ys - Hs / 2 + 0.2)]).unsqueeze(0)
+    other = F.interpolate(torch.randn(1, 2, 5, 9, generator=g) * 4, size=(Hs, Ws), mode="bilinear")
+    # all sources within the halo of the tile at x 64..95, y 32..47 pulled into it: ~2300 records for a capacity of 1536
+    pinch = torch.stack([-0.45 * (xs - 79.5), -0.6 * (ys - 39.5)]).unsqueeze(0)
+    for fname, fl in (("smooth", smooth), ("long", longf), ("nan", nanf), ("converge", conv), ("pinch", pinch)):
+        ones = torch.ones(1, 1, Hs, Ws)
+        ref = -1 * oracle.ops.softsplat(fl, fl, None, "avg")
+        gap = oracle.ops.softsplat(ones, fl, None, "avg") < 0.999
+        ref = torch.where(gap, torch.full_like(ref, float(max(Hs, Ws))), ref) * 2
+        got = ops.flow_reverse(D(fl.contiguous()))
+        n_out, n_all = _outliers(torch.nan_to_num(got.cpu()), torch.nan_to_num(ref), 2e-4)
+        # the hole test (ones-splat < 0.999) can flip for a pixel sitting on the threshold: allow isolated flips
+        rows.append((f"flow_reverse {fname}", 0.0 if n_out <= 3 else _diff(got, ref), 2e-4, f"outliers {n_out}/{n_all}"))
+        for tt in (0.25, 0.5):
+            refd = oracle.drm.calc_drm_rife(tt, fl, other, True)["drm_t1_t01"]
+            gotd = ops.drm_rife_linear(D(fl.contiguous()), D(other.contiguous()), tt, 1e-4)
+            n_out, n_all = _outliers(torch.nan_to_num(gotd.cpu()), torch.nan_to_num(refd), 2e-5)
+            rows.append((f"drm_rife_linear {fname} t={tt}", 0.0 if n_out <= 3 else _diff(gotd, refd), 2e-5, f"outliers {n_out}/{n_all}"))
     for sl in (1.0, 2.0):
         tl = torch.randn(1, 13, int(H / sl), int(W / sl), generator=g)
         m = torch.sigmoid(F.interpolate(tl, scale_factor=sl, mode="bilinear", align_corners=False)[:, 4:5])
