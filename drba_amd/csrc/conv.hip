@@ -24,7 +24,7 @@
 //         partial accumulators are reduced through LDS at the end.  For small maps, where a
 //         serial K loop over all input channels is the latency floor.
 //
-// MODE 0: conv3x3.  MODE 1: one output phase (py,px) of ConvTranspose2d(k=4,s=2,p=1):
+// MODE 0: conv3x3.  MODE 1: one row phase py (both column phases px) of ConvTranspose2d(k=4,s=2,p=1):
 //   out[o, 2j+py, 2i+px] = b[o] + sum_{c, a, b in {0,1}} in[c, j+dy(py,a), i+dx(px,b)] * W[c, o, ky(py,a), kx(px,b)]
 //   with (py=0: (ky,dy) = (1,0),(3,-1); py=1: (0,+1),(2,0)), same along x: a 2x2-tap convolution
 //   over the same haloed input tile; blockIdx.z carries the phase.
@@ -60,14 +60,17 @@ struct ConvCfg {
   static constexpr int SPB = (CK * CHS + NL - 1) / NL;
   static constexpr int CG = CK / 4;                      // MFMA k-groups per tap per chunk
   static constexpr int FRAG = NTAP * CG * NT * 64;       // packed weight floats per (cout tile[, phase], chunk)
-  static constexpr int NTILES = RW * MW * NT;
+  // MODE 1: a workgroup computes BOTH column phases (px = 0, 1) of its row phase, so that its lanes own runs of
+  // consecutive output columns (coalesced stores; 64 scattered dwords per store instruction otherwise)
+  static constexpr int NPX = (MODE == 1) ? 2 : 1;
+  static constexpr int NTILES = NPX * RW * MW * NT;
   // Weight path: KS=1 stages the chunk's fragment block through LDS (shared by the 4 waves, 16-byte LDS-direct
   // loads); KS=4 (small maps, wave-private chunks) reads B fragments straight from L2 -- staging them per
   // wave would quadruple the LDS writes (measured: 40 -> 56 us on the 64-ch 136x240 ResConv).
   static constexpr bool WLDS = (KS == 1);
   static constexpr int SPW = WLDS ? (FRAG / 4 + NL - 1) / NL : 0;   // 16-byte weight loads per lane per chunk
   static constexpr int FPAD = WLDS ? ((FRAG / 4 + 63) / 64) * 256 : 0;  // fragment block rounded up to whole wave loads
-  static constexpr int BUFALL = BUF + FPAD;              // input tile (+ weight fragments) of one chunk
+  static constexpr int BUFALL = BUF + NPX * FPAD;        // input tile (+ weight fragments of every column phase) of one chunk
   static constexpr int LDS_STAGE = 2 * BUFALL * (KS == 1 ? 1 : 4);
   static constexpr int LDS_RED = (KS == 1) ? 0 : 4 * NTILES * 256;
   static constexpr int LDS_FLOATS = LDS_STAGE > LDS_RED ? LDS_STAGE : LDS_RED;
@@ -95,10 +98,10 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
   // the window every cout tile / deconv phase re-reads then hit that XCD's L2 instead of being fetched by up to 8.
   const int nbx = gridDim.x, nby = gridDim.y;
   int t = xcd_band((int)(blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z)), (int)(nbx * nby * gridDim.z));
-  int phase = 0;
+  int py = 0;
   if (MODE == 1) {
-    phase = t & 3;
-    t >>= 2;
+    py = t & 1;
+    t >>= 1;
   }
   const int cz = t % n_ctiles;
   t /= n_ctiles;
@@ -106,7 +109,6 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
   t /= nbx;
   const int by = t % nby, n = t / nby;
   const int x0 = bx * TW, y0 = by * TH;
-  const int py = phase >> 1, px = phase & 1;
   in += (size_t)n * Cin * H * W;
   if (MODE == 0) {
     out += (size_t)n * Cout * Ho * Wo;
@@ -116,13 +118,16 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
     out += (size_t)n * Cout * (2 * H) * (2 * W);
   }
 
-  f32x4 acc[RW][MW][NT];
+  constexpr int NPX = Cfg::NPX;
+  f32x4 acc[NPX][RW][MW][NT];
 #pragma unroll
-  for (int a = 0; a < RW; ++a)
+  for (int p = 0; p < NPX; ++p)
 #pragma unroll
-    for (int b = 0; b < MW; ++b)
+    for (int a = 0; a < RW; ++a)
 #pragma unroll
-      for (int c = 0; c < NT; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < MW; ++b)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[p][a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = (Cin + CK - 1) / CK;
   float *buf0 = smem + (KS == 1 ? 0 : wave * 2 * Cfg::BUFALL);
@@ -132,10 +137,12 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
   const int a_off = kq * CHS + (row0 * S) * TC + m * S;
   const int gy0 = y0 * S - 1, gx0 = x0 * S - 1;
   const int q_first = (KS == 1) ? 0 : wave, q_step = (KS == 1) ? 1 : 4;
-  const float *wf_base = wfrag + ((size_t)(MODE == 0 ? cz : cz * 4 + phase) * nchunks) * Cfg::FRAG;
+  // packed weights: [cout tile][phase = 2*py + px][chunk][FRAG]; the two column phases of this row phase are adjacent
+  const float *wf_base = wfrag + ((size_t)(MODE == 0 ? cz : cz * 4 + 2 * py) * nchunks) * Cfg::FRAG;
+  const size_t px_stride = (size_t)nchunks * Cfg::FRAG;  // floats between the px = 0 and px = 1 fragment blocks
   // deconv tap -> tile offsets: tap = 2a+b; row = rw + 1 + dy, py=0: dy={0,-1}; py=1: dy={+1,0}
   const int dro[2] = {py ? 2 : 1, py ? 1 : 0};
-  const int dco[2] = {px ? 2 : 1, px ? 1 : 0};
+  const int dco[2][2] = {{1, 0}, {2, 1}};  // [px][b]
 
   // ---- staging: global -> LDS without passing through registers.  Each lane owns the same (row, col) of the
   // window for every channel, so its byte offset inside a channel plane is computed once; the channel / chunk
@@ -145,7 +152,7 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
   const unsigned plane_bytes = (unsigned)H * (unsigned)W * 4u;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, Cin * (int)plane_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc((void *)wf_base, 0, nchunks * Cfg::FRAG * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void *)wf_base, 0, NPX * nchunks * Cfg::FRAG * 4, 0x00020000);
   unsigned voff[SPB];
 #pragma unroll
   for (int i = 0; i < SPB; ++i) {
@@ -165,10 +172,13 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(buf + i * NL + wslot), 4, voff[i], soff, 0, 0);
     if (Cfg::WLDS) {
 #pragma unroll
-      for (int i = 0; i < SPW; ++i)  // lanes past the fragment block fetch the next chunk's head into LDS padding
-        if (i * NL + wslot < Cfg::FRAG / 4)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(buf + Cfg::BUF + (i * NL + wslot) * 4), 16,
-                                                 (unsigned)(i * NL + ltid) * 16u, (unsigned)q * (Cfg::FRAG * 4), 0, 0);
+      for (int p = 0; p < NPX; ++p)
+#pragma unroll
+        for (int i = 0; i < SPW; ++i)  // lanes past the fragment block fetch the next chunk's head into LDS padding
+          if (i * NL + wslot < Cfg::FRAG / 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs_w, (lds_ptr)(buf + Cfg::BUF + p * Cfg::FPAD + (i * NL + wslot) * 4), 16, (unsigned)(i * NL + ltid) * 16u,
+                (unsigned)(((size_t)p * px_stride + (size_t)q * Cfg::FRAG) * 4), 0, 0);
     }
   };
   auto sync = [&]() {  // the chunk just requested has landed and everybody is done reading the other buffer
@@ -192,13 +202,14 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
       // Software-pipelined over the (tap, k-group) steps: the A/B fragments of step j+1 are read from LDS while the
       // MFMAs of step j issue, so a wave waits for LDS once per chunk instead of once per step (left to the
       // compiler, the reads sit directly in front of the MFMAs that consume them: MFMA pipe 55-65 % busy).
-      constexpr int NSTEP = NTAP * CG;
+      constexpr int NSTEP = NPX * NTAP * CG;  // (column phase,) tap, k-group
       float av[2][RW][MW], bv[2][NT];
       auto fetch = [&](int j, int slot) {
-        const int tap = j / CG, cg = j - tap * CG;
-        const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[tap & 1];
+        const int p = j / (NTAP * CG), jj = j - p * (NTAP * CG);
+        const int tap = jj / CG, cg = jj - tap * CG;
+        const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[p][tap & 1];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = wb[((tap * CG + cg) * NT + nt) * 64];
+        for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = wb[p * Cfg::FPAD + ((tap * CG + cg) * NT + nt) * 64];
 #pragma unroll
         for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
@@ -207,7 +218,7 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
       fetch(0, 0);
 #pragma unroll
       for (int j = 0; j < NSTEP; ++j) {
-        const int slot = j & 1;
+        const int slot = j & 1, p = j / (NTAP * CG);
         if (j + 1 < NSTEP) fetch(j + 1, slot ^ 1);
 #pragma unroll
         for (int rw = 0; rw < RW; ++rw)
@@ -219,7 +230,7 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
             if (PRE) a = a > 0.f ? a : pre_slope * a;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[slot][nt], acc[rw][mw][nt], 0, 0, 0);
+              acc[p][rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[slot][nt], acc[p][rw][mw][nt], 0, 0, 0);
           }
         // keep the issue order: the LDS reads of step j+1, then the MFMAs of step j
         __builtin_amdgcn_sched_group_barrier(0x100, RW * MW + NT, 0);
@@ -229,37 +240,40 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
       // split-K: the B fragments come from L2 (global loads); the compiler hoists them across the taps on its own,
       // and pinning an LDS-style pipeline here serialises one L2 round trip per step (measured 21 -> 48 us)
 #pragma unroll
-      for (int tap = 0; tap < NTAP; ++tap) {
-        const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[tap & 1];
+      for (int p = 0; p < NPX; ++p)
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg) {
-          float bv[NT];
+        for (int tap = 0; tap < NTAP; ++tap) {
+          const float *at = (MODE == 0) ? ab + (tap / 3) * TC + (tap % 3) : ab + dro[tap >> 1] * TC + dco[p][tap & 1];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[((tap * CG + cg) * NT + nt) * 64];
+          for (int cg = 0; cg < CG; ++cg) {
+            float bv[NT];
 #pragma unroll
-          for (int rw = 0; rw < RW; ++rw)
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[p * px_stride + ((tap * CG + cg) * NT + nt) * 64];
 #pragma unroll
-            for (int mw = 0; mw < MW; ++mw) {
-              float a = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
-              if (PRE) a = a > 0.f ? a : pre_slope * a;
+            for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[rw][mw][nt], 0, 0, 0);
-            }
+              for (int mw = 0; mw < MW; ++mw) {
+                float a = at[(cg * 4) * CHS + (rw * S) * TC + mw * 16 * S];
+                if (PRE) a = a > 0.f ? a : pre_slope * a;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[p][rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[p][rw][mw][nt], 0, 0, 0);
+              }
+          }
         }
-      }
     }
     sync();
   }
 
   // ---- epilogue
   const bool vec = (Wo & 3) == 0;
-  auto store_tile = [&](int rw, int mw, int nt, f32x4 v) {
+  auto store_tile = [&](int rw, int mw, int nt, f32x4 v, f32x4 v1) {  // v1: the px = 1 phase of a transposed conv
+    (void)v1;
     const int co = cz * Cfg::NTC + nt * 16 + m;
     const int y = y0 + row0 + rw;
     const int xb = x0 + mw * 16 + kq * 4;
-    if (co >= Cout) return;
-    const float bs = bias ? bias[co] : 0.f;
+    if (co >= Cout && !(MODE == 1 && pixel_shuffle)) return;  // (PixelShuffle: Cout % 4 == 0, lane pairs stay together)
+    const float bs = (bias && co < Cout) ? bias[co] : 0.f;
     if (MODE == 0) {
       // y = acc + bias; ResConv: y = y*beta + res; otherwise y += res (+ res2); then the post activation:
       // act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10
@@ -303,19 +317,46 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
           out[idx + k] = post(t);
         }
       }
-    } else {  // transposed conv phase: bias, scatter to (2j+py, 2i+px) [+ PixelShuffle(2)]
-      if (y >= H) return;
+    } else {
+      // transposed conv, row phase py, both column phases: lane (cout m, column group kq) holds the input columns
+      // xb..xb+3 for px = 0 (v) and px = 1 (v1), i.e. the 8 consecutive output columns 2*xb .. 2*xb+7 of row 2y+py.
       const int Hd = 2 * H, Wd = 2 * W;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = xb + k;
-        if (i >= W) continue;
-        const int oy = 2 * y + py, ox = 2 * i + px;
-        if (pixel_shuffle) {  // [Cout/4, 2*Hd, 2*Wd]
-          const int c13 = co >> 2, si = (co >> 1) & 1, sj = co & 1;
-          out[((size_t)c13 * (2 * Hd) + (2 * oy + si)) * (2 * Wd) + (2 * ox + sj)] = v[k] + bs;
+      const int oy = 2 * y + py;
+      if (!pixel_shuffle) {
+        if (y >= H || xb >= W) return;
+        float *dst = out + ((size_t)co * Hd + oy) * Wd + 2 * xb;
+        if (xb + 3 < W && (Wd & 3) == 0) {
+          *reinterpret_cast<f32x4 *>(dst) = (f32x4){v[0] + bs, v1[0] + bs, v[1] + bs, v1[1] + bs};
+          *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){v[2] + bs, v1[2] + bs, v[3] + bs, v1[3] + bs};
         } else {
-          out[((size_t)co * Hd + oy) * Wd + ox] = v[k] + bs;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (xb + k < W) {
+              dst[2 * k] = v[k] + bs;
+              dst[2 * k + 1] = v1[k] + bs;
+            }
+        }
+      } else {
+        // + PixelShuffle(2): cout = 4*c13 + 2*si + sj lands at row 2*oy+si, column 2*(2i+px)+sj = 4i + 2px + sj of plane
+        // c13.  Lanes m and m^1 (sj = 0 / 1, same c13 and si) exchange their values, after which each holds the 4
+        // consecutive columns 4i..4i+3 for every i; the even lane stores i = xb, xb+1, the odd lane i = xb+2, xb+3.
+        const int c13 = co >> 2, si = (co >> 1) & 1, sj = co & 1;
+        f32x4 o0, o1;  // partner's px=0 / px=1 values (bias of ITS cout added before the exchange)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] += bs;
+          v1[k] += bs;
+          o0[k] = __shfl_xor(v[k], 1, 64);
+          o1[k] = __shfl_xor(v1[k], 1, 64);
+        }
+        if (co >= Cout || y >= H || xb >= W) return;
+        float *dst = out + ((size_t)c13 * (2 * Hd) + (2 * oy + si)) * (size_t)(2 * Wd) + 4 * xb;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int k = sj * 2 + kk;  // even lane: input columns xb, xb+1; odd lane: xb+2, xb+3
+          if (xb + k >= W) continue;
+          const f32x4 q = sj ? (f32x4){o0[k], v[k], o1[k], v1[k]} : (f32x4){v[k], o0[k], v1[k], o1[k]};
+          *reinterpret_cast<f32x4 *>(dst + 4 * k) = q;
         }
       }
     }
@@ -327,20 +368,29 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
 #pragma unroll
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) store_tile(rw, mw, nt, acc[rw][mw][nt]);
+        for (int nt = 0; nt < NT; ++nt) store_tile(rw, mw, nt, acc[0][rw][mw][nt], acc[NPX - 1][rw][mw][nt]);
   } else {
     // cross-wave K reduction: partials -> LDS, then wave w finishes tiles t == w (mod 4)
-    constexpr int NTILES = Cfg::NTILES;
+    constexpr int NTILES = Cfg::NTILES, NT1 = RW * MW * NT;  // NTILES = NPX * NT1, phase-major
     __syncthreads();  // every wave is done with its staging buffers
     f32x4 *red = reinterpret_cast<f32x4 *>(smem);
 #pragma unroll
-    for (int rw = 0; rw < RW; ++rw)
+    for (int p = 0; p < NPX; ++p)
 #pragma unroll
-      for (int mw = 0; mw < MW; ++mw)
+      for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          red[(wave * NTILES + (rw * MW + mw) * NT + nt) * 64 + lane] = acc[rw][mw][nt];
+        for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            red[(wave * NTILES + p * NT1 + (rw * MW + mw) * NT + nt) * 64 + lane] = acc[p][rw][mw][nt];
     __syncthreads();
+    auto total = [&](int t) -> f32x4 {
+      f32x4 v = red[(0 * NTILES + t) * 64 + lane];
+      v += red[(1 * NTILES + t) * 64 + lane];
+      v += red[(2 * NTILES + t) * 64 + lane];
+      v += red[(3 * NTILES + t) * 64 + lane];
+      return v;
+    };
 #pragma unroll
     for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
@@ -349,11 +399,7 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
         for (int nt = 0; nt < NT; ++nt) {
           const int t = (rw * MW + mw) * NT + nt;
           if ((t & 3) != wave) continue;
-          f32x4 v = red[(0 * NTILES + t) * 64 + lane];
-          v += red[(1 * NTILES + t) * 64 + lane];
-          v += red[(2 * NTILES + t) * 64 + lane];
-          v += red[(3 * NTILES + t) * 64 + lane];
-          store_tile(rw, mw, nt, v);
+          store_tile(rw, mw, nt, total(t), total((NPX - 1) * NT1 + t));
         }
   }
 #endif
@@ -392,11 +438,11 @@ using D5 = ConvCfg<1, 1, 1, 4, 2, 8, 1>;  // 4x64 px x 32 cout
 constexpr int kNumDeconvCfg = 6;
 
 struct CfgInfo {
-  int S, TH, TW, NTC, NT, CK, KS, RW, MW, NTAP, per_chunk, lds_bytes;  // per_chunk: packed floats per (cout tile[, phase], chunk)
+  int S, TH, TW, NTC, NT, CK, KS, RW, MW, NTAP, NPX, per_chunk, lds_bytes;  // per_chunk: packed floats per (cout tile[, phase], chunk)
 };
 template <class C>
 constexpr CfgInfo cfg_info() {
-  return {C::S, C::TH, C::TW, C::NTC, C::NT, C::CK, C::KS, C::RW, C::MW, C::NTAP, C::FRAG, C::LDS_FLOATS * 4};
+  return {C::S, C::TH, C::TW, C::NTC, C::NT, C::CK, C::KS, C::RW, C::MW, C::NTAP, C::NPX, C::FRAG, C::LDS_FLOATS * 4};
 }
 const CfgInfo kConv[kNumConvCfg] = {cfg_info<C0>(), cfg_info<C1>(), cfg_info<C2>(), cfg_info<C3>(), cfg_info<C4>(),
                                     cfg_info<C5>(), cfg_info<C6>(), cfg_info<C7>(), cfg_info<C8>(), cfg_info<C9>(),
@@ -410,7 +456,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
            float pre_slope, int ps, hipStream_t s) {
   const int n_ct = (Cout + Cfg::NTC - 1) / Cfg::NTC;
   const int gh = Cfg::MODE == 0 ? Ho : H, gw = Cfg::MODE == 0 ? Wo : W;
-  dim3 g((gw + Cfg::TW - 1) / Cfg::TW, (gh + Cfg::TH - 1) / Cfg::TH, N * n_ct * (Cfg::MODE == 0 ? 1 : 4));
+  dim3 g((gw + Cfg::TW - 1) / Cfg::TW, (gh + Cfg::TH - 1) / Cfg::TH, N * n_ct * (Cfg::MODE == 0 ? 1 : 2));  // x2: row phases
   // PRE: PReLU pre-activation compiled into the MFMA loop (FeatureNet / MetricNet / GridNet convolutions)
   auto go = [&](auto kernel) -> int {
     if (Cfg::LDS_FLOATS * sizeof(float) > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950: 160 KB per CU)
@@ -443,7 +489,7 @@ int pick(const CfgInfo *tab, int ntab, int stride, int Cin, int Cout, int gh, in
     const double blocks =
         (double)((gw + c.TW - 1) / c.TW) * ((gh + c.TH - 1) / c.TH) * ((Cout + c.NTC - 1) / c.NTC) * zmul;
     const double cpw = (c.KS == 1) ? nch : (nch + 3) / 4;  // chunks per wave
-    const double mfma_cyc = c.RW * c.MW * c.NT * (double)c.NTAP * (c.CK / 4) * cpw * 32.0;
+    const double mfma_cyc = c.NPX * c.RW * c.MW * c.NT * (double)c.NTAP * (c.CK / 4) * cpw * 32.0;
     const double fixed = cpw * 900.0 + (c.KS == 4 ? 1500.0 : 0.0) + 2500.0;
     int bpc = 160 * 1024 / (c.lds_bytes > 0 ? c.lds_bytes : 1);
     if (bpc > 3) bpc = 3;
@@ -553,7 +599,7 @@ int drba_deconv4x4_pick_cfg(int Cin, int Cout, int H, int W) {
   if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   const int ov = env_override("DRBA_DECONV_CFG", kNumDeconvCfg);
   if (ov >= 0) return ov;
-  return pick(kDeconv, kNumDeconvCfg, 1, Cin, Cout, H, W, 4);
+  return pick(kDeconv, kNumDeconvCfg, 1, Cin, Cout, H, W, 2);  // two row-phase workgroups per tile
 }
 
 size_t drba_deconv4x4_packed_floats(int Cin, int Cout, int cfg) {
