@@ -176,17 +176,61 @@ __global__ void __launch_bounds__(256) gelu_kernel(const float *__restrict__ x, 
   }
 }
 
-// in-place softmax over each row of x*scale (+ mask[(row / rows_per_mat) % n_masks][row % rows_per_mat][:]); one block per row
+// in-place softmax over each row of x/scale (+ mask[(row / rows_per_mat) % n_masks][row % rows_per_mat][:]).
+// The row lives in registers between the single read and the single write: ROWS_PER_BLOCK = 4 -> one wave per row
+// (window attention, 540 columns: no barriers, shuffles only), ROWS_PER_BLOCK = 1 -> one workgroup per row (up to
+// 256 * EPT columns: the 2160- and 8640-column rows of the 1/8-resolution layers).
+template <int EPT, int ROWS_PER_BLOCK>
 __global__ void __launch_bounds__(256)
-softmax_rows_kernel(float *__restrict__ x, const float *__restrict__ mask, int cols, int rows_per_mat, int n_masks,
-                    float scale) {
+softmax_rows_kernel(float *__restrict__ x, const float *__restrict__ mask, size_t rows, int cols, int rows_per_mat,
+                    int n_masks, float scale) {
+  __shared__ float red[4];
+  constexpr int LANES = 256 / ROWS_PER_BLOCK;  // threads cooperating on one row
+  const int sub = threadIdx.x / LANES, t = threadIdx.x - sub * LANES;
+  const size_t row = (size_t)blockIdx.x * ROWS_PER_BLOCK + sub;
+  const bool live = row < rows;
+  float *p = x + (live ? row : 0) * cols;
+  const float *m = mask ? mask + (((row / rows_per_mat) % n_masks) * (size_t)rows_per_mat + (row % rows_per_mat)) * cols : nullptr;
+  float v[EPT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int c = t + i * LANES;
+    v[i] = -INFINITY;
+    if (live && c < cols) {
+      v[i] = p[c] / scale;  // scores / sqrt(c): the reference divides
+      if (m) v[i] += m[c];
+    }
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = ROWS_PER_BLOCK == 1 ? block_max256(mx, red) : wave_max(mx);
+  if (ROWS_PER_BLOCK != 1) mx = __shfl(mx, 0, 64);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    v[i] = expf(v[i] - mx);  // exp(-inf) = 0 for the padding slots
+    s += v[i];
+  }
+  s = ROWS_PER_BLOCK == 1 ? block_sum256(s, red) : wave_sum(s);
+  if (ROWS_PER_BLOCK != 1) s = __shfl(s, 0, 64);
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int c = t + i * LANES;
+    if (live && c < cols) p[c] = v[i] / s;
+  }
+}
+
+// rows too long for registers: three passes over the row in global memory, one workgroup per row
+__global__ void __launch_bounds__(256)
+softmax_rows_long_kernel(float *__restrict__ x, const float *__restrict__ mask, int cols, int rows_per_mat, int n_masks,
+                         float scale) {
   __shared__ float red[4];
   const size_t row = blockIdx.x;
   float *p = x + row * cols;
   const float *m = mask ? mask + (((row / rows_per_mat) % n_masks) * (size_t)rows_per_mat + (row % rows_per_mat)) * cols : nullptr;
   float mx = -INFINITY;
   for (int c = threadIdx.x; c < cols; c += 256) {
-    float v = p[c] / scale;  // scores / sqrt(c): the reference divides
+    float v = p[c] / scale;
     if (m) v += m[c];
     p[c] = v;
     mx = fmaxf(mx, v);
@@ -480,8 +524,19 @@ int drba_gelu(const float *x, float *out, size_t n, void *stream) {
 int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks, float scale,
                       void *stream) {
   if (!x || rows == 0 || cols <= 0 || rows_per_mat <= 0 || !(scale > 0.f) || (mask && n_masks <= 0)) return DRBA_EINVAL;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, mask, cols,
-                     rows_per_mat, mask ? n_masks : 1, scale);
+  hipStream_t s = (hipStream_t)stream;
+  const int nm = mask ? n_masks : 1;
+#define DRBA_SOFTMAX(EPT, RPB)                                                                                     \
+  hipLaunchKernelGGL((softmax_rows_kernel<EPT, RPB>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(kBlock), 0, s, x, \
+                     mask, rows, cols, rows_per_mat, nm, scale)
+  if (cols <= 64 * 9) DRBA_SOFTMAX(9, 4);
+  else if (cols <= 64 * 16) DRBA_SOFTMAX(16, 4);
+  else if (cols <= 256 * 9) DRBA_SOFTMAX(9, 1);
+  else if (cols <= 256 * 34) DRBA_SOFTMAX(34, 1);
+  else
+    hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(kBlock), 0, s, x, mask, cols, rows_per_mat, nm,
+                       scale);
+#undef DRBA_SOFTMAX
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
