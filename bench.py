@@ -43,6 +43,7 @@ CONFIGS = {
     "1080p": ((1080, 1920), 1.0, "rife -t 2, 1080p synthetic (net 1088x1920), scale 1.0"),
     "4k": ((2160, 3840), 0.5, "rife -t 2, 4K synthetic (net 2176x3840), scale 0.5"),
     "480p": ((480, 854), 1.0, "rife -t 2, 480p synthetic (net 512x896), scale 1.0"),
+    "4k_s1": ((2160, 3840), 1.0, "rife -t 2, 4K synthetic (net 2176x3840), scale 1.0"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
