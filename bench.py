@@ -8,6 +8,9 @@ in HBM) -> to_inp (u8->fp32 + bilinear resize to the network size) -> warm
 RIFE.inference_ts_drba(I0, I1, I2, ts=[0.75, 1.25], reuse, linear=True) -> to_out for the two
 model-generated frames (resize back + *255 truncation, still on the device).  Decode/encode and
 PCIe are outside the metric.  value = model-generated frames of ALL ranks / max-rank time.
+As in drba_amd.infer.interpolate_stream the loop reads one frame ahead, so the next step's coarse flow runs on a
+side stream under this step's interpolation (`--no-lookahead` disables it); every frame is converted and encoded
+exactly once either way, and the K timed steps contain K coarse-flow computations.
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU): frame-level data parallelism, every
 rank interpolates its own contiguous shard of the clip (weak scaling: per-GPU work fixed); the only
@@ -60,6 +63,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=1)
     p.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU baseline (capped by affinity)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-lookahead", action="store_true", help="do not overlap the next step's coarse flow (A/B runs)")
     return p.parse_args()
 
 
@@ -102,12 +106,21 @@ def gpu_leg(args, rank, world):
     state = {"I0": I0, "I1": I1, "reuse": None, "k": 2}
     sink = []
 
+    lookahead = not args.no_lookahead
+
     def step():
-        I2 = to_inp(state["k"])
-        out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True)
+        # the driver reads one frame ahead (as drba_amd.infer.interpolate_stream does): the next step's coarse flow
+        # overlaps this step's interpolation on a side stream; every frame is still converted / encoded exactly once
+        I2 = state.pop("next", None)
+        if I2 is None:
+            I2 = to_inp(state["k"])
+        nxt = to_inp(state["k"] + 1) if lookahead else None
+        out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True,
+                                                      lookahead=nxt)
         for x in out:
             sink.append(to_out(x))
         state["I0"], state["I1"] = state["I1"], I2
+        state["next"] = nxt
         state["k"] += 1
 
     def fence():

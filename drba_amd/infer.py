@@ -95,12 +95,15 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
     if on_step:
         on_step(idx)
 
-    # ---- steady state: one (I0, I1, I2) triplet per source frame
-    while True:
-        i2 = video_io.read_frame()
-        if i2 is None:
-            break
-        I2 = to_inp(i2, dst_size)
+    # ---- steady state: one (I0, I1, I2) triplet per source frame.  The loop reads one frame ahead of the reference's
+    # (same frames, same order, same outputs): a model that supports it starts the next step's coarse flow on a side
+    # stream while this step's frames are synthesised (RIFE.inference_ts_drba(..., lookahead=)).
+    can_look = bool(getattr(model, "supports_lookahead", False))
+    i2 = video_io.read_frame()
+    I2 = to_inp(i2, dst_size) if i2 is not None else None
+    while i2 is not None:
+        i3 = video_io.read_frame()
+        I3 = to_inp(i3, dst_size) if i3 is not None else None
         ts = _tools.calc_t(idx, times, mapper)
         cut_right = bool(check_scene(I1, I2, scdet_threshold)) if enable_scdet else False
         if cut_left and cut_right:
@@ -113,10 +116,13 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
             reuse = None
             out = model.inference_ts(I0, I1, ts[ts <= 1])
             out.extend([I1 for _ in ts[ts > 1] - 1])
+        elif can_look and I3 is not None:
+            out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=I3)
         else:
             out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)
         emit(out, src_size)
         I0, I1 = I1, I2
+        i2, I2 = i3, I3
         cut_left = cut_right
         idx += 1
         if on_step:

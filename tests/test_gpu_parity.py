@@ -91,3 +91,32 @@ def test_gmfss_plain_end_to_end_parity(hip_backend, oracle_backend, golden_dir):
     _assert_rows(rows)
     for name, _, tol, extra in rows:
         assert float(extra.split("vs_fixture=")[1]) <= tol, f"{name}: {extra}"
+
+
+def test_lookahead_flow_matches_inline(hip_backend):
+    """inference_ts_drba(..., lookahead=next frame) computes the next step's coarse flow on a side stream; the frames
+    and the reuse state must equal the inline computation (same kernels, other stream)."""
+    from drba_amd.utils import synth
+    sd = synth.ifnet_state_dict(seed=0)
+    H, W = 128, 192
+    fr = [f.to(hip_backend.dev) for f in cases.rife_frames(H, W)]
+    ts = np.array([0.75, 1.25])
+
+    def run(look):
+        m = hip_backend.make_rife(sd, 1.0)
+        outs = []
+        reuse = None
+        for k in range(2):  # (f0,f1,f2) then (f1,f2,f3)
+            nxt = fr[k + 3] if (look and k + 3 < len(fr)) else None
+            o, reuse = m.inference_ts_drba(fr[k], fr[k + 1], fr[k + 2], ts, reuse, True, lookahead=nxt)
+            if look and k == 0:
+                assert m._pending is not None and m._pending[0] is fr[2] and m._pending[1] is fr[3]
+            outs += o
+        torch.cuda.synchronize()
+        return outs, reuse, m
+
+    a, ra, ma = run(True)
+    b, rb, _ = run(False)
+    assert ma._pending is None  # the second step consumed the lookahead and had no further frame
+    for x, y in zip(a + list(ra), b + list(rb)):
+        assert float((x - y).abs().max()) <= 1e-6
