@@ -109,6 +109,9 @@ class RIFE:
         flow = _ops.ifblock_update(self.ifnet.block[0].core(xin), None, H, W, s)
         flow01 = _ops.flow_reverse(flow[:, :2])   # 2 * (-splat_avg(flow50)), holes -> 2*max(H, W)
         flow10 = _ops.flow_reverse(flow[:, 2:])
+        if _ops.PAIR_FEATURES and f0.is_cuda:  # the stages' pair-interleaved copies, made where the features are made
+            _ops.pair_interleaved(f0)          # (with a lookahead this runs on the side stream, off the critical path)
+            _ops.pair_interleaved(f1)
         return flow01, flow10, f0, f1
 
     def _warm_step(self, I0, I1, I2, flow10, f1, f0, kinds, t_dev):
