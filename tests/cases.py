@@ -265,8 +265,9 @@ def flatten(name, value):
     return [(name, value)]
 
 
-def compare_to_fixture(z, key, t):
-    """Max abs difference between tensor t and fixture entry `key` in npz z (NaNs must coincide)."""
+def compare_to_fixture(z, key, t, count_above=None):
+    """Max abs difference between tensor t and fixture entry `key` in npz z (NaNs must coincide).
+    count_above=tol -> (max, number of compared elements above tol, number compared)."""
     a = t.detach().float().cpu().contiguous().numpy()
     if f"{key}/full" in z.files:
         ref = z[f"{key}/full"]
@@ -279,4 +280,7 @@ def compare_to_fixture(z, key, t):
     nan_r, nan_g = np.isnan(ref), np.isnan(got)
     assert (nan_r == nan_g).all(), f"{key}: NaN pattern differs"
     d = np.abs(np.where(nan_r, 0, ref) - np.where(nan_g, 0, got))
-    return float(d.max()) if d.size else 0.0
+    mx = float(d.max()) if d.size else 0.0
+    if count_above is None:
+        return mx
+    return mx, int((d > count_above).sum()), int(d.size)
