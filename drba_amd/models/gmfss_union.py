@@ -5,6 +5,7 @@ import torch
 
 from drba_amd import ops as _ops
 from drba_amd.models.drm import calc_drm_gmfss, calc_drm_rife_auxiliary
+from drba_amd.models.lookahead import Lookahead
 from drba_amd.models.model_gmfss_union.GMFSS import Model, _half
 from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
 from drba_amd.models.utils.tools import convert, resize
@@ -44,9 +45,24 @@ class GMFSS_UNION:
                 output.append(self.model.inference(I0, I1, reuse, timestep0=float(t), timestep1=float(1 - t), rife=rife))
         return output
 
-    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False):
+    supports_lookahead = True
+    _look = None
+
+    def _pair_state(self, a, b):
+        """model.reuse(a, b), taken from a matching lookahead if there is one (models/lookahead.py)."""
+        res = self._look.take(a, b) if self._look is not None else None
+        return res if res is not None else self.model.reuse(a, b, self.scale)
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False, lookahead=None):
+        """`lookahead` (not in the reference): the frame that will be I2 of the next call; its pair state
+        model.reuse(I2, lookahead) -- FeatureNet, GMFlow in both directions, MetricNet: hundreds of small launches --
+        is started on a side stream and overlaps this call's splats and GridNet."""
         reuseI1I0 = self.model.reuse(I1, I0, self.scale) if reuse is None else reuse
-        reuseI1I2 = self.model.reuse(I1, I2, self.scale)
+        reuseI1I2 = self._pair_state(I1, I2)
+        if lookahead is not None and I2.is_cuda:
+            if self._look is None:
+                self._look = Lookahead()
+            self._look.start(I2, lookahead, lambda: self.model.reuse(I2, lookahead, self.scale))
         flow10, metric10 = reuseI1I0[0], reuseI1I0[2]
         flow12, metric12 = reuseI1I2[0], reuseI1I2[2]
         I0s, I1s, I2s = _half(I0), _half(I1), _half(I2)

@@ -1,0 +1,52 @@
+"""One-frame lookahead on a side HIP stream (not in the reference).
+
+The per-pair state a DRBA step needs for its NEW frame pair (RIFE: encoder + block0 coarse flow + flow reversal;
+GMFSS: FeatureNet + GMFlow both ways + MetricNet) depends only on the two frames, so once the driver has read the next
+frame it can be computed while the current step's frames are synthesised.  Those kernels are small and latency-bound
+(hundreds of launches on 1/4..1/16-resolution maps for GMFlow), the synthesis kernels are large: overlapping them on
+two streams fills the chip.  The result is handed to the next call by frame identity; a scene cut or any other call
+pattern simply leaves it unused."""
+import torch
+
+
+def _tensors(x):
+    if torch.is_tensor(x):
+        yield x
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            yield from _tensors(y)
+
+
+class Lookahead:
+    def __init__(self):
+        self.side = None
+        self.pending = None  # (frame a, frame b, result, completion event on the side stream)
+
+    def start(self, a, b, fn, inputs=()):
+        """Run fn() on the side stream after everything enqueued so far on the caller's stream; keep its result for
+        take(a, b).  `inputs`: further tensors fn reads (their memory must outlive the side-stream work)."""
+        if not a.is_cuda:
+            return
+        main = torch.cuda.current_stream(a.device)
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=a.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            for t in _tensors((a, b, inputs)):
+                t.record_stream(self.side)
+            res = fn()
+            done = torch.cuda.Event()
+            done.record(self.side)
+        for t in _tensors(res):
+            t.record_stream(main)  # consumed on the caller's stream by the next step
+        self.pending = (a, b, res, done)
+
+    def take(self, a, b):
+        """The prefetched result for the pair (a, b), or None.  The caller's stream is made to wait for it."""
+        pend, self.pending = self.pending, None
+        if pend is not None and pend[0] is a and pend[1] is b:
+            torch.cuda.current_stream(a.device).wait_event(pend[3])
+            return pend[2]
+        return None

@@ -48,8 +48,18 @@ class Model:
         ld = lambda n: torch.load(f"{path}/{n}.pkl", map_location="cpu")  # noqa: E731
         self.load_state_dicts(ld("flownet"), ld("metric"), ld("feat"), ld("fusionnet"), device)
 
+    def _features(self, img):
+        """FeatureNet pyramid of a frame, computed once per frame tensor (the reference recomputes it for both pairs a
+        frame belongs to, GMFSS.py:56-57; same values)."""
+        f = getattr(img, "_drba_feat", None)
+        if f is None:
+            f = self.feat_ext(img)
+            if img.is_cuda:
+                img._drba_feat = f
+        return f
+
     def reuse(self, img0, img1, scale):
-        feat0, feat1 = self.feat_ext(img0), self.feat_ext(img1)
+        feat0, feat1 = self._features(img0), self._features(img1)
         img0, img1 = _half(img0), _half(img1)
         if scale != 1.0:
             if0, if1 = _half(img0, scale), _half(img1, scale)

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from drba_amd import ops as _ops
+from drba_amd.models.lookahead import Lookahead
 from drba_amd.models.drm import calc_drm_rife
 from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
 from drba_amd.models.utils.tools import convert
@@ -52,8 +53,7 @@ class _WarmStepGraph:
 
 class RIFE:
     supports_lookahead = True  # inference_ts_drba(..., lookahead=next frame): see prefetch_flow
-    _side = None     # side HIP stream for the lookahead calc_flow
-    _pending = None  # (frame a, frame b, calc_flow(a, b) results, completion event on the side stream)
+    _look = None     # models/lookahead.Lookahead, created on first use
 
     def __init__(self, weights="weights/train_log_rife_426_heavy", scale=1.0, device=None):
         device = _ops.default_device() if device is None else torch.device(device)
@@ -155,35 +155,18 @@ class RIFE:
         return [passthru[k] if k in passthru else o for k, o in zip(kinds, outs)], new_reuse
 
     def prefetch_flow(self, a, b, fa=None):
-        """Start calc_flow(a, b) on a side HIP stream (a's features `fa` if already known).  The next
-        inference_ts_drba(_, a, b, ...) picks the result up instead of computing it: the encoder of the new frame,
-        block0 on a 1/16-resolution map and the flow reversal are small, latency-bound launches that leave most of
-        the chip idle, so they are overlapped with the previous step's full-resolution stages."""
-        if not a.is_cuda:
-            return
-        main = torch.cuda.current_stream(a.device)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=a.device)
-        ready = torch.cuda.Event()
-        ready.record(main)  # a, b (and fa) are produced on the main stream or earlier on the side stream
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(ready)
-            for t in (a, b) + ((fa,) if fa is not None else ()):
-                t.record_stream(self._side)
-            res = self.calc_flow(a, b, f0=fa)
-            done = torch.cuda.Event()
-            done.record(self._side)
-        for t in res:
-            t.record_stream(main)  # consumed on the main stream by the next step
-        self._pending = (a, b, res, done)
+        """Start calc_flow(a, b) on the side stream (a's features `fa` if already known): the encoder of the new
+        frame, block0 on a 1/16-resolution map and the flow reversal are small, latency-bound launches that leave
+        most of the chip idle, so they are overlapped with the current step's full-resolution stages.  The next
+        inference_ts_drba(_, a, b, ...) picks the result up (models/lookahead.py)."""
+        if self._look is None:
+            self._look = Lookahead()
+        self._look.start(a, b, lambda: self.calc_flow(a, b, f0=fa), inputs=(fa,) if fa is not None else ())
 
     def _flow_pair(self, a, b, fa):
         """calc_flow(a, b), taken from a matching lookahead if there is one."""
-        pend, self._pending = self._pending, None
-        if pend is not None and pend[0] is a and pend[1] is b:
-            torch.cuda.current_stream(a.device).wait_event(pend[3])
-            return pend[2]
-        return self.calc_flow(a, b, f0=fa)
+        res = self._look.take(a, b) if self._look is not None else None
+        return res if res is not None else self.calc_flow(a, b, f0=fa)
 
     def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False, lookahead=None):
         """reference rife.py:77-109.  `lookahead` (not in the reference): the frame that will be I2 of the next call;

@@ -109,13 +109,36 @@ def test_lookahead_flow_matches_inline(hip_backend):
             nxt = fr[k + 3] if (look and k + 3 < len(fr)) else None
             o, reuse = m.inference_ts_drba(fr[k], fr[k + 1], fr[k + 2], ts, reuse, True, lookahead=nxt)
             if look and k == 0:
-                assert m._pending is not None and m._pending[0] is fr[2] and m._pending[1] is fr[3]
+                assert m._look.pending is not None and m._look.pending[0] is fr[2] and m._look.pending[1] is fr[3]
             outs += o
         torch.cuda.synchronize()
         return outs, reuse, m
 
     a, ra, ma = run(True)
     b, rb, _ = run(False)
-    assert ma._pending is None  # the second step consumed the lookahead and had no further frame
+    assert ma._look.pending is None  # the second step consumed the lookahead and had no further frame
     for x, y in zip(a + list(ra), b + list(rb)):
         assert float((x - y).abs().max()) <= 1e-6
+
+
+def test_gmfss_union_lookahead_matches_inline(hip_backend):
+    """Same for GMFSS_UNION: the pair state model.reuse(I2, next) prefetched on the side stream (and the per-frame
+    FeatureNet cache) must give the frames of the inline computation."""
+    from drba_amd.utils import synth
+    sds = synth.gmfss_union_state_dicts(seed=0)
+    fr = [f.to(hip_backend.dev) for f in cases.gmfss_frames(128, 256)]
+    ts = np.array([0.75, 1.25])
+
+    def run(look):
+        frames = [f.clone() for f in fr]  # fresh tensors: no cached per-frame state from the other run
+        m = hip_backend.make_gmfss_union(sds, 1.0)
+        outs, reuse = [], None
+        for k in range(2):
+            nxt = frames[k + 3] if (look and k + 3 < len(frames)) else None
+            o, reuse = m.inference_ts_drba(frames[k], frames[k + 1], frames[k + 2], ts, reuse, True, lookahead=nxt)
+            outs += o
+        torch.cuda.synchronize()
+        return outs
+
+    for x, y in zip(run(True), run(False)):
+        assert float((x - y).abs().max()) <= 1e-5

@@ -28,6 +28,7 @@ def main():
     p.add_argument("--scale", type=float, default=1.0)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--no-lookahead", action="store_true")
     a = p.parse_args()
     dev = torch.device("cuda", 0)
     sds = synth.gmfss_union_state_dicts(0)
@@ -46,13 +47,14 @@ def main():
     I0, I1, reuse, k = to_inp(0), to_inp(1), None, 2
     ts = np.array([0.75, 1.25])
     sink = []
-    t0 = None
+    t0 = nxt = None
     for it in range(a.warmup + a.steps):
         if it == a.warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        I2 = to_inp(k)
-        out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, True)
+        I2 = nxt if nxt is not None else to_inp(k)
+        nxt = None if a.no_lookahead else to_inp(k + 1)  # the driver reads one frame ahead (drba_amd/infer.py)
+        out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, True, lookahead=nxt)
         sink = [ops.f32nchw_to_u8hwc(ops.resize_bilinear(x, src_size)) for x in out]
         I0, I1, k = I1, I2, k + 1
     torch.cuda.synchronize()
