@@ -88,6 +88,7 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
         reuse = warm_reuse(model, inp(a), inp(a + 1))
 
     # ---- loop iterations [a, b): infer.py:112-156 with idx == k
+    can_look = bool(getattr(model, "supports_lookahead", False))
     for k in range(a, b):
         I0, I1, I2 = inp(k), inp(k + 1), inp(k + 2)
         ts = _tools.calc_t(k, times, mapper)
@@ -100,6 +101,9 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
         elif cut_right:
             reuse = None
             res = list(model.inference_ts(I0, I1, ts[ts <= 1])) + [I1 for _ in ts[ts > 1] - 1]
+        elif can_look and k + 1 < b and k + 3 < n:
+            # one-frame lookahead inside the shard (drba_amd/models/lookahead.py): frame k+3 is I2 of iteration k+1
+            res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=inp(k + 3))
         else:
             res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)
         emit(res)
