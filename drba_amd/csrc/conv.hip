@@ -10,12 +10,14 @@
 //   A: one ds_read_b32 from the LDS input tile [CK][rows][cols]; channel stride == 16 (mod 32)
 //      for stride 1 and odd for stride 2, which makes the read bank-conflict free.
 //   B: weights are pre-packed on the host in MFMA *fragment order*
-//      ([cout tile][chunk][tap][cg][nt][64 lanes]): a chunk's block is contiguous, so it is staged
-//      with float4 global loads + ds_write_b128 and a B operand is one conflict-free ds_read_b32
-//      (lane-linear).  (Feeding B straight from L2 was measured first: hipcc sinks the loads next
-//      to their MFMAs and every k-step eats an L1/L2 round trip -- 35 % MFMA utilisation.)
-// Input tile and weight block are double-buffered in LDS with the next chunk's global loads
-// issued before the current chunk's MFMAs (register staging), one workgroup barrier per chunk.
+//      ([cout tile][chunk][tap][cg][nt][64 lanes]): a chunk's block is contiguous and a B operand is one
+//      conflict-free ds_read_b32 (lane-linear).  (Feeding B straight from L2 was measured first: hipcc sinks the
+//      loads next to their MFMAs and every k-step eats an L1/L2 round trip -- 35 % MFMA utilisation.)
+// Staging is LDS-direct (buffer_load ... lds, no registers, no address math in the chunk loop): the chunk's input
+// windows and its weight block land in one of two LDS buffers while the MFMAs run on the other; one
+// s_waitcnt vmcnt(0) + workgroup barrier per chunk.  The MFMA loop itself is software-pipelined by hand (the LDS
+// reads of step j+1 issue before the MFMAs of step j).  Workgroups are remapped so that an XCD owns a contiguous run
+// of tiles (private L2s).
 // Accumulator D: lane holds cout l&15 for pixels 4*(l>>4)..+3 -> one float4 store along x.
 //
 // KS = 1: the 4 waves split the tile's rows (TH = 4*RW) and share the LDS input tile.
@@ -27,7 +29,8 @@
 // MODE 0: conv3x3.  MODE 1: one row phase py (both column phases px) of ConvTranspose2d(k=4,s=2,p=1):
 //   out[o, 2j+py, 2i+px] = b[o] + sum_{c, a, b in {0,1}} in[c, j+dy(py,a), i+dx(px,b)] * W[c, o, ky(py,a), kx(px,b)]
 //   with (py=0: (ky,dy) = (1,0),(3,-1); py=1: (0,+1),(2,0)), same along x: a 2x2-tap convolution
-//   over the same haloed input tile; blockIdx.z carries the phase.
+//   over the same haloed input tile; the workgroup index carries the row phase, both column phases are computed
+//   by the same workgroup so that its stores are runs of consecutive output columns.
 #include "common.hpp"
 
 #include <stdlib.h>
