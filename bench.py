@@ -116,7 +116,7 @@ def gpu_leg(args, rank, world):
             I2 = to_inp(state["k"])
         nxt = to_inp(state["k"] + 1) if lookahead else None
         out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True,
-                                                      lookahead=nxt)
+                                                      lookahead=None if nxt is None else (nxt, TS))
         for x in out:
             sink.append(to_out(x))
         state["I0"], state["I1"] = state["I1"], I2

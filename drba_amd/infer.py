@@ -117,7 +117,8 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
             out = model.inference_ts(I0, I1, ts[ts <= 1])
             out.extend([I1 for _ in ts[ts > 1] - 1])
         elif can_look and I3 is not None:
-            out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=I3)
+            out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True,
+                                                 lookahead=(I3, _tools.calc_t(idx + 1, times, mapper)))
         else:
             out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)
         emit(out, src_size)

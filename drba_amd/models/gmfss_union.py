@@ -5,7 +5,7 @@ import torch
 
 from drba_amd import ops as _ops
 from drba_amd.models.drm import calc_drm_gmfss, calc_drm_rife_auxiliary
-from drba_amd.models.lookahead import Lookahead
+from drba_amd.models.lookahead import Lookahead, split as split_lookahead
 from drba_amd.models.model_gmfss_union.GMFSS import Model, _half
 from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
 from drba_amd.models.utils.tools import convert, resize
@@ -59,6 +59,7 @@ class GMFSS_UNION:
         is started on a side stream and overlaps this call's splats and GridNet."""
         reuseI1I0 = self.model.reuse(I1, I0, self.scale) if reuse is None else reuse
         reuseI1I2 = self._pair_state(I1, I2)
+        lookahead, _ = split_lookahead(lookahead)
         if lookahead is not None and I2.is_cuda:
             if self._look is None:
                 self._look = Lookahead()

@@ -15,6 +15,16 @@ def _tensors(x):
     elif isinstance(x, (list, tuple)):
         for y in x:
             yield from _tensors(y)
+    elif isinstance(x, dict):
+        for y in x.values():
+            yield from _tensors(y)
+
+
+def split(lookahead):
+    """`lookahead` argument of inference_ts_drba: the next frame, or (next frame, timesteps of the next call)."""
+    if isinstance(lookahead, (tuple, list)):
+        return lookahead[0], lookahead[1]
+    return lookahead, None
 
 
 class Lookahead:

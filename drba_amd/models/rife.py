@@ -13,6 +13,7 @@ import torch
 
 from drba_amd import ops as _ops
 from drba_amd.models.lookahead import Lookahead
+from drba_amd.models.lookahead import split as split_lookahead
 from drba_amd.models.drm import calc_drm_rife
 from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
 from drba_amd.models.utils.tools import convert
@@ -154,34 +155,11 @@ class RIFE:
         passthru = {"c0": I0, "c1": I1, "c2": I2}
         return [passthru[k] if k in passthru else o for k, o in zip(kinds, outs)], new_reuse
 
-    def prefetch_flow(self, a, b, fa=None):
-        """Start calc_flow(a, b) on the side stream (a's features `fa` if already known): the encoder of the new
-        frame, block0 on a 1/16-resolution map and the flow reversal are small, latency-bound launches that leave
-        most of the chip idle, so they are overlapped with the current step's full-resolution stages.  The next
-        inference_ts_drba(_, a, b, ...) picks the result up (models/lookahead.py)."""
-        if self._look is None:
-            self._look = Lookahead()
-        self._look.start(a, b, lambda: self.calc_flow(a, b, f0=fa), inputs=(fa,) if fa is not None else ())
+    SIDE_STAGES = int(os.environ.get("DRBA_SIDE_STAGES", "3"))  # IFNet stages of the NEXT step run by the lookahead
 
-    def _flow_pair(self, a, b, fa):
-        """calc_flow(a, b), taken from a matching lookahead if there is one."""
-        res = self._look.take(a, b) if self._look is not None else None
-        return res if res is not None else self.calc_flow(a, b, f0=fa)
-
-    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False, lookahead=None):
-        """reference rife.py:77-109.  `lookahead` (not in the reference): the frame that will be I2 of the next call;
-        its calc_flow(I2, lookahead) is started on a side stream and overlaps this call's interpolation."""
-        if reuse and linear and self.use_graphs and I0.is_cuda:
-            r = self._graphed_step(I0, I1, I2, ts, reuse)
-            if r is not None:
-                return r
-        flow10, flow01, f1, f0 = self.calc_flow(I1, I0) if not reuse else reuse
-        if reuse is None:
-            flow12, flow21, f1, f2 = self._flow_pair(I1, I2, None)
-        else:
-            flow12, flow21, f1, f2 = self._flow_pair(I1, I2, reuse[2])
-        if lookahead is not None:
-            self.prefetch_flow(I2, lookahead, f2)
+    def _items(self, I0, I1, I2, ts, linear, flow10, flow12, f0, f1, f2):
+        """DRM maps and the (img0, img1, timestep, f0, f1) work items of one step; output holds pass-through frames
+        and, for the frames to synthesise, their index into items."""
         output, items = [], []
         for t in ts:
             if t == 0:
@@ -203,4 +181,56 @@ class RIFE:
                        else calc_drm_rife(t, flow10, flow12, False)["drm_t1_t12"])
                 output.append(len(items))
                 items.append((I1, I2, drm, f1, f2))
-        return self._fill(output, items), (flow21, flow12, f2, f1)
+        return output, items
+
+    def prefetch_flow(self, a, b, fa=None, then=None, also_reads=()):
+        """Start calc_flow(a, b) on the side stream (a's features `fa` if already known): the encoder of the new
+        frame, block0 on a 1/16-resolution map and the flow reversal are small, latency-bound launches that leave
+        most of the chip idle, so they are overlapped with the current step's full-resolution stages.  The next
+        inference_ts_drba(_, a, b, ...) picks the result up (models/lookahead.py).  `then(result)`, if given, runs
+        right after on the same stream and its return value is kept alongside."""
+        if self._look is None:
+            self._look = Lookahead()
+
+        def work():
+            res = self.calc_flow(a, b, f0=fa)
+            return res, (then(res) if then is not None else None)
+        self._look.start(a, b, work, inputs=tuple(t for t in (fa,) + tuple(also_reads) if t is not None))
+
+    def _flow_pair(self, a, b, fa):
+        """(calc_flow(a, b), staged low-resolution stages or None), from a matching lookahead if there is one."""
+        got = self._look.take(a, b) if self._look is not None else None
+        return got if got is not None else (self.calc_flow(a, b, f0=fa), None)
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False, lookahead=None):
+        """reference rife.py:77-109.  `lookahead` (not in the reference): the frame that will be I2 of the next call,
+        or (that frame, the next call's ts).  calc_flow(I2, next) -- and, when the timesteps are known, the DRM maps
+        and the first SIDE_STAGES low-resolution IFNet stages of the next step -- run on a side stream under this
+        call's full-resolution stages; the next call resumes from there if its arguments match."""
+        if reuse and linear and self.use_graphs and I0.is_cuda:
+            r = self._graphed_step(I0, I1, I2, ts, reuse)
+            if r is not None:
+                return r
+        flow10, flow01, f1, f0 = self.calc_flow(I1, I0) if not reuse else reuse
+        (flow12, flow21, f1, f2), staged = self._flow_pair(I1, I2, None if reuse is None else reuse[2])
+        nxt, ts_nxt = split_lookahead(lookahead)
+        if nxt is not None:
+            then = None
+            if ts_nxt is not None and linear and 0 < self.SIDE_STAGES < 5:
+                ts_nxt = np.array(ts_nxt, dtype=np.float64)
+
+                def then(res):  # the next step: (I0, I1, I2) = (I1, I2, nxt), its reuse = (flow21, flow12, f2, f1)
+                    out_n, items_n = self._items(I1, I2, nxt, ts_nxt, True, flow21, res[0], f1, f2, res[3])
+                    state = self.ifnet.forward_pairs(items_n, self.scale_list, 0, self.SIDE_STAGES) if items_n else None
+                    return {"I0": I1, "flow10": flow21, "ts": ts_nxt, "output": out_n, "items": items_n, "state": state}
+            self.prefetch_flow(I2, nxt, f2, then, also_reads=(I1, flow21, f1))
+        if (staged is not None and linear and staged["I0"] is I0 and staged["flow10"] is flow10
+                and np.array_equal(staged["ts"], np.asarray(ts, dtype=np.float64))):
+            output, items = staged["output"], staged["items"]
+            if items:
+                frames = self.ifnet.forward_pairs(items, self.scale_list, self.SIDE_STAGES, 5, staged["state"])
+                output = [frames[o] if isinstance(o, int) else o for o in output]
+        else:
+            output, items = self._items(I0, I1, I2, ts, linear, flow10, flow12, f0, f1, f2)
+            output = self._fill(output, items)
+        return output, (flow21, flow12, f2, f1)

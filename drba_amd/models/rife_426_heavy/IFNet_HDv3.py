@@ -111,19 +111,22 @@ class IFNet:
             s_prev = s
         return _ops.warp_blend(img0, img1, flow, tmp, s_prev), flow_list
 
-    def forward_pairs(self, items, scale_list=(8, 4, 2, 1)):
+    def forward_pairs(self, items, scale_list=(8, 4, 2, 1), first=0, last=5, state=None):
         """Several interpolations of one frame size in one pass: items = [(img0, img1, timestep, f0, f1), ...].
         The samples are independent (IFNet_HDv3.py:126-177 applied to each); stacking them makes every
         convolution of a stage one launch over the batch, which fills the 256 CUs better than the 1/16..1/64
-        resolution maps of a single 1080p frame do and halves the launch count of a `-t 2` step."""
+        resolution maps of a single 1080p frame do and halves the launch count of a `-t 2` step.
+        Stages [first, last) are run; last < 5 returns the carried state (per-sample flows, head output, its scale)
+        instead of frames, and `state` resumes from it (models/rife.py runs the low-resolution stages of the NEXT
+        step on a side stream)."""
         B = len(items)
-        if B == 1:
+        if B == 1 and first == 0 and last == 5:
             img0, img1, t, f0, f1 = items[0]
             return [self.forward_pair(img0, img1, t, scale_list, f0, f1)[0]]
         _, _, H, W = items[0][0].shape
-        flows, tmp = [None] * B, None
-        s_prev = 1.0
-        for i in range(5):
+        flows, tmp, s_prev = state if state is not None else ([None] * B, None, 1.0)
+        flows = list(flows)
+        for i in range(first, last):
             s = scale_list[i]
             h, w = int(np.floor(H * (1.0 / s))), int(np.floor(W * (1.0 / s)))
             xin = torch.empty((B, 52 if i else 39, h, w), dtype=torch.float32, device=items[0][0].device)
@@ -134,6 +137,8 @@ class IFNet:
             for k in range(B):
                 flows[k] = _ops.ifblock_update(tmp[k:k + 1], flows[k], H, W, s)
             s_prev = s
+        if last < 5:
+            return flows, tmp, s_prev
         return [_ops.warp_blend(it[0], it[1], flows[k], tmp[k:k + 1], s_prev) for k, it in enumerate(items)]
 
     def __call__(self, x, timestep=0.5, scale_list=(8, 4, 2, 1), training=False, fastmode=True, ensemble=False,

@@ -103,7 +103,7 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
             res = list(model.inference_ts(I0, I1, ts[ts <= 1])) + [I1 for _ in ts[ts > 1] - 1]
         elif can_look and k + 1 < b and k + 3 < n:
             # one-frame lookahead inside the shard (drba_amd/models/lookahead.py): frame k+3 is I2 of iteration k+1
-            res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=inp(k + 3))
+            res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=(inp(k + 3), _tools.calc_t(k + 1, times, mapper)))
         else:
             res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)
         emit(res)
