@@ -16,6 +16,13 @@ _d = C.c_double
 _z = C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/drba_hip.h one to one
+class ConvLayer(C.Structure):
+    """drba_conv_layer_t (include/drba_hip.h)."""
+    _fields_ = [("packed_w", C.c_void_p), ("bias", C.c_void_p), ("beta", C.c_void_p), ("cin", C.c_int), ("cout", C.c_int),
+                ("stride", C.c_int), ("act", C.c_int), ("cfg", C.c_int), ("residual", C.c_int), ("deconv", C.c_int),
+                ("pixel_shuffle", C.c_int)]
+
+
 SIGNATURES = {
     "drba_abi_version": (_i, []),
     "drba_timing_slots": (_i, []),
@@ -47,6 +54,7 @@ SIGNATURES = {
     "drba_deconv4x4_pick_cfg": (_i, [_i, _i, _i, _i]),
     "drba_deconv4x4_packed_floats": (_z, [_i, _i, _i]),
     "drba_deconv4x4_pack": (_i, [_p, _p, _i, _i, _i]),
+    "drba_conv_chain": (_i, [_p, _p, _p, _p, C.POINTER(ConvLayer), _i, _i, _i, _i, _p]),
     "drba_deconv4x4s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _i, _i, _i, _i, _f, _p]),
     "drba_pair_interleave": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -660,4 +660,36 @@ int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, 
   return DRBA_EUNSUPPORTED;
 }
 
+// A chain of convolutions launched from one call (the IFBlock cores and the context encoder are 4..11 dependent
+// layers; issuing them from C++ costs a few microseconds per launch instead of a Python/ctypes round trip each, which
+// is what bounds the step once the GPU side is below 4 ms).  Layer i reads the previous layer's output (layer 0 reads
+// `in`), writes `out` if it is the last one and otherwise alternates between scratch0 / scratch1; `residual` adds the
+// layer's own input in the epilogue (ResConv).  Each scratch buffer must hold the largest intermediate tensor.
+int drba_conv_chain(const float *in, float *out, float *scratch0, float *scratch1, const drba_conv_layer_t *layers,
+                    int n_layers, int N, int H, int W, void *stream) {
+  if (!in || !out || !layers || n_layers <= 0 || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  if (n_layers > 1 && (!scratch0 || !scratch1)) return DRBA_EINVAL;
+  float *buf[2] = {scratch0, scratch1};
+  const float *src = in;
+  int h = H, w = W;
+  for (int i = 0; i < n_layers; ++i) {
+    const drba_conv_layer_t &L = layers[i];
+    float *dst = (i == n_layers - 1) ? out : buf[i & 1];
+    int rc;
+    if (L.deconv) {
+      rc = drba_deconv4x4s2(src, L.packed_w, L.bias, dst, N, L.cin, h, w, L.cout, L.pixel_shuffle, 0, 0.f, L.cfg, stream);
+      h *= 2;
+      w *= 2;
+    } else {
+      rc = drba_conv3x3(src, L.packed_w, L.bias, L.beta, L.residual ? src : nullptr, nullptr, dst, N, L.cin, h, w, L.cout,
+                        L.stride, L.act, 0.f, 0, 0.f, L.cfg, stream);
+      h = (h - 1) / L.stride + 1;
+      w = (w - 1) / L.stride + 1;
+    }
+    if (rc != DRBA_OK) return rc;
+    src = dst;
+  }
+  return DRBA_OK;
+}
+
 }  // extern "C"

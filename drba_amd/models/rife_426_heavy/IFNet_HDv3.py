@@ -28,8 +28,11 @@ class Head:
         self.cnn1 = _ops.Conv3x3(g("cnn1.weight"), g("cnn1.bias"), stride=1, act=True, device=device)
         self.cnn2 = _ops.Conv3x3(g("cnn2.weight"), g("cnn2.bias"), stride=1, act=True, device=device)
         self.cnn3 = _ops.Deconv4x4(g("cnn3.weight"), g("cnn3.bias"), pixel_shuffle=False, device=device)
+        self.chain = _ops.ConvChain([(self.cnn0, False), (self.cnn1, False), (self.cnn2, False), (self.cnn3, False)])
 
     def __call__(self, x, feat=False):
+        if not feat:
+            return self.chain(x)
         x0 = self.cnn0(x)
         x1 = self.cnn1(x0)
         x2 = self.cnn2(x1)
@@ -50,12 +53,12 @@ class IFBlock:
             _ops.Conv3x3(g(f"convblock.{j}.conv.weight"), g(f"convblock.{j}.conv.bias"), stride=1, act=True,
                          beta=g(f"convblock.{j}.beta"), device=device) for j in range(8)]
         self.lastconv = _ops.Deconv4x4(g("lastconv.0.weight"), g("lastconv.0.bias"), pixel_shuffle=True, device=device)
+        self.chain = _ops.ConvChain([(self.conv0_0, False), (self.conv0_1, False)] + [(rc, True) for rc in self.convblock]
+                                    + [(self.lastconv, False)])
 
     def core(self, x):
-        x = self.conv0_1(self.conv0_0(x))
-        for rc in self.convblock:
-            x = rc(x, residual=x)  # lrelu(conv(x) * beta + x)
-        return self.lastconv(x)  # [1, 13, 4h, 4w]
+        """conv0 -> 8 x ResConv (lrelu(conv(x) * beta + x)) -> deconv + PixelShuffle: [N, 13, 4h, 4w]; one library call."""
+        return self.chain(x)
 
     def __call__(self, x, flow=None, scale=1):
         """Reference call form: x is the already concatenated full-resolution input (IFNet_HDv3.py:84-96)."""

@@ -373,6 +373,86 @@ class Deconv4x4:
         return out
 
 
+class ConvChain:
+    """A fixed sequence of Conv3x3 / Deconv4x4 layers (`residual=True` entries are ResConv layers adding their own
+    input) issued by ONE library call (drba_conv_chain): the host cost of an IFBlock core drops from eleven
+    Python/ctypes round trips to one.  The first call for a shape runs layer by layer (that is where the autotuner
+    picks each layer's configuration); so does any call while bench.py's per-launch timing is armed."""
+
+    def __init__(self, layers):
+        self.layers = [(l, bool(r)) for l, r in layers]  # (layer, residual)
+        self._plans = {}
+
+    def _eager(self, x):
+        for layer, res in self.layers:
+            x = layer(x, residual=x) if res else layer(x)
+        return x
+
+    def _plan(self, n, h, w, device):
+        lib = _lib.load()
+        descs = (_lib.ConvLayer * len(self.layers))()
+        keep, sizes = [], []
+        hh, ww = h, w
+        for i, (layer, res) in enumerate(self.layers):
+            d = descs[i]
+            if isinstance(layer, Deconv4x4):
+                key = ("deconv4x4", n, layer.cin, layer.cout, hh, ww, layer.ps)
+                cfg = layer.force_cfg if layer.force_cfg is not None else (
+                    _tuned.get(key) if AUTOTUNE else lib.drba_deconv4x4_pick_cfg(layer.cin, layer.cout, hh, ww))
+                if cfg is None or layer.pre_slope is not None:
+                    return None
+                d.deconv, d.pixel_shuffle, d.stride, d.act, d.residual = 1, layer.ps, 1, 0, 0
+                hh, ww = 2 * hh, 2 * ww
+                sizes.append(n * (layer.cout // 4 if layer.ps else layer.cout) * hh * ww * (4 if layer.ps else 1))
+            else:
+                key = ("conv3x3", n, layer.cin, layer.cout, hh, ww, layer.stride)
+                ho, wo = (hh - 1) // layer.stride + 1, (ww - 1) // layer.stride + 1
+                cfg = layer.force_cfg if layer.force_cfg is not None else (
+                    _tuned.get(key) if AUTOTUNE else lib.drba_conv3x3_pick_cfg(layer.cin, layer.cout, ho, wo, layer.stride))
+                if cfg is None or layer.pre_slope is not None or layer.post_slope != 0.0:
+                    return None
+                d.deconv, d.pixel_shuffle, d.stride, d.act, d.residual = 0, 0, layer.stride, layer.act, 1 if res else 0
+                d.beta = 0 if layer.beta is None else layer.beta.data_ptr()
+                hh, ww = ho, wo
+                sizes.append(n * layer.cout * hh * ww)
+            layer._keep.add(cfg)
+            wp = layer._pack(cfg)
+            keep.append(wp)
+            d.packed_w, d.bias = wp.data_ptr(), (0 if layer.bias is None else layer.bias.data_ptr())
+            d.cin, d.cout, d.cfg = layer.cin, layer.cout, cfg
+        last = self.layers[-1][0]
+        out_shape = ((n, last.cout // 4, 2 * hh, 2 * ww) if (isinstance(last, Deconv4x4) and last.ps)
+                     else (n, last.cout, hh, ww))
+        return {"descs": descs, "keep": keep, "scratch": max(sizes[:-1]) if len(sizes) > 1 else 0, "out_shape": out_shape,
+                "bufs": {}}
+
+    def __call__(self, x):
+        x = _f32(x)
+        n, _, h, w = x.shape
+        key = (n, h, w)
+        plan = self._plans.get(key)
+        if plan is None and key in self._plans:  # known: not chainable
+            return self._eager(x)
+        if TIMING is not None or not x.is_cuda:
+            return self._eager(x)
+        if plan is None:
+            plan = self._plans[key] = self._plan(n, h, w, x.device)
+            if plan is None:
+                if AUTOTUNE:
+                    del self._plans[key]  # configurations not tuned yet: this eager call tunes them, retry next time
+                return self._eager(x)
+        stream = _stream()
+        bufs = plan["bufs"].get(stream.value)
+        if bufs is None:  # scratch per stream: the same block runs on the main and on the lookahead stream
+            m = max(plan["scratch"], 1)
+            bufs = plan["bufs"][stream.value] = (torch.empty(m, dtype=torch.float32, device=x.device),
+                                                 torch.empty(m, dtype=torch.float32, device=x.device))
+        out = torch.empty(plan["out_shape"], dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().drba_conv_chain(_p(x), _p(out), _p(bufs[0]), _p(bufs[1]), plan["descs"], len(self.layers), n,
+                                               h, w, stream), "drba_conv_chain")
+        return out
+
+
 # ----------------------------------------------------------------------------- IFNet glue
 PAIR_FEATURES = True  # warped stages read the encoder features from a pair-interleaved copy (half the gather instructions)
 

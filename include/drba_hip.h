@@ -123,6 +123,19 @@ int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, 
                      int N, int Cin, int H, int W, int Cout, int pixel_shuffle, int pre_act, float pre_slope,
                      int cfg, void *stream);
 
+/* ---- a chain of convolution layers in one call ------------------------------------------------
+ * replaces: IFBlock.conv0 + convblock + lastconv (IFNet_HDv3.py:64-83, :90-96) or Head (:28-47) issued layer by
+ * layer.  Layer i reads layer i-1's output (layer 0: `in`); the last layer writes `out`, the others alternate
+ * between scratch0 / scratch1 (each sized for the largest intermediate).  conv layers: drba_conv3x3 semantics with
+ * `residual` = add the layer's own input in the epilogue (needs beta for the ResConv form); deconv layers:
+ * drba_deconv4x4s2 semantics.  packed_w / cfg as for the single-layer entry points. */
+typedef struct drba_conv_layer {
+  const float *packed_w, *bias, *beta;
+  int cin, cout, stride, act, cfg, residual, deconv, pixel_shuffle;
+} drba_conv_layer_t;
+int drba_conv_chain(const float *in, float *out, float *scratch0, float *scratch1,
+                    const drba_conv_layer_t *layers, int n_layers, int N, int H, int W, void *stream);
+
 /* ---- IFNet glue (IFNet_HDv3.py:84-96, :126-177) -------------------------------------------
  * Build one IFBlock's input at 1/scale resolution without materialising the full-resolution
  * concat: channels [warp(img0,flow[:2]) 3, warp(img1,flow[2:4]) 3, warp(f0) 16, warp(f1) 16,

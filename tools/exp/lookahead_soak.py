@@ -17,7 +17,7 @@ def run(look):
     for k in range(N):
         I2 = nxt if nxt is not None else fr(k + 2)
         nxt = fr(k + 3) if look else None
-        out, reuse = m.inference_ts_drba(I0, I1, I2, ts, reuse, True, lookahead=nxt)
+        out, reuse = m.inference_ts_drba(I0, I1, I2, ts, reuse, True, lookahead=None if nxt is None else (nxt, ts))
         sums += [o.double().sum().item() for o in out] + [o[0, :, ::97, ::89].clone() for o in out]
         I0, I1 = I1, I2
     torch.cuda.synchronize()
