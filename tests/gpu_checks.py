@@ -118,6 +118,32 @@ def check_conv_layers(dev):
                 rows.append((f"deconv cfg{cfg} [{cin}->{cout} {h}x{w} ps={ps}]", _diff(got, ref), 5e-5, ""))
             except Exception as e:  # noqa: BLE001
                 rows.append((f"deconv cfg{cfg}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    # drba_conv_chain (an IFBlock core issued by one native call) against the same layers issued one by one and
+    # against the CPU composition, batch of 2, ragged size
+    try:
+        c, h, w = 32, 38, 54
+        x = torch.randn(2, 52, h, w, generator=g)
+        mk = lambda co, ci, k=3: torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5  # noqa: E731
+        w0, w1, wr = mk(c // 2, 52), mk(c, c // 2), [mk(c, c) for _ in range(3)]
+        wl = torch.randn(c, 52, 4, 4, generator=g) / (c * 4) ** 0.5
+        bs = lambda n: torch.randn(n, generator=g) * 0.1  # noqa: E731
+        b0, b1, br, bl = bs(c // 2), bs(c), [bs(c) for _ in range(3)], bs(52)
+        betas = [torch.rand(1, c, 1, 1, generator=g) + 0.5 for _ in range(3)]
+        ref = F.leaky_relu(F.conv2d(F.leaky_relu(F.conv2d(x, w0, b0, stride=2, padding=1), 0.2), w1, b1, stride=2, padding=1), 0.2)
+        for wt, bb, be in zip(wr, br, betas):
+            ref = F.leaky_relu(F.conv2d(ref, wt, bb, padding=1) * be + ref, 0.2)
+        ref = F.pixel_shuffle(F.conv_transpose2d(ref, wl, bl, stride=2, padding=1), 2)
+        layers = [(ops.Conv3x3(w0, b0, stride=2, act=True, device=dev), False), (ops.Conv3x3(w1, b1, stride=2, act=True, device=dev), False)]
+        layers += [(ops.Conv3x3(wt, bb, act=True, beta=be, device=dev), True) for wt, bb, be in zip(wr, br, betas)]
+        layers += [(ops.Deconv4x4(wl, bl, pixel_shuffle=True, device=dev), False)]
+        chain = ops.ConvChain(layers)
+        first = chain(x.to(dev))   # layer by layer: the autotuner picks the configurations
+        second = chain(x.to(dev))  # one drba_conv_chain call
+        assert chain._plans.get((2, h, w)) is not None, "the second call must have used the native chain"
+        rows.append(("conv_chain vs cpu", _diff(second, ref), 2e-5 * max(1.0, float(ref.abs().max())), ""))
+        rows.append(("conv_chain vs layer-by-layer", _diff(second, first), 0.0, "bit-exact"))
+    except Exception as e:  # noqa: BLE001
+        rows.append(("conv_chain", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     return rows
 
 
