@@ -10,8 +10,6 @@ import argparse
 import os
 import time
 
-import numpy as np
-
 from drba_amd.models.utils import tools as _tools
 
 
