@@ -194,30 +194,65 @@ class GMFlow:
         return _ops.local_attn_flow(q[0].contiguous(), k[0].contiguous(), flow, radius)
 
     # ---------------------------------------------------------------- forward (gmflow.py:92-185)
+    def _match(self, f0, f1, flow, corr_r, prop_r):
+        """Correlation softmax (global or local) + flow propagation of one direction at one scale."""
+        _, c, h, w = f0.shape
+        if corr_r == -1:
+            scores = torch.matmul(f0.view(c, h * w).t(), f1.view(c, h * w)).contiguous()
+            pred = _ops.softmax_expect2(scores, None, w, c ** 0.5).view(1, 2, h, w)
+        else:
+            pred = _ops.local_corr_flow(f0, f1, corr_r)
+        flow = pred if flow is None else _ops.add_act(flow, pred)
+        return self._propagate(f0, flow, local=prop_r > 0, radius=prop_r)
+
+    def _upsample(self, flow, f0):
+        """learned convex upsampling x4 (gmflow.py:67-90)"""
+        m = self.up0(torch.cat((flow, f0), 1))
+        _, _, h, w = flow.shape
+        m = torch.add(torch.matmul(self.up2[0], m.view(256, h * w)), self.up2[1].view(144, 1))  # 1x1 conv = plain GEMM
+        return _ops.convex_upsample(m.view(1, 144, h, w), flow, 4)
+
+    def _refine(self, fa, fb, flow, splits, corr_r, prop_r):
+        """One finer scale of one direction: warp the other frame's features by the upsampled flow, transformer, match."""
+        _, _, h, w = fa.shape
+        flow = _ops.resize_bilinear_ac(flow, (h, w), 2.0)  # x2 bilinear (align_corners=True), * 2
+        fb = _ops.flow_warp(fb, flow)
+        fa, fb = self._add_position(fa, fb, splits)
+        fa, fb = self.transformer(fa, fb, splits)
+        return self._match(fa, fb, flow, corr_r, prop_r), fa
+
     def __call__(self, img0, img1, attn_splits_list=(2, 8), corr_radius_list=(-1, 4), prop_radius_list=(-1, 1), **kw):
         x = _ops.channel_normalize3(torch.cat((img0, img1), 0).contiguous(), _MEAN, _STD)
         feats = self.encoder(x)[::-1]  # low -> high resolution
         flow = None
         for idx, (splits, corr_r, prop_r) in enumerate(zip(attn_splits_list, corr_radius_list, prop_radius_list)):
             f0, f1 = feats[idx][0:1].contiguous(), feats[idx][1:2].contiguous()
-            _, c, h, w = f0.shape
             if idx > 0:
-                flow = _ops.resize_bilinear_ac(flow, (h, w), 2.0)  # x2 bilinear (align_corners=True), * 2
-                f1 = _ops.flow_warp(f1, flow)
-            f0, f1 = self._add_position(f0, f1, splits)
-            f0, f1 = self.transformer(f0, f1, splits)
-            if corr_r == -1:
-                scores = torch.matmul(f0.view(c, h * w).t(), f1.view(c, h * w)).contiguous()
-                pred = _ops.softmax_expect2(scores, None, w, c ** 0.5).view(1, 2, h, w)
+                flow, f0 = self._refine(f0, f1, flow, splits, corr_r, prop_r)
             else:
-                pred = _ops.local_corr_flow(f0, f1, corr_r)
-            flow = pred if flow is None else _ops.add_act(flow, pred)
-            flow = self._propagate(f0, flow, local=prop_r > 0, radius=prop_r)
-        # learned convex upsampling x4 (gmflow.py:67-90)
-        m = self.up0(torch.cat((flow, f0), 1))
-        _, _, h, w = flow.shape
-        m = torch.add(torch.matmul(self.up2[0], m.view(256, h * w)), self.up2[1].view(144, 1))  # 1x1 conv = plain GEMM
-        return _ops.convex_upsample(m.view(1, 144, h, w), flow, 4)
+                f0, f1 = self._add_position(f0, f1, splits)
+                f0, f1 = self.transformer(f0, f1, splits)
+                flow = self._match(f0, f1, None, corr_r, prop_r)
+        return self._upsample(flow, f0)
+
+    def bidirectional(self, img0, img1, attn_splits_list=(2, 8), corr_radius_list=(-1, 4), prop_radius_list=(-1, 1)):
+        """(self(img0, img1), self(img1, img0)) -- what Model.reuse needs (GMFSS.py:64-65) -- sharing what the two calls
+        have in common: the CNN encoder of both frames and the coarsest transformer pass.  The transformer treats its
+        two inputs symmetrically (transformer.py:236-302: both orders are concatenated along the batch), so the swapped
+        call computes the same two feature maps in the other order; only from the first flow-dependent warp on do the
+        directions differ.  Same values as two separate calls, about a third less work."""
+        assert len(attn_splits_list) == 2, "two scales (the DRBA configuration)"
+        x = _ops.channel_normalize3(torch.cat((img0, img1), 0).contiguous(), _MEAN, _STD)
+        feats = self.encoder(x)[::-1]
+        c0, c1 = feats[0][0:1].contiguous(), feats[0][1:2].contiguous()
+        t0, t1 = self._add_position(c0, c1, attn_splits_list[0])
+        t0, t1 = self.transformer(t0, t1, attn_splits_list[0])
+        flow_a = self._match(t0, t1, None, corr_radius_list[0], prop_radius_list[0])
+        flow_b = self._match(t1, t0, None, corr_radius_list[0], prop_radius_list[0])
+        h0, h1 = feats[1][0:1].contiguous(), feats[1][1:2].contiguous()
+        flow_a, fa = self._refine(h0, h1, flow_a, attn_splits_list[1], corr_radius_list[1], prop_radius_list[1])
+        flow_b, fb = self._refine(h1, h0, flow_b, attn_splits_list[1], corr_radius_list[1], prop_radius_list[1])
+        return self._upsample(flow_a, fa), self._upsample(flow_b, fb)
 
     forward = __call__
 

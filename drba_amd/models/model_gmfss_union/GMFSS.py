@@ -65,8 +65,7 @@ class Model:
             if0, if1 = _half(img0, scale), _half(img1, scale)
         else:
             if0, if1 = img0, img1
-        flow01 = self.flownet(if0, if1)
-        flow10 = self.flownet(if1, if0)
+        flow01, flow10 = self.flownet.bidirectional(if0, if1)  # == (flownet(if0, if1), flownet(if1, if0))
         if scale != 1.0:
             _, _, h, w = img0.shape
             up = lambda f: _ops.affine(_ops.resize_bilinear_scale(f, (h, w), scale), 1.0 / scale, 0.0)  # noqa: E731

@@ -150,3 +150,17 @@ def test_gmfss_union_lookahead_matches_inline(hip_backend):
 
     for x, y in zip(run(True), run(False)):
         assert float((x - y).abs().max()) <= 1e-5
+
+
+def test_gmflow_bidirectional_equals_two_calls(hip_backend):
+    """GMFlow.bidirectional shares the encoder and the coarsest transformer pass between the two directions; it must
+    return what two separate forward calls return."""
+    from drba_amd.models.gmflow.gmflow import GMFlow
+    from drba_amd.utils import synth
+    import torch.nn.functional as F
+    net = GMFlow(synth.gmfss_union_state_dicts(seed=0)["flownet"], hip_backend.dev)
+    I0, I1 = [F.interpolate(f, scale_factor=0.5, mode="bilinear", align_corners=False).to(hip_backend.dev)
+              for f in cases.gmfss_frames(128, 256)[:2]]
+    a, b = net.bidirectional(I0, I1)
+    a2, b2 = net(I0, I1), net(I1, I0)
+    assert float((a - a2).abs().max()) <= 1e-5 and float((b - b2).abs().max()) <= 1e-5
