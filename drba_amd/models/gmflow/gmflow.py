@@ -8,6 +8,7 @@ go to the vendor BLAS through torch.matmul, and window split / merge / roll are 
 views.  No arithmetic other than those GEMMs happens in torch.
 """
 import math
+import os
 
 import torch
 
@@ -129,7 +130,17 @@ class GMFlow:
         return self._mask[key]
 
     # ---------------------------------------------------------------- transformer (transformer.py)
+    FUSED_ATTENTION = os.environ.get("DRBA_FUSED_ATTENTION", "1") != "0"
+
     def _attention(self, q, k, v, h, w, splits, shift):
+        b, _, c = q.shape
+        scale = c ** 0.5
+        if self.FUSED_ATTENTION and c == C:
+            return _ops.window_attention(q, k, v, h, w, max(splits, 1), shift and splits > 1, scale)
+        return self._attention_unfused(q, k, v, h, w, splits, shift)
+
+    def _attention_unfused(self, q, k, v, h, w, splits, shift):
+        """The reference's formulation step by step (BLAS GEMMs + masked softmax kernel); kept as the cross-check."""
         b, _, c = q.shape
         scale = c ** 0.5
         if splits <= 1:

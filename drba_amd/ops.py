@@ -633,6 +633,17 @@ def gelu(x):
     return out
 
 
+def window_attention(q, k, v, h, w, splits, shift, scale):
+    """single_head_split_window_attention (transformer.py:46-113) fused: q, k, v [B, h*w, 128] -> [B, h*w, 128]."""
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    b, n, c = q.shape
+    assert n == h * w and k.shape == q.shape and v.shape == q.shape
+    out = torch.empty_like(q)
+    _lib.check(_lib.load().drba_window_attention(_p(q), _p(k), _p(v), _p(out), b, h, w, c, int(splits), int(bool(shift)),
+                                                 float(scale), _stream()), "drba_window_attention")
+    return out
+
+
 def softmax_rows_(scores, scale, mask=None):
     """In-place softmax over the last dim of scores [M, L, cols] / scale (+ mask [n_masks, L, cols] cycled over M)."""
     assert scores.is_contiguous() and scores.dtype == torch.float32

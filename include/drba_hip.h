@@ -198,6 +198,12 @@ int drba_channel_normalize3(const float *in, float *out, int N, size_t HW, const
 int drba_layernorm(const float *x, const float *w, const float *b, const float *residual, float *out,
                    size_t rows, int cols, float eps, void *stream);
 int drba_gelu(const float *x, float *out, size_t n, void *stream); /* nn.GELU(), erf form */
+/* single_head_split_window_attention (transformer.py:46-113) in one kernel: q, k, v, out are [B, H*W, C] (C = 128);
+ * the roll by half a window (shift != 0), the splits x splits window partition, the -100 region mask of
+ * generate_shift_window_attn_mask (transformer.py:19-43), softmax(q k^T / scale) v and the inverse partition / roll
+ * are applied through index maps; the score matrix is never stored.  splits = 1, shift = 0 is full attention. */
+int drba_window_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int W, int C,
+                          int splits, int shift, float scale, void *stream);
 /* in-place row softmax of x/scale + mask[(row/rows_per_mat) % n_masks][row % rows_per_mat] (transformer.py:91-96) */
 int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks,
                       float scale, void *stream);

@@ -370,3 +370,24 @@ def check_gmfss_plain(hip, ora, golden, tol=1e-3):
     for k in o:
         rows.append((k, _diff(g[k], o[k]), tol, f"vs_fixture={cases.compare_to_fixture(golden, k, g[k]):.2e}"))
     return rows
+
+
+# ----------------------------------------------------------------------------------------- fused window attention
+def check_window_attention(dev):
+    """drba_window_attention against the oracle's step-by-step formulation (oracle/gmflow.py window_attention =
+    transformer.py:46-105) and against the unfused HIP path, on windows whose length is not a multiple of the key
+    chunk, shorter than one chunk, exactly one chunk, the two GMFSS_UNION 1080p shapes, and full attention."""
+    from drba_amd import ops
+    from oracle import gmflow as ogm
+    rows = []
+    shapes = [(2, 36, 60, 2, True), (2, 36, 60, 2, False), (1, 24, 40, 8, True), (1, 16, 32, 2, True), (1, 16, 24, 1, False),
+              (1, 72, 120, 2, True), (2, 144, 240, 8, True)]
+    for idx, (b, h, w, splits, shift) in enumerate(shapes):
+        q, k, v = [cases.rnd((b, h * w, 128), 70 + 3 * idx + j, 1.5) for j in range(3)]
+        wh, ww = h // splits, w // splits
+        mask = ogm.shift_window_mask(h, w, wh, ww, wh // 2, ww // 2) if shift else None
+        want = ogm.window_attention(q, k, v, splits, shift, h, w, mask)
+        got = ops.window_attention(q.to(dev), k.to(dev), v.to(dev), h, w, splits, shift, 128 ** 0.5)
+        rows.append((f"window_attention b{b} {h}x{w} splits{splits} shift{int(shift)} (L={wh * ww})", _diff(got, want), 2e-5,
+                     f"ref_absmax={float(want.abs().max()):.3g}"))
+    return rows

@@ -164,3 +164,8 @@ def test_gmflow_bidirectional_equals_two_calls(hip_backend):
     a, b = net.bidirectional(I0, I1)
     a2, b2 = net(I0, I1), net(I1, I0)
     assert float((a - a2).abs().max()) <= 1e-5 and float((b - b2).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_window_attention(hip_backend):
+    _assert_rows(gpu_checks.check_window_attention(hip_backend.dev))
