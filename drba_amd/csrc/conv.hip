@@ -453,6 +453,15 @@ const CfgInfo kConv[kNumConvCfg] = {cfg_info<C0>(), cfg_info<C1>(), cfg_info<C2>
 const CfgInfo kDeconv[kNumDeconvCfg] = {cfg_info<D0>(), cfg_info<D1>(), cfg_info<D2>(),
                                         cfg_info<D3>(), cfg_info<D4>(), cfg_info<D5>()};
 
+// Raises the kernel's dynamic-LDS limit past the default 64 KB (gfx950: 160 KB per CU); once per kernel instantiation.
+template <class Cfg, bool PRE>
+hipError_t lds_limit() {
+  if (Cfg::LDS_FLOATS * sizeof(float) <= 64 * 1024) return hipSuccess;
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma<Cfg, PRE>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_FLOATS * (int)sizeof(float));
+  return e;
+}
+
 template <class Cfg>
 int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, const float *res2,
            float *out, int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int act, float post_slope, int pre_act,
@@ -461,18 +470,13 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   const int gh = Cfg::MODE == 0 ? Ho : H, gw = Cfg::MODE == 0 ? Wo : W;
   dim3 g((gw + Cfg::TW - 1) / Cfg::TW, (gh + Cfg::TH - 1) / Cfg::TH, N * n_ct * (Cfg::MODE == 0 ? 1 : 2));  // x2: row phases
   // PRE: PReLU pre-activation compiled into the MFMA loop (FeatureNet / MetricNet / GridNet convolutions)
-  auto go = [&](auto kernel) -> int {
-    if (Cfg::LDS_FLOATS * sizeof(float) > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950: 160 KB per CU)
-      static const hipError_t lds_ok =  // once per kernel (one static per instantiation of this generic lambda)
-          hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              Cfg::LDS_FLOATS * (int)sizeof(float));
-      if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
-    }
+  auto go = [&](auto kernel, hipError_t lds_ok) -> int {
+    if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     DRBA_LAUNCH_TIMED(kernel, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2, out, Cin, H,
                       W, Cout, Ho, Wo, act, post_slope, pre_slope, n_ct, ps);
     return DRBA_OK;
   };
-  const int rc = pre_act ? go(conv_mfma<Cfg, true>) : go(conv_mfma<Cfg, false>);
+  const int rc = pre_act ? go(conv_mfma<Cfg, true>, lds_limit<Cfg, true>()) : go(conv_mfma<Cfg, false>, lds_limit<Cfg, false>());
   if (rc != DRBA_OK) return rc;
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;

@@ -18,6 +18,12 @@
 //
 // Per call at GMFSS_UNION 1080p (fine scale: 128 windows x 540 tokens x 128 channels) the reference formulation moves
 // 2 x 149 MB of scores through HBM three times; this kernel reads q, k, v once and writes the output once.
+//
+// Measured (tools/attn_bench.py, MI355X): fine scale 230 us (83 TFLOP/s fp32) against 560-780 us for BLAS QK^T +
+// softmax kernel + BLAS PV + the roll / split copies; coarse scale (8 windows x 2160 tokens) 348 us against 335-440 us.
+// In-kernel cycle counters put QK^T at 34 cycles per MFMA (32 is the issue rate) and PV at 43; the coarse launch is
+// limited by its shape -- 272 workgroups on 256 CUs, so 16 CUs carry two -- not by the inner loops.  Splitting each
+// chunk's keys over two waves (8-wave workgroups) was tried to raise the waves per SIMD there and was slower (365 us).
 #include "common.hpp"
 
 using namespace drba;
@@ -34,25 +40,32 @@ constexpr int kLdsBytes = (2 * kKeys * kStride + kKeys) * 4;  // 67.8 KB: two wo
 
 struct Geometry {
   int h, w, splits, wh, ww, sh, sw, L, shift;
+  unsigned ww_magic;  // ceil(2^32 / ww): t / ww == umulhi(t, ww_magic) for t, ww < 2^16
 };
 
-// rolled-image position of token t of window win -> source row in the [b, h*w, C] arrays, and its mask region
-__device__ __forceinline__ size_t token_row(const Geometry &g, int win, int t, int &region) {
+// rolled-image position of token t of window (bi, wy, wx) -> source row in the [b, h*w, C] arrays, and its mask region
+struct Window {
+  int bi, y0, x0;
+};
+__device__ __forceinline__ Window window_of(const Geometry &g, int win) {
   const int per = g.splits * g.splits;
   const int bi = win / per, wi = win - bi * per;
   const int wy = wi / g.splits, wx = wi - wy * g.splits;
-  const int ly = t / g.ww, lx = t - ly * g.ww;
-  const int y = wy * g.wh + ly, x = wx * g.ww + lx;
+  return Window{bi, wy * g.wh, wx * g.ww};
+}
+__device__ __forceinline__ unsigned token_row(const Geometry &g, const Window &wd, int t, int &region) {
+  const int ly = (int)__umulhi((unsigned)t, g.ww_magic), lx = t - ly * g.ww;
+  const int y = wd.y0 + ly, x = wd.x0 + lx;
   region = 0;
   int sy = y, sx = x;
   if (g.shift) {
-    region = 3 * (y < g.h - g.wh ? 0 : (y < g.h - g.sh ? 1 : 2)) + (x < g.w - g.ww ? 0 : (x < g.w - g.sw ? 1 : 2));
+    region = 3 * ((y >= g.h - g.wh) + (y >= g.h - g.sh)) + (x >= g.w - g.ww) + (x >= g.w - g.sw);
     sy = y + g.sh;
-    if (sy >= g.h) sy -= g.h;
+    sy -= sy >= g.h ? g.h : 0;
     sx = x + g.sw;
-    if (sx >= g.w) sx -= g.w;
+    sx -= sx >= g.w ? g.w : 0;
   }
-  return ((size_t)bi * g.h + sy) * g.w + sx;
+  return (unsigned)((wd.bi * g.h + sy) * g.w + sx);
 }
 
 __global__ void __launch_bounds__(256)
@@ -62,6 +75,8 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
   extern __shared__ __attribute__((aligned(16))) float lds[];  // kLdsBytes: keys, values, key regions
   float *Ks = lds, *Vs = lds + kKeys * kStride;
   int *Kreg = reinterpret_cast<int *>(lds + 2 * kKeys * kStride);
+  constexpr int TPW = 4;  // key tiles of a chunk
+  constexpr int LIT = 8;  // loader iterations per thread
 
   // all query tiles of a window on one XCD (workgroups are dealt round-robin over the 8 XCDs): the window's k / v
   // are then fetched into one L2 instead of eight
@@ -69,6 +84,7 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
   const int xcd = lin & 7, slot = lin >> 3;
   const int win = (slot / qtiles) * 8 + xcd, qt = slot - (slot / qtiles) * qtiles;
   if (win >= nwin) return;
+  const Window wd = window_of(g, win);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,70 +94,95 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
   const int qtok = qt * kRows + wave * 16 + n16;
   const bool qlive = qtok < g.L;
   int qreg;
-  const size_t qrow = token_row(g, win, qlive ? qtok : g.L - 1, qreg);
+  const size_t qrow = token_row(g, wd, min(qtok, g.L - 1), qreg);
   f32x4 qf[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) qf[j] = *reinterpret_cast<const f32x4 *>(q + qrow * kC + 16 * j + 4 * grp);
 
   // ---- chunk loader: thread -> (key = tid/32 + 8*it, 4 channels at 4*(tid%32))
   const int lkey = tid >> 5, lc4 = (tid & 31) * 4;
-  f32x4 pk[8], pv[8];
-  int preg[8];
+  f32x4 pk[LIT], pv[LIT];
   auto fetch = [&](int chunk) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int t = chunk * kKeys + lkey + 8 * it;
-      const size_t row = token_row(g, win, t < g.L ? t : g.L - 1, preg[it]);
+    for (int it = 0; it < LIT; ++it) {
+      int unused;
+      const size_t row = token_row(g, wd, min(chunk * kKeys + lkey + 8 * it, g.L - 1), unused);
       pk[it] = *reinterpret_cast<const f32x4 *>(k + row * kC + lc4);
       pv[it] = *reinterpret_cast<const f32x4 *>(v + row * kC + lc4);
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int chunk) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < LIT; ++it) {
       const int key = lkey + 8 * it;
       *reinterpret_cast<f32x4 *>(&Ks[key * kStride + lc4]) = pk[it];
       *reinterpret_cast<f32x4 *>(&Vs[key * kStride + lc4]) = pv[it];
-      if ((tid & 31) == 0) Kreg[key] = preg[it];
+    }
+    if (g.shift && tid < kKeys) {
+      int region;
+      token_row(g, wd, min(chunk * kKeys + tid, g.L - 1), region);
+      Kreg[tid] = region;
     }
   };
 
-  f32x4 o[8];  // O^T tiles: o[dt][i] = O[q = n16][channel 16*dt + 4*grp + i]
+  // O^T tiles.  Tile dt < 4 holds channels 4*m + dt in its row m, tile dt >= 4 channels 64 + 4*m + (dt - 4): a lane's
+  // A operands for the 8 tiles are then two 16-byte LDS reads of one value row, and o[dt][i] = O[q = n16][channel
+  // 16*grp + 4*i + dt (+64)], i.e. 2 x 16 contiguous output channels per lane
+  f32x4 o[8];
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
   const int chunks = (g.L + kKeys - 1) / kKeys;
+  const float inv_scale = 1.f / scale;
   fetch(0);
   for (int ch = 0; ch < chunks; ++ch) {
     __syncthreads();  // every wave is done reading the previous chunk
-    stage();
+    stage(ch);
     __syncthreads();
     if (ch + 1 < chunks) fetch(ch + 1);
 
-    // ---- S^T tiles: s[t][i] = <K[key = 16t + 4*grp + i], Q[q = n16]>
-    f32x4 s[4];
+    // ---- S^T tiles: s[t][i] = <K[key = 16*t + 4*grp + i], Q[q = n16]>.  One 16-byte K fragment feeds 4 MFMAs;
+    // fragments are read two steps ahead of their use so the LDS latency sits under the MFMAs of the steps before
+    f32x4 s[TPW];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TPW; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *kbase = &Ks[n16 * kStride + 4 * grp];
+    constexpr int QK_STEPS = 8 * TPW;
+    auto kfrag = [&](int step) {  // step = j * TPW + t
+      return *reinterpret_cast<const f32x4 *>(kbase + 16 * (step % TPW) * kStride + 16 * (step / TPW));
+    };
+    f32x4 kring[3];
+    kring[0] = kfrag(0), kring[1] = kfrag(1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int step = 0; step < QK_STEPS; ++step) {
+      if (step + 2 < QK_STEPS) kring[(step + 2) % 3] = kfrag(step + 2);
+      const f32x4 kf = kring[step % 3];
+      const int j = step / TPW, t = step % TPW;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f32x4 kf = *reinterpret_cast<const f32x4 *>(&Ks[(16 * t + n16) * kStride + 16 * j + 4 * grp]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[j][i], s[t], 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[j][i], s[t], 0, 0, 0);
     }
+
+    // first value fragments of the PV product: in flight under the softmax arithmetic
+    const float *vbase = &Vs[4 * grp * kStride + 4 * n16];
+    auto vfrag = [&](int step, int half) {  // step = t * 4 + i
+      return *reinterpret_cast<const f32x4 *>(vbase + (16 * (step / 4) + (step % 4)) * kStride + 64 * half);
+    };
+    f32x4 vring[2][2];
+    vring[0][0] = vfrag(0, 0), vring[0][1] = vfrag(0, 1);
 
     // ---- scale, mask, online softmax
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int4 kr = *reinterpret_cast<const int4 *>(&Kreg[16 * t + 4 * grp]);
-      const int krs[4] = {kr.x, kr.y, kr.z, kr.w};
+    for (int t = 0; t < TPW; ++t) {
+      int krs[4] = {0, 0, 0, 0};
+      if (g.shift) {
+        const int4 kr = *reinterpret_cast<const int4 *>(&Kreg[16 * t + 4 * grp]);
+        krs[0] = kr.x, krs[1] = kr.y, krs[2] = kr.z, krs[3] = kr.w;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float x = s[t][i] / scale;  // the reference divides (transformer.py:91)
+        float x = s[t][i] * inv_scale;  // scores / sqrt(C) (transformer.py:91)
         if (g.shift && krs[i] != qreg) x += -100.f;
         if (ch * kKeys + 16 * t + 4 * grp + i >= g.L) x = -INFINITY;
         s[t][i] = x;
@@ -150,11 +191,11 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx);       // finite: every chunk holds at least one real key
     const float alpha = __expf(m_run - m_new);  // 0 on the first chunk
     float ls = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         s[t][i] = __expf(s[t][i] - m_new);
@@ -167,22 +208,28 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
 
-    // ---- O^T += V^T P^T: A = V^T (row = channel 16*dt + n16, k = key 16t + 4*grp + i), B = P^T (this lane's s[t][i])
+    // ---- O^T += V^T P^T: A = V^T (row m = n16 of tile dt, k = key 16t + 4*grp + i), B = P^T (this lane's s[t][i])
+    constexpr int PV_STEPS = 4 * TPW;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int step = 0; step < PV_STEPS; ++step) {
+      if (step + 1 < PV_STEPS) vring[(step + 1) & 1][0] = vfrag(step + 1, 0), vring[(step + 1) & 1][1] = vfrag(step + 1, 1);
+      const float p = s[step / 4][step % 4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float *vrow = &Vs[(16 * t + 4 * grp + i) * kStride + n16];
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16 * dt], s[t][i], o[dt], 0, 0, 0);
+      for (int dt = 0; dt < 4; ++dt) {
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vring[step & 1][0][dt], p, o[dt], 0, 0, 0);
+        o[4 + dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vring[step & 1][1][dt], p, o[4 + dt], 0, 0, 0);
       }
     }
   }
 
   if (qlive) {
     const float inv = 1.f / l_run;
+    float *orow = out + qrow * kC + 16 * grp;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4 *>(out + qrow * kC + 16 * dt + 4 * grp) = o[dt] * inv;
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4 *>(orow + 4 * i) = f32x4{o[0][i], o[1][i], o[2][i], o[3][i]} * inv;
+      *reinterpret_cast<f32x4 *>(orow + 64 + 4 * i) = f32x4{o[4][i], o[5][i], o[6][i], o[7][i]} * inv;
+    }
   }
 #endif
 }
@@ -197,15 +244,18 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
   drba_attn::Geometry g;
   g.h = H, g.w = W, g.splits = splits, g.wh = H / splits, g.ww = W / splits;
   g.sh = g.wh / 2, g.sw = g.ww / 2, g.L = g.wh * g.ww, g.shift = shift ? 1 : 0;
+  if (g.ww < 2 || g.ww >= 65536 || g.L >= 65536) return DRBA_EUNSUPPORTED;  // range of the multiply-shift division
+  g.ww_magic = (unsigned)(((1ull << 32) + g.ww - 1) / g.ww);
   const int nwin = B * splits * splits;
   const int qtiles = (g.L + drba_attn::kRows - 1) / drba_attn::kRows;
   const int groups = (nwin + 7) / 8;
+  const dim3 grid((unsigned)(groups * 8 * qtiles));
   static const hipError_t lds_ok =  // beyond the default 64 KB dynamic-LDS limit
       hipFuncSetAttribute(reinterpret_cast<const void *>(drba_attn::window_attention_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, drba_attn::kLdsBytes);
   if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
-  DRBA_LAUNCH_TIMED(drba_attn::window_attention_kernel, dim3((unsigned)(groups * 8 * qtiles)), dim3(kBlock), drba_attn::kLdsBytes,
-                    (hipStream_t)stream, q, k, v, out, g, nwin, qtiles, scale);
+  DRBA_LAUNCH_TIMED(drba_attn::window_attention_kernel, grid, dim3(kBlock), drba_attn::kLdsBytes, (hipStream_t)stream, q, k, v,
+                    out, g, nwin, qtiles, scale);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
