@@ -32,6 +32,7 @@
 //   over the same haloed input tile; the workgroup index carries the row phase, both column phases are computed
 //   by the same workgroup so that its stores are runs of consecutive output columns.
 #include "common.hpp"
+#include "conv_split.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -529,8 +530,17 @@ int env_override(const char *name, int ntab) {
 
 extern "C" {
 
-int drba_conv3x3_num_cfgs(void) { return kNumConvCfg; }
-int drba_conv3x3_cfg_stride(int cfg) { return (cfg < 0 || cfg >= kNumConvCfg) ? DRBA_EINVAL : kConv[cfg].S; }
+// cfg ids: 0..kNumConvCfg-1 the fp32 MFMA table above, then the split-bf16 family of conv_split.hip (stride 1, Cin a
+// multiple of 32; drba_conv3x3_packed_floats returns 0 for a layer a config cannot run).  DRBA_CONV_SPLIT=0 hides it.
+static bool split_enabled() {
+  static const bool on = !(getenv("DRBA_CONV_SPLIT") && atoi(getenv("DRBA_CONV_SPLIT")) == 0);
+  return on;
+}
+int drba_conv3x3_num_cfgs(void) { return kNumConvCfg + (split_enabled() ? conv_split_num_cfgs() : 0); }
+int drba_conv3x3_cfg_stride(int cfg) {
+  if (cfg >= kNumConvCfg && cfg < drba_conv3x3_num_cfgs()) return 1;
+  return (cfg < 0 || cfg >= kNumConvCfg) ? DRBA_EINVAL : kConv[cfg].S;
+}
 int drba_deconv4x4_num_cfgs(void) { return kNumDeconvCfg; }
 
 // DRBA_CONV_CFG=<id> / DRBA_DECONV_CFG=<id> in the environment override the choice (experiments only).
@@ -543,6 +553,7 @@ int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride) {
 }
 
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
+  if (cfg >= kNumConvCfg) return cfg < drba_conv3x3_num_cfgs() ? conv_split_packed_floats(Cin, Cout, cfg - kNumConvCfg) : 0;
   if (cfg < 0 || cfg >= kNumConvCfg || Cin <= 0 || Cout <= 0) return 0;
   return packed_floats(kConv[cfg], Cin, Cout, 1);
 }
@@ -550,6 +561,7 @@ size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
 // fragment order: packed[(((cz*nchunks + q)*9 + tap)*CG + cg)*NT + nt][lane] =
 //   w[cz*NTC + nt*16 + (lane&15)][q*CK + cg*4 + (lane>>4)][tap], zero outside Cout/Cin
 int drba_conv3x3_pack(const float *w, float *packed, int Cin, int Cout, int cfg) {
+  if (cfg >= kNumConvCfg && cfg < drba_conv3x3_num_cfgs()) return conv_split_pack(w, packed, Cin, Cout, cfg - kNumConvCfg);
   if (!w || !packed || cfg < 0 || cfg >= kNumConvCfg || Cin <= 0 || Cout <= 0) return DRBA_EINVAL;
   const CfgInfo &c = kConv[cfg];
   const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK, CG = c.CK / 4;
@@ -572,10 +584,15 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
                  const float *residual2, float *out, int N, int Cin, int H, int W, int Cout, int stride, int act,
                  float post_slope, int pre_act, float pre_slope, int cfg, void *stream) {
   if (!in || !packed_w || !out || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
-  if (cfg < 0 || cfg >= kNumConvCfg || kConv[cfg].S != stride) return DRBA_EINVAL;
   if (beta && !residual) return DRBA_EINVAL;
   if (residual2 && !residual) return DRBA_EINVAL;
   if (act < 0 || act > 4) return DRBA_EINVAL;
+  if (cfg >= kNumConvCfg && cfg < drba_conv3x3_num_cfgs()) {
+    if (stride != 1) return DRBA_EINVAL;
+    return conv_split_launch(cfg - kNumConvCfg, in, packed_w, bias, beta, residual, residual2, out, N, Cin, H, W, Cout, act,
+                             post_slope, pre_act, pre_slope, stream);
+  }
+  if (cfg < 0 || cfg >= kNumConvCfg || kConv[cfg].S != stride) return DRBA_EINVAL;
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   hipStream_t s = (hipStream_t)stream;
 #define DRBA_CASE(ID, T) \

@@ -1,0 +1,16 @@
+// Split-bf16 3x3 convolution family (conv_split.hip), reached through drba_conv3x3 with cfg ids that follow the fp32
+// table of conv.hip.
+#pragma once
+#include <stddef.h>
+
+namespace drba {
+
+int conv_split_num_cfgs();
+bool conv_split_supports(int Cin, int Cout, int id);  // stride 1, Cin a multiple of 32
+size_t conv_split_packed_floats(int Cin, int Cout, int id);
+int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id);
+int conv_split_launch(int id, const float *in, const float *packed_w, const float *bias, const float *beta,
+                      const float *residual, const float *residual2, float *out, int N, int Cin, int H, int W, int Cout,
+                      int act, float post_slope, int pre_act, float pre_slope, void *stream);
+
+}  // namespace drba

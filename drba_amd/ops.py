@@ -303,7 +303,8 @@ class Conv3x3:
         if self.force_cfg is not None:
             cfg = self.force_cfg
         elif AUTOTUNE and x.is_cuda:
-            cands = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_stride(c) == self.stride]
+            cands = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_stride(c) == self.stride
+                     and lib.drba_conv3x3_packed_floats(self.cin, self.cout, c) > 0]  # 0: the config cannot run this layer
             cfg = _tune(("conv3x3", n, cin, self.cout, h, w, self.stride), cands, lambda c: lib.drba_conv3x3(
                 _p(x), _p(self._pack(c)), _p(self.bias), _p(self.beta), _p(res), _p(res2), _p(out), n, cin, h, w,
                 self.cout, self.stride, self.act, self.post_slope, pre, ps, c, _stream()))

@@ -105,6 +105,34 @@ def check_conv_layers(dev):
                 rows.append((f"conv cfg{cfg} [{cin}->{cout} {h}x{w} s{stride}]", _diff(got, ref), 5e-5, ""))
             except Exception as e:  # noqa: BLE001
                 rows.append((f"conv cfg{cfg}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    # the split-bf16 family (conv_split.hip: fp32 operands as three bf16 terms, six MFMA products): same tolerance as
+    # the fp32 kernels, against the fp64-accumulated CPU convolution so that the check measures THIS kernel's error
+    lib = ops._lib.load()
+    n_fp32 = 14
+    for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
+        for (nb, cin, cout, h, w, kind) in ((1, 32, 40, 11, 45, "conv"), (2, 96, 32, 9, 70, "res"), (1, 64, 16, 5, 130, "pre")):
+            try:
+                x = torch.randn(nb, cin, h, w, generator=g) * 3.0
+                wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+                b = torch.randn(cout, generator=g) * 0.1
+                xd, wd, bd = x.double(), wt.double(), b.double()
+                if kind == "res":
+                    wt = torch.randn(cin, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+                    b = torch.randn(cin, generator=g) * 0.1
+                    beta = torch.rand(1, cin, 1, 1, generator=g) + 0.5
+                    ref = F.leaky_relu(F.conv2d(xd, wt.double(), b.double(), padding=1) * beta.double() + xd, 0.2)
+                    got = ops.Conv3x3(wt, b, 1, True, beta, device=dev, cfg=cfg)(x.to(dev), residual=x.to(dev))
+                elif kind == "pre":
+                    ref = F.conv2d(F.prelu(xd, torch.tensor([0.25], dtype=torch.float64)), wd, bd, padding=1)
+                    got = ops.Conv3x3(wt, b, 1, None, None, device=dev, cfg=cfg, pre_slope=0.25)(x.to(dev))
+                else:
+                    ref = F.leaky_relu(F.conv2d(xd, wd, bd, padding=1), 0.2)
+                    got = ops.Conv3x3(wt, b, 1, True, None, device=dev, cfg=cfg)(x.to(dev))
+                scale = float(ref.abs().max())
+                rows.append((f"conv split cfg{cfg} {kind} [{nb}x{cin}->{cout} {h}x{w}]", _diff(got, ref.float()),
+                             5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+            except Exception as e:  # noqa: BLE001
+                rows.append((f"conv split cfg{cfg} {kind}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     for cfg in range(6):
         for (cin, cout, h, w, ps) in ((20, 52, 11, 45, True), (9, 16, 6, 70, False)):
             try:
