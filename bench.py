@@ -49,6 +49,8 @@ CONFIGS = {
     "4k_s1": ((2160, 3840), 1.0, "rife -t 2, 4K synthetic (net 2176x3840), scale 1.0"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense; the split-bf16 convolution spends 6 bf16 MFMA products per fp32 multiply
+N_FP32_CONV_CFGS = 14  # drba_conv3x3 cfg ids below this are the fp32 MFMA kernels, the rest the split-bf16 family
 HBM_PEAK_GBS = 8000.0
 TS = np.array([0.75, 1.25])  # what `-t 2` yields every step (infer.py:76-87)
 
@@ -180,16 +182,24 @@ def gpu_leg(args, rank, world):
             med = sorted(durs)[len(durs) // 2]
             good = [d for d in durs if d <= 1.5 * med] or durs
             avg_s = sum(good) / len(good) / 1e3
+            extra = {}
             if unit == "flop":
-                ach, peak, u, bound = work / avg_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
-                name = f"conv_mfma {k[1][1]}->{k[1][2]}ch {k[1][3]}x{k[1][4]} s{k[1][5]} N{k[1][6]} (ResConv)"
+                split = k[0] == "conv3x3" and k[1][0] >= N_FP32_CONV_CFGS
+                # algorithmic fp32 flops of the layer against the matrix-core peak of the kernel that ran: fp32 MFMA, or
+                # for the split-bf16 family (six bf16 MFMA products per fp32 product) the dense bf16 peak / 6
+                peak = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if split else FP32_MFMA_PEAK_TFLOPS
+                ach, u, bound = work / avg_s / 1e12, "TFLOP/s", "mfma"
+                kern = "conv_split_mfma" if split else "conv_mfma"
+                name = f"{kern} {k[1][1]}->{k[1][2]}ch {k[1][3]}x{k[1][4]} s{k[1][5]} N{k[1][6]} (ResConv)"
+                extra = {"peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32 multiply" if split
+                         else "dense fp32 MFMA"}
             else:
                 ach, peak, u, bound = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
                 name = f"ifblock_input_kernel<true> {k[1][0]}ch {k[1][1]}x{k[1][2]} -> {k[1][3]}x{k[1][4]}"
             return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
                     "traffic": traffic.get(name), "kernel": name, "launches": cnt, "avg_us": round(avg_s * 1e6, 2),
                     "algorithmic_per_launch": work, "cfg": k[1][0] if unit == "flop" else None,
-                    "ms_per_step": round(avg_s * 1e3 * cnt / n_instr, 3)}
+                    "ms_per_step": round(avg_s * 1e3 * cnt / n_instr, 3), **extra}
 
         n_instr = len(range(0, args.steps, roof_every))  # instrumented steps
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])

@@ -271,8 +271,9 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
 
   // ---- epilogue
   const bool vec = (Wo & 3) == 0;
-  auto store_tile = [&](int rw, int mw, int nt, f32x4 v, f32x4 v1) {  // v1: the px = 1 phase of a transposed conv
+  auto store_tile = [&](auto post, int rw, int mw, int nt, f32x4 v, f32x4 v1) {  // v1: the px = 1 phase of a transposed conv
     (void)v1;
+    (void)post;
     const int co = cz * Cfg::NTC + nt * 16 + m;
     const int y = y0 + row0 + rw;
     const int xb = x0 + mw * 16 + kq * 4;
@@ -284,15 +285,6 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
       if (y >= Ho || xb >= Wo) return;
       const float bt = beta ? beta[co] : 0.f;
       const size_t idx = ((size_t)co * Ho + y) * Wo + xb;
-      auto post = [&](float t) -> float {
-        switch (act) {
-          case 1: return lrelu02(t);
-          case 2: return t > 0.f ? t : post_slope * t;
-          case 3: return fmaxf(t, 0.f);
-          case 4: return tanhf(t) * 10.f;
-        }
-        return t;
-      };
       if (vec) {
         f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (res) r = *reinterpret_cast<const f32x4 *>(res + idx);
@@ -366,46 +358,58 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
     }
   };
 
-  if (KS == 1) {
-#pragma unroll
-    for (int rw = 0; rw < RW; ++rw)
-#pragma unroll
-      for (int mw = 0; mw < MW; ++mw)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) store_tile(rw, mw, nt, acc[0][rw][mw][nt], acc[NPX - 1][rw][mw][nt]);
-  } else {
-    // cross-wave K reduction: partials -> LDS, then wave w finishes tiles t == w (mod 4)
-    constexpr int NTILES = Cfg::NTILES, NT1 = RW * MW * NT;  // NTILES = NPX * NT1, phase-major
-    __syncthreads();  // every wave is done with its staging buffers
-    f32x4 *red = reinterpret_cast<f32x4 *>(smem);
-#pragma unroll
-    for (int p = 0; p < NPX; ++p)
-#pragma unroll
+  // The post activation is selected ONCE around the tile loops: selected per element, every inlined copy of the switch
+  // (with a tanhf expansion to jump over) ends up in the epilogue and its instruction fetch costs more than the stores.
+  auto finish = [&](auto post) {
+    if (KS == 1) {
+  #pragma unroll
       for (int rw = 0; rw < RW; ++rw)
-#pragma unroll
+  #pragma unroll
         for (int mw = 0; mw < MW; ++mw)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            red[(wave * NTILES + p * NT1 + (rw * MW + mw) * NT + nt) * 64 + lane] = acc[p][rw][mw][nt];
-    __syncthreads();
-    auto total = [&](int t) -> f32x4 {
-      f32x4 v = red[(0 * NTILES + t) * 64 + lane];
-      v += red[(1 * NTILES + t) * 64 + lane];
-      v += red[(2 * NTILES + t) * 64 + lane];
-      v += red[(3 * NTILES + t) * 64 + lane];
-      return v;
-    };
-#pragma unroll
-    for (int rw = 0; rw < RW; ++rw)
-#pragma unroll
-      for (int mw = 0; mw < MW; ++mw)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int t = (rw * MW + mw) * NT + nt;
-          if ((t & 3) != wave) continue;
-          store_tile(rw, mw, nt, total(t), total((NPX - 1) * NT1 + t));
-        }
-  }
+  #pragma unroll
+          for (int nt = 0; nt < NT; ++nt) store_tile(post, rw, mw, nt, acc[0][rw][mw][nt], acc[NPX - 1][rw][mw][nt]);
+    } else {
+      // cross-wave K reduction: partials -> LDS, then wave w finishes tiles t == w (mod 4)
+      constexpr int NTILES = Cfg::NTILES, NT1 = RW * MW * NT;  // NTILES = NPX * NT1, phase-major
+      __syncthreads();  // every wave is done with its staging buffers
+      f32x4 *red = reinterpret_cast<f32x4 *>(smem);
+  #pragma unroll
+      for (int p = 0; p < NPX; ++p)
+  #pragma unroll
+        for (int rw = 0; rw < RW; ++rw)
+  #pragma unroll
+          for (int mw = 0; mw < MW; ++mw)
+  #pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              red[(wave * NTILES + p * NT1 + (rw * MW + mw) * NT + nt) * 64 + lane] = acc[p][rw][mw][nt];
+      __syncthreads();
+      auto total = [&](int t) -> f32x4 {
+        f32x4 v = red[(0 * NTILES + t) * 64 + lane];
+        v += red[(1 * NTILES + t) * 64 + lane];
+        v += red[(2 * NTILES + t) * 64 + lane];
+        v += red[(3 * NTILES + t) * 64 + lane];
+        return v;
+      };
+  #pragma unroll
+      for (int rw = 0; rw < RW; ++rw)
+  #pragma unroll
+        for (int mw = 0; mw < MW; ++mw)
+  #pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int t = (rw * MW + mw) * NT + nt;
+            if ((t & 3) != wave) continue;
+            store_tile(post, rw, mw, nt, total(t), total((NPX - 1) * NT1 + t));
+          }
+    }
+  };
+  if (MODE == 1) finish([](float t) { return t; });
+  else switch (act) {
+      case 1: finish([](float t) { return lrelu02(t); }); break;
+      case 2: finish([post_slope](float t) { return t > 0.f ? t : post_slope * t; }); break;
+      case 3: finish([](float t) { return fmaxf(t, 0.f); }); break;
+      case 4: finish([](float t) { return tanhf(t) * 10.f; }); break;
+      default: finish([](float t) { return t; }); break;
+    }
 #endif
 }
 

@@ -68,6 +68,10 @@ struct TileCtx {
   int x0, y0, cz, n;
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global-memory queue
+// (s_waitcnt vmcnt(0)): here that would expose, once per tile, the latency of the epilogue stores just issued.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <class Cfg, bool PRE>
 __global__ void __launch_bounds__(256, 2)  // at least two workgroups per CU: <= 256 registers
 conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
@@ -151,15 +155,6 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   };
 
   const bool vec = (W & 3) == 0;
-  auto post = [&](float v) -> float {
-    switch (act) {
-      case 1: return lrelu02(v);
-      case 2: return v > 0.f ? v : post_slope * v;
-      case 3: return fmaxf(v, 0.f);
-      case 4: return tanhf(v) * 10.f;
-    }
-    return v;
-  };
 
   int work = blockIdx.x;
   if (work >= total) return;
@@ -199,9 +194,9 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bw[d][pl] = wload(d, pl);
-      __syncthreads();  // every wave is done reading the previous chunk
+      lds_barrier();  // every wave is done reading the previous chunk
       stage();
-      __syncthreads();
+      lds_barrier();
       if (q + 1 < nchunks) fetch(ctx, q + 1);
       else if (next < total) fetch(nctx, 0);
 
@@ -254,49 +249,60 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     }
 
     // ---- epilogue (conv.hip MODE 0): y = acc + bias; ResConv: y = y*beta + res; otherwise y += res (+ res2); then
-    // the post activation: act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10
+    // the post activation: act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10.  The activation is
+    // selected ONCE around the tile loops: selected per element, the inlined copies of the switch (each with a tanhf
+    // expansion to jump over) made the epilogue 10k instructions and as slow as the tile's MFMAs.
     const size_t img = (size_t)ctx.n * Cout * HW;
+    auto epilogue = [&](auto post) {
 #pragma unroll
-    for (int rw = 0; rw < RW; ++rw)
+      for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-      for (int mw = 0; mw < MW; ++mw)
+        for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          f32x4 v = acc[rw][mw][nt];
-          const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
-          const int y = ctx.y0 + row0 + rw;
-          const int xb = ctx.x0 + mw * 16 + kq * 4;
-          if (co >= Cout || y >= H || xb >= W) continue;
-          const size_t idx = img + ((size_t)co * H + y) * W + xb;
-          if (vec) {
-            f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (res) r = *reinterpret_cast<const f32x4 *>(res + idx);
-            if (res2) r2 = *reinterpret_cast<const f32x4 *>(res2 + idx);
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x4 v = acc[rw][mw][nt];
+            const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
+            const int y = ctx.y0 + row0 + rw;
+            const int xb = ctx.x0 + mw * 16 + kq * 4;
+            if (co >= Cout || y >= H || xb >= W) continue;
+            const size_t idx = img + ((size_t)co * H + y) * W + xb;
+            if (vec) {
+              f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+              if (res) r = *reinterpret_cast<const f32x4 *>(res + idx);
+              if (res2) r2 = *reinterpret_cast<const f32x4 *>(res2 + idx);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              float u = v[k] + bs[nt];
-              if (beta) u = u * bt[nt] + r[k];
-              else {
-                if (res) u = u + r[k];
-                if (res2) u = u + r2[k];
+              for (int k = 0; k < 4; ++k) {
+                float u = v[k] + bs[nt];
+                if (beta) u = u * bt[nt] + r[k];
+                else {
+                  if (res) u = u + r[k];
+                  if (res2) u = u + r2[k];
+                }
+                v[k] = post(u);
               }
-              v[k] = post(u);
-            }
-            *reinterpret_cast<f32x4 *>(out + idx) = v;
-          } else {
+              *reinterpret_cast<f32x4 *>(out + idx) = v;
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (xb + k >= W) continue;
-              float u = v[k] + bs[nt];
-              if (beta) u = u * bt[nt] + res[idx + k];
-              else {
-                if (res) u = u + res[idx + k];
-                if (res2) u = u + res2[idx + k];
+              for (int k = 0; k < 4; ++k) {
+                if (xb + k >= W) continue;
+                float u = v[k] + bs[nt];
+                if (beta) u = u * bt[nt] + res[idx + k];
+                else {
+                  if (res) u = u + res[idx + k];
+                  if (res2) u = u + res2[idx + k];
+                }
+                out[idx + k] = post(u);
               }
-              out[idx + k] = post(u);
             }
           }
-        }
+    };
+    switch (act) {
+      case 1: epilogue([](float v) { return lrelu02(v); }); break;
+      case 2: epilogue([post_slope](float v) { return v > 0.f ? v : post_slope * v; }); break;
+      case 3: epilogue([](float v) { return fmaxf(v, 0.f); }); break;
+      case 4: epilogue([](float v) { return tanhf(v) * 10.f; }); break;
+      default: epilogue([](float v) { return v; }); break;
+    }
     if (next >= total) break;
     work = next;
     ctx = nctx;
