@@ -22,6 +22,7 @@ def main():
     sections.append(("drm", gpu_checks.check_cases(cases.drm_cases(), hip, ora, 2e-5, np.load(os.path.join(GOLD, "drm.npz")))))
     sections.append(("conv", gpu_checks.check_conv_layers(hip.dev)))
     sections.append(("glue", gpu_checks.check_glue(hip.dev)))
+    sections.append(("window attention", gpu_checks.check_window_attention(hip.dev)))
     sections.append(("scdet", gpu_checks.check_scdet(hip, np.load(os.path.join(GOLD, "scdet.npz")))))
     gold = np.load(os.path.join(GOLD, "rife.npz"))
     for scale, size in cases.RIFE_CONFIGS:
