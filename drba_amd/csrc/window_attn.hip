@@ -54,7 +54,7 @@ __device__ __forceinline__ Window window_of(const Geometry &g, int win) {
   return Window{bi, wy * g.wh, wx * g.ww};
 }
 __device__ __forceinline__ unsigned token_row(const Geometry &g, const Window &wd, int t, int &region) {
-  const int ly = (int)__umulhi((unsigned)t, g.ww_magic), lx = t - ly * g.ww;
+  const int ly = g.ww == 1 ? t : (int)__umulhi((unsigned)t, g.ww_magic), lx = t - ly * g.ww;  // ceil(2^32/1) overflows
   const int y = wd.y0 + ly, x = wd.x0 + lx;
   region = 0;
   int sy = y, sx = x;
@@ -70,7 +70,7 @@ __device__ __forceinline__ unsigned token_row(const Geometry &g, const Window &w
 
 __global__ void __launch_bounds__(256)
 window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-                        float *__restrict__ out, Geometry g, int nwin, int qtiles, float scale) {
+                        float *__restrict__ out, Geometry g, int nwin, int qtiles, float scale, int ldq, int ldk, int ldv) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) float lds[];  // kLdsBytes: keys, values, key regions
   float *Ks = lds, *Vs = lds + kKeys * kStride;
@@ -97,7 +97,7 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
   const size_t qrow = token_row(g, wd, min(qtok, g.L - 1), qreg);
   f32x4 qf[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) qf[j] = *reinterpret_cast<const f32x4 *>(q + qrow * kC + 16 * j + 4 * grp);
+  for (int j = 0; j < 8; ++j) qf[j] = *reinterpret_cast<const f32x4 *>(q + qrow * ldq + 16 * j + 4 * grp);
 
   // ---- chunk loader: thread -> (key = tid/32 + 8*it, 4 channels at 4*(tid%32))
   const int lkey = tid >> 5, lc4 = (tid & 31) * 4;
@@ -107,8 +107,8 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
     for (int it = 0; it < LIT; ++it) {
       int unused;
       const size_t row = token_row(g, wd, min(chunk * kKeys + lkey + 8 * it, g.L - 1), unused);
-      pk[it] = *reinterpret_cast<const f32x4 *>(k + row * kC + lc4);
-      pv[it] = *reinterpret_cast<const f32x4 *>(v + row * kC + lc4);
+      pk[it] = *reinterpret_cast<const f32x4 *>(k + row * ldk + lc4);
+      pv[it] = *reinterpret_cast<const f32x4 *>(v + row * ldv + lc4);
     }
   };
   auto stage = [&](int chunk) {
@@ -237,15 +237,19 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
 }  // namespace drba_attn
 
 extern "C" int drba_window_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int W, int C,
-                                     int splits, int shift, float scale, void *stream) {
+                                     int splits, int shift, float scale, int ldq, int ldk, int ldv, void *stream) {
   if (!q || !k || !v || !out || B <= 0 || H <= 0 || W <= 0 || splits <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
   if (C != drba_attn::kC) return DRBA_EUNSUPPORTED;  // GMFlow's feature_channels
+  if (ldq < C || ldk < C || ldv < C || ((ldq | ldk | ldv) & 3)) return DRBA_EINVAL;  // rows are read as 16-byte vectors
   if (H % splits || W % splits) return DRBA_EINVAL;  // the reference's window split needs whole windows
   drba_attn::Geometry g;
   g.h = H, g.w = W, g.splits = splits, g.wh = H / splits, g.ww = W / splits;
   g.sh = g.wh / 2, g.sw = g.ww / 2, g.L = g.wh * g.ww, g.shift = shift ? 1 : 0;
-  if (g.ww < 2 || g.ww >= 65536 || g.L >= 65536) return DRBA_EUNSUPPORTED;  // range of the multiply-shift division
-  g.ww_magic = (unsigned)(((1ull << 32) + g.ww - 1) / g.ww);
+  if (g.ww >= 65536 || g.L >= 65536) return DRBA_EUNSUPPORTED;  // range of the multiply-shift division
+  // a window one pixel wide or high has shift 0 in that direction; the reference builds its mask with slice(-0, None),
+  // which is the whole axis -- a degenerate table this kernel's coordinate rule does not reproduce
+  if (g.shift && (g.sh == 0 || g.sw == 0)) return DRBA_EUNSUPPORTED;
+  g.ww_magic = g.ww == 1 ? 0u : (unsigned)(((1ull << 32) + g.ww - 1) / g.ww);
   const int nwin = B * splits * splits;
   const int qtiles = (g.L + drba_attn::kRows - 1) / drba_attn::kRows;
   const int groups = (nwin + 7) / 8;
@@ -255,7 +259,7 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
                           hipFuncAttributeMaxDynamicSharedMemorySize, drba_attn::kLdsBytes);
   if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
   DRBA_LAUNCH_TIMED(drba_attn::window_attention_kernel, grid, dim3(kBlock), drba_attn::kLdsBytes, (hipStream_t)stream, q, k, v,
-                    out, g, nwin, qtiles, scale);
+                    out, g, nwin, qtiles, scale, ldq, ldk, ldv);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -73,6 +73,9 @@ class GMFlow:
             for part, ffn in (("self_attn", False), ("cross_attn_ffn", True)):
                 p = f"transformer.layers.{i}.{part}."
                 d = {n: g(p + n + ".weight") for n in ("q_proj", "k_proj", "v_proj", "merge")}
+                # fused projections: self-attention projects one tensor three times, cross-attention its target twice
+                d["qkv_proj"] = torch.cat((d["q_proj"], d["k_proj"], d["v_proj"]), 0).contiguous()
+                d["kv_proj"] = torch.cat((d["k_proj"], d["v_proj"]), 0).contiguous()
                 d["n1w"], d["n1b"] = g(p + "norm1.weight"), g(p + "norm1.bias")
                 if ffn:
                     d["mlp0"], d["mlp2"] = g(p + "mlp.0.weight"), g(p + "mlp.2.weight")
@@ -135,12 +138,16 @@ class GMFlow:
     def _attention(self, q, k, v, h, w, splits, shift):
         b, _, c = q.shape
         scale = c ** 0.5
-        if self.FUSED_ATTENTION and c == C:
-            return _ops.window_attention(q, k, v, h, w, max(splits, 1), shift and splits > 1, scale)
+        k_ = max(splits, 1)
+        shifted = bool(shift) and splits > 1
+        degenerate = shifted and (h // k_ < 2 or w // k_ < 2)  # the reference's mask table is ill-formed there: keep it
+        if self.FUSED_ATTENTION and c == C and not degenerate:
+            return _ops.window_attention(q, k, v, h, w, k_, shifted, scale)
         return self._attention_unfused(q, k, v, h, w, splits, shift)
 
     def _attention_unfused(self, q, k, v, h, w, splits, shift):
         """The reference's formulation step by step (BLAS GEMMs + masked softmax kernel); kept as the cross-check."""
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()  # column slices of a fused projection output
         b, _, c = q.shape
         scale = c ** 0.5
         if splits <= 1:
@@ -161,7 +168,14 @@ class GMFlow:
         return out.reshape(b, -1, c)
 
     def _layer(self, d, source, target, h, w, splits, shift, ffn):
-        q, k, v = _linear(source, d["q_proj"]), _linear(target, d["k_proj"]), _linear(target, d["v_proj"])
+        if self.FUSED_ATTENTION and source is target:  # one [tokens, 3C] GEMM; the attention kernel reads column slices
+            qkv = _linear(source, d["qkv_proj"])
+            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        elif self.FUSED_ATTENTION:
+            q, kv = _linear(source, d["q_proj"]), _linear(target, d["kv_proj"])
+            k, v = kv[..., :C], kv[..., C:]
+        else:
+            q, k, v = _linear(source, d["q_proj"]), _linear(target, d["k_proj"]), _linear(target, d["v_proj"])
         msg = _linear(self._attention(q, k, v, h, w, splits, shift), d["merge"])
         if not ffn:
             return _ops.layernorm(msg, d["n1w"], d["n1b"], residual=source)

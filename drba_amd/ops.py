@@ -243,7 +243,8 @@ def _tune(shape_key, candidates, run, reps=3):
         return _tuned[shape_key]
     best, best_ms = None, None
     for cfg in candidates:
-        run(cfg)  # warm: packs weights, faults pages
+        if run(cfg) != 0:  # warm: packs weights, faults pages; a configuration that refuses the shape is not a candidate
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -253,6 +254,8 @@ def _tune(shape_key, candidates, run, reps=3):
         ms = e0.elapsed_time(e1)
         if best_ms is None or ms < best_ms:
             best, best_ms = cfg, ms
+    if best is None:
+        raise _lib.DrbaHipError(f"no kernel configuration accepts {shape_key}")
     _tuned[shape_key] = best
     return best
 
@@ -635,13 +638,22 @@ def gelu(x):
 
 
 def window_attention(q, k, v, h, w, splits, shift, scale):
-    """single_head_split_window_attention (transformer.py:46-113) fused: q, k, v [B, h*w, 128] -> [B, h*w, 128]."""
-    q, k, v = _f32(q), _f32(k), _f32(v)
+    """single_head_split_window_attention (transformer.py:46-113) fused: q, k, v [B, h*w, 128] -> [B, h*w, 128].
+    q, k, v may be last-dim slices of a wider tensor (a fused projection output): only the row stride is used."""
     b, n, c = q.shape
     assert n == h * w and k.shape == q.shape and v.shape == q.shape
-    out = torch.empty_like(q)
+
+    def rows(t):  # fp32 on the device, unit stride along channels, one constant stride between consecutive tokens
+        sliced_ok = (t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(0) == n * t.stride(1)
+                     and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0 and t.is_cuda)
+        if t.is_contiguous() or not sliced_ok:
+            t = _f32(t)  # no copy for a contiguous fp32 device tensor; raises for a CPU tensor
+        return t, t.stride(1)
+
+    (q, ldq), (k, ldk), (v, ldv) = rows(q), rows(k), rows(v)
+    out = torch.empty((b, n, c), dtype=torch.float32, device=q.device)
     _lib.check(_lib.load().drba_window_attention(_p(q), _p(k), _p(v), _p(out), b, h, w, c, int(splits), int(bool(shift)),
-                                                 float(scale), _stream()), "drba_window_attention")
+                                                 float(scale), ldq, ldk, ldv, _stream()), "drba_window_attention")
     return out
 
 

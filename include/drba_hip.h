@@ -203,7 +203,9 @@ int drba_gelu(const float *x, float *out, size_t n, void *stream); /* nn.GELU(),
  * generate_shift_window_attn_mask (transformer.py:19-43), softmax(q k^T / scale) v and the inverse partition / roll
  * are applied through index maps; the score matrix is never stored.  splits = 1, shift = 0 is full attention. */
 int drba_window_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int W, int C,
-                          int splits, int shift, float scale, void *stream);
+                          int splits, int shift, float scale, int ldq, int ldk, int ldv, void *stream);
+/* ldq / ldk / ldv: row strides in floats (>= C, multiples of 4; 16-byte aligned bases): q, k, v may be column slices
+ * of one fused projection output [B*H*W, 3C]; out rows are C apart */
 /* in-place row softmax of x/scale + mask[(row/rows_per_mat) % n_masks][row % rows_per_mat] (transformer.py:91-96) */
 int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks,
                       float scale, void *stream);

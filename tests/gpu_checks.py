@@ -409,7 +409,7 @@ def check_window_attention(dev):
     from oracle import gmflow as ogm
     rows = []
     shapes = [(2, 36, 60, 2, True), (2, 36, 60, 2, False), (1, 24, 40, 8, True), (1, 16, 32, 2, True), (1, 16, 24, 1, False),
-              (1, 72, 120, 2, True), (2, 144, 240, 8, True)]
+              (1, 72, 120, 2, True), (2, 144, 240, 8, True), (1, 16, 8, 8, False)]
     for idx, (b, h, w, splits, shift) in enumerate(shapes):
         q, k, v = [cases.rnd((b, h * w, 128), 70 + 3 * idx + j, 1.5) for j in range(3)]
         wh, ww = h // splits, w // splits
@@ -418,4 +418,8 @@ def check_window_attention(dev):
         got = ops.window_attention(q.to(dev), k.to(dev), v.to(dev), h, w, splits, shift, 128 ** 0.5)
         rows.append((f"window_attention b{b} {h}x{w} splits{splits} shift{int(shift)} (L={wh * ww})", _diff(got, want), 2e-5,
                      f"ref_absmax={float(want.abs().max()):.3g}"))
+        if idx == 0:  # q, k, v as column slices of one [tokens, 3C] tensor (the fused projection's output): same bits
+            qkv = torch.cat((q, k, v), -1).to(dev)
+            got2 = ops.window_attention(qkv[..., :128], qkv[..., 128:256], qkv[..., 256:], h, w, splits, shift, 128 ** 0.5)
+            rows.append(("window_attention on column slices of a fused qkv tensor", float((got2 - got).abs().max()), 0.0, ""))
     return rows
