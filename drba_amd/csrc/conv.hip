@@ -1,6 +1,9 @@
 // 3x3 convolution (stride 1/2, pad 1) and ConvTranspose2d(4, 2, 1) as fp32 implicit GEMM on
 // v_mfma_f32_16x16x4_f32 (exact fp32: bit-equal to a k-ordered fmaf chain; gfx950 has no
-// TF32/xf32 path and bf16 inputs break the 1e-3 parity bar, SURVEY.md 'Hard parts').
+// TF32/xf32 path and plain bf16 inputs break the 1e-3 parity bar, SURVEY.md 'Hard parts').
+// Stride-1 layers with Cin % 32 == 0 also have the split-bf16 kernels of conv_split.hip (three bf16 terms per
+// fp32 operand, fp32-level error) behind the same entry points; this file stays the kernel for stride 2,
+// transposed convolutions, ragged channel counts and small maps.
 //
 // GEMM view per workgroup (4 waves = one per SIMD):
 //   M = output pixels : a TH x TW tile, split into 16-pixel row segments (MFMA rows)

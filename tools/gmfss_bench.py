@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GMFSS_UNION / GMFSS steady-state throughput on one MI355X (not the headline metric; DESIGN.md quotes it).
 
-    python tools/gmfss_bench.py [--model gmfss_union|gmfss] [--size 1080p|720p|480p] [--scale S] [--steps K] [--warmup W]
+    python tools/gmfss_bench.py [--model gmfss_union|gmfss] [--size 4k|1080p|720p|480p] [--scale S] [--steps K] [--warmup W]
 
 Step = to_inp + warm inference_ts_drba(I0, I1, I2, ts=[0.75, 1.25], reuse, linear=True) + to_out, as bench.py."""
 import argparse
@@ -18,7 +18,7 @@ from drba_amd import ops  # noqa: E402
 from drba_amd.models.utils import tools  # noqa: E402
 from drba_amd.utils import synth  # noqa: E402
 
-SIZES = {"1080p": (1080, 1920), "720p": (720, 1280), "480p": (480, 854)}
+SIZES = {"4k": (2160, 3840), "1080p": (1080, 1920), "720p": (720, 1280), "480p": (480, 854)}
 
 
 def main():
