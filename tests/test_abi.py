@@ -52,6 +52,65 @@ def test_conv_weight_packing_layout(cin, cout, stride):
     assert np.array_equal(nz, np.sort(w.numpy().reshape(-1)))  # every weight exactly once
 
 
+def test_split_conv_weight_packing_reconstructs_fp32():
+    """conv_split.hip packs every weight as three bf16 terms h + m + l (cfg ids after the fp32 table): their sum must be
+    the fp32 weight up to its last mantissa bit, every weight exactly once, and a layer the family cannot run
+    (Cin not a multiple of 32) reports 0 packed floats so that hosts skip it."""
+    lib = _lib.load()
+    n_fp32 = 14
+    assert lib.drba_conv3x3_num_cfgs() > n_fp32
+    g = torch.Generator().manual_seed(5)
+    for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
+        assert lib.drba_conv3x3_cfg_stride(cfg) == 1
+        assert lib.drba_conv3x3_packed_floats(20, 32, cfg) == 0
+        cin, cout = 64, 40
+        n = lib.drba_conv3x3_packed_floats(cin, cout, cfg)
+        assert n > 0
+        w = torch.randn(cout, cin, 3, 3, generator=g) * torch.logspace(-3, 3, cout).view(-1, 1, 1, 1)
+        buf = torch.full((n,), float("nan"))
+        assert lib.drba_conv3x3_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr()), cin, cout, cfg) == 0
+        bits = buf.view(torch.int16).numpy().astype(np.uint16).astype(np.uint32) << 16  # bf16 -> fp32 bit patterns
+        vals = bits.view(np.float32).astype(np.float64).reshape(-1, 3, 64, 8)            # [fragment][plane][lane][i]
+        total = vals.sum(1).reshape(-1)
+        nz = np.sort(total[total != 0])
+        ref = np.sort(w.numpy().astype(np.float64).reshape(-1))
+        assert nz.size == ref.size
+        assert np.max(np.abs(nz - ref) / np.abs(ref)) < 2.0 ** -23  # 8 + 8 + 8 mantissa bits
+
+
+def test_autotune_skips_configurations_that_refuse_the_shape(monkeypatch):
+    from drba_amd import ops
+
+    class _Ev:
+        t = 0.0
+
+        def __init__(self, enable_timing=True):
+            pass
+
+        def record(self):
+            self.at = _Ev.t
+
+        def synchronize(self):
+            pass
+
+        def elapsed_time(self, other):
+            return other.at - self.at
+
+    monkeypatch.setattr(ops.torch.cuda, "Event", _Ev)
+    monkeypatch.setattr(ops, "_tuned", {})
+    cost = {3: 5.0, 4: 1.0, 5: 2.0}
+
+    def run(cfg):
+        if cfg == 4:
+            return -3  # the fastest-looking candidate refuses the shape (returns without launching)
+        _Ev.t += cost[cfg]
+        return 0
+
+    assert ops._tune(("shape",), [3, 4, 5], run) == 5
+    with pytest.raises(_lib.DrbaHipError):
+        ops._tune(("other",), [4], run)
+
+
 def test_deconv_weight_packing_layout():
     lib = _lib.load()
     cin, cout = 32, 52

@@ -29,6 +29,7 @@ def timeit(fn, reps=10):
 
 layers = [("grid 32->32 full", 1, 32, 32, 1152, 1920), ("grid 64->64 half", 1, 64, 64, 576, 960), ("grid 96->96 quarter", 1, 96, 96, 288, 480),
           ("feat 32->32 full", 1, 32, 32, 1152, 1920), ("b4.res 1080p N2", 2, 32, 32, 272, 480), ("b3.res 1080p N2", 2, 64, 64, 136, 240),
+          ("b2.res 1080p N2", 2, 96, 96, 68, 120), ("b1.res 1080p N2", 2, 128, 128, 34, 60), ("b2.res 1080p N1", 1, 96, 96, 68, 120),
           ("b4.res 4K N2", 2, 32, 32, 544, 960), ("b3.res 4K N2", 2, 64, 64, 272, 480), ("b2.res 4K N2", 2, 96, 96, 136, 240)]
 g = torch.Generator().manual_seed(0)
 for name, n, cin, cout, h, w in layers:
@@ -47,5 +48,6 @@ for name, n, cin, cout, h, w in layers:
     best32 = min(r for r in res if r[1] < 14)
     bests = min(r for r in res if r[1] >= 14)
     d = float((outs[bests[1]] - outs[best32[1]]).abs().max())
+    print(" ".join(f"{c}:{u:.0f}" for u, c in res if c < 14), end=" || ")
     print(f"{name:22s} fp32 cfg{best32[1]:2d} {best32[0]:7.1f} us {flop / best32[0] / 1e6:6.1f} TF/s | split cfg{bests[1]:2d} {bests[0]:7.1f} us "
           f"{flop / bests[0] / 1e6:6.1f} TF/s | " + " ".join(f"{c}:{u:.0f}" for u, c in res if c >= 14) + f" | max diff {d:.2e}", flush=True)
