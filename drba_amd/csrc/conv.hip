@@ -548,7 +548,7 @@ int drba_conv3x3_cfg_stride(int cfg) {
   if (cfg >= kNumConvCfg && cfg < drba_conv3x3_num_cfgs()) return 1;
   return (cfg < 0 || cfg >= kNumConvCfg) ? DRBA_EINVAL : kConv[cfg].S;
 }
-int drba_deconv4x4_num_cfgs(void) { return kNumDeconvCfg; }
+int drba_deconv4x4_num_cfgs(void) { return kNumDeconvCfg + (split_enabled() ? deconv_split_num_cfgs() : 0); }
 
 // DRBA_CONV_CFG=<id> / DRBA_DECONV_CFG=<id> in the environment override the choice (experiments only).
 int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride) {
@@ -634,6 +634,8 @@ int drba_deconv4x4_pick_cfg(int Cin, int Cout, int H, int W) {
 }
 
 size_t drba_deconv4x4_packed_floats(int Cin, int Cout, int cfg) {
+  if (cfg >= kNumDeconvCfg)
+    return cfg < drba_deconv4x4_num_cfgs() ? deconv_split_packed_floats(Cin, Cout, cfg - kNumDeconvCfg) : 0;
   if (cfg < 0 || cfg >= kNumDeconvCfg || Cin <= 0 || Cout <= 0) return 0;
   return packed_floats(kDeconv[cfg], Cin, Cout, 4);
 }
@@ -641,6 +643,8 @@ size_t drba_deconv4x4_packed_floats(int Cin, int Cout, int cfg) {
 // w: [Cin, Cout, 4, 4].  packed[((((cz*4 + phase)*nchunks + q)*4 + tap)*CG + cg)*NT + nt][lane], tap = 2a+b,
 // ky = py ? (a ? 2 : 0) : (a ? 3 : 1), kx likewise from (px, b).
 int drba_deconv4x4_pack(const float *w, float *packed, int Cin, int Cout, int cfg) {
+  if (cfg >= kNumDeconvCfg && cfg < drba_deconv4x4_num_cfgs())
+    return deconv_split_pack(w, packed, Cin, Cout, cfg - kNumDeconvCfg);
   if (!w || !packed || cfg < 0 || cfg >= kNumDeconvCfg || Cin <= 0 || Cout <= 0) return DRBA_EINVAL;
   const CfgInfo &c = kDeconv[cfg];
   const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + c.CK - 1) / c.CK, CG = c.CK / 4;
@@ -669,8 +673,11 @@ int drba_deconv4x4_pack(const float *w, float *packed, int Cin, int Cout, int cf
 int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, float *out, int N, int Cin, int H,
                      int W, int Cout, int pixel_shuffle, int pre_act, float pre_slope, int cfg, void *stream) {
   if (!in || !packed_w || !out || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
-  if (cfg < 0 || cfg >= kNumDeconvCfg) return DRBA_EINVAL;
   if (pixel_shuffle && (Cout & 3)) return DRBA_EINVAL;
+  if (cfg >= kNumDeconvCfg && cfg < drba_deconv4x4_num_cfgs())
+    return deconv_split_launch(cfg - kNumDeconvCfg, in, packed_w, bias, out, N, Cin, H, W, Cout, pixel_shuffle, pre_act,
+                               pre_slope, stream);
+  if (cfg < 0 || cfg >= kNumDeconvCfg) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
 #define DRBA_CASE(ID, T) \
   case ID:               \

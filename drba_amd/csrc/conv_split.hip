@@ -35,9 +35,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 32;  // channels per chunk = the K of one bf16 MFMA
 
-template <int RW_, int MW_, int NT_>
+// MODE 0: conv3x3 stride 1.  MODE 1: one row phase py (both column phases px) of ConvTranspose2d(k=4, s=2, p=1), a
+// 2x2-tap convolution over the same haloed window (tap offsets and phase algebra as in conv.hip).
+template <int MODE_, int RW_, int MW_, int NT_>
 struct SplitCfg {
-  static constexpr int RW = RW_, MW = MW_, NT = NT_;
+  static constexpr int MODE = MODE_, RW = RW_, MW = MW_, NT = NT_;
+  static constexpr int NTAP = MODE == 0 ? 9 : 4, NPX = MODE == 0 ? 1 : 2;
   static constexpr int TH = 4 * RW, TW = 16 * MW, NTC = 16 * NT;
   static constexpr int TR = TH + 2, TC = TW + 2, NPIX = TR * TC;
   // LDS: [plane 3][group 4][NPIXP][8 bf16]; NPIXP*16 bytes == 64 (mod 256) spreads the four channel groups of a wave
@@ -46,7 +49,7 @@ struct SplitCfg {
   static constexpr int LDS_BYTES = 3 * 4 * NPIXP * 16;
   static constexpr int ITEMS = NPIX * 4;                 // (pixel, channel group) staging items per chunk
   static constexpr int LIT = (ITEMS + 255) / 256;        // per thread
-  static constexpr int FRAG_U4 = 9 * NT * 3 * 64;        // 16-byte units of packed weights per (cout tile, chunk)
+  static constexpr int FRAG_U4 = NTAP * NT * 3 * 64;     // 16-byte units of packed weights per (cout tile[, phase], chunk)
   static constexpr int BDEPTH = (RW * MW >= 4) ? 2 : 4;  // weight fetch distance in steps (>= ~700 cycles of MFMAs)
 };
 
@@ -65,7 +68,7 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &h, unsigned &
 }
 
 struct TileCtx {
-  int x0, y0, cz, n;
+  int x0, y0, cz, n, py;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global-memory queue
@@ -77,8 +80,9 @@ __global__ void __launch_bounds__(256, 2)  // at least two workgroups per CU: <=
 conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                 const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
                 float *__restrict__ out, int Cin, int H, int W, int Cout, int act, float post_slope, float pre_slope,
-                int n_ctiles, int nbx, int nby, int total) {
+                int n_ctiles, int nbx, int nby, int total, int pixel_shuffle) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MODE = Cfg::MODE, NTAP = Cfg::NTAP, NPX = Cfg::NPX;
   constexpr int RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, TH = Cfg::TH, TW = Cfg::TW, TC = Cfg::TC;
   constexpr int NPIX = Cfg::NPIX, NPIXP = Cfg::NPIXP, LIT = Cfg::LIT;
   extern __shared__ __attribute__((aligned(16))) u32x4 tile[];  // [plane][group][NPIXP]
@@ -97,6 +101,11 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   auto decode = [&](int work) -> TileCtx {
     int t = xcd_band(work, total);
     TileCtx c;
+    c.py = 0;
+    if (MODE == 1) {  // the two row phases of a window back to back: the second one finds it in L2
+      c.py = t & 1;
+      t >>= 1;
+    }
     c.cz = t % n_ctiles;
     t /= n_ctiles;
     const int bx = t % nbx;
@@ -111,7 +120,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   // zero padding) without a branch.
   const unsigned img_bytes = (unsigned)((size_t)Cin * HW * 4);
   const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, n_ctiles * nchunks * Cfg::FRAG_U4 * 16, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, n_ctiles * (MODE == 0 ? 1 : 4) * nchunks * Cfg::FRAG_U4 * 16, 0x00020000);
   float pre[LIT][8];
   auto fetch = [&](const TileCtx &c, int q) {
     const __amdgpu_buffer_rsrc_t irsrc =
@@ -161,13 +170,15 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   TileCtx ctx = decode(work);
   fetch(ctx, 0);
   while (true) {
-    f32x4 acc[RW][MW][NT];
+    f32x4 acc[NPX][RW][MW][NT];
 #pragma unroll
-    for (int a = 0; a < RW; ++a)
+    for (int p = 0; p < NPX; ++p)
 #pragma unroll
-      for (int b = 0; b < MW; ++b)
+      for (int a = 0; a < RW; ++a)
 #pragma unroll
-        for (int c = 0; c < NT; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MW; ++b)
+#pragma unroll
+          for (int c = 0; c < NT; ++c) acc[p][a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int next = work + (int)gridDim.x;
     TileCtx nctx = ctx;
     if (next < total) nctx = decode(next);
@@ -184,10 +195,14 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       // Weight fragments are fetched D steps (a step = one tap of one cout tile: RW*MW*6 MFMAs) ahead of their use: a
       // chunk's fragments (27 KB per cout tile) do not stay in the 32 KB L1 next to the activations, so a fetch is
       // an L2 round trip.  The first D are independent of LDS and stay in flight across the staging barriers.
-      constexpr int STEPS = 9 * NT, D = Cfg::BDEPTH;
-      const int wq = (ctx.cz * nchunks + q) * (Cfg::FRAG_U4 * 16);  // byte offset of this (cout tile, chunk): scalar
+      // A "tap slot" ts is a (column phase, tap) pair: 9 for the convolution, 2 x 4 for the transposed one.
+      constexpr int NTS = NPX * NTAP, STEPS = NTS * NT, D = Cfg::BDEPTH;
+      // byte offset of this (cout tile[, row phase], chunk); the px = 1 block of a transposed conv follows nchunks later
+      const int wq = ((MODE == 0 ? ctx.cz : ctx.cz * 4 + 2 * ctx.py) * nchunks + q) * (Cfg::FRAG_U4 * 16);
+      const int px_bytes = nchunks * (Cfg::FRAG_U4 * 16);
       auto wload = [&](int step, int pl) -> u32x4 {
-        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wq + (step * 3 + pl) * 1024, 0);
+        const int p = step / (NTAP * NT), r = step - p * (NTAP * NT);  // r = tap * NT + nt
+        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wq + p * px_bytes + (r * 3 + pl) * 1024, 0);
       };
       u32x4 bw[D][3];
 #pragma unroll
@@ -200,26 +215,30 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       if (q + 1 < nchunks) fetch(ctx, q + 1);
       else if (next < total) fetch(nctx, 0);
 
-      // activation fragments: one tap ahead
+      // activation fragments: one tap slot ahead.  Transposed conv, tap = 2a + b: window row rw + dro[a] with
+      // dro = {1, 0} (py = 0) / {2, 1} (py = 1), window column x + dco[px][b] with dco = {{1, 0}, {2, 1}} (conv.hip).
       u32x4 af[2][RW][MW][3];
-      auto load_a = [&](int tap, int slot_) {
-        const int ky = tap / 3, kx = tap - ky * 3;
+      auto load_a = [&](int ts, int slot_) {
+        const int p = ts / NTAP, tap = ts - p * NTAP;
+        const int ro = MODE == 0 ? tap / 3 : ((tap >> 1) ? 0 : 1) + ctx.py;
+        const int co = MODE == 0 ? tap % 3 : ((tap & 1) ? 0 : 1) + p;
 #pragma unroll
         for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw) {
-            const int slot = kq * NPIXP + (row0 + rw + ky) * TC + mw * 16 + m + kx;
+            const int slot = kq * NPIXP + (row0 + rw + ro) * TC + mw * 16 + m + co;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) af[slot_][rw][mw][pl] = tile[4 * pl * NPIXP + slot];
           }
       };
       load_a(0, 0);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) load_a(tap + 1, (tap + 1) & 1);
+      for (int ts = 0; ts < NTS; ++ts) {
+        if (ts + 1 < NTS) load_a(ts + 1, (ts + 1) & 1);
+        const int p = ts / NTAP;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const int step = tap * NT + nt;
+          const int step = ts * NT + nt;
           const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[step % D][0]);
           const bf16x8 bm = __builtin_bit_cast(bf16x8, bw[step % D][1]);
           const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[step % D][2]);
@@ -227,17 +246,17 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
           for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
             for (int mw = 0; mw < MW; ++mw) {
-              const bf16x8 ah = __builtin_bit_cast(bf16x8, af[tap & 1][rw][mw][0]);
-              const bf16x8 am = __builtin_bit_cast(bf16x8, af[tap & 1][rw][mw][1]);
-              const bf16x8 al = __builtin_bit_cast(bf16x8, af[tap & 1][rw][mw][2]);
-              f32x4 c = acc[rw][mw][nt];
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, af[ts & 1][rw][mw][0]);
+              const bf16x8 am = __builtin_bit_cast(bf16x8, af[ts & 1][rw][mw][1]);
+              const bf16x8 al = __builtin_bit_cast(bf16x8, af[ts & 1][rw][mw][2]);
+              f32x4 c = acc[p][rw][mw][nt];
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);  // smallest terms first
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-              acc[rw][mw][nt] = c;
+              acc[p][rw][mw][nt] = c;
             }
           if (step + D < STEPS) {
 #pragma unroll
@@ -252,56 +271,115 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     // the post activation: act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10.  The activation is
     // selected ONCE around the tile loops: selected per element, the inlined copies of the switch (each with a tanhf
     // expansion to jump over) made the epilogue 10k instructions and as slow as the tile's MFMAs.
-    const size_t img = (size_t)ctx.n * Cout * HW;
-    auto epilogue = [&](auto post) {
+    if constexpr (MODE == 0) {
+      const size_t img = (size_t)ctx.n * Cout * HW;
+      auto epilogue = [&](auto post) {
+  #pragma unroll
+        for (int rw = 0; rw < RW; ++rw)
+  #pragma unroll
+          for (int mw = 0; mw < MW; ++mw)
+  #pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              f32x4 v = acc[0][rw][mw][nt];
+              const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
+              const int y = ctx.y0 + row0 + rw;
+              const int xb = ctx.x0 + mw * 16 + kq * 4;
+              if (co >= Cout || y >= H || xb >= W) continue;
+              const size_t idx = img + ((size_t)co * H + y) * W + xb;
+              if (vec) {
+                f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (res) r = *reinterpret_cast<const f32x4 *>(res + idx);
+                if (res2) r2 = *reinterpret_cast<const f32x4 *>(res2 + idx);
+  #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  float u = v[k] + bs[nt];
+                  if (beta) u = u * bt[nt] + r[k];
+                  else {
+                    if (res) u = u + r[k];
+                    if (res2) u = u + r2[k];
+                  }
+                  v[k] = post(u);
+                }
+                *reinterpret_cast<f32x4 *>(out + idx) = v;
+              } else {
+  #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  if (xb + k >= W) continue;
+                  float u = v[k] + bs[nt];
+                  if (beta) u = u * bt[nt] + res[idx + k];
+                  else {
+                    if (res) u = u + res[idx + k];
+                    if (res2) u = u + res2[idx + k];
+                  }
+                  out[idx + k] = post(u);
+                }
+              }
+            }
+      };
+      switch (act) {
+        case 1: epilogue([](float v) { return lrelu02(v); }); break;
+        case 2: epilogue([post_slope](float v) { return v > 0.f ? v : post_slope * v; }); break;
+        case 3: epilogue([](float v) { return fmaxf(v, 0.f); }); break;
+        case 4: epilogue([](float v) { return tanhf(v) * 10.f; }); break;
+        default: epilogue([](float v) { return v; }); break;
+      }
+    } else {
+      // transposed conv, row phase py, both column phases: lane (cout m, column group kq) holds the input columns
+      // xb..xb+3 for px = 0 (v) and px = 1 (v1), i.e. the 8 consecutive output columns 2*xb .. 2*xb+7 of row 2y+py
+      // (conv.hip MODE 1; bias only)
+      const int Hd = 2 * H, Wd = 2 * W;
+      float *oimg = out + (size_t)ctx.n * Cout * Hd * Wd;
 #pragma unroll
       for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
         for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            f32x4 v = acc[rw][mw][nt];
+            f32x4 v = acc[0][rw][mw][nt], v1 = acc[NPX - 1][rw][mw][nt];
             const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
             const int y = ctx.y0 + row0 + rw;
             const int xb = ctx.x0 + mw * 16 + kq * 4;
-            if (co >= Cout || y >= H || xb >= W) continue;
-            const size_t idx = img + ((size_t)co * H + y) * W + xb;
-            if (vec) {
-              f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-              if (res) r = *reinterpret_cast<const f32x4 *>(res + idx);
-              if (res2) r2 = *reinterpret_cast<const f32x4 *>(res2 + idx);
+            const int oy = 2 * y + ctx.py;
+            const float b0 = bs[nt];
+            if (!pixel_shuffle) {
+              if (co >= Cout || y >= H || xb >= W) continue;
+              float *dst = oimg + ((size_t)co * Hd + oy) * Wd + 2 * xb;
+              if (xb + 3 < W && (Wd & 3) == 0) {
+                *reinterpret_cast<f32x4 *>(dst) = (f32x4){v[0] + b0, v1[0] + b0, v[1] + b0, v1[1] + b0};
+                *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){v[2] + b0, v1[2] + b0, v[3] + b0, v1[3] + b0};
+              } else {
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                float u = v[k] + bs[nt];
-                if (beta) u = u * bt[nt] + r[k];
-                else {
-                  if (res) u = u + r[k];
-                  if (res2) u = u + r2[k];
-                }
-                v[k] = post(u);
+                for (int k = 0; k < 4; ++k)
+                  if (xb + k < W) {
+                    dst[2 * k] = v[k] + b0;
+                    dst[2 * k + 1] = v1[k] + b0;
+                  }
               }
-              *reinterpret_cast<f32x4 *>(out + idx) = v;
             } else {
+              // + PixelShuffle(2): cout = 4*c13 + 2*si + sj lands at row 2*oy+si, column 4i + 2px + sj of plane c13.
+              // Lanes m and m^1 (sj = 0 / 1, same c13 and si) exchange their values, after which each holds the 4
+              // consecutive columns 4i..4i+3 for every i; the even lane stores i = xb, xb+1, the odd lane xb+2, xb+3.
+              const int c13 = co >> 2, si = (co >> 1) & 1, sj = co & 1;
+              f32x4 o0, o1;
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
+                v[k] += b0;
+                v1[k] += b0;
+                o0[k] = __shfl_xor(v[k], 1, 64);
+                o1[k] = __shfl_xor(v1[k], 1, 64);
+              }
+              if (co >= Cout || y >= H || xb >= W) continue;
+              float *dst = out + (size_t)ctx.n * (Cout / 4) * (2 * Hd) * (size_t)(2 * Wd) +
+                    ((size_t)c13 * (2 * Hd) + (2 * oy + si)) * (size_t)(2 * Wd) + 4 * xb;
+#pragma unroll
+              for (int kk = 0; kk < 2; ++kk) {
+                const int k = sj * 2 + kk;  // even lane: input columns xb, xb+1; odd lane: xb+2, xb+3
                 if (xb + k >= W) continue;
-                float u = v[k] + bs[nt];
-                if (beta) u = u * bt[nt] + res[idx + k];
-                else {
-                  if (res) u = u + res[idx + k];
-                  if (res2) u = u + res2[idx + k];
-                }
-                out[idx + k] = post(u);
+                const f32x4 qv = sj ? (f32x4){o0[k], v[k], o1[k], v1[k]} : (f32x4){v[k], o0[k], v1[k], o1[k]};
+                *reinterpret_cast<f32x4 *>(dst + 4 * k) = qv;
               }
             }
           }
-    };
-    switch (act) {
-      case 1: epilogue([](float v) { return lrelu02(v); }); break;
-      case 2: epilogue([post_slope](float v) { return v > 0.f ? v : post_slope * v; }); break;
-      case 3: epilogue([](float v) { return fmaxf(v, 0.f); }); break;
-      case 4: epilogue([](float v) { return tanhf(v) * 10.f; }); break;
-      default: epilogue([](float v) { return v; }); break;
     }
     if (next >= total) break;
     work = next;
@@ -311,13 +389,16 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 }
 
 // ------------------------------------------------------------------------------------------ host side
-//                  RW MW NT
-using S0 = SplitCfg<1, 2, 2>;  // 4x32 px x 32 cout
-using S1 = SplitCfg<1, 2, 4>;  // 4x32 px x 64 cout
-using S2 = SplitCfg<1, 2, 6>;  // 4x32 px x 96 cout
-using S3 = SplitCfg<1, 4, 2>;  // 4x64 px x 32 cout
-using S4 = SplitCfg<2, 2, 2>;  // 8x32 px x 32 cout
+//                  M  RW MW NT
+using S0 = SplitCfg<0, 1, 2, 2>;  // 4x32 px x 32 cout
+using S1 = SplitCfg<0, 1, 2, 4>;  // 4x32 px x 64 cout
+using S2 = SplitCfg<0, 1, 2, 6>;  // 4x32 px x 96 cout
+using S3 = SplitCfg<0, 1, 4, 2>;  // 4x64 px x 32 cout
+using S4 = SplitCfg<0, 2, 2, 2>;  // 8x32 px x 32 cout
 constexpr int kNum = 5;
+using T0 = SplitCfg<1, 1, 2, 2>;  // transposed: 4x32 input px x 32 cout (both column phases)
+using T1 = SplitCfg<1, 1, 2, 4>;  // 4x32 x 64 (8x32 and 4x64 tiles need > 256 registers with two phases' accumulators)
+constexpr int kNumT = 2;
 struct Info {
   int NT, NTC, frag_u4;
 };
@@ -326,6 +407,7 @@ constexpr Info info() {
   return {C::NT, C::NTC, C::FRAG_U4};
 }
 const Info kInfo[kNum] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>()};
+const Info kInfoT[kNumT] = {info<T0>(), info<T1>()};
 
 template <class Cfg, bool PRE>
 hipError_t lds_limit() {
@@ -338,10 +420,10 @@ hipError_t lds_limit() {
 template <class Cfg>
 int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, const float *res2,
            float *out, int N, int Cin, int H, int W, int Cout, int act, float post_slope, int pre_act, float pre_slope,
-           hipStream_t s) {
+           int pixel_shuffle, hipStream_t s) {
   const int n_ct = (Cout + Cfg::NTC - 1) / Cfg::NTC;
   const int nbx = (W + Cfg::TW - 1) / Cfg::TW, nby = (H + Cfg::TH - 1) / Cfg::TH;
-  const long long total = (long long)nbx * nby * N * n_ct;
+  const long long total = (long long)nbx * nby * N * n_ct * (Cfg::MODE == 0 ? 1 : 2);  // x2: row phases
   if (total >= (1ll << 31)) return DRBA_EUNSUPPORTED;
   // persistent grid: what the 256 CUs can hold (LDS-limited workgroups per CU, at most 3 by registers), a multiple of 8
   int per_cu = 160 * 1024 / Cfg::LDS_BYTES;
@@ -353,7 +435,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     DRBA_LAUNCH_TIMED(kernel, g, dim3(256), Cfg::LDS_BYTES, s, in, wf, bias, beta, res, res2, out, Cin, H, W, Cout, act,
-                      post_slope, pre_slope, n_ct, nbx, nby, (int)total);
+                      post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle);
     return DRBA_OK;
   };
   const int rc = pre_act ? go(conv_split_mfma<Cfg, true>, lds_limit<Cfg, true>())
@@ -436,13 +518,82 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
 #define DRBA_CASE(ID, T) \
   case ID:               \
     return launch<T>(in, packed_w, bias, beta, residual, residual2, out, N, Cin, H, W, Cout, act, post_slope, pre_act, \
-                     pre_slope, s);
+                     pre_slope, 0, s);
   switch (id) {
     DRBA_CASE(0, S0)
     DRBA_CASE(1, S1)
     DRBA_CASE(2, S2)
     DRBA_CASE(3, S3)
     DRBA_CASE(4, S4)
+  }
+#undef DRBA_CASE
+  return DRBA_EUNSUPPORTED;
+}
+
+// ---- transposed convolution (ConvTranspose2d k=4, s=2, p=1), cfg ids after conv.hip's fp32 deconv table
+int deconv_split_num_cfgs() { return drba_conv_split::kNumT; }
+
+bool deconv_split_supports(int Cin, int Cout, int id) {
+  return id >= 0 && id < drba_conv_split::kNumT && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
+}
+
+size_t deconv_split_packed_floats(int Cin, int Cout, int id) {
+  if (!deconv_split_supports(Cin, Cout, id)) return 0;
+  const drba_conv_split::Info &c = drba_conv_split::kInfoT[id];
+  const size_t n_ct = (Cout + c.NTC - 1) / c.NTC, nch = Cin / drba_conv_split::CK;
+  return n_ct * 4 * nch * c.frag_u4 * 4;
+}
+
+// w: [Cin, Cout, 4, 4].  packed (16-byte units): [cout tile][phase = 2*py + px][chunk][tap = 2a + b][nt][plane][lane],
+// ky = py ? (a ? 2 : 0) : (a ? 3 : 1), kx likewise from (px, b) -- the phase algebra of conv.hip's drba_deconv4x4_pack
+int deconv_split_pack(const float *w, float *packed, int Cin, int Cout, int id) {
+  using namespace drba_conv_split;
+  if (!w || !packed || !deconv_split_supports(Cin, Cout, id)) return DRBA_EINVAL;
+  const Info &c = kInfoT[id];
+  const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = Cin / CK;
+  memset(packed, 0, sizeof(float) * deconv_split_packed_floats(Cin, Cout, id));
+  unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
+  for (int cz = 0; cz < n_ct; ++cz)
+    for (int phase = 0; phase < 4; ++phase) {
+      const int py = phase >> 1, px = phase & 1;
+      for (int q = 0; q < nch; ++q)
+        for (int tap = 0; tap < 4; ++tap) {
+          const int a = tap >> 1, b = tap & 1;
+          const int ky = py ? (a ? 2 : 0) : (a ? 3 : 1);
+          const int kx = px ? (b ? 2 : 0) : (b ? 3 : 1);
+          for (int nt = 0; nt < c.NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int co = cz * c.NTC + nt * 16 + (lane & 15);
+              if (co >= Cout) continue;
+              for (int i = 0; i < 8; ++i) {
+                const int ci = q * CK + 8 * (lane >> 4) + i;
+                const float x = w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+                const float h = bf16_round(x), m = bf16_round(x - h), l = bf16_round(x - h - m);
+                const float term[3] = {h, m, l};
+                for (int pl = 0; pl < 3; ++pl) {
+                  const size_t unit = ((((((size_t)cz * 4 + phase) * nch + q) * 4 + tap) * c.NT + nt) * 3 + pl);
+                  dst[(unit * 64 + lane) * 8 + i] = bf16_bits(term[pl]);
+                }
+              }
+            }
+        }
+    }
+  return DRBA_OK;
+}
+
+int deconv_split_launch(int id, const float *in, const float *packed_w, const float *bias, float *out, int N, int Cin, int H,
+                        int W, int Cout, int pixel_shuffle, int pre_act, float pre_slope, void *stream) {
+  using namespace drba_conv_split;
+  if (!deconv_split_supports(Cin, Cout, id)) return DRBA_EUNSUPPORTED;
+  if ((size_t)Cin * H * W * 4 >= (1ull << 31)) return DRBA_EUNSUPPORTED;  // 32-bit byte offsets inside an image
+  hipStream_t s = (hipStream_t)stream;
+#define DRBA_CASE(ID, T) \
+  case ID:               \
+    return launch<T>(in, packed_w, bias, nullptr, nullptr, nullptr, out, N, Cin, H, W, Cout, 0, 0.f, pre_act, pre_slope, \
+                     pixel_shuffle, s);
+  switch (id) {
+    DRBA_CASE(0, T0)
+    DRBA_CASE(1, T1)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;

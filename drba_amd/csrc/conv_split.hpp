@@ -13,4 +13,13 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
                       const float *residual, const float *residual2, float *out, int N, int Cin, int H, int W, int Cout,
                       int act, float post_slope, int pre_act, float pre_slope, void *stream);
 
+
+// transposed convolution 4x4 s2 p1 (cfg ids after conv.hip's fp32 deconv table)
+int deconv_split_num_cfgs();
+bool deconv_split_supports(int Cin, int Cout, int id);
+size_t deconv_split_packed_floats(int Cin, int Cout, int id);
+int deconv_split_pack(const float *w, float *packed, int Cin, int Cout, int id);
+int deconv_split_launch(int id, const float *in, const float *packed_w, const float *bias, float *out, int N, int Cin, int H,
+                        int W, int Cout, int pixel_shuffle, int pre_act, float pre_slope, void *stream);
+
 }  // namespace drba

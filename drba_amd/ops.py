@@ -360,7 +360,8 @@ class Deconv4x4:
         if self.force_cfg is not None:
             cfg = self.force_cfg
         elif AUTOTUNE and x.is_cuda:
-            cfg = _tune(("deconv4x4", n, cin, self.cout, h, w, self.ps), list(range(lib.drba_deconv4x4_num_cfgs())),
+            cands = [c for c in range(lib.drba_deconv4x4_num_cfgs()) if lib.drba_deconv4x4_packed_floats(cin, self.cout, c) > 0]
+            cfg = _tune(("deconv4x4", n, cin, self.cout, h, w, self.ps), cands,
                         lambda c: lib.drba_deconv4x4s2(_p(x), _p(self._pack(c)), _p(self.bias), _p(out), n, cin, h, w,
                                                        self.cout, self.ps, pre, ps_, c, _stream()))
             self._keep.add(cfg)

@@ -146,6 +146,24 @@ def check_conv_layers(dev):
                 rows.append((f"deconv cfg{cfg} [{cin}->{cout} {h}x{w} ps={ps}]", _diff(got, ref), 5e-5, ""))
             except Exception as e:  # noqa: BLE001
                 rows.append((f"deconv cfg{cfg}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    # split-bf16 transposed convolution (cfg ids after the fp32 deconv table), against fp64
+    for cfg in range(6, lib.drba_deconv4x4_num_cfgs()):
+        for (nb, cin, cout, h, w, ps, pre) in ((1, 32, 52, 11, 45, True, None), (2, 64, 16, 6, 70, False, None), (1, 96, 40, 9, 33, False, 0.25),
+                                                (1, 32, 52, 8, 64, True, None)):
+            try:
+                x = torch.randn(nb, cin, h, w, generator=g) * 2.0
+                wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+                b = torch.randn(cout, generator=g) * 0.1
+                xin = x.double() if pre is None else F.prelu(x.double(), torch.tensor([pre], dtype=torch.float64))
+                ref = F.conv_transpose2d(xin, wt.double(), b.double(), stride=2, padding=1)
+                if ps:
+                    ref = F.pixel_shuffle(ref, 2)
+                got = ops.Deconv4x4(wt, b, ps, device=dev, cfg=cfg, pre_slope=pre)(x.to(dev))
+                scale = float(ref.abs().max())
+                rows.append((f"deconv split cfg{cfg} [{nb}x{cin}->{cout} {h}x{w} ps={ps} pre={pre}]", _diff(got, ref.float()),
+                             5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+            except Exception as e:  # noqa: BLE001
+                rows.append((f"deconv split cfg{cfg}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     # drba_conv_chain (an IFBlock core issued by one native call) against the same layers issued one by one and
     # against the CPU composition, batch of 2, ragged size
     try:
