@@ -72,6 +72,9 @@ SIGNATURES = {
     "drba_layernorm": (_i, [_p, _p, _p, _p, _p, _z, _i, _f, _p]),
     "drba_gelu": (_i, [_p, _p, _z, _p]),
     "drba_window_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
+    "drba_linear_split_packed_floats": (_z, [_i, _i]),
+    "drba_linear_split_pack": (_i, [_p, _p, _i, _i]),
+    "drba_linear_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "drba_softmax_rows": (_i, [_p, _p, _z, _i, _i, _i, _f, _p]),
     "drba_softmax_expect2": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "drba_local_corr_flow": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -19,6 +19,8 @@ _MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
 def _linear(x, w, b=None):
+    if isinstance(w, _ops.LinearSplit):
+        return w(x)
     y = torch.matmul(x, w.t())
     return y if b is None else torch.add(y, b)  # bias add of the two flow-attention projections (128 floats)
 
@@ -76,9 +78,15 @@ class GMFlow:
                 # fused projections: self-attention projects one tensor three times, cross-attention its target twice
                 d["qkv_proj"] = torch.cat((d["q_proj"], d["k_proj"], d["v_proj"]), 0).contiguous()
                 d["kv_proj"] = torch.cat((d["k_proj"], d["v_proj"]), 0).contiguous()
+                if self.SPLIT_LINEAR:  # drba_linear_split (three-term bf16 MFMA, fp32-level error) instead of the BLAS
+                    for n in ("qkv_proj", "kv_proj", "q_proj", "merge"):
+                        d[n] = _ops.LinearSplit(d[n], device=dev)
                 d["n1w"], d["n1b"] = g(p + "norm1.weight"), g(p + "norm1.bias")
                 if ffn:
                     d["mlp0"], d["mlp2"] = g(p + "mlp.0.weight"), g(p + "mlp.2.weight")
+                    if self.SPLIT_LINEAR:
+                        d["mlp0"] = _ops.LinearSplit(d["mlp0"], gelu=True, device=dev)  # GELU in the epilogue
+                        d["mlp2"] = _ops.LinearSplit(d["mlp2"], device=dev)
                     d["n2w"], d["n2b"] = g(p + "norm2.weight"), g(p + "norm2.bias")
                 lay[part] = d
             self.layers.append(lay)
@@ -134,6 +142,7 @@ class GMFlow:
 
     # ---------------------------------------------------------------- transformer (transformer.py)
     FUSED_ATTENTION = os.environ.get("DRBA_FUSED_ATTENTION", "1") != "0"
+    SPLIT_LINEAR = os.environ.get("DRBA_LINEAR_SPLIT", "1") != "0"  # 0: the transformer's linears through the vendor BLAS
 
     def _attention(self, q, k, v, h, w, splits, shift):
         b, _, c = q.shape
@@ -180,7 +189,9 @@ class GMFlow:
         if not ffn:
             return _ops.layernorm(msg, d["n1w"], d["n1b"], residual=source)
         msg = _ops.layernorm(msg, d["n1w"], d["n1b"])
-        hid = _ops.gelu(_linear(torch.cat([source, msg], dim=-1), d["mlp0"]))
+        hid = _linear(torch.cat([source, msg], dim=-1), d["mlp0"])
+        if not isinstance(d["mlp0"], _ops.LinearSplit):  # (the split kernel applies GELU in its epilogue)
+            hid = _ops.gelu(hid)
         return _ops.layernorm(_linear(hid, d["mlp2"]), d["n2w"], d["n2b"], residual=source)
 
     def transformer(self, f0, f1, splits):

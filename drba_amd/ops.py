@@ -638,6 +638,36 @@ def gelu(x):
     return out
 
 
+class LinearSplit:
+    """nn.Linear on token-major activations ([..., K] -> [..., N]) through drba_linear_split; optional fused GELU."""
+
+    def __init__(self, weight, bias=None, gelu=False, device=None):
+        w = weight.detach().float().cpu().contiguous()
+        self.n, self.k = w.shape
+        lib = _lib.load()
+        n = lib.drba_linear_split_packed_floats(self.k, self.n)
+        if n == 0:
+            raise _lib.DrbaHipError(f"drba_linear_split needs K % 32 == 0 (K={self.k})")
+        buf = torch.empty(n, dtype=torch.float32)
+        _lib.check(lib.drba_linear_split_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr()), self.k, self.n),
+                   "drba_linear_split_pack")
+        self.packed = buf.to(device)
+        self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
+        self.gelu = 1 if gelu else 0
+
+    def __call__(self, x):
+        assert x.shape[-1] == self.k
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.k)  # a view for contiguous inputs and for row-strided column slices
+        if x2.dtype != torch.float32 or x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16 or not x2.is_cuda:
+            x2 = _f32(x2)
+        m = x2.shape[0]
+        out = torch.empty((m, self.n), dtype=torch.float32, device=x2.device)
+        _lib.check(_lib.load().drba_linear_split(_p(x2), _p(self.packed), _p(self.bias), _p(out), m, self.k, self.n,
+                                                 x2.stride(0), self.gelu, _stream()), "drba_linear_split")
+        return out.view(*lead, self.n)
+
+
 def window_attention(q, k, v, h, w, splits, shift, scale):
     """single_head_split_window_attention (transformer.py:46-113) fused: q, k, v [B, h*w, 128] -> [B, h*w, 128].
     q, k, v may be last-dim slices of a wider tensor (a fused projection output): only the row stride is used."""

@@ -206,6 +206,14 @@ int drba_window_attention(const float *q, const float *k, const float *v, float 
                           int splits, int shift, float scale, int ldq, int ldk, int ldv, void *stream);
 /* ldq / ldk / ldv: row strides in floats (>= C, multiples of 4; 16-byte aligned bases): q, k, v may be column slices
  * of one fused projection output [B*H*W, 3C]; out rows are C apart */
+/* nn.Linear on token-major activations (transformer.py:142-208: q/k/v/merge projections, MLP 256 -> 1024 -> GELU -> 128):
+ * out[M, N] = x[M, K] (row stride ldx floats) . w[N, K]^T (+ bias) (, exact GELU).  fp32 operands evaluated as three bf16
+ * terms each on the bf16 matrix cores with fp32-level error (conv_split); K % 32 == 0.  The weight is packed
+ * once with drba_linear_split_pack (host buffers; drba_linear_split_packed_floats floats). */
+size_t drba_linear_split_packed_floats(int K, int N);
+int drba_linear_split_pack(const float *w /*[N,K] host*/, float *packed, int K, int N);
+int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
+                      int gelu, void *stream);
 /* in-place row softmax of x/scale + mask[(row/rows_per_mat) % n_masks][row % rows_per_mat] (transformer.py:91-96) */
 int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks,
                       float scale, void *stream);

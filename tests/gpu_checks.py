@@ -441,3 +441,28 @@ def check_window_attention(dev):
             got2 = ops.window_attention(qkv[..., :128], qkv[..., 128:256], qkv[..., 256:], h, w, splits, shift, 128 ** 0.5)
             rows.append(("window_attention on column slices of a fused qkv tensor", float((got2 - got).abs().max()), 0.0, ""))
     return rows
+
+
+# ----------------------------------------------------------------------------------------- split-bf16 linear
+def check_linear_split(dev):
+    """drba_linear_split against an fp64 nn.Linear: ragged token counts, N not a multiple of the 128-feature tile, a
+    row-strided input (column slice of a wider tensor), bias, fused GELU, the transformer's shapes."""
+    from drba_amd import ops
+    rows = []
+    g = torch.Generator().manual_seed(77)
+    for (m, k, n, gelu, bias, sliced) in ((1000, 128, 384, False, False, False), (333, 256, 1024, True, False, False),
+                                          (4100, 1024, 128, False, True, False), (70, 128, 40, False, True, True),
+                                          (17280, 128, 128, False, False, True), (69120, 256, 1024, True, False, False)):
+        x = torch.randn(m, k + (64 if sliced else 0), generator=g) * 2.0
+        w = torch.randn(n, k, generator=g) / k ** 0.5
+        b = torch.randn(n, generator=g) * 0.1 if bias else None
+        xd = x.to(dev)
+        xin = xd[:, 32:32 + k] if sliced else xd
+        ref = F.linear(x[:, 32:32 + k].double() if sliced else x.double(), w.double(), None if b is None else b.double())
+        if gelu:
+            ref = F.gelu(ref)
+        got = ops.LinearSplit(w, b, gelu=gelu, device=dev)(xin.view(2, m // 2, k) if (m % 2 == 0 and not sliced) else xin)
+        scale = float(ref.abs().max())
+        rows.append((f"linear_split [{m}x{k}] -> {n} gelu={int(gelu)} bias={int(bias)} sliced={int(sliced)}",
+                     _diff(got.reshape(m, n), ref.float()), 5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+    return rows

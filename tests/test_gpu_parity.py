@@ -169,3 +169,8 @@ def test_gmflow_bidirectional_equals_two_calls(hip_backend):
 @pytest.mark.gpu
 def test_window_attention(hip_backend):
     _assert_rows(gpu_checks.check_window_attention(hip_backend.dev))
+
+
+@pytest.mark.gpu
+def test_linear_split(hip_backend):
+    _assert_rows(gpu_checks.check_linear_split(hip_backend.dev))
