@@ -3,15 +3,18 @@
 // cores with fp32-level accuracy: both operands are split into three bf16 terms and the six leading partial products
 // are accumulated in fp32, exactly as in conv_split.hip (see there for the error argument and the measured MFMA rates).
 //
-// GEMM view per workgroup (4 waves): MT x 16 tokens by 4 x NTW x 16 output features (64 x 256 for wide layers, 128 x 128
-// for the 128-feature ones), K in chunks of 32; 96 MFMAs per wave per chunk and barrier.
+// GEMM view per workgroup (4 waves): 64 tokens x 128 output features, K in chunks of 32.
 //   MFMA A operand = weights (row = output feature), B operand = activations (column = token): the accumulator then
 //   holds 4 consecutive output features of ONE token per lane -> a float4 store into the token-major output.
-//   Activations: thread (token, channel group of 8) loads 32 contiguous bytes of its row, splits them and writes the
-//     three planes to LDS ([plane][group][token][8 x bf16], double-buffered: one barrier per chunk); every wave reads all
-//     token tiles of the chunk (3 16-byte reads each).
-//   Weights: split and packed in fragment order on the host; wave w owns NTW consecutive output-feature tiles and
-//     fetches their 3 x NTW fragments per chunk straight from L2, one chunk ahead.
+//   The waves split the TOKENS (16 each) and each computes all 8 feature tiles for its own, so an activation fragment
+//   never crosses waves: lane (token, channel group) loads 32 contiguous bytes of its row, splits them and holds the
+//   three bf16 operands in registers -- no LDS round trip for the activations.
+//   The weight fragments of the chunk (8 x 3 KB, split on the host and packed in fragment order) are copied
+//   global -> LDS by LDS-direct loads (no registers, no VALU), double-buffered, one s_waitcnt vmcnt(0) + barrier per
+//   chunk; each is read once per wave and feeds 6 MFMAs.  108 registers: 4 workgroups per CU -- measured, occupancy
+//   matters more here than blocking: 64 tokens per wave (372 registers) 88 TFLOP/s, 32 per wave 132, 16 per wave 146
+//   on the 1024 -> 128 layer (fp32-equivalent; rocBLAS fp32: 110).  An earlier form that shared the split activations
+//   through LDS and kept the weights in registers reached 116.
 //   Epilogue: + bias, optional exact GELU (erf form, as nn.GELU()).
 #include "common.hpp"
 
@@ -28,15 +31,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 32;    // K per chunk = the K of one bf16 MFMA
-template <int MT_, int NTW_>
-struct LinCfg {
-  static constexpr int MT = MT_, NTW = NTW_;   // token tiles per workgroup (shared by the waves), feature tiles per wave
-  static constexpr int TM = 16 * MT, TN = 64 * NTW;
-  static constexpr int PLANE = 4 * TM + 4;     // 16-byte units per plane: [group 4][token] (+4: planes on different banks)
-  static constexpr int BUF = 3 * PLANE;
-  static constexpr int SIT = TM * 4 / 256;     // staging items (token, channel group) per thread per chunk
-};
-
 __device__ __forceinline__ void split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -54,110 +48,115 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
+typedef __attribute__((address_space(3))) void *lds_ptr;
+
+template <int MTW_, int NT_>
+struct LinCfg {
+  static constexpr int MTW = MTW_, NT = NT_;
+  static constexpr int TM = 64 * MTW, TN = 16 * NT;
+  static constexpr int WBUF = NT * 3 * 64;  // 16-byte units of weight fragments per chunk
+};
+
 template <class Cfg, bool GELU>
 __global__ void __launch_bounds__(256)
 linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
-                    float *__restrict__ out, int M, int K, int N, int ldx, int n_ntiles) {
+                     float *__restrict__ out, int M, int K, int N, int ldx, int n_ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int MT = Cfg::MT, NTW = Cfg::NTW, TM = Cfg::TM, TN = Cfg::TN, PLANE = Cfg::PLANE, BUF = Cfg::BUF, SIT = Cfg::SIT;
-  __shared__ __attribute__((aligned(16))) u32x4 lds[2 * BUF];
+  constexpr int MTW = Cfg::MTW, NT = Cfg::NT, TM = Cfg::TM, WBUF = Cfg::WBUF;
+  __shared__ __attribute__((aligned(16))) u32x4 wl[2 * WBUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kq = lane >> 4;
-  // feature tile innermost: the workgroups sharing a token tile run back to back (its rows stay in L2)
   const int t = xcd_band((int)blockIdx.x, (int)gridDim.x);
   const int bn = t % n_ntiles, bm = t / n_ntiles;
-  const int m0 = bm * TM, n0 = bn * TN;
-  const int nchunks = K / CK;
+  const int m0 = bm * TM + wave * (16 * MTW), ft0 = bn * NT;
+  const int nchunks = K / CK, n_ftiles = (N + 15) >> 4;
 
-  // staging: item = (token, channel group of 8): 32 contiguous bytes of the token's row per chunk; lanes run along tokens
-  f32x4 pa[SIT], pb[SIT];
-  const float *srow[SIT];
-  bool sok[SIT];
+  // weights: fragment (nt, plane) of chunk q lives at 16-byte unit ((ft0 + nt) * nchunks + q) * 3 * 64 + plane * 64 + lane
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, n_ftiles * nchunks * 3 * 1024, 0x00020000);
+  auto wissue = [&](int q, int buf) {  // NT * 3 one-KB fragments, round-robin over the 4 waves
 #pragma unroll
-  for (int it = 0; it < SIT; ++it) {
-    const int item = tid + 256 * it, stok = item % TM, sgrp = item / TM;
-    sok[it] = m0 + stok < M;
-    srow[it] = x + (size_t)(sok[it] ? m0 + stok : 0) * ldx + sgrp * 8;
-  }
-  auto fetch = [&](int q) {
-#pragma unroll
-    for (int it = 0; it < SIT; ++it) {
-      pa[it] = sok[it] ? *reinterpret_cast<const f32x4 *>(srow[it] + q * CK) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      pb[it] = sok[it] ? *reinterpret_cast<const f32x4 *>(srow[it] + q * CK + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < (NT * 3 + 3) / 4; ++i) {
+      const int f = wave + 4 * i;  // fragment index nt * 3 + plane (wave-uniform)
+      if (f < NT * 3) {
+        const int nt = f / 3, pl = f - nt * 3;
+        const int ft = min(ft0 + nt, n_ftiles - 1);  // tiles past N: any valid fragment, their results are not stored
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(wl + buf * WBUF + f * 64), 16, (unsigned)lane * 16u,
+                                                 (unsigned)(((ft * nchunks + q) * 3 + pl) * 1024), 0, 0);
+      }
     }
   };
-  auto stage = [&](int buf) {
+
+  // activations: lane (token n16 of tile mt, channel group kq) <- 32 bytes of its row per chunk
+  const float *xrow[MTW];
+  bool xok[MTW];
 #pragma unroll
-    for (int it = 0; it < SIT; ++it) {
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int tok = m0 + mt * 16 + n16;
+    xok[mt] = tok < M;
+    xrow[mt] = x + (size_t)(xok[mt] ? tok : 0) * ldx + kq * 8;
+  }
+  f32x4 ra[MTW], rb[MTW];
+  auto xfetch = [&](int q) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      ra[mt] = xok[mt] ? *reinterpret_cast<const f32x4 *>(xrow[mt] + q * CK) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      rb[mt] = xok[mt] ? *reinterpret_cast<const f32x4 *>(xrow[mt] + q * CK + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  f32x4 acc[MTW][NT];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  xfetch(0);
+  wissue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  auto chunk = [&](int q, auto curc) {
+    constexpr int cur = decltype(curc)::value;
+    // split this chunk's activations, then put the next chunk's loads in flight under the MFMAs
+    bf16x8 xh[MTW], xm[MTW], xl[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
       u32x4 h, mm, l;
-      const float v[8] = {pa[it][0], pa[it][1], pa[it][2], pa[it][3], pb[it][0], pb[it][1], pb[it][2], pb[it][3]};
+      const float v[8] = {ra[mt][0], ra[mt][1], ra[mt][2], ra[mt][3], rb[mt][0], rb[mt][1], rb[mt][2], rb[mt][3]};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned hh, hm, hl;
         split2(v[2 * i], v[2 * i + 1], hh, hm, hl);
         h[i] = hh, mm[i] = hm, l[i] = hl;
       }
-      const int item = tid + 256 * it;
-      u32x4 *b = lds + buf * BUF + (item / TM) * TM + item % TM;
-      b[0] = h, b[PLANE] = mm, b[2 * PLANE] = l;
+      xh[mt] = __builtin_bit_cast(bf16x8, h), xm[mt] = __builtin_bit_cast(bf16x8, mm), xl[mt] = __builtin_bit_cast(bf16x8, l);
     }
-  };
-
-  // weight fragments of this wave: [feature tile][chunk][plane][lane]
-  const int ftile0 = (n0 >> 4) + wave * NTW;
-  const int n_ftiles = (N + 15) >> 4;
-  u32x4 wf[2][NTW][3];
-  auto wfetch = [&](int q, int slot) {
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const int ft = min(ftile0 + nt, n_ftiles - 1);  // tiles past N: any valid fragment, their results are not stored
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wf[slot][nt][pl] = wfrag[(((size_t)ft * nchunks + q) * 3 + pl) * 64 + lane];
+    if (q + 1 < nchunks) {
+      xfetch(q + 1);
+      wissue(q + 1, cur ^ 1);  // that buffer was last read in the previous chunk, before the previous barrier
     }
-  };
-
-  f32x4 acc[MT][NTW];
+    const u32x4 *wb = wl + cur * WBUF + lane;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 0) * 64]);
+      const bf16x8 wm = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 1) * 64]);
+      const bf16x8 wlo = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 2) * 64]);
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  fetch(0);
-  wfetch(0, 0);
-  stage(0);
-  if (nchunks > 1) fetch(1);
-  lds_barrier();
-  // one chunk; `cur` (LDS buffer and weight-register slot) is a compile-time constant -- indexed with q & 1 the
-  // fragment registers become a scratch array
-  auto chunk = [&](int q, auto curc) {
-    constexpr int cur = decltype(curc)::value;
-    if (q + 1 < nchunks) wfetch(q + 1, cur ^ 1);
-    const u32x4 *tb = lds + cur * BUF + kq * TM + n16;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const bf16x8 xh = __builtin_bit_cast(bf16x8, tb[mt * 16]);
-      const bf16x8 xm = __builtin_bit_cast(bf16x8, tb[PLANE + mt * 16]);
-      const bf16x8 xl = __builtin_bit_cast(bf16x8, tb[2 * PLANE + mt * 16]);
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[cur][nt][0]);
-        const bf16x8 wm = __builtin_bit_cast(bf16x8, wf[cur][nt][1]);
-        const bf16x8 wl = __builtin_bit_cast(bf16x8, wf[cur][nt][2]);
+      for (int mt = 0; mt < MTW; ++mt) {
         f32x4 c = acc[mt][nt];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);  // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt], c, 0, 0, 0);  // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt], c, 0, 0, 0);
         acc[mt][nt] = c;
       }
     }
     if (q + 1 < nchunks) {
-      stage(cur ^ 1);  // the other buffer: last read in the previous chunk, before the previous barrier
-      if (q + 2 < nchunks) fetch(q + 2);
-      lds_barrier();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's weights are in LDS (and its activations in registers)
+      __builtin_amdgcn_s_barrier();
     }
   };
   for (int q = 0; q < nchunks; q += 2) {
@@ -165,24 +164,19 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
     if (q + 1 < nchunks) chunk(q + 1, std::integral_constant<int, 1>{});
   }
 
-  // accumulator: lane (token n16 of tile mt, feature rows 4*kq..+3 of tile nt) -> one float4 of the token's output row
   const bool vec = (N & 3) == 0;
-  f32x4 bv[NTW];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    const int f = (ftile0 + nt) * 16 + kq * 4;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int f = (ft0 + nt) * 16 + kq * 4;
+    if (f >= N) continue;
+    f32x4 bv;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bv[nt][i] = (bias && f + i < N) ? bias[f + i] : 0.f;
-  }
+    for (int i = 0; i < 4; ++i) bv[i] = (bias && f + i < N) ? bias[f + i] : 0.f;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int tok = m0 + mt * 16 + n16;
-    if (tok >= M) continue;
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const int f = (ftile0 + nt) * 16 + kq * 4;
-      if (f >= N) continue;
-      f32x4 v = acc[mt][nt] + bv[nt];
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int tok = m0 + mt * 16 + n16;
+      if (tok >= M) continue;
+      f32x4 v = acc[mt][nt] + bv;
       if (GELU) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
@@ -250,15 +244,11 @@ int drba_linear_split(const float *x, const float *packed_w, const float *bias, 
   if (K % CK) return DRBA_EUNSUPPORTED;
   if (ldx < K || (ldx & 3)) return DRBA_EINVAL;  // rows are read as 16-byte vectors
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(packed_w);
-  auto go = [&](auto cfg) {
-    using Cfg = decltype(cfg);
-    const int n_ntiles = (N + Cfg::TN - 1) / Cfg::TN, n_mtiles = (M + Cfg::TM - 1) / Cfg::TM;
-    const dim3 grid((unsigned)(n_ntiles * n_mtiles));
-    if (gelu) DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, ldx, n_ntiles);
-    else DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, ldx, n_ntiles);
-  };
-  if (N > 128) go(LinCfg<4, 4>{});  // 64 tokens x 256 features
-  else go(LinCfg<8, 2>{});          // 128 tokens x 128 features
+  using Cfg = LinCfg<1, 8>;
+  const int n_ntiles = (N + Cfg::TN - 1) / Cfg::TN, n_mtiles = (M + Cfg::TM - 1) / Cfg::TM;
+  const dim3 grid((unsigned)(n_ntiles * n_mtiles));
+  if (gelu) DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, ldx, n_ntiles);
+  else DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, ldx, n_ntiles);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
