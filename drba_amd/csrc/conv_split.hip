@@ -274,12 +274,13 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     if constexpr (MODE == 0) {
       const size_t img = (size_t)ctx.n * Cout * HW;
       auto epilogue = [&](auto post) {
-  #pragma unroll
-        for (int rw = 0; rw < RW; ++rw)
-  #pragma unroll
-          for (int mw = 0; mw < MW; ++mw)
-  #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+        // column tiles innermost: the 64-byte halves of a 128-byte row segment are stored back to back (merged in L2)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+            for (int mw = 0; mw < MW; ++mw) {
               f32x4 v = acc[0][rw][mw][nt];
               const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
               const int y = ctx.y0 + row0 + rw;
@@ -290,7 +291,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
                 f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (res) r = *reinterpret_cast<const f32x4 *>(res + idx);
                 if (res2) r2 = *reinterpret_cast<const f32x4 *>(res2 + idx);
-  #pragma unroll
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
                   float u = v[k] + bs[nt];
                   if (beta) u = u * bt[nt] + r[k];
@@ -302,7 +303,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
                 }
                 *reinterpret_cast<f32x4 *>(out + idx) = v;
               } else {
-  #pragma unroll
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
                   if (xb + k >= W) continue;
                   float u = v[k] + bs[nt];
