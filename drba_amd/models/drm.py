@@ -4,6 +4,8 @@ calc_drm_rife with linear=True (the only form the driver uses, infer.py:143) run
 fused kernels per direction (distance + ratio + scale + splat scatter, then normalise +
 hole fill).  The remaining variants compose the generic HIP operators.
 """
+import torch
+
 from drba_amd import ops as _ops
 from drba_amd.models.softsplat.softsplat import softsplat as warp
 
@@ -21,9 +23,11 @@ def _unaligned(flow10, flow12, t, linear, eps):
 
 
 def _aligned(value, flow, metric, mode, ones):
-    out = warp(value, flow, metric, mode)
-    cover = warp(ones, flow, metric, mode)
-    return _ops.fill_holes(out, cover, value)
+    """warp(value) and warp(ones) along the same (flow, metric): softsplat treats channels independently (same weights,
+    same normaliser, same accumulation order), so both maps are splatted as one 2-channel tensor -- one sort and one
+    gather instead of two, bit-identical to the reference's two calls (drm.py:96-104, :184-192)."""
+    both = warp(torch.cat((value, ones), 1), flow, metric, mode)
+    return _ops.fill_holes(both[:, 0:1].contiguous(), both[:, 1:2].contiguous(), value)
 
 
 def calc_drm_rife(t, flow10, flow12, linear=False):
