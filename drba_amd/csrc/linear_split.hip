@@ -15,7 +15,8 @@
 //   matters more here than blocking: 64 tokens per wave (372 registers) 88 TFLOP/s, 32 per wave 132, 16 per wave 146
 //   on the 1024 -> 128 layer (fp32-equivalent; rocBLAS fp32: 110).  An earlier form that shared the split activations
 //   through LDS and kept the weights in registers reached 116.
-//   Epilogue: + bias, optional exact GELU (erf form, as nn.GELU()).
+//   Epilogue: + bias, then optionally the exact GELU (erf form, as nn.GELU()) or -- for the 128-feature layers, where
+//   a wave holds whole output rows -- LayerNorm(128) with its affine and the residual add.
 #include "common.hpp"
 
 #include <string.h>
@@ -57,10 +58,13 @@ struct LinCfg {
   static constexpr int WBUF = NT * 3 * 64;  // 16-byte units of weight fragments per chunk
 };
 
-template <class Cfg, bool GELU>
+// EPI 0: + bias.  EPI 1: + bias, GELU.  EPI 2 (N == the workgroup's 128 features): + bias, LayerNorm over the row
+// (nn.LayerNorm(128): biased variance, eps) * ln_w + ln_b, + residual row -- transformer.py:178-185, :203-207.
+template <class Cfg, int EPI>
 __global__ void __launch_bounds__(256)
 linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
-                     float *__restrict__ out, int M, int K, int N, int ldx, int n_ntiles) {
+                     float *__restrict__ out, int M, int K, int N, int ldx, int n_ntiles, const float *__restrict__ ln_w,
+                     const float *__restrict__ ln_b, const float *__restrict__ residual, float eps) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MTW = Cfg::MTW, NT = Cfg::NT, TM = Cfg::TM, WBUF = Cfg::WBUF;
   __shared__ __attribute__((aligned(16))) u32x4 wl[2 * WBUF];
@@ -164,6 +168,49 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
     if (q + 1 < nchunks) chunk(q + 1, std::integral_constant<int, 1>{});
   }
 
+  if constexpr (EPI == 2) {
+    // a lane holds 32 of its token's 128 outputs (features 16*nt + 4*kq + i); the other 96 sit in the lanes with the
+    // same token and the other three kq -> two xor-shuffles complete a row sum
+    auto row_sum = [](float v) {
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      return v;
+    };
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int tok = m0 + mt * 16 + n16;
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int f = nt * 16 + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (bias) acc[mt][nt][i] += bias[f + i];
+          sum += acc[mt][nt][i];
+        }
+      }
+      const float mean = row_sum(sum) * (1.f / 128.f);
+      float var = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d = acc[mt][nt][i] - mean;
+          var += d * d;
+        }
+      const float inv = 1.f / sqrtf(row_sum(var) * (1.f / 128.f) + eps);
+      if (tok >= M) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int f = nt * 16 + kq * 4;
+        const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + f), gb = *reinterpret_cast<const f32x4 *>(ln_b + f);
+        f32x4 v = (acc[mt][nt] - mean) * inv * gw + gb;
+        if (residual) v = *reinterpret_cast<const f32x4 *>(residual + (size_t)tok * 128 + f) + v;
+        *reinterpret_cast<f32x4 *>(out + (size_t)tok * 128 + f) = v;
+      }
+    }
+    return;
+  }
   const bool vec = (N & 3) == 0;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -177,7 +224,7 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
       const int tok = m0 + mt * 16 + n16;
       if (tok >= M) continue;
       f32x4 v = acc[mt][nt] + bv;
-      if (GELU) {
+      if (EPI == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
       }
@@ -237,8 +284,8 @@ int drba_linear_split_pack(const float *w, float *packed, int K, int N) {
   return DRBA_OK;
 }
 
-int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
-                      int gelu, void *stream) {
+static int linear_launch(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
+                         int epi, const float *ln_w, const float *ln_b, const float *residual, float eps, void *stream) {
   using namespace drba_linear;
   if (!x || !packed_w || !out || M <= 0 || K <= 0 || N <= 0) return DRBA_EINVAL;
   if (K % CK) return DRBA_EUNSUPPORTED;
@@ -247,10 +294,27 @@ int drba_linear_split(const float *x, const float *packed_w, const float *bias, 
   using Cfg = LinCfg<1, 8>;
   const int n_ntiles = (N + Cfg::TN - 1) / Cfg::TN, n_mtiles = (M + Cfg::TM - 1) / Cfg::TM;
   const dim3 grid((unsigned)(n_ntiles * n_mtiles));
-  if (gelu) DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, ldx, n_ntiles);
-  else DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, ldx, n_ntiles);
+#define DRBA_LIN(E)                                                                                                      \
+  DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
+                    ldx, n_ntiles, ln_w, ln_b, residual, eps)
+  if (epi == 2) DRBA_LIN(2);
+  else if (epi == 1) DRBA_LIN(1);
+  else DRBA_LIN(0);
+#undef DRBA_LIN
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
+}
+
+int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
+                      int gelu, void *stream) {
+  return linear_launch(x, packed_w, bias, out, M, K, N, ldx, gelu ? 1 : 0, nullptr, nullptr, nullptr, 0.f, stream);
+}
+
+int drba_linear_split_layernorm(const float *x, const float *packed_w, const float *bias, const float *ln_w,
+                                const float *ln_b, const float *residual, float *out, int M, int K, int ldx, float eps,
+                                void *stream) {
+  if (!ln_w || !ln_b || !(eps > 0.f)) return DRBA_EINVAL;
+  return linear_launch(x, packed_w, bias, out, M, K, 128, ldx, 2, ln_w, ln_b, residual, eps, stream);
 }
 
 }  // extern "C"

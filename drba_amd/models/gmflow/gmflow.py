@@ -185,13 +185,18 @@ class GMFlow:
             k, v = kv[..., :C], kv[..., C:]
         else:
             q, k, v = _linear(source, d["q_proj"]), _linear(target, d["k_proj"]), _linear(target, d["v_proj"])
-        msg = _linear(self._attention(q, k, v, h, w, splits, shift), d["merge"])
+        att = self._attention(q, k, v, h, w, splits, shift)
+        fused_ln = isinstance(d["merge"], _ops.LinearSplit)  # LayerNorm (+ residual) in the GEMM's epilogue
         if not ffn:
-            return _ops.layernorm(msg, d["n1w"], d["n1b"], residual=source)
-        msg = _ops.layernorm(msg, d["n1w"], d["n1b"])
+            if fused_ln:
+                return d["merge"].layernorm(att, d["n1w"], d["n1b"], residual=source)
+            return _ops.layernorm(_linear(att, d["merge"]), d["n1w"], d["n1b"], residual=source)
+        msg = d["merge"].layernorm(att, d["n1w"], d["n1b"]) if fused_ln else _ops.layernorm(_linear(att, d["merge"]), d["n1w"], d["n1b"])
         hid = _linear(torch.cat([source, msg], dim=-1), d["mlp0"])
         if not isinstance(d["mlp0"], _ops.LinearSplit):  # (the split kernel applies GELU in its epilogue)
             hid = _ops.gelu(hid)
+        if isinstance(d["mlp2"], _ops.LinearSplit):
+            return d["mlp2"].layernorm(hid, d["n2w"], d["n2b"], residual=source)
         return _ops.layernorm(_linear(hid, d["mlp2"]), d["n2w"], d["n2b"], residual=source)
 
     def transformer(self, f0, f1, splits):

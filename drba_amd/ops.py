@@ -655,17 +655,32 @@ class LinearSplit:
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
         self.gelu = 1 if gelu else 0
 
-    def __call__(self, x):
+    def _rows(self, x):
         assert x.shape[-1] == self.k
-        lead = x.shape[:-1]
         x2 = x.reshape(-1, self.k)  # a view for contiguous inputs and for row-strided column slices
         if x2.dtype != torch.float32 or x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16 or not x2.is_cuda:
             x2 = _f32(x2)
+        return x2
+
+    def __call__(self, x):
+        lead, x2 = x.shape[:-1], self._rows(x)
         m = x2.shape[0]
         out = torch.empty((m, self.n), dtype=torch.float32, device=x2.device)
         _lib.check(_lib.load().drba_linear_split(_p(x2), _p(self.packed), _p(self.bias), _p(out), m, self.k, self.n,
                                                  x2.stride(0), self.gelu, _stream()), "drba_linear_split")
         return out.view(*lead, self.n)
+
+    def layernorm(self, x, ln_w, ln_b, residual=None, eps=1e-5):
+        """residual + LayerNorm(self(x)) * ln_w + ln_b in the GEMM's epilogue (128 output features only)."""
+        assert self.n == 128 and not self.gelu
+        lead, x2 = x.shape[:-1], self._rows(x)
+        m = x2.shape[0]
+        res = None if residual is None else _f32(residual)
+        out = torch.empty((m, 128), dtype=torch.float32, device=x2.device)
+        _lib.check(_lib.load().drba_linear_split_layernorm(_p(x2), _p(self.packed), _p(self.bias), _p(_f32(ln_w)), _p(_f32(ln_b)),
+                                                           _p(res), _p(out), m, self.k, x2.stride(0), float(eps), _stream()),
+                   "drba_linear_split_layernorm")
+        return out.view(*lead, 128)
 
 
 def window_attention(q, k, v, h, w, splits, shift, scale):

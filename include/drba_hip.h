@@ -214,6 +214,11 @@ size_t drba_linear_split_packed_floats(int K, int N);
 int drba_linear_split_pack(const float *w /*[N,K] host*/, float *packed, int K, int N);
 int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
                       int gelu, void *stream);
+/* the same for N = 128 with the layer's norm fused (transformer.py:178-185, :203-207):
+ * out[M,128] = (residual ? residual : 0) + LayerNorm_128(x . w^T + bias) * ln_w + ln_b */
+int drba_linear_split_layernorm(const float *x, const float *packed_w, const float *bias, const float *ln_w,
+                                const float *ln_b, const float *residual, float *out, int M, int K, int ldx, float eps,
+                                void *stream);
 /* in-place row softmax of x/scale + mask[(row/rows_per_mat) % n_masks][row % rows_per_mat] (transformer.py:91-96) */
 int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks,
                       float scale, void *stream);

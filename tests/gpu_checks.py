@@ -465,4 +465,19 @@ def check_linear_split(dev):
         scale = float(ref.abs().max())
         rows.append((f"linear_split [{m}x{k}] -> {n} gelu={int(gelu)} bias={int(bias)} sliced={int(sliced)}",
                      _diff(got.reshape(m, n), ref.float()), 5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+    # LayerNorm(128) (+ residual) in the epilogue, against fp64
+    for (m, k, bias, with_res) in ((1000, 128, False, True), (4111, 1024, True, False), (69120, 128, False, True)):
+        x = torch.randn(m, k, generator=g) * 2.0
+        w = torch.randn(128, k, generator=g) / k ** 0.5
+        b = torch.randn(128, generator=g) * 0.1 if bias else None
+        lw, lb = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+        res = torch.randn(m, 128, generator=g) if with_res else None
+        y = F.linear(x.double(), w.double(), None if b is None else b.double())
+        ref = F.layer_norm(y, (128,), lw.double(), lb.double(), 1e-5)
+        if with_res:
+            ref = res.double() + ref
+        got = ops.LinearSplit(w, b, device=dev).layernorm(x.to(dev), lw.to(dev), lb.to(dev), None if res is None else res.to(dev))
+        scale = float(ref.abs().max())
+        rows.append((f"linear_split + LayerNorm [{m}x{k}] bias={int(bias)} residual={int(with_res)}", _diff(got, ref.float()),
+                     1e-5 * max(1.0, scale), f"|ref|max={scale:.2f}"))
     return rows
