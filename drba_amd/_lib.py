@@ -75,6 +75,7 @@ SIGNATURES = {
     "drba_linear_split_packed_floats": (_z, [_i, _i]),
     "drba_linear_split_pack": (_i, [_p, _p, _i, _i]),
     "drba_linear_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "drba_linear_split_cat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "drba_linear_split_layernorm": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "drba_softmax_rows": (_i, [_p, _p, _z, _i, _i, _i, _f, _p]),
     "drba_softmax_expect2": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),

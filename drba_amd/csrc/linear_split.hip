@@ -64,7 +64,8 @@ template <class Cfg, int EPI>
 __global__ void __launch_bounds__(256)
 linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                      float *__restrict__ out, int M, int K, int N, int ldx, int n_ntiles, const float *__restrict__ ln_w,
-                     const float *__restrict__ ln_b, const float *__restrict__ residual, float eps) {
+                     const float *__restrict__ ln_b, const float *__restrict__ residual, float eps,
+                     const float *__restrict__ x2, int ldx2, int q_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MTW = Cfg::MTW, NT = Cfg::NT, TM = Cfg::TM, WBUF = Cfg::WBUF;
   __shared__ __attribute__((aligned(16))) u32x4 wl[2 * WBUF];
@@ -93,20 +94,23 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
   };
 
   // activations: lane (token n16 of tile mt, channel group kq) <- 32 bytes of its row per chunk
-  const float *xrow[MTW];
+  // chunks [0, q_split) come from x, the rest from x2 (the MLP's input cat(source, message) without the copy)
+  const float *xrow[MTW], *xrow2[MTW];
   bool xok[MTW];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
     const int tok = m0 + mt * 16 + n16;
     xok[mt] = tok < M;
     xrow[mt] = x + (size_t)(xok[mt] ? tok : 0) * ldx + kq * 8;
+    xrow2[mt] = x2 ? x2 + (size_t)(xok[mt] ? tok : 0) * ldx2 + kq * 8 - (size_t)q_split * CK : xrow[mt];
   }
   f32x4 ra[MTW], rb[MTW];
   auto xfetch = [&](int q) {
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-      ra[mt] = xok[mt] ? *reinterpret_cast<const f32x4 *>(xrow[mt] + q * CK) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      rb[mt] = xok[mt] ? *reinterpret_cast<const f32x4 *>(xrow[mt] + q * CK + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float *src = (q < q_split ? xrow[mt] : xrow2[mt]) + q * CK;
+      ra[mt] = xok[mt] ? *reinterpret_cast<const f32x4 *>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      rb[mt] = xok[mt] ? *reinterpret_cast<const f32x4 *>(src + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
 
@@ -285,18 +289,21 @@ int drba_linear_split_pack(const float *w, float *packed, int K, int N) {
 }
 
 static int linear_launch(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
-                         int epi, const float *ln_w, const float *ln_b, const float *residual, float eps, void *stream) {
+                         int epi, const float *ln_w, const float *ln_b, const float *residual, float eps, void *stream,
+                         const float *x2 = nullptr, int ldx2 = 0, int K1 = 0) {
   using namespace drba_linear;
   if (!x || !packed_w || !out || M <= 0 || K <= 0 || N <= 0) return DRBA_EINVAL;
   if (K % CK) return DRBA_EUNSUPPORTED;
-  if (ldx < K || (ldx & 3)) return DRBA_EINVAL;  // rows are read as 16-byte vectors
+  if ((ldx & 3) || ldx < (x2 ? K1 : K)) return DRBA_EINVAL;  // rows are read as 16-byte vectors
+  if (x2 && (K1 <= 0 || K1 >= K || K1 % CK || (ldx2 & 3) || ldx2 < K - K1)) return DRBA_EINVAL;
+  const int q_split = x2 ? K1 / CK : K / CK;
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(packed_w);
   using Cfg = LinCfg<1, 8>;
   const int n_ntiles = (N + Cfg::TN - 1) / Cfg::TN, n_mtiles = (M + Cfg::TM - 1) / Cfg::TM;
   const dim3 grid((unsigned)(n_ntiles * n_mtiles));
 #define DRBA_LIN(E)                                                                                                      \
   DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
-                    ldx, n_ntiles, ln_w, ln_b, residual, eps)
+                    ldx, n_ntiles, ln_w, ln_b, residual, eps, x2, ldx2, q_split)
   if (epi == 2) DRBA_LIN(2);
   else if (epi == 1) DRBA_LIN(1);
   else DRBA_LIN(0);
@@ -308,6 +315,13 @@ static int linear_launch(const float *x, const float *packed_w, const float *bia
 int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
                       int gelu, void *stream) {
   return linear_launch(x, packed_w, bias, out, M, K, N, ldx, gelu ? 1 : 0, nullptr, nullptr, nullptr, 0.f, stream);
+}
+
+int drba_linear_split_cat(const float *x1, const float *x2, const float *packed_w, const float *bias, float *out, int M,
+                          int K1, int K2, int N, int ldx1, int ldx2, int gelu, void *stream) {
+  if (!x2) return DRBA_EINVAL;
+  return linear_launch(x1, packed_w, bias, out, M, K1 + K2, N, ldx1, gelu ? 1 : 0, nullptr, nullptr, nullptr, 0.f, stream, x2,
+                       ldx2, K1);
 }
 
 int drba_linear_split_layernorm(const float *x, const float *packed_w, const float *bias, const float *ln_w,

@@ -192,9 +192,10 @@ class GMFlow:
                 return d["merge"].layernorm(att, d["n1w"], d["n1b"], residual=source)
             return _ops.layernorm(_linear(att, d["merge"]), d["n1w"], d["n1b"], residual=source)
         msg = d["merge"].layernorm(att, d["n1w"], d["n1b"]) if fused_ln else _ops.layernorm(_linear(att, d["merge"]), d["n1w"], d["n1b"])
-        hid = _linear(torch.cat([source, msg], dim=-1), d["mlp0"])
-        if not isinstance(d["mlp0"], _ops.LinearSplit):  # (the split kernel applies GELU in its epilogue)
-            hid = _ops.gelu(hid)
+        if isinstance(d["mlp0"], _ops.LinearSplit):  # reads cat(source, msg) in place; GELU in the epilogue
+            hid = d["mlp0"].cat(source, msg)
+        else:
+            hid = _ops.gelu(_linear(torch.cat([source, msg], dim=-1), d["mlp0"]))
         if isinstance(d["mlp2"], _ops.LinearSplit):
             return d["mlp2"].layernorm(hid, d["n2w"], d["n2b"], residual=source)
         return _ops.layernorm(_linear(hid, d["mlp2"]), d["n2w"], d["n2b"], residual=source)

@@ -670,6 +670,23 @@ class LinearSplit:
                                                  x2.stride(0), self.gelu, _stream()), "drba_linear_split")
         return out.view(*lead, self.n)
 
+    def cat(self, x1, x2):
+        """self(torch.cat((x1, x2), -1)) without the concatenation: the kernel reads the first K1 features of a row from
+        x1 and the rest from x2."""
+        k1, k2 = x1.shape[-1], x2.shape[-1]
+        assert k1 + k2 == self.k and x1.shape[:-1] == x2.shape[:-1]
+        lead = x1.shape[:-1]
+        self.k, keep = k1, self.k
+        a = self._rows(x1)
+        self.k = k2
+        b = self._rows(x2)
+        self.k = keep
+        m = a.shape[0]
+        out = torch.empty((m, self.n), dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().drba_linear_split_cat(_p(a), _p(b), _p(self.packed), _p(self.bias), _p(out), m, k1, k2, self.n,
+                                                     a.stride(0), b.stride(0), self.gelu, _stream()), "drba_linear_split_cat")
+        return out.view(*lead, self.n)
+
     def layernorm(self, x, ln_w, ln_b, residual=None, eps=1e-5):
         """residual + LayerNorm(self(x)) * ln_w + ln_b in the GEMM's epilogue (128 output features only)."""
         assert self.n == 128 and not self.gelu

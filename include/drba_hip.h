@@ -214,6 +214,10 @@ size_t drba_linear_split_packed_floats(int K, int N);
 int drba_linear_split_pack(const float *w /*[N,K] host*/, float *packed, int K, int N);
 int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
                       int gelu, void *stream);
+/* the same on cat(x1, x2) along the features without materialising it (transformer.py:201: mlp(cat(source, message))):
+ * x1 [M, K1], x2 [M, K2], w [N, K1 + K2]; K1, K2 multiples of 32 */
+int drba_linear_split_cat(const float *x1, const float *x2, const float *packed_w, const float *bias, float *out, int M,
+                          int K1, int K2, int N, int ldx1, int ldx2, int gelu, void *stream);
 /* the same for N = 128 with the layer's norm fused (transformer.py:178-185, :203-207):
  * out[M,128] = (residual ? residual : 0) + LayerNorm_128(x . w^T + bias) * ln_w + ln_b */
 int drba_linear_split_layernorm(const float *x, const float *packed_w, const float *bias, const float *ln_w,

@@ -465,6 +465,12 @@ def check_linear_split(dev):
         scale = float(ref.abs().max())
         rows.append((f"linear_split [{m}x{k}] -> {n} gelu={int(gelu)} bias={int(bias)} sliced={int(sliced)}",
                      _diff(got.reshape(m, n), ref.float()), 5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+    # cat(x1, x2) read in place
+    x1, x2 = torch.randn(1234, 128, generator=g), torch.randn(1234, 128, generator=g)
+    w = torch.randn(1024, 256, generator=g) / 16.0
+    ref = F.gelu(F.linear(torch.cat((x1, x2), -1).double(), w.double()))
+    got = ops.LinearSplit(w, None, gelu=True, device=dev).cat(x1.to(dev), x2.to(dev))
+    rows.append(("linear_split on cat(x1, x2) without the copy, GELU", _diff(got, ref.float()), 5e-6 * max(1.0, float(ref.abs().max())), ""))
     # LayerNorm(128) (+ residual) in the epilogue, against fp64
     for (m, k, bias, with_res) in ((1000, 128, False, True), (4111, 1024, True, False), (69120, 128, False, True)):
         x = torch.randn(m, k, generator=g) * 2.0
