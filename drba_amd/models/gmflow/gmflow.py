@@ -277,21 +277,31 @@ class GMFlow:
                 flow = self._match(f0, f1, None, corr_r, prop_r)
         return self._upsample(flow, f0)
 
-    def bidirectional(self, img0, img1, attn_splits_list=(2, 8), corr_radius_list=(-1, 4), prop_radius_list=(-1, 1)):
+    def encode_frame(self, img):
+        """CNN encoder outputs [1/8-res, 1/4-res] of ONE frame (normalisation included).  InstanceNorm keeps the samples
+        of a batch independent (backbone.py), so a frame's features do not depend on its partner: Model.reuse caches them
+        per frame instead of re-encoding the frame for both pairs it belongs to."""
+        return self.encoder(_ops.channel_normalize3(img.contiguous(), _MEAN, _STD))[::-1]
+
+    def bidirectional(self, img0, img1, attn_splits_list=(2, 8), corr_radius_list=(-1, 4), prop_radius_list=(-1, 1),
+                      feats=None):
         """(self(img0, img1), self(img1, img0)) -- what Model.reuse needs (GMFSS.py:64-65) -- sharing what the two calls
         have in common: the CNN encoder of both frames and the coarsest transformer pass.  The transformer treats its
         two inputs symmetrically (transformer.py:236-302: both orders are concatenated along the batch), so the swapped
         call computes the same two feature maps in the other order; only from the first flow-dependent warp on do the
         directions differ.  Same values as two separate calls, about a third less work."""
         assert len(attn_splits_list) == 2, "two scales (the DRBA configuration)"
-        x = _ops.channel_normalize3(torch.cat((img0, img1), 0).contiguous(), _MEAN, _STD)
-        feats = self.encoder(x)[::-1]
-        c0, c1 = feats[0][0:1].contiguous(), feats[0][1:2].contiguous()
+        if feats is None:
+            x = _ops.channel_normalize3(torch.cat((img0, img1), 0).contiguous(), _MEAN, _STD)
+            both = self.encoder(x)[::-1]
+            c0, c1 = both[0][0:1].contiguous(), both[0][1:2].contiguous()
+            h0, h1 = both[1][0:1].contiguous(), both[1][1:2].contiguous()
+        else:  # (encode_frame(img0), encode_frame(img1))
+            (c0, h0), (c1, h1) = feats
         t0, t1 = self._add_position(c0, c1, attn_splits_list[0])
         t0, t1 = self.transformer(t0, t1, attn_splits_list[0])
         flow_a = self._match(t0, t1, None, corr_radius_list[0], prop_radius_list[0])
         flow_b = self._match(t1, t0, None, corr_radius_list[0], prop_radius_list[0])
-        h0, h1 = feats[1][0:1].contiguous(), feats[1][1:2].contiguous()
         flow_a, fa = self._refine(h0, h1, flow_a, attn_splits_list[1], corr_radius_list[1], prop_radius_list[1])
         flow_b, fb = self._refine(h1, h0, flow_b, attn_splits_list[1], corr_radius_list[1], prop_radius_list[1])
         return self._upsample(flow_a, fa), self._upsample(flow_b, fb)

@@ -58,14 +58,26 @@ class Model:
                 img._drba_feat = f
         return f
 
+    def _encoded(self, frame, flow_input, scale):
+        """GMFlow's CNN encoding of `flow_input` (the frame at flow resolution), cached on the frame tensor per scale."""
+        c = getattr(frame, "_drba_gmf", None)
+        if c is None or c[0] != scale:
+            c = (scale, self.flownet.encode_frame(flow_input))
+            if frame.is_cuda:
+                frame._drba_gmf = c
+        return c[1]
+
     def reuse(self, img0, img1, scale):
         feat0, feat1 = self._features(img0), self._features(img1)
+        f0_src, f1_src = img0, img1
         img0, img1 = _half(img0), _half(img1)
         if scale != 1.0:
             if0, if1 = _half(img0, scale), _half(img1, scale)
         else:
             if0, if1 = img0, img1
-        flow01, flow10 = self.flownet.bidirectional(if0, if1)  # == (flownet(if0, if1), flownet(if1, if0))
+        # == (flownet(if0, if1), flownet(if1, if0)); each frame's CNN encoding is kept on the frame tensor, like its
+        # FeatureNet pyramid: a frame is the second of one pair and the first of the next
+        flow01, flow10 = self.flownet.bidirectional(if0, if1, feats=(self._encoded(f0_src, if0, scale), self._encoded(f1_src, if1, scale)))
         if scale != 1.0:
             _, _, h, w = img0.shape
             up = lambda f: _ops.affine(_ops.resize_bilinear_scale(f, (h, w), scale), 1.0 / scale, 0.0)  # noqa: E731
