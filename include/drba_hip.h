@@ -32,8 +32,8 @@ const char *drba_error_string(int code);
 
 /* ---- per-launch kernel timing (measurement only; bench.py's roofline object) ---------------
  * drba_timing_arm(slot) attaches event pair `slot` to the dispatch packet of the NEXT drba_conv3x3 /
- * drba_deconv4x4s2 / drba_ifblock_input launch on this thread; drba_timing_elapsed_ms waits for
- * that launch and returns the kernel's own execution time. */
+ * drba_deconv4x4s2 / drba_ifblock_input / drba_window_attention / drba_linear_split* launch on this thread;
+ * drba_timing_elapsed_ms waits for that launch and returns the kernel's own execution time. */
 int drba_timing_slots(void);
 int drba_timing_arm(int slot);
 int drba_timing_elapsed_ms(int slot, float *ms);
