@@ -22,8 +22,11 @@
 // Measured (tools/attn_bench.py, MI355X): fine scale 230 us (83 TFLOP/s fp32) against 560-780 us for BLAS QK^T +
 // softmax kernel + BLAS PV + the roll / split copies; coarse scale (8 windows x 2160 tokens) 348 us against 335-440 us.
 // In-kernel cycle counters put QK^T at 34 cycles per MFMA (32 is the issue rate) and PV at 43; the coarse launch is
-// limited by its shape -- 272 workgroups on 256 CUs, so 16 CUs carry two -- not by the inner loops.  Splitting each
+// limited by its shape -- 272 workgroups on 256 CUs, so 16 CUs carry two -- not by the inner loops: such launches split
+// each window's keys into 4 runs (separate workgroups, merged by window_attention_merge): 260 us.  Splitting each
 // chunk's keys over two waves (8-wave workgroups) was tried to raise the waves per SIMD there and was slower (365 us).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 using namespace drba;
@@ -70,7 +73,8 @@ __device__ __forceinline__ unsigned token_row(const Geometry &g, const Window &w
 
 __global__ void __launch_bounds__(256)
 window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-                        float *__restrict__ out, Geometry g, int nwin, int qtiles, float scale, int ldq, int ldk, int ldv) {
+                        float *__restrict__ out, Geometry g, int nwin, int qtiles, float scale, int ldq, int ldk, int ldv, int ksplit,
+                        float *__restrict__ part) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) float lds[];  // kLdsBytes: keys, values, key regions
   float *Ks = lds, *Vs = lds + kKeys * kStride;
@@ -81,7 +85,13 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
   // all query tiles of a window on one XCD (workgroups are dealt round-robin over the 8 XCDs): the window's k / v
   // are then fetched into one L2 instead of eight
   const int lin = blockIdx.x;
-  const int xcd = lin & 7, slot = lin >> 3;
+  const int xcd = lin & 7;
+  int slot = lin >> 3;
+  // key split (launches with fewer than two workgroups per CU, e.g. GMFlow's coarse scale: 8 windows x 34 query tiles):
+  // workgroup (window, query tile, ks) walks one contiguous run of the window's key chunks and leaves
+  // its running (max, sum, unnormalised O) in `part`; window_attention_merge combines the runs
+  const int ks = slot % ksplit;
+  slot /= ksplit;
   const int win = (slot / qtiles) * 8 + xcd, qt = slot - (slot / qtiles) * qtiles;
   if (win >= nwin) return;
   const Window wd = window_of(g, win);
@@ -133,10 +143,11 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
   for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int chunks = (g.L + kKeys - 1) / kKeys;
+  const int all_chunks = (g.L + kKeys - 1) / kKeys, per = (all_chunks + ksplit - 1) / ksplit;
+  const int ch0 = ks * per, chunks = min(all_chunks, ch0 + per);  // this workgroup's chunks: [ch0, chunks)
   const float inv_scale = 1.f / scale;
-  fetch(0);
-  for (int ch = 0; ch < chunks; ++ch) {
+  if (ch0 < chunks) fetch(ch0);
+  for (int ch = ch0; ch < chunks; ++ch) {
     __syncthreads();  // every wave is done reading the previous chunk
     stage(ch);
     __syncthreads();
@@ -222,6 +233,22 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
     }
   }
 
+  if (ksplit > 1) {
+    // partial state of query row (window, token) for key run ks: [m, l, pad, pad, O[128]] (132 floats)
+    if (qlive) {
+      float *prow = part + (((size_t)win * g.L + qtok) * ksplit + ks) * 132;
+      if (grp == 0) {
+        prow[0] = m_run;
+        prow[1] = l_run;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4 *>(prow + 4 + 16 * grp + 4 * i) = f32x4{o[0][i], o[1][i], o[2][i], o[3][i]};
+        *reinterpret_cast<f32x4 *>(prow + 4 + 64 + 16 * grp + 4 * i) = f32x4{o[4][i], o[5][i], o[6][i], o[7][i]};
+      }
+    }
+    return;
+  }
   if (qlive) {
     const float inv = 1.f / l_run;
     float *orow = out + qrow * kC + 16 * grp;
@@ -234,10 +261,54 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
 #endif
 }
 
+// out row = sum_ks exp(m_ks - m) O_ks / sum_ks exp(m_ks - m) l_ks, m = max_ks m_ks; one wave per query row, 2 channels per lane
+__global__ void __launch_bounds__(256)
+window_attention_merge(const float *__restrict__ part, float *__restrict__ out, Geometry g, int nwin, int ksplit) {
+  const int lane = threadIdx.x & 63;
+  const size_t rowi = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rowi >= (size_t)nwin * g.L) return;
+  const int win = (int)(rowi / g.L), tok = (int)(rowi - (size_t)win * g.L);
+  const float *p = part + rowi * ksplit * 132;
+  float m = -INFINITY;
+  for (int s = 0; s < ksplit; ++s) m = fmaxf(m, p[s * 132]);
+  float l = 0.f, a = 0.f, b = 0.f;
+  for (int s = 0; s < ksplit; ++s) {
+    const float ms = p[s * 132];
+    const float w = ms == -INFINITY ? 0.f : __expf(ms - m);  // a run without keys (short windows) has m = -inf, l = 0
+    l += w * p[s * 132 + 1];
+    a += w * p[s * 132 + 4 + 2 * lane];
+    b += w * p[s * 132 + 4 + 2 * lane + 1];
+  }
+  int region;
+  const Window wd = window_of(g, win);
+  const size_t orow = token_row(g, wd, tok, region);
+  const float inv = 1.f / l;
+  out[orow * kC + 2 * lane] = a * inv;
+  out[orow * kC + 2 * lane + 1] = b * inv;
+}
+
 }  // namespace drba_attn
 
+// floats of workspace drba_window_attention needs for this shape (0: none)
+static int attn_ksplit(int nwin, int L) {
+  const int qtiles = (L + drba_attn::kRows - 1) / drba_attn::kRows, chunks = (L + drba_attn::kKeys - 1) / drba_attn::kKeys;
+  const long long wgs = (long long)((nwin + 7) / 8) * 8 * qtiles;
+  if (wgs >= 2 * 256 || chunks < 8) return 1;  // two workgroups per CU already, or too few chunks to share out
+  static const int force = getenv("DRBA_ATTN_KSPLIT") ? atoi(getenv("DRBA_ATTN_KSPLIT")) : 0;
+  if (force > 0) return force;
+  return chunks >= 16 ? 4 : 2;  // measured on 8 windows x 2160 tokens: 349 us unsplit, 287 us in two runs, 260 us in four
+}
+
+extern "C" size_t drba_window_attention_ws_floats(int B, int H, int W, int splits) {
+  if (B <= 0 || H <= 0 || W <= 0 || splits <= 0 || H % splits || W % splits) return 0;
+  const int nwin = B * splits * splits, L = (H / splits) * (W / splits);
+  const int ks = attn_ksplit(nwin, L);
+  return ks > 1 ? (size_t)nwin * L * ks * 132 : 0;
+}
+
 extern "C" int drba_window_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int W, int C,
-                                     int splits, int shift, float scale, int ldq, int ldk, int ldv, void *stream) {
+                                     int splits, int shift, float scale, int ldq, int ldk, int ldv, float *ws,
+                                     void *stream) {
   if (!q || !k || !v || !out || B <= 0 || H <= 0 || W <= 0 || splits <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
   if (C != drba_attn::kC) return DRBA_EUNSUPPORTED;  // GMFlow's feature_channels
   if (ldq < C || ldk < C || ldv < C || ((ldq | ldk | ldv) & 3)) return DRBA_EINVAL;  // rows are read as 16-byte vectors
@@ -253,13 +324,17 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
   const int nwin = B * splits * splits;
   const int qtiles = (g.L + drba_attn::kRows - 1) / drba_attn::kRows;
   const int groups = (nwin + 7) / 8;
-  const dim3 grid((unsigned)(groups * 8 * qtiles));
+  const int ksplit = ws ? attn_ksplit(nwin, g.L) : 1;  // without a workspace every workgroup walks all keys
+  const dim3 grid((unsigned)(groups * 8 * qtiles * ksplit));
   static const hipError_t lds_ok =  // beyond the default 64 KB dynamic-LDS limit
       hipFuncSetAttribute(reinterpret_cast<const void *>(drba_attn::window_attention_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, drba_attn::kLdsBytes);
   if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
   DRBA_LAUNCH_TIMED(drba_attn::window_attention_kernel, grid, dim3(kBlock), drba_attn::kLdsBytes, (hipStream_t)stream, q, k, v,
-                    out, g, nwin, qtiles, scale, ldq, ldk, ldv);
+                    out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws);
+  if (ksplit > 1)
+    hipLaunchKernelGGL(drba_attn::window_attention_merge, dim3((unsigned)(((size_t)nwin * g.L + 3) / 4)), dim3(kBlock), 0,
+                       (hipStream_t)stream, ws, out, g, nwin, ksplit);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -715,8 +715,11 @@ def window_attention(q, k, v, h, w, splits, shift, scale):
 
     (q, ldq), (k, ldk), (v, ldv) = rows(q), rows(k), rows(v)
     out = torch.empty((b, n, c), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.load().drba_window_attention(_p(q), _p(k), _p(v), _p(out), b, h, w, c, int(splits), int(bool(shift)),
-                                                 float(scale), ldq, ldk, ldv, _stream()), "drba_window_attention")
+    lib = _lib.load()
+    nws = lib.drba_window_attention_ws_floats(b, h, w, int(splits))
+    ws = _workspace(q.device, nws) if nws else None
+    _lib.check(lib.drba_window_attention(_p(q), _p(k), _p(v), _p(out), b, h, w, c, int(splits), int(bool(shift)),
+                                         float(scale), ldq, ldk, ldv, _p(ws), _stream()), "drba_window_attention")
     return out
 
 

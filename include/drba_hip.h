@@ -203,7 +203,10 @@ int drba_gelu(const float *x, float *out, size_t n, void *stream); /* nn.GELU(),
  * generate_shift_window_attn_mask (transformer.py:19-43), softmax(q k^T / scale) v and the inverse partition / roll
  * are applied through index maps; the score matrix is never stored.  splits = 1, shift = 0 is full attention. */
 int drba_window_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int W, int C,
-                          int splits, int shift, float scale, int ldq, int ldk, int ldv, void *stream);
+                          int splits, int shift, float scale, int ldq, int ldk, int ldv, float *ws, void *stream);
+/* ws: drba_window_attention_ws_floats(B, H, W, splits) floats (may be 0 / NULL): shapes with few, long windows split each
+ * window's keys over several workgroups and merge the partial softmax states through it */
+size_t drba_window_attention_ws_floats(int B, int H, int W, int splits);
 /* ldq / ldk / ldv: row strides in floats (>= C, multiples of 4; 16-byte aligned bases): q, k, v may be column slices
  * of one fused projection output [B*H*W, 3C]; out rows are C apart */
 /* nn.Linear on token-major activations (transformer.py:142-208: q/k/v/merge projections, MLP 256 -> 1024 -> GELU -> 128):
