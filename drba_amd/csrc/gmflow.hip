@@ -286,27 +286,36 @@ softmax_expect2_kernel(const float *__restrict__ scores, const float *__restrict
 // One lane per pixel with the (2r+1)^2 running dot products in registers: the channel loop reads feature0 once and
 // feature1's neighbourhood with loads that coalesce across the lanes of a row (NCHW planes), instead of one wave per
 // pixel with its lanes strided over 64 channel planes (2.8 ms -> 0.2 ms at 144x240, 128 channels, r = 4).
+// A workgroup owns 64 pixels (a 32 x 2 tile, one per lane) and its 4 waves split the channels: at 144 x 240 one lane
+// per pixel alone is 540 waves for 1024 SIMDs, each with a 128-deep dependent loop; four partial dot products per tap,
+// summed through LDS by wave 0, put a wave on every SIMD twice over and quarter the loop.
 template <int R>
 __global__ void __launch_bounds__(256)
 local_corr_flow_kernel(const float *__restrict__ f0, const float *__restrict__ f1, float *__restrict__ out, int C, int H,
                        int W, float scale) {
   constexpr int N = 2 * R + 1;
+  __shared__ float red[3][N * N][64];
   const size_t P = (size_t)H * W;
-  const Tile2D tp = tile_pixel(W, H);
-  if (!tp.valid) return;
-  const int x = tp.x, y = tp.y;
-  const size_t p = (size_t)y * W + x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_x = (W + 31) / 32;
+  const int t = xcd_band(blockIdx.x, gridDim.x);
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int x = tx * 32 + (lane & 31), y = ty * 2 + (lane >> 5);
+  const bool valid = x < W && y < H;
+  const int xc = min(x, W - 1), yc = min(y, H - 1);  // lanes past the image compute on a valid pixel and do not store
+  const size_t p = (size_t)yc * W + xc;
   float acc[N * N];
 #pragma unroll
-  for (int t = 0; t < N * N; ++t) acc[t] = 0.f;
+  for (int k = 0; k < N * N; ++k) acc[k] = 0.f;
   // clamped tap addresses: out-of-image taps read a valid pixel and are overridden below
   int offy[N], offx[N];
 #pragma unroll
   for (int d = 0; d < N; ++d) {
-    offy[d] = min(max(y + d - R, 0), H - 1) * W;
-    offx[d] = min(max(x + d - R, 0), W - 1);
+    offy[d] = min(max(yc + d - R, 0), H - 1) * W;
+    offx[d] = min(max(xc + d - R, 0), W - 1);
   }
-  for (int c = 0; c < C; ++c) {
+  const int c0 = (C * wave) / 4, c1 = (C * (wave + 1)) / 4;
+  for (int c = c0; c < c1; ++c) {
     const float a = f0[(size_t)c * P + p];
     const float *pl = f1 + (size_t)c * P;
 #pragma unroll
@@ -314,6 +323,14 @@ local_corr_flow_kernel(const float *__restrict__ f0, const float *__restrict__ f
 #pragma unroll
       for (int dx = 0; dx < N; ++dx) acc[dy * N + dx] += a * pl[offy[dy] + offx[dx]];
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < N * N; ++k) red[wave - 1][k][lane] = acc[k];
+  }
+  __syncthreads();
+  if (wave > 0 || !valid) return;
+#pragma unroll
+  for (int k = 0; k < N * N; ++k) acc[k] += red[0][k][lane] + red[1][k][lane] + red[2][k][lane];
   float mx = -INFINITY;
 #pragma unroll
   for (int dy = 0; dy < N; ++dy)
@@ -553,8 +570,8 @@ int drba_softmax_expect2(const float *scores, const float *vals, float *out, int
 int drba_local_corr_flow(const float *f0, const float *f1, float *out, int C, int H, int W, int radius, void *stream) {
   if (!f0 || !f1 || !out || C <= 0 || H <= 0 || W <= 0 || radius <= 0) return DRBA_EINVAL;
   if (radius != 4) return DRBA_EUNSUPPORTED;  // the radius GMFlow's refinement stage uses (gmflow.py corr_radius_list)
-  hipLaunchKernelGGL(local_corr_flow_kernel<4>, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, f0, f1, out, C,
-                     H, W, sqrtf((float)C));
+  hipLaunchKernelGGL(local_corr_flow_kernel<4>, dim3((unsigned)(((W + 31) / 32) * ((H + 1) / 2))), dim3(kBlock), 0,
+                     (hipStream_t)stream, f0, f1, out, C, H, W, sqrtf((float)C));
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -354,6 +354,13 @@ def check_gmfss_parts(dev, size=(128, 256)):
             gt = net.transformer(oa.to(dev).contiguous(), ob.to(dev).contiguous(), splits)
             row(f"gmflow transformer splits{splits} f0", gt[0], ot[0], 1e-4 * max(1.0, float(ot[0].abs().max())))
             row(f"gmflow transformer splits{splits} f1", gt[1], ot[1], 1e-4 * max(1.0, float(ot[1].abs().max())))
+        # local correlation -> flow on a ragged size (partial 32 x 2 tiles, odd height) and the 1080p fine-scale size
+        for (hh_, ww_) in ((13, 45), (144, 240)):
+            a, b = cases.rnd((1, 128, hh_, ww_), 91, 0.6), cases.rnd((1, 128, hh_, ww_), 92, 0.6)
+            ref64 = ogm.local_correlation_softmax(a.double(), b.double(), 4)
+            floor = float((ogm.local_correlation_softmax(a, b, 4).double() - ref64).abs().max())  # the fp32 oracle's own error
+            rows.append((f"local_corr_flow r4 {hh_}x{ww_} (vs fp64)", _diff(ops.local_corr_flow(a.to(dev), b.to(dev), 4), ref64.float()),
+                         max(2e-5, 3.0 * floor), f"fp32_oracle_vs_fp64={floor:.2e}"))
         oflow = ogm.gmflow(sds["flownet"], h0, h1)
         gflow = net(h0.to(dev), h1.to(dev))
         row("gmflow flow01", gflow, oflow, 1e-3)
