@@ -503,6 +503,62 @@ splat_sorted_gather(const float *__restrict__ in, const int *__restrict__ start,
     if (c < gc) out[(size_t)c * P + p] = mode == 0 ? acc[c] : acc[c] / nrm;
 }
 
+// Feature tensors (C >= 16, C % 4 == 0): the gather's cost is the NUMBER of source loads (one per record per channel,
+// each a scattered 4-byte read), so the source is first rewritten channel-quad interleaved ([C/4][P][4]: one coalesced
+// pass) and a record then fetches 4 channels with one 16-byte load.  Same products per channel as
+// splat_sorted_gather.
+__global__ void __launch_bounds__(256) quad_interleave_kernel(const float *__restrict__ in, float *__restrict__ out, int C4, size_t P) {
+  const size_t total = (size_t)C4 * P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t q = i / P, p = i - q * P;
+    const float *src = in + (q * 4) * P + p;
+    *reinterpret_cast<float4 *>(out + i * 4) = make_float4(src[0], src[P], src[2 * P], src[3 * P]);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+splat_sorted_gather_quad(const float *__restrict__ inq, const int *__restrict__ start, const SplatRec *__restrict__ rec,
+                         float *__restrict__ out, int C, int H, int W, int mode, int eps, int chunks) {
+  const int n = blockIdx.y / chunks, chunk = blockIdx.y - n * chunks;
+  const int c0 = chunk * kChunk, gq = min(kChunk, C - c0) / 4;  // channel quads in this chunk (C % 4 == 0)
+  const size_t P = (size_t)H * W, Pk = (size_t)(H + 1) * (W + 1);
+  const float4 *src = reinterpret_cast<const float4 *>(inq) + ((size_t)n * (C / 4) + c0 / 4) * P;
+  start += (size_t)n * Pk;
+  out += ((size_t)n * C + c0) * P;
+  const Tile2D tp = tile_pixel(W, H);
+  if (!tp.valid) return;
+  const int x = tp.x, y = tp.y;
+  float acc[kChunk];
+#pragma unroll
+  for (int c = 0; c < kChunk; ++c) acc[c] = 0.f;
+  float nrm = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const size_t k1 = (size_t)(y - dy + 1) * (W + 1) + x;  // key of (x-1, y-dy), see splat_sorted_gather
+    const int s0 = start[k1], s1 = start[k1 + 1], s2 = start[k1 + 2];
+    for (int s = s0; s < s2; ++s) {
+      const SplatRec r = rec[s];
+      const int dx = s < s1 ? 1 : 0;
+      const float w = r.m * (splat_weight_1d(r.X, floorf(r.X), dx) * splat_weight_1d(r.Y, floorf(r.Y), dy));
+      nrm += w;
+#pragma unroll
+      for (int q = 0; q < kChunk / 4; ++q) {
+        const float4 v = src[(size_t)min(q, gq - 1) * P + r.src];  // branch-free: tail quads repeat the last one
+        acc[4 * q] += v.x * w, acc[4 * q + 1] += v.y * w, acc[4 * q + 2] += v.z * w, acc[4 * q + 3] += v.w * w;
+      }
+    }
+  }
+  if (mode != 0) {
+    if (eps == 0) nrm = nrm + 0.0000001f;
+    else if (eps == 1) nrm = (nrm == 0.f) ? 1.f : nrm;
+    else nrm = fmaxf(nrm, 0.0000001f) + (nrm != nrm ? nrm : 0.f);  // clip(min=1e-7); NaN stays NaN
+  }
+  const size_t p = (size_t)y * W + x;
+#pragma unroll
+  for (int c = 0; c < kChunk; ++c)
+    if (c < 4 * gq) out[(size_t)c * P + p] = mode == 0 ? acc[c] : acc[c] / nrm;
+}
+
 // ------------------------------------------------------------------------------------------ small elementwise
 __global__ void __launch_bounds__(256) drm_ratio_kernel(const float *__restrict__ f10, const float *__restrict__ f12, float eps,
                                  float *__restrict__ r10, float *__restrict__ r12, int H, int W) {
@@ -580,10 +636,13 @@ extern "C" {
 
 static size_t sort_keys(int N, int H, int W) { return (size_t)N * (H + 1) * (W + 1); }
 
+static bool splat_quad(int C) { return C >= 16 && (C & 3) == 0; }
+
 size_t drba_softsplat_ws_floats(int N, int C, int H, int W) {
-  (void)C;  // [cnt: L][start: L + 1][block sums][rec: 4 * N*P]
+  // [cnt: L][start: L + 1][block sums][rec: 4 * N*P][quad-interleaved copy of the input: N*C*P, feature tensors only]
   const size_t L = sort_keys(N, H, W);
-  return 2 * L + 8 + (L + kScanPerBlock - 1) / kScanPerBlock + 8 + 4 * (size_t)N * H * W;
+  return 2 * L + 8 + (L + kScanPerBlock - 1) / kScanPerBlock + 8 + 4 * (size_t)N * H * W + 4 +
+         (splat_quad(C) ? (size_t)N * C * H * W : 0);
 }
 
 int drba_softsplat(const float *in, const float *flow, const float *metric, float *out, float *ws, int N, int C,
@@ -607,8 +666,15 @@ int drba_softsplat(const float *in, const float *flow, const float *metric, floa
   hipLaunchKernelGGL(scan_add, dim3((unsigned)((L + 255) / 256)), dim3(kBlock), 0, s, start, bsum, L);
   hipLaunchKernelGGL(splat_sort_fill, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, metric, start, cnt, rec, H, W, mode);
   const int chunks = (C + kChunk - 1) / kChunk;
-  hipLaunchKernelGGL(splat_sorted_gather, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, in, start, rec, out, C, H,
-                     W, mode, eps, chunks);
+  if (splat_quad(C)) {
+    float *inq = (float *)(((uintptr_t)(rec + (size_t)N * P) + 15) & ~(uintptr_t)15);
+    hipLaunchKernelGGL(quad_interleave_kernel, dim3(grid_for((size_t)N * (C / 4) * P)), dim3(kBlock), 0, s, in, inq, N * (C / 4), P);
+    hipLaunchKernelGGL(splat_sorted_gather_quad, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, inq, start, rec, out, C,
+                       H, W, mode, eps, chunks);
+  } else {
+    hipLaunchKernelGGL(splat_sorted_gather, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, in, start, rec, out, C, H,
+                       W, mode, eps, chunks);
+  }
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

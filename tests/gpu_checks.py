@@ -496,3 +496,25 @@ def check_linear_split(dev):
         rows.append((f"linear_split + LayerNorm [{m}x{k}] bias={int(bias)} residual={int(with_res)}", _diff(got, ref.float()),
                      1e-5 * max(1.0, scale), f"|ref|max={scale:.2f}"))
     return rows
+
+
+# ----------------------------------------------------------------------------------------- feature splats
+def check_splat_quad(dev):
+    """Feature tensors (C >= 16, C % 4 == 0) are splatted from a channel-quad interleaved copy (16-byte source loads).
+    Channels are independent in softsplat, so the same tensor splatted as a 15- and a 17-channel piece (the scalar-load
+    kernel) must agree up to the order in which records of one target pixel are summed (the counting sort places them
+    by atomic arrival, so two launches of the SAME kernel differ by that much too)."""
+    from drba_amd.models.softsplat.softsplat import softsplat
+    rows = []
+    h, w, c = 37, 83, 32
+    x = cases.rnd((2, c, h, w), 5, 1.0).to(dev)
+    flow = (cases.rnd((2, 2, h, w), 6, 6.0)).to(dev)
+    metric = cases.rnd((2, 1, h, w), 7, 0.5).to(dev)
+    for mode in ("sum", "avg", "linear", "soft"):
+        m = metric if mode == "soft" else (metric.abs() + 0.5 if mode == "linear" else None)  # linear: a positive normaliser
+        whole = softsplat(x, flow, m, mode)
+        parts = torch.cat((softsplat(x[:, :15].contiguous(), flow, m, mode), softsplat(x[:, 15:].contiguous(), flow, m, mode)), 1)
+        scale = float(parts.abs().max())
+        rows.append((f"softsplat {mode}: quad-interleaved source vs scalar-load kernel", float((whole - parts).abs().max()),
+                     2e-6 * max(1.0, scale), f"absmax={scale:.2f}"))
+    return rows

@@ -24,6 +24,7 @@ def main():
     sections.append(("glue", gpu_checks.check_glue(hip.dev)))
     sections.append(("window attention", gpu_checks.check_window_attention(hip.dev)))
     sections.append(("linear (split-bf16)", gpu_checks.check_linear_split(hip.dev)))
+    sections.append(("feature splats", gpu_checks.check_splat_quad(hip.dev)))
     sections.append(("scdet", gpu_checks.check_scdet(hip, np.load(os.path.join(GOLD, "scdet.npz")))))
     gold = np.load(os.path.join(GOLD, "rife.npz"))
     for scale, size in cases.RIFE_CONFIGS:

@@ -174,3 +174,8 @@ def test_window_attention(hip_backend):
 @pytest.mark.gpu
 def test_linear_split(hip_backend):
     _assert_rows(gpu_checks.check_linear_split(hip_backend.dev))
+
+
+@pytest.mark.gpu
+def test_feature_splat_quad_source(hip_backend):
+    _assert_rows(gpu_checks.check_splat_quad(hip_backend.dev))
