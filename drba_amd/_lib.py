@@ -25,9 +25,11 @@ class ConvLayer(C.Structure):
 
 SIGNATURES = {
     "drba_abi_version": (_i, []),
-    "drba_timing_slots": (_i, []),
-    "drba_timing_arm": (_i, [_i]),
-    "drba_timing_elapsed_ms": (_i, [_i, C.POINTER(C.c_float)]),
+    "drba_trace_begin": (_i, []),
+    "drba_trace_end": (_i, []),
+    "drba_trace_resume": (_i, []),
+    "drba_trace_count": (_i, []),
+    "drba_trace_get": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.POINTER(C.c_float)]),
     "drba_error_string": (C.c_char_p, [_i]),
     "drba_softsplat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "drba_softsplat_ws_floats": (_z, [_i, _i, _i, _i]),

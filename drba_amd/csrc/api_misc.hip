@@ -1,21 +1,71 @@
 // ABI version and error strings of libdrba_hip.so.
 #include "common.hpp"
 
+#include <cxxabi.h>
+
+#include <cstdlib>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// Kernel trace (measurement only): between drba_trace_begin() and drba_trace_end() EVERY kernel launch of the library
+// carries an event pair on its own dispatch packet (hipExtLaunchKernelGGL), so each record is the kernel's own
+// execution time -- what rocprofv3's kernel trace reports -- and bench.py can rank the whole step by kernel symbol.
+// Process-global state driven by ONE host thread (the launches of both HIP streams come from the same thread).
 namespace {
-constexpr int kTimingSlots = 4096;
-hipEvent_t g_ev[kTimingSlots][2];
-bool g_ev_made[kTimingSlots];
-int g_armed = -1;
+constexpr int kTraceSlots = 16384;
+struct Rec {
+  const std::string *name;
+  unsigned gx, gy, gz;
+};
+hipEvent_t g_ev[kTraceSlots][2];
+bool g_ev_made[kTraceSlots];
+std::vector<Rec> g_recs;
+std::unordered_map<const void *, std::string> g_names;
+
+const std::string &kernel_name(const void *host_fn, const char *fallback, hipStream_t stream) {
+  auto it = g_names.find(host_fn);
+  if (it != g_names.end()) return it->second;
+  std::string nm;
+  const char *mangled = hipKernelNameRefByPtr(host_fn, stream);
+  if (mangled && *mangled) {
+    int status = 1;
+    char *dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    nm = (status == 0 && dem) ? dem : mangled;
+    std::free(dem);
+    // rocprofv3 prints "name(args)"; keep the name part so that records group like its kernel-name column minus arguments
+    int depth = 0;
+    for (size_t i = 0; i < nm.size(); ++i) {
+      if (nm[i] == '<') ++depth;
+      else if (nm[i] == '>') --depth;
+      else if (nm[i] == '(' && depth == 0) {
+        nm.resize(i);
+        break;
+      }
+    }
+    if (nm.rfind("void ", 0) == 0) nm.erase(0, 5);
+  } else {
+    nm = fallback;
+  }
+  (void)hipGetLastError();
+  return g_names.emplace(host_fn, nm).first->second;
+}
 }  // namespace
 
 namespace drba {
-TimedLaunch take_armed_timing() {
+bool g_trace_on = false;
+
+TimedLaunch trace_launch(const void *host_fn, const char *fallback, dim3 grid, hipStream_t stream) {
   TimedLaunch t{nullptr, nullptr};
-  if (g_armed >= 0) {
-    t.start = g_ev[g_armed][0];
-    t.stop = g_ev[g_armed][1];
-    g_armed = -1;
+  const size_t slot = g_recs.size();
+  if (slot >= (size_t)kTraceSlots) return t;
+  if (!g_ev_made[slot]) {
+    if (hipEventCreate(&g_ev[slot][0]) != hipSuccess || hipEventCreate(&g_ev[slot][1]) != hipSuccess) return t;
+    g_ev_made[slot] = true;
   }
+  g_recs.push_back(Rec{&kernel_name(host_fn, fallback, stream), grid.x, grid.y, grid.z});
+  t.start = g_ev[slot][0];
+  t.stop = g_ev[slot][1];
   return t;
 }
 }  // namespace drba
@@ -24,22 +74,33 @@ extern "C" {
 
 int drba_abi_version(void) { return 1; }
 
-int drba_timing_slots(void) { return kTimingSlots; }
-
-int drba_timing_arm(int slot) {
-  if (slot < 0 || slot >= kTimingSlots) return DRBA_EINVAL;
-  if (!g_ev_made[slot]) {
-    if (hipEventCreate(&g_ev[slot][0]) != hipSuccess || hipEventCreate(&g_ev[slot][1]) != hipSuccess) return DRBA_ELAUNCH;
-    g_ev_made[slot] = true;
-  }
-  g_armed = slot;
+int drba_trace_begin(void) {
+  g_recs.clear();
+  drba::g_trace_on = true;
   return DRBA_OK;
 }
 
-int drba_timing_elapsed_ms(int slot, float *ms) {
-  if (slot < 0 || slot >= kTimingSlots || !ms || !g_ev_made[slot]) return DRBA_EINVAL;
-  if (hipEventSynchronize(g_ev[slot][1]) != hipSuccess) return DRBA_ELAUNCH;
-  return hipEventElapsedTime(ms, g_ev[slot][0], g_ev[slot][1]) == hipSuccess ? DRBA_OK : DRBA_ELAUNCH;
+int drba_trace_resume(void) {
+  drba::g_trace_on = true;
+  return DRBA_OK;
+}
+
+int drba_trace_end(void) {
+  drba::g_trace_on = false;
+  return DRBA_OK;
+}
+
+int drba_trace_count(void) { return (int)g_recs.size(); }
+
+int drba_trace_get(int i, const char **name, unsigned *grid3, float *ms) {
+  if (i < 0 || (size_t)i >= g_recs.size() || !name || !grid3 || !ms) return DRBA_EINVAL;
+  if (hipEventSynchronize(g_ev[i][1]) != hipSuccess) return DRBA_ELAUNCH;
+  if (hipEventElapsedTime(ms, g_ev[i][0], g_ev[i][1]) != hipSuccess) return DRBA_ELAUNCH;
+  *name = g_recs[i].name->c_str();
+  grid3[0] = g_recs[i].gx;
+  grid3[1] = g_recs[i].gy;
+  grid3[2] = g_recs[i].gz;
+  return DRBA_OK;
 }
 
 const char *drba_error_string(int code) {

@@ -14,21 +14,28 @@
 
 namespace drba {
 
-// Per-launch kernel timing for bench.py's roofline object: drba_timing_arm(slot) makes the NEXT timed launch attach
-// the slot's event pair to its own dispatch packet (hipExtLaunchKernelGGL), so the pair brackets exactly the kernel
+// Kernel trace for bench.py's roofline object (api_misc.hip): while drba_trace_begin() is in effect every launch
+// attaches an event pair to its own dispatch packet (hipExtLaunchKernelGGL), so the pair brackets exactly the kernel
 // -- the duration rocprofv3's kernel trace reports -- without the barrier packets an event recorded on the stream
-// adds before and after the launch.  Defined in api_misc.hip.
+// adds before and after the launch.  Every kernel launch of the library goes through DRBA_LAUNCH.
 struct TimedLaunch {
-  hipEvent_t start, stop;  // both null when not armed
+  hipEvent_t start, stop;  // both null when the trace is full
 };
-TimedLaunch take_armed_timing();
+extern bool g_trace_on;
+TimedLaunch trace_launch(const void *host_fn, const char *fallback_name, dim3 grid, hipStream_t stream);
 
-#define DRBA_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                              \
-  do {                                                                                                        \
-    const drba::TimedLaunch tl_ = drba::take_armed_timing();                                                  \
-    if (tl_.start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tl_.start, tl_.stop, 0, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                   \
+#define DRBA_LAUNCH(kernel, grid, block, lds, stream, ...)                                                     \
+  do {                                                                                                         \
+    if (drba::g_trace_on) {                                                                                    \
+      const drba::TimedLaunch tl_ = drba::trace_launch((const void *)(kernel), #kernel, grid, stream);         \
+      if (tl_.start) {                                                                                         \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tl_.start, tl_.stop, 0, __VA_ARGS__);          \
+        break;                                                                                                 \
+      }                                                                                                        \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                         \
   } while (0)
+#define DRBA_LAUNCH_TIMED DRBA_LAUNCH
 
 constexpr int kBlock = 256;      // 4 waves: one per SIMD of a CU
 constexpr int kMaxBlocks = 2048; // 256 CUs x 8: grid-stride beyond this (guide G11)

@@ -480,7 +480,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   // PRE: PReLU pre-activation compiled into the MFMA loop (FeatureNet / MetricNet / GridNet convolutions)
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
-    DRBA_LAUNCH_TIMED(kernel, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2, out, Cin, H,
+    DRBA_LAUNCH(kernel, g, dim3(256), Cfg::LDS_FLOATS * sizeof(float), s, in, wpk, bias, beta, res, res2, out, Cin, H,
                       W, Cout, Ho, Wo, act, post_slope, pre_slope, n_ct, ps);
     return DRBA_OK;
   };

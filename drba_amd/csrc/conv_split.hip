@@ -435,7 +435,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(wpk);
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
-    DRBA_LAUNCH_TIMED(kernel, g, dim3(256), Cfg::LDS_BYTES, s, in, wf, bias, beta, res, res2, out, Cin, H, W, Cout, act,
+    DRBA_LAUNCH(kernel, g, dim3(256), Cfg::LDS_BYTES, s, in, wf, bias, beta, res, res2, out, Cin, H, W, Cout, act,
                       post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle);
     return DRBA_OK;
   };

@@ -488,7 +488,7 @@ int drba_conv_direct(const float *in, const float *w, const float *bias, float *
     return DRBA_EINVAL;
   const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
   const int cblocks = (Cout + kCob - 1) / kCob;
-  hipLaunchKernelGGL(conv_direct_kernel, dim3(tiles_for(Wo, Ho), N * cblocks), dim3(kBlock), 0, (hipStream_t)stream, in, w,
+  DRBA_LAUNCH(conv_direct_kernel, dim3(tiles_for(Wo, Ho), N * cblocks), dim3(kBlock), 0, (hipStream_t)stream, in, w,
                      bias, out, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, cblocks);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -499,15 +499,15 @@ size_t drba_instance_norm_ws_floats(int planes) { return (size_t)(planes > 0 ? p
 int drba_instance_norm(const float *in, float *out, float *ws, int planes, size_t HW, float eps, int relu, void *stream) {
   if (!in || !out || !ws || planes <= 0 || HW == 0) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(instance_norm_stats_kernel, dim3(kInChunks, planes), dim3(kBlock), 0, s, in, ws, HW);
-  hipLaunchKernelGGL(instance_norm_apply_kernel, dim3(kInChunks, planes), dim3(kBlock), 0, s, in, ws, out, HW, eps, relu);
+  DRBA_LAUNCH(instance_norm_stats_kernel, dim3(kInChunks, planes), dim3(kBlock), 0, s, in, ws, HW);
+  DRBA_LAUNCH(instance_norm_apply_kernel, dim3(kInChunks, planes), dim3(kBlock), 0, s, in, ws, out, HW, eps, relu);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
 int drba_add_act(const float *a, const float *b, float *out, size_t n, int relu, void *stream) {
   if (!a || !b || !out || n == 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(add_act_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, a, b, out, n, relu);
+  DRBA_LAUNCH(add_act_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, a, b, out, n, relu);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -516,7 +516,7 @@ int drba_channel_normalize3(const float *in, float *out, int N, size_t HW, const
                             void *stream) {
   if (!in || !out || !mean3 || !std3 || N <= 0 || HW == 0) return DRBA_EINVAL;
   const size_t n = (size_t)N * 3 * HW;
-  hipLaunchKernelGGL(channel_affine_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, in, out, 3, HW,
+  DRBA_LAUNCH(channel_affine_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, in, out, 3, HW,
                      mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], n);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -525,7 +525,7 @@ int drba_channel_normalize3(const float *in, float *out, int N, size_t HW, const
 int drba_layernorm(const float *x, const float *w, const float *b, const float *residual, float *out, size_t rows,
                    int cols, float eps, void *stream) {
   if (!x || !w || !b || !out || rows == 0 || cols <= 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, w, b,
+  DRBA_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, w, b,
                      residual, out, rows, cols, eps);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -533,7 +533,7 @@ int drba_layernorm(const float *x, const float *w, const float *b, const float *
 
 int drba_gelu(const float *x, float *out, size_t n, void *stream) {
   if (!x || !out || n == 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(gelu_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, out, n);
+  DRBA_LAUNCH(gelu_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, out, n);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -544,14 +544,14 @@ int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int ro
   hipStream_t s = (hipStream_t)stream;
   const int nm = mask ? n_masks : 1;
 #define DRBA_SOFTMAX(EPT, RPB)                                                                                     \
-  hipLaunchKernelGGL((softmax_rows_kernel<EPT, RPB>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(kBlock), 0, s, x, \
+  DRBA_LAUNCH((softmax_rows_kernel<EPT, RPB>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(kBlock), 0, s, x, \
                      mask, rows, cols, rows_per_mat, nm, scale)
   if (cols <= 64 * 9) DRBA_SOFTMAX(9, 4);
   else if (cols <= 64 * 16) DRBA_SOFTMAX(16, 4);
   else if (cols <= 256 * 9) DRBA_SOFTMAX(9, 1);
   else if (cols <= 256 * 34) DRBA_SOFTMAX(34, 1);
   else
-    hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(kBlock), 0, s, x, mask, cols, rows_per_mat, nm,
+    DRBA_LAUNCH(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(kBlock), 0, s, x, mask, cols, rows_per_mat, nm,
                        scale);
 #undef DRBA_SOFTMAX
   DRBA_CHECK_LAUNCH();
@@ -561,7 +561,7 @@ int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int ro
 int drba_softmax_expect2(const float *scores, const float *vals, float *out, int rows, int cols, int w, float scale,
                          void *stream) {
   if (!scores || !out || rows <= 0 || cols <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
-  hipLaunchKernelGGL(softmax_expect2_kernel, dim3(rows), dim3(kBlock), 0, (hipStream_t)stream, scores, vals, out, rows,
+  DRBA_LAUNCH(softmax_expect2_kernel, dim3(rows), dim3(kBlock), 0, (hipStream_t)stream, scores, vals, out, rows,
                      cols, w, scale);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -570,7 +570,7 @@ int drba_softmax_expect2(const float *scores, const float *vals, float *out, int
 int drba_local_corr_flow(const float *f0, const float *f1, float *out, int C, int H, int W, int radius, void *stream) {
   if (!f0 || !f1 || !out || C <= 0 || H <= 0 || W <= 0 || radius <= 0) return DRBA_EINVAL;
   if (radius != 4) return DRBA_EUNSUPPORTED;  // the radius GMFlow's refinement stage uses (gmflow.py corr_radius_list)
-  hipLaunchKernelGGL(local_corr_flow_kernel<4>, dim3((unsigned)(((W + 31) / 32) * ((H + 1) / 2))), dim3(kBlock), 0,
+  DRBA_LAUNCH(local_corr_flow_kernel<4>, dim3((unsigned)(((W + 31) / 32) * ((H + 1) / 2))), dim3(kBlock), 0,
                      (hipStream_t)stream, f0, f1, out, C, H, W, sqrtf((float)C));
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -580,7 +580,7 @@ int drba_local_attn_flow(const float *q_tok, const float *k_tok, const float *fl
                          int radius, void *stream) {
   if (!q_tok || !k_tok || !flow || !out || C <= 0 || H <= 0 || W <= 0 || radius <= 0) return DRBA_EINVAL;
   const size_t P = (size_t)H * W;
-  hipLaunchKernelGGL(local_attn_flow_kernel, dim3((unsigned)((P + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, q_tok,
+  DRBA_LAUNCH(local_attn_flow_kernel, dim3((unsigned)((P + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, q_tok,
                      k_tok, flow, out, C, H, W, radius, sqrtf((float)C));
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -588,7 +588,7 @@ int drba_local_attn_flow(const float *q_tok, const float *k_tok, const float *fl
 
 int drba_convex_upsample(const float *mask, const float *flow, float *out, int h, int w, int factor, void *stream) {
   if (!mask || !flow || !out || h <= 0 || w <= 0 || factor <= 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(convex_upsample_kernel, dim3(grid_for((size_t)h * w * factor * factor)), dim3(kBlock), 0,
+  DRBA_LAUNCH(convex_upsample_kernel, dim3(grid_for((size_t)h * w * factor * factor)), dim3(kBlock), 0,
                      (hipStream_t)stream, mask, flow, out, h, w, factor);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -596,7 +596,7 @@ int drba_convex_upsample(const float *mask, const float *flow, float *out, int h
 
 int drba_flow_warp(const float *in, const float *flow, float *out, int C, int H, int W, void *stream) {
   if (!in || !flow || !out || C <= 0 || H <= 1 || W <= 1) return DRBA_EINVAL;
-  hipLaunchKernelGGL(flow_warp_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H,
+  DRBA_LAUNCH(flow_warp_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H,
                      W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -605,7 +605,7 @@ int drba_flow_warp(const float *in, const float *flow, float *out, int C, int H,
 int drba_resize_bilinear_ac(const float *in, float *out, int NC, int Hin, int Win, int Hout, int Wout, float mul,
                             void *stream) {
   if (!in || !out || NC <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(resize_ac_kernel, dim3(grid_for((size_t)NC * Hout * Wout)), dim3(kBlock), 0, (hipStream_t)stream, in,
+  DRBA_LAUNCH(resize_ac_kernel, dim3(grid_for((size_t)NC * Hout * Wout)), dim3(kBlock), 0, (hipStream_t)stream, in,
                      out, NC, Hin, Win, Hout, Wout, mul);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;

@@ -125,7 +125,7 @@ extern "C" {
 int drba_metric_input(const float *img0, const float *img1, const float *flow01, const float *flow10, float *out, int H,
                       int W, void *stream) {
   if (!img0 || !img1 || !flow01 || !flow10 || !out || H <= 1 || W <= 1) return DRBA_EINVAL;
-  hipLaunchKernelGGL(metric_input_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1,
+  DRBA_LAUNCH(metric_input_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1,
                      flow01, flow10, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -133,7 +133,7 @@ int drba_metric_input(const float *img0, const float *img1, const float *flow01,
 
 int drba_pixel_shuffle2(const float *in, float *out, int C, int H, int W, void *stream) {
   if (!in || !out || C <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(tiles_for(2 * W, 2 * H)), dim3(kBlock), 0, (hipStream_t)stream, in, out,
+  DRBA_LAUNCH(pixel_shuffle2_kernel, dim3(tiles_for(2 * W, 2 * H)), dim3(kBlock), 0, (hipStream_t)stream, in, out,
                      C, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -142,7 +142,7 @@ int drba_pixel_shuffle2(const float *in, float *out, int C, int H, int W, void *
 int drba_timestep_fix(const float *t0, const float *t1, const float *cover0, const float *cover1, float *out0,
                       float *out1, size_t n, void *stream) {
   if (!t0 || !t1 || !cover0 || !cover1 || !out0 || !out1 || n == 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(timestep_fix_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, t0, t1, cover0,
+  DRBA_LAUNCH(timestep_fix_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, t0, t1, cover0,
                      cover1, out0, out1, n);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -151,7 +151,7 @@ int drba_timestep_fix(const float *t0, const float *t1, const float *cover0, con
 int drba_swap_select(const float *x, const float *y, const float *t0, const float *t1, float *out_x, float *out_y, int C,
                      int H, int W, float thr, void *stream) {
   if (!x || !y || !t0 || !t1 || !out_x || !out_y || C <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(swap_select_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, x, y, t0,
+  DRBA_LAUNCH(swap_select_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, x, y, t0,
                      t1, out_x, out_y, C, (size_t)H * W, thr);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -159,7 +159,7 @@ int drba_swap_select(const float *x, const float *y, const float *t0, const floa
 
 int drba_clamp(const float *in, float *out, float lo, float hi, size_t n, void *stream) {
   if (!in || !out || n == 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, in, out, lo, hi, n);
+  DRBA_LAUNCH(clamp_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, in, out, lo, hi, n);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -376,7 +376,7 @@ extern "C" {
 int drba_resize_bilinear(const float *in, float *out, int NC, int Hin, int Win, int Hout, int Wout, float scale_y,
                          float scale_x, void *stream) {
   if (!in || !out || NC <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for((size_t)NC * Hout * Wout)), dim3(kBlock), 0,
+  DRBA_LAUNCH(resize_bilinear_kernel, dim3(grid_for((size_t)NC * Hout * Wout)), dim3(kBlock), 0,
                      (hipStream_t)stream, in, out, NC, Hin, Win, Hout, Wout, scale_y, scale_x);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -385,7 +385,7 @@ int drba_resize_bilinear(const float *in, float *out, int NC, int Hin, int Win, 
 int drba_pair_interleave(const float *in, float *out, int C, int H, int W, void *stream) {
   if (!in || !out || C <= 0 || (C & 1) || H <= 0 || W <= 0) return DRBA_EINVAL;
   const size_t P = (size_t)H * W;
-  hipLaunchKernelGGL(pair_interleave_kernel, dim3(grid_for((size_t)(C / 2) * P)), dim3(kBlock), 0, (hipStream_t)stream, in,
+  DRBA_LAUNCH(pair_interleave_kernel, dim3(grid_for((size_t)(C / 2) * P)), dim3(kBlock), 0, (hipStream_t)stream, in,
                      out, C / 2, P);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -393,14 +393,14 @@ int drba_pair_interleave(const float *in, float *out, int C, int H, int W, void 
 
 int drba_u8hwc_to_f32nchw(const uint8_t *in, float *out, int H, int W, void *stream) {
   if (!in || !out || H <= 0 || W <= 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, in, out, H, W);
+  DRBA_LAUNCH(u8_to_f32_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, in, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
 int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *stream) {
   if (!in || !out || H <= 0 || W <= 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(f32_to_u8_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, in, out, H, W);
+  DRBA_LAUNCH(f32_to_u8_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, in, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -424,25 +424,25 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
   const int quad_tiles = single ? tiles_for(w, h) : ((w + 15) / 16) * ((h + 3) / 4);
 #define DRBA_ARGS \
   img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, timestep_scalar, flow, tmp_prev, hp, wp, ips, out, H, W, h, w, scale
-#define DRBA_LAUNCH(HF, SG)                                                                                        \
+#define DRBA_IFIN(HF, SG)                                                                                            \
   do {                                                                                                             \
     if (var == 0) {                                                                                                \
-      DRBA_LAUNCH_TIMED((ifblock_input_pixel<HF, SG>), dim3(tiles_for(w, h)), b, 0, s, DRBA_ARGS);                 \
+      DRBA_LAUNCH((ifblock_input_pixel<HF, SG>), dim3(tiles_for(w, h)), b, 0, s, DRBA_ARGS);                 \
     } else if (var == 1) {                                                                                         \
-      DRBA_LAUNCH_TIMED((ifblock_input_kernel<HF, SG, 1>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                  \
+      DRBA_LAUNCH((ifblock_input_kernel<HF, SG, 1>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                  \
     } else {                                                                                                       \
-      DRBA_LAUNCH_TIMED((ifblock_input_kernel<HF, SG, 4>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                  \
+      DRBA_LAUNCH((ifblock_input_kernel<HF, SG, 4>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                  \
     }                                                                                                              \
   } while (0)
   if (flow) {
-    if (single) DRBA_LAUNCH(true, true);
-    else DRBA_LAUNCH(true, false);
+    if (single) DRBA_IFIN(true, true);
+    else DRBA_IFIN(true, false);
   } else {
-    if (single) DRBA_LAUNCH(false, true);
-    else DRBA_LAUNCH(false, false);
+    if (single) DRBA_IFIN(false, true);
+    else DRBA_IFIN(false, false);
   }
 #undef DRBA_ARGS
-#undef DRBA_LAUNCH
+#undef DRBA_IFIN
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -450,7 +450,7 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
 int drba_ifblock_update(const float *tmp, const float *flow_in, float *flow_out, float *mask, float *feat, int h,
                         int w, int H, int W, float scale, void *stream) {
   if (!tmp || !flow_out || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
-  hipLaunchKernelGGL(ifblock_update_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, tmp,
+  DRBA_LAUNCH(ifblock_update_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, tmp,
                      flow_in, flow_out, mask, feat, h, w, H, W, scale, (float)(1.0 / (double)scale));
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -460,7 +460,7 @@ int drba_warp_blend(const float *img0, const float *img1, const float *flow, con
                     float scale, float *out, int H, int W, void *stream) {
   if (!img0 || !img1 || !flow || !mask_lo || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f))
     return DRBA_EINVAL;
-  hipLaunchKernelGGL(warp_blend_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1,
+  DRBA_LAUNCH(warp_blend_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1,
                      flow, mask_lo, h, w, (float)(1.0 / (double)scale), out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;

@@ -302,7 +302,7 @@ static int linear_launch(const float *x, const float *packed_w, const float *bia
   const int n_ntiles = (N + Cfg::TN - 1) / Cfg::TN, n_mtiles = (M + Cfg::TM - 1) / Cfg::TM;
   const dim3 grid((unsigned)(n_ntiles * n_mtiles));
 #define DRBA_LIN(E)                                                                                                      \
-  DRBA_LAUNCH_TIMED((linear_split_kernel<Cfg, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
+  DRBA_LAUNCH((linear_split_kernel<Cfg, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
                     ldx, n_ntiles, ln_w, ln_b, residual, eps, x2, ldx2, q_split)
   if (epi == 2) DRBA_LIN(2);
   else if (epi == 1) DRBA_LIN(1);

@@ -119,7 +119,7 @@ extern "C" int drba_ssim3d_32(const float *x1, const float *x2, float *out, void
     sum += G.g[k];
   }
   for (int k = 0; k < 11; ++k) G.g[k] /= sum;
-  hipLaunchKernelGGL(ssim3d_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x1, x2, out, G);
+  DRBA_LAUNCH(ssim3d_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x1, x2, out, G);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -660,19 +660,19 @@ int drba_softsplat(const float *in, const float *flow, const float *metric, floa
   int *bsum = start + ((L + 1 + 3) & ~(size_t)3);      // nb entries
   SplatRec *rec = (SplatRec *)(((uintptr_t)(bsum + nb) + 15) & ~(uintptr_t)15);
   if (hipMemsetAsync(cnt, 0, L * sizeof(int), s) != hipSuccess) return DRBA_ELAUNCH;
-  hipLaunchKernelGGL(splat_sort_count, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, cnt, H, W);
-  hipLaunchKernelGGL(scan_block, dim3(nb), dim3(kBlock), 0, s, cnt, start, bsum, L);
-  hipLaunchKernelGGL(scan_sums, dim3(1), dim3(kBlock), 0, s, bsum, nb, start + L);
-  hipLaunchKernelGGL(scan_add, dim3((unsigned)((L + 255) / 256)), dim3(kBlock), 0, s, start, bsum, L);
-  hipLaunchKernelGGL(splat_sort_fill, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, metric, start, cnt, rec, H, W, mode);
+  DRBA_LAUNCH(splat_sort_count, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, cnt, H, W);
+  DRBA_LAUNCH(scan_block, dim3(nb), dim3(kBlock), 0, s, cnt, start, bsum, L);
+  DRBA_LAUNCH(scan_sums, dim3(1), dim3(kBlock), 0, s, bsum, nb, start + L);
+  DRBA_LAUNCH(scan_add, dim3((unsigned)((L + 255) / 256)), dim3(kBlock), 0, s, start, bsum, L);
+  DRBA_LAUNCH(splat_sort_fill, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, metric, start, cnt, rec, H, W, mode);
   const int chunks = (C + kChunk - 1) / kChunk;
   if (splat_quad(C)) {
     float *inq = (float *)(((uintptr_t)(rec + (size_t)N * P) + 15) & ~(uintptr_t)15);
-    hipLaunchKernelGGL(quad_interleave_kernel, dim3(grid_for((size_t)N * (C / 4) * P)), dim3(kBlock), 0, s, in, inq, N * (C / 4), P);
-    hipLaunchKernelGGL(splat_sorted_gather_quad, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, inq, start, rec, out, C,
+    DRBA_LAUNCH(quad_interleave_kernel, dim3(grid_for((size_t)N * (C / 4) * P)), dim3(kBlock), 0, s, in, inq, N * (C / 4), P);
+    DRBA_LAUNCH(splat_sorted_gather_quad, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, inq, start, rec, out, C,
                        H, W, mode, eps, chunks);
   } else {
-    hipLaunchKernelGGL(splat_sorted_gather, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, in, start, rec, out, C, H,
+    DRBA_LAUNCH(splat_sorted_gather, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, in, start, rec, out, C, H,
                        W, mode, eps, chunks);
   }
   DRBA_CHECK_LAUNCH();
@@ -684,9 +684,9 @@ int drba_backwarp(const float *in, const float *flow, float *out, int N, int C, 
   if (!in || !flow || !out || N <= 0 || C <= 0 || H <= 1 || W <= 1 || padding < 0 || padding > 1) return DRBA_EINVAL;
   dim3 g(grid_for((size_t)H * W), N);
   if (padding == 0)
-    hipLaunchKernelGGL(backwarp_kernel<false>, g, dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H, W);
+    DRBA_LAUNCH(backwarp_kernel<false>, g, dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H, W);
   else
-    hipLaunchKernelGGL(backwarp_kernel<true>, g, dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H, W);
+    DRBA_LAUNCH(backwarp_kernel<true>, g, dim3(kBlock), 0, (hipStream_t)stream, in, flow, out, C, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -694,7 +694,7 @@ int drba_backwarp(const float *in, const float *flow, float *out, int N, int C, 
 int drba_flow_distance(const float *flow, float *out, int N, int H, int W, void *stream) {
   if (!flow || !out || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   dim3 g(grid_for((size_t)H * W), N);
-  hipLaunchKernelGGL(distance_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, flow, out, H, W);
+  DRBA_LAUNCH(distance_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, flow, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -704,10 +704,10 @@ int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, in
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
   if (hipMemsetAsync(ws, 0, (size_t)N * P * 3 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
-  hipLaunchKernelGGL(splat_long_prepass<0>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f,
+  DRBA_LAUNCH(splat_long_prepass<0>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f,
                      (const float *)nullptr, 0.f, ws, H, W);
   dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);
-  hipLaunchKernelGGL(splat_tiled<0>, g, dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f, (const float *)nullptr,
+  DRBA_LAUNCH(splat_tiled<0>, g, dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f, (const float *)nullptr,
                      0.f, ws, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -719,10 +719,10 @@ int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float 
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
   if (hipMemsetAsync(ws, 0, (size_t)N * P * 2 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
-  hipLaunchKernelGGL(splat_long_prepass<1>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev,
+  DRBA_LAUNCH(splat_long_prepass<1>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev,
                      eps, ws, H, W);
   dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);
-  hipLaunchKernelGGL(splat_tiled<1>, g, dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev, eps, ws, out, H, W);
+  DRBA_LAUNCH(splat_tiled<1>, g, dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev, eps, ws, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -731,14 +731,14 @@ int drba_drm_ratio(const float *flow10, const float *flow12, float eps, float *d
                    int W, void *stream) {
   if (!flow10 || !flow12 || (!drm10 && !drm12) || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   dim3 g(grid_for((size_t)H * W), N);
-  hipLaunchKernelGGL(drm_ratio_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, flow10, flow12, eps, drm10, drm12, H, W);
+  DRBA_LAUNCH(drm_ratio_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, flow10, flow12, eps, drm10, drm12, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
 int drba_affine(const float *a, float mul, float add, float *out, size_t n, void *stream) {
   if (!a || !out || n == 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, a, mul, add, out, n);
+  DRBA_LAUNCH(affine_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, a, mul, add, out, n);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -746,21 +746,21 @@ int drba_affine(const float *a, float mul, float add, float *out, size_t n, void
 int drba_mul_map(const float *x, const float *map, float *out, int N, int C, int H, int W, void *stream) {
   if (!x || !map || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   dim3 g(grid_for((size_t)H * W), N);
-  hipLaunchKernelGGL(mul_map_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, x, map, out, C, (size_t)H * W);
+  DRBA_LAUNCH(mul_map_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, x, map, out, C, (size_t)H * W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
 int drba_fill_holes(const float *aligned, const float *cover, const float *value, float *out, size_t n, void *stream) {
   if (!aligned || !cover || !value || !out || n == 0) return DRBA_EINVAL;
-  hipLaunchKernelGGL(fill_holes_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, aligned, cover, value, out, n);
+  DRBA_LAUNCH(fill_holes_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, aligned, cover, value, out, n);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
 int drba_drm_retime(const float *drm, float *out, double t, double precision, size_t n, void *stream) {
   if (!drm || !out || n == 0 || !(precision > 0)) return DRBA_EINVAL;
-  hipLaunchKernelGGL(drm_retime_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, drm, out, t, precision, n);
+  DRBA_LAUNCH(drm_retime_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, drm, out, t, precision, n);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

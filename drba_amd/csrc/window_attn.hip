@@ -330,10 +330,10 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
       hipFuncSetAttribute(reinterpret_cast<const void *>(drba_attn::window_attention_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, drba_attn::kLdsBytes);
   if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
-  DRBA_LAUNCH_TIMED(drba_attn::window_attention_kernel, grid, dim3(kBlock), drba_attn::kLdsBytes, (hipStream_t)stream, q, k, v,
+  DRBA_LAUNCH(drba_attn::window_attention_kernel, grid, dim3(kBlock), drba_attn::kLdsBytes, (hipStream_t)stream, q, k, v,
                     out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws);
   if (ksplit > 1)
-    hipLaunchKernelGGL(drba_attn::window_attention_merge, dim3((unsigned)(((size_t)nwin * g.L + 3) / 4)), dim3(kBlock), 0,
+    DRBA_LAUNCH(drba_attn::window_attention_merge, dim3((unsigned)(((size_t)nwin * g.L + 3) / 4)), dim3(kBlock), 0,
                        (hipStream_t)stream, ws, out, g, nwin, ksplit);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;

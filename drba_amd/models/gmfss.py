@@ -36,6 +36,12 @@ class GMFSS:
     supports_lookahead = True
     _look = None
 
+    def warm_reuse(self, Ia, Ib):
+        """The `reuse` a DRBA step ending on the pair (Ia, Ib) hands to the next step (gmfss.py:70-72): model.reuse(Ia, Ib)
+        with the roles swapped.  Used by drba_amd.parallel to rebuild the state entering a shard."""
+        r = self.model.reuse(Ia, Ib, self.scale)
+        return [v for pair in zip(r[1::2], r[0::2]) for v in pair]
+
     def _pair_state(self, a, b):
         """model.reuse(a, b), taken from a matching lookahead if there is one (models/lookahead.py)."""
         res = self._look.take(a, b) if self._look is not None else None

@@ -115,6 +115,11 @@ class RIFE:
             _ops.pair_interleaved(f1)
         return flow01, flow10, f0, f1
 
+    def warm_reuse(self, Ia, Ib):
+        """The `reuse` a DRBA step ending on the pair (Ia, Ib) hands to the next step (rife.py:82-85,109)."""
+        flow_ab, flow_ba, fa, fb = self.calc_flow(Ia, Ib)
+        return (flow_ba, flow_ab, fb, fa)
+
     def _warm_step(self, I0, I1, I2, flow10, f1, f0, kinds, t_dev):
         """The steady-state body of inference_ts_drba with linear DRM; timesteps come from device memory."""
         flow12, flow21, f1, f2 = self.calc_flow(I1, I2, f0=f1)

@@ -52,33 +52,66 @@ def _workspace(device, nfloats):
     return buf
 
 
-# Optional per-launch timing (bench.py's roofline leg).  When TIMING is a dict
-# {"want": callable(kind, key) -> bool, "records": []}: each selected launch appends (kind, key, work, unit, slot).
-# `slot` names an event pair inside libdrba_hip.so that is attached to the launch's own dispatch packet
-# (drba_timing_arm -> hipExtLaunchKernelGGL), so the pair brackets exactly the kernel's execution, as rocprofv3's
-# kernel trace does; an event recorded on the stream before/after a launch adds a barrier packet each side and reads
-# ~10 us long.  bench.py turns the slots into durations with timing_ms() after the timed region.
-TIMING = None
+# Optional kernel trace (bench.py's roofline leg).  While TRACE is a list, the library times EVERY kernel it launches
+# (drba_trace_begin: an event pair on each launch's own dispatch packet, so a record is the kernel's own execution time,
+# as rocprofv3's kernel trace reports it -- an event recorded on the stream before/after a launch adds a barrier packet
+# each side and reads ~10 us long).  The wrappers below that know their kernel's algorithmic work append
+# (first trace index, [(work, unit, label), ...]) for the launches of the call they just made; bench.py joins these tags
+# with the library's records (kernel name, grid, duration) after the timed region.
+TRACE = None
+
+
+def trace_begin():
+    global TRACE
+    _lib.check(_lib.load().drba_trace_begin(), "drba_trace_begin")
+    TRACE = []
+
+
+def trace_pause():
+    """Stop recording (steps outside the instrumented ones); the records made so far stay readable."""
+    _lib.check(_lib.load().drba_trace_end(), "drba_trace_end")
+
+
+def trace_resume():
+    _lib.check(_lib.load().drba_trace_resume(), "drba_trace_resume")
+
+
+def trace_end():
+    """-> [{"name", "grid", "ms", "work", "unit", "label"}] for every launch recorded, in launch order."""
+    global TRACE
+    lib = _lib.load()
+    _lib.check(lib.drba_trace_end(), "drba_trace_end")
+    tags, TRACE = TRACE or [], None
+    recs = []
+    name, grid, ms = C.c_char_p(), (C.c_uint * 3)(), C.c_float()
+    for i in range(lib.drba_trace_count()):
+        _lib.check(lib.drba_trace_get(i, C.byref(name), grid, C.byref(ms)), "drba_trace_get")
+        recs.append({"name": name.value.decode(), "grid": tuple(grid), "ms": float(ms.value), "work": None, "unit": None,
+                     "label": None})
+    for first, items in tags:
+        for k, it in enumerate(items):
+            if it is not None and first + k < len(recs):
+                recs[first + k]["work"], recs[first + k]["unit"], recs[first + k]["label"] = it
+    return recs
 
 
 def _timed(kind, key, work, unit, launch):
-    t = TIMING
-    if t is None or not t["want"](kind, key):
+    """Run `launch`; when tracing, tag its (single) kernel launch with its algorithmic work."""
+    if TRACE is None:
         return launch()
-    lib = _lib.load()
-    slot = len(t["records"])
-    if slot >= lib.drba_timing_slots():
-        return launch()
-    _lib.check(lib.drba_timing_arm(slot), "drba_timing_arm")
+    first = _lib.load().drba_trace_count()
     r = launch()
-    t["records"].append((kind, key, work, unit, slot))
+    TRACE.append((first, [(work, unit, f"{kind} {key}")]))
     return r
 
 
-def timing_ms(slot):
-    ms = C.c_float(0.0)
-    _lib.check(_lib.load().drba_timing_elapsed_ms(int(slot), C.byref(ms)), "drba_timing_elapsed_ms")
-    return float(ms.value)
+def _tag(first, items):
+    if TRACE is not None:
+        TRACE.append((first, items))
+
+
+def _trace_pos():
+    return _lib.load().drba_trace_count() if TRACE is not None else 0
 
 
 # ----------------------------------------------------------------------------- splat / warp / drm
@@ -123,7 +156,9 @@ def flow_reverse(flow):
     n, _, h, w = flow.shape
     out = torch.empty_like(flow)
     ws = _workspace(flow.device, n * h * w * 3)
+    first = _trace_pos()
     _lib.check(_lib.load().drba_flow_reverse(_p(flow), _p(out), _p(ws), n, h, w, _stream()), "drba_flow_reverse")
+    _tag(first, [None, (16.0 * n * h * w, "byte", f"flow_reverse {(n, h, w)}")])  # long-flow prepass, then the tiled splat
     return out
 
 
@@ -133,8 +168,10 @@ def drm_rife_linear(flow_self, flow_other, t, eps=1e-4, t_dev=None):
     n, _, h, w = a.shape
     out = torch.empty((n, 1, h, w), dtype=torch.float32, device=a.device)
     ws = _workspace(a.device, n * h * w * 2)
+    first = _trace_pos()
     _lib.check(_lib.load().drba_drm_rife_linear(_p(a), _p(b), float(t), _p(t_dev), float(eps), _p(out), _p(ws), n, h,
                                                 w, _stream()), "drba_drm_rife_linear")
+    _tag(first, [None, (20.0 * n * h * w, "byte", f"drm_rife_linear {(n, h, w)}")])  # long-flow prepass, then the tiled splat
     return out
 
 
@@ -186,8 +223,9 @@ def resize_bilinear(x, size):
     out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
     sy = float(np.float32(h) / np.float32(ho))  # ATen: static_cast<float>(in) / out
     sx = float(np.float32(w) / np.float32(wo))
-    _lib.check(_lib.load().drba_resize_bilinear(_p(x), _p(out), n * c, h, w, ho, wo, sy, sx, _stream()),
-               "drba_resize_bilinear")
+    nbytes = 4.0 * n * c * (min(h * w, 4 * ho * wo) + ho * wo)
+    _lib.check(_timed("resize_bilinear", (n * c, h, w, ho, wo), nbytes, "byte", lambda: _lib.load().drba_resize_bilinear(
+        _p(x), _p(out), n * c, h, w, ho, wo, sy, sx, _stream())), "drba_resize_bilinear")
     return out
 
 
@@ -208,7 +246,8 @@ def u8hwc_to_f32nchw(img_u8):
     img_u8 = img_u8.contiguous()
     h, w = img_u8.shape[:2]
     out = torch.empty((1, 3, h, w), dtype=torch.float32, device=img_u8.device)
-    _lib.check(_lib.load().drba_u8hwc_to_f32nchw(_p(img_u8), _p(out), h, w, _stream()), "drba_u8hwc_to_f32nchw")
+    _lib.check(_timed("u8hwc_to_f32nchw", (h, w), 15.0 * h * w, "byte", lambda: _lib.load().drba_u8hwc_to_f32nchw(
+        _p(img_u8), _p(out), h, w, _stream())), "drba_u8hwc_to_f32nchw")
     return out
 
 
@@ -217,7 +256,8 @@ def f32nchw_to_u8hwc(x):
     assert x.shape[0] == 1 and x.shape[1] == 3
     h, w = x.shape[2:]
     out = torch.empty((h, w, 3), dtype=torch.uint8, device=x.device)
-    _lib.check(_lib.load().drba_f32nchw_to_u8hwc(_p(x), _p(out), h, w, _stream()), "drba_f32nchw_to_u8hwc")
+    _lib.check(_timed("f32nchw_to_u8hwc", (h, w), 15.0 * h * w, "byte", lambda: _lib.load().drba_f32nchw_to_u8hwc(
+        _p(x), _p(out), h, w, _stream())), "drba_f32nchw_to_u8hwc")
     return out
 
 
@@ -371,7 +411,7 @@ class Deconv4x4:
             cfg = lib.drba_deconv4x4_pick_cfg(self.cin, self.cout, h, w)
         _lib.check(min(cfg, 0), "drba_deconv4x4_pick_cfg")
         wp = self._pack(cfg)
-        key = (cfg, cin, self.cout, h, w, 2)
+        key = (cfg, cin, self.cout, h, w, 2, n)
         _lib.check(_timed("deconv4x4", key, 2.0 * self.cout * cin * 16 * h * w * n, "flop", lambda: lib.drba_deconv4x4s2(
             _p(x), _p(wp), _p(self.bias), _p(out), n, cin, h, w, self.cout, self.ps, pre, ps_, cfg, _stream())),
             "drba_deconv4x4s2")
@@ -396,7 +436,7 @@ class ConvChain:
     def _plan(self, n, h, w, device):
         lib = _lib.load()
         descs = (_lib.ConvLayer * len(self.layers))()
-        keep, sizes = [], []
+        keep, sizes, tags = [], [], []
         hh, ww = h, w
         for i, (layer, res) in enumerate(self.layers):
             d = descs[i]
@@ -407,6 +447,8 @@ class ConvChain:
                 if cfg is None or layer.pre_slope is not None:
                     return None
                 d.deconv, d.pixel_shuffle, d.stride, d.act, d.residual = 1, layer.ps, 1, 0, 0
+                tags.append((2.0 * layer.cout * layer.cin * 16 * hh * ww * n, "flop",
+                             f"deconv4x4 {(cfg, layer.cin, layer.cout, hh, ww, 2, n)}"))
                 hh, ww = 2 * hh, 2 * ww
                 sizes.append(n * (layer.cout // 4 if layer.ps else layer.cout) * hh * ww * (4 if layer.ps else 1))
             else:
@@ -420,6 +462,8 @@ class ConvChain:
                 d.beta = 0 if layer.beta is None else layer.beta.data_ptr()
                 hh, ww = ho, wo
                 sizes.append(n * layer.cout * hh * ww)
+                tags.append((2.0 * layer.cout * layer.cin * 9 * ho * wo * n, "flop",
+                             f"conv3x3 {(cfg, layer.cin, layer.cout, ho, wo, layer.stride, n)}"))
             layer._keep.add(cfg)
             wp = layer._pack(cfg)
             keep.append(wp)
@@ -429,7 +473,7 @@ class ConvChain:
         out_shape = ((n, last.cout // 4, 2 * hh, 2 * ww) if (isinstance(last, Deconv4x4) and last.ps)
                      else (n, last.cout, hh, ww))
         return {"descs": descs, "keep": keep, "scratch": max(sizes[:-1]) if len(sizes) > 1 else 0, "out_shape": out_shape,
-                "bufs": {}}
+                "bufs": {}, "tags": tags}
 
     def __call__(self, x):
         x = _f32(x)
@@ -438,7 +482,7 @@ class ConvChain:
         plan = self._plans.get(key)
         if plan is None and key in self._plans:  # known: not chainable
             return self._eager(x)
-        if TIMING is not None or not x.is_cuda:
+        if not x.is_cuda:
             return self._eager(x)
         if plan is None:
             plan = self._plans[key] = self._plan(n, h, w, x.device)
@@ -453,8 +497,10 @@ class ConvChain:
             bufs = plan["bufs"][stream.value] = (torch.empty(m, dtype=torch.float32, device=x.device),
                                                  torch.empty(m, dtype=torch.float32, device=x.device))
         out = torch.empty(plan["out_shape"], dtype=torch.float32, device=x.device)
+        first = _trace_pos()
         _lib.check(_lib.load().drba_conv_chain(_p(x), _p(out), _p(bufs[0]), _p(bufs[1]), plan["descs"], len(self.layers), n,
                                                h, w, stream), "drba_conv_chain")
+        _tag(first, plan["tags"])  # one launch per layer, in order
         return out
 
 
@@ -468,7 +514,8 @@ def pair_interleaved(f):
     if fp is None:
         n, c, h, w = f.shape
         fp = torch.empty((c // 2, h, w, 2), dtype=torch.float32, device=f.device)
-        _lib.check(_lib.load().drba_pair_interleave(_p(f), _p(fp), c, h, w, _stream()), "drba_pair_interleave")
+        _lib.check(_timed("pair_interleave", (c, h, w), 8.0 * c * h * w, "byte", lambda: _lib.load().drba_pair_interleave(
+            _p(f), _p(fp), c, h, w, _stream())), "drba_pair_interleave")
         f._drba_pair = fp
     return fp
 
@@ -517,8 +564,9 @@ def ifblock_update(tmp, flow_in, H, W, scale, want_mask_feat=False):
         feat = torch.empty((1, 8, H, W), dtype=torch.float32, device=dev)
     if flow_in is not None:
         flow_in = _f32(flow_in)
-    _lib.check(_lib.load().drba_ifblock_update(_p(tmp), _p(flow_in), _p(flow), _p(mask), _p(feat), h, w, H, W,
-                                               float(scale), _stream()), "drba_ifblock_update")
+    nbytes = 4.0 * (13 * h * w + (4 if flow_in is not None else 0) * H * W + (13 if want_mask_feat else 4) * H * W)
+    _lib.check(_timed("ifblock_update", (h, w, H, W), nbytes, "byte", lambda: _lib.load().drba_ifblock_update(
+        _p(tmp), _p(flow_in), _p(flow), _p(mask), _p(feat), h, w, H, W, float(scale), _stream())), "drba_ifblock_update")
     return (flow, mask, feat) if want_mask_feat else flow
 
 
@@ -529,8 +577,10 @@ def warp_blend(img0, img1, flow, tmp_last, scale):
     h, w = tmp_last.shape[2], tmp_last.shape[3]
     mask_lo = tmp_last[:, 4:5]  # contiguous plane of the [1,13,h,w] tensor
     out = torch.empty((1, 3, H, W), dtype=torch.float32, device=img0.device)
-    _lib.check(_lib.load().drba_warp_blend(_p(img0), _p(img1), _p(flow), C.c_void_p(mask_lo.data_ptr()), h, w,
-                                           float(scale), _p(out), H, W, _stream()), "drba_warp_blend")
+    nbytes = 4.0 * ((6 + 4 + 3) * H * W + h * w)
+    _lib.check(_timed("warp_blend", (H, W), nbytes, "byte", lambda: _lib.load().drba_warp_blend(
+        _p(img0), _p(img1), _p(flow), C.c_void_p(mask_lo.data_ptr()), h, w, float(scale), _p(out), H, W, _stream())),
+        "drba_warp_blend")
     return out
 
 

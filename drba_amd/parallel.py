@@ -40,12 +40,31 @@ def warm_reuse(model, Ia, Ib):
     return (flow_ba, flow_ab, fb, fa)
 
 
+def emission_counts(n_frames, src_fps, dst_fps, times, world):
+    """Output frames per emission (head / loop iteration / tail) of every rank: [[count, ...] per rank].
+    Every branch of the driver loop emits len(calc_t(idx)) frames (copies at scene cuts replace synthesised frames one
+    for one, infer.py:98-103,121-143,160-162), so the counts are known to all ranks without any communication."""
+    mapper = _tools.TMapper(src_fps, dst_fps, times)
+    n_loop = max(n_frames - 2, 0)
+    out = []
+    for r, (a, b) in enumerate(partition(n_loop, world)):
+        c = [len(_tools.calc_t(0, times, mapper))] if r == 0 else []
+        c += [len(_tools.calc_t(k, times, mapper)) for k in range(a, b)]
+        if r == world - 1 and n_frames >= 2:
+            c.append(len(_tools.calc_t(n_frames - 2, times, mapper)))
+        out.append(c)
+    return out
+
+
 def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, enable_scdet=False, scdet_threshold=0.3,
-                      to_inp=None, to_out=None, check_scene=None):
+                      to_inp=None, to_out=None, check_scene=None, sink=None):
     """Run this rank's share of the clip.  `frames` is a random-access sequence of uint8 HWC frames
     (every rank can index it; only its own range plus the halo is touched).
     Returns the list of output frames (whatever to_out returns) this rank is responsible for, in order.
-    Concatenating the lists of ranks 0..world-1 gives exactly the sequential driver's output."""
+    Concatenating the lists of ranks 0..world-1 gives exactly the sequential driver's output.
+    `sink(list_of_frames)`, if given, receives each emission (head / one loop iteration / tail) as it is produced
+    instead (StreamedGather.push: the frames travel to the writer rank while the next steps compute) and the
+    function returns []."""
     to_inp = to_inp or _tools.to_inp
     to_out = to_out or _tools.to_out
     check_scene = check_scene or _tools.check_scene
@@ -70,7 +89,11 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
     out = []
 
     def emit(xs):
-        out.extend(to_out(x, src_size) for x in xs)
+        fr = [to_out(x, src_size) for x in xs]
+        if sink is not None:
+            sink(fr)
+        else:
+            out.extend(fr)
 
     # ---- head (rank 0 only): infer.py:93-110
     if rank == 0:
@@ -117,6 +140,89 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
     return out
 
 
+def _default_device(group=None):
+    """Where collective buffers must live: the current GPU for the nccl (= RCCL) backend, host memory for gloo."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+class StreamedGather:
+    """The RCCL gather of finished uint8 frames to the writer rank, overlapped with the computation.
+
+    One gather at the end of a shard leaves the xGMI links idle while the GPUs compute and the GPUs idle while the
+    frames travel (8 ranks x 40 1080p frames = 2 GB into rank 0).  Here the emissions (head / loop iteration / tail)
+    of a rank are grouped into rounds of `chunk` emissions; after its j-th round every rank contributes a fixed-size
+    padded buffer to an ASYNCHRONOUS dist.gather (RCCL runs it on its own stream, under the next steps' kernels).  All
+    sizes follow from emission_counts(), which every rank computes locally, so ranks with fewer emissions (no head /
+    tail) still take part in every round and the collectives are issued in the same order everywhere.
+    finish() returns the ordered frame list on rank 0 (None elsewhere)."""
+
+    def __init__(self, rank, world, counts, chunk=4, device=None, group=None, frame_shape=None):
+        self.rank, self.world, self.group, self.chunk = rank, world, group, max(1, int(chunk))
+        self.dev = device if device is not None else (_default_device(group) if world > 1 else None)
+        self.counts = counts
+        self.n_rounds = max((len(c) + self.chunk - 1) // self.chunk for c in counts) if counts else 0
+        # frames rank r contributes in round j
+        self.per_round = [[sum(c[j * self.chunk:(j + 1) * self.chunk]) for j in range(self.n_rounds)] for c in counts]
+        self.cap = [max(self.per_round[r][j] for r in range(world)) for j in range(self.n_rounds)]
+        self.pending, self.emissions, self.round = [], 0, 0
+        self.handles, self.recv, self.keep = [], [], []
+        self.shape = None if frame_shape is None else tuple(frame_shape)  # (H, W, 3) of an output frame, if known
+        self.local = []  # world == 1: plain accumulation
+
+    def _tensor(self, f):
+        t = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
+        return t.to(self.dev, non_blocking=True) if self.dev is not None else t
+
+    def _issue(self):
+        """The gather of round self.round (every rank calls this the same number of times, in the same order)."""
+        import torch.distributed as dist
+        j = self.round
+        want = self.per_round[self.rank][j]
+        assert len(self.pending) == want, (self.rank, j, len(self.pending), want)
+        if self.shape is None:  # ranks whose first rounds are empty learn the frame shape from rank 0
+            shp = [tuple(self.pending[0].shape) if self.pending else None]
+            dist.broadcast_object_list(shp, src=0, group=self.group)
+            self.shape = shp[0]
+        buf = torch.empty((max(self.cap[j], 1),) + self.shape, dtype=torch.uint8, device=self.dev)
+        if self.pending:
+            torch.stack(self.pending, out=buf[:want])
+        recv = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
+        self.handles.append(dist.gather(buf, recv, dst=0, group=self.group, async_op=True))
+        self.recv.append(recv)
+        self.keep.append(buf)
+        self.pending = []
+        self.round += 1
+
+    def push(self, frames):
+        """One emission of this rank (a list of uint8 HWC frames)."""
+        if self.world == 1:
+            self.local.extend(frames)
+            return
+        self.pending.extend(self._tensor(f) for f in frames)
+        self.emissions += 1
+        if self.emissions % self.chunk == 0 or self.emissions == len(self.counts[self.rank]):
+            self._issue()
+
+    def finish(self):
+        if self.world == 1:
+            return list(self.local)
+        assert self.emissions == len(self.counts[self.rank]), "every emission must be pushed before finish()"
+        while self.round < self.n_rounds:  # ranks with fewer emissions: empty contributions to the remaining rounds
+            self._issue()
+        for h in self.handles:
+            h.wait()
+        if self.rank != 0:
+            return None
+        out = []
+        for r in range(self.world):
+            for j in range(self.n_rounds):
+                out.extend(self.recv[j][r][k] for k in range(self.per_round[r][j]))
+        return out
+
+
 def gather_frames(local_frames, rank, world, device=None, group=None):
     """Gather every rank's finished uint8 frames on rank 0 (the writer), in rank order.
 
@@ -125,7 +231,7 @@ def gather_frames(local_frames, rank, world, device=None, group=None):
     import torch.distributed as dist
     if world == 1:
         return list(local_frames)
-    dev = device if device is not None else torch.device("cpu")
+    dev = device if device is not None else _default_device(group)
     as_t = [f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f)) for f in local_frames]
     shape = tuple(as_t[0].shape) if as_t else None
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]

@@ -30,13 +30,18 @@ extern "C" {
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 
-/* ---- per-launch kernel timing (measurement only; bench.py's roofline object) ---------------
- * drba_timing_arm(slot) attaches event pair `slot` to the dispatch packet of the NEXT drba_conv3x3 /
- * drba_deconv4x4s2 / drba_ifblock_input / drba_window_attention / drba_linear_split* launch on this thread;
- * drba_timing_elapsed_ms waits for that launch and returns the kernel's own execution time. */
-int drba_timing_slots(void);
-int drba_timing_arm(int slot);
-int drba_timing_elapsed_ms(int slot, float *ms);
+/* ---- kernel trace (measurement only; bench.py's roofline object) ---------------------------
+ * Between drba_trace_begin() and drba_trace_end() every kernel the library launches (on any stream, from the one host
+ * thread that drives it) carries an event pair on its own dispatch packet, i.e. each record is the kernel's own
+ * execution time, as rocprofv3's kernel trace reports it.  drba_trace_begin() clears the records, drba_trace_end() stops
+ * recording and drba_trace_resume() continues without clearing.  drba_trace_count() = records so far (launch order);
+ * drba_trace_get(i, ...) waits for launch i and returns its demangled kernel name (without the argument list), its
+ * grid in workgroups and its duration.  Not part of the reference's surface. */
+int drba_trace_begin(void);
+int drba_trace_end(void);
+int drba_trace_resume(void);
+int drba_trace_count(void);
+int drba_trace_get(int i, const char **name, unsigned *grid3, float *ms);
 
 /* ---- forward splat ----------------------------------------------------------------------
  * replaces: models/softsplat/softsplat.py:248-293 (softsplat) + :306-367 (kernel softsplat_out)

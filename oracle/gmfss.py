@@ -182,6 +182,12 @@ class GmfssUnionOracle:
         self.pad_size = 128
 
     @torch.no_grad()
+    def warm_reuse(self, Ia, Ib):
+        """reuse entering the step after a DRBA step on (.., Ia, Ib): model.reuse(Ia, Ib), roles swapped."""
+        r = self.model.reuse(Ia, Ib, self.scale)
+        return [v for pair in zip(r[1::2], r[0::2]) for v in pair]
+
+    @torch.no_grad()
     def inference_ts(self, I0, I1, ts):
         reuse = self.model.reuse(I0, I1, self.scale)
         out = []
@@ -235,6 +241,12 @@ class GmfssOracle:
         self.model = GmfssModel(flownet, metric, feat, fusion, union=False)
         self.scale = scale
         self.pad_size = 64
+
+    @torch.no_grad()
+    def warm_reuse(self, Ia, Ib):
+        """reuse entering the step after a DRBA step on (.., Ia, Ib): model.reuse(Ia, Ib), roles swapped."""
+        r = self.model.reuse(Ia, Ib, self.scale)
+        return [v for pair in zip(r[1::2], r[0::2]) for v in pair]
 
     @torch.no_grad()
     def inference_ts(self, I0, I1, ts):

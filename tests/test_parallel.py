@@ -42,20 +42,41 @@ class _IO:
 def _clip(case):
     if case == "cut":
         return synth.make_clip(9, 64, 128, seed=3, cut_at=4)
+    if case.startswith("gmfss"):  # GMFlow needs >= 128 x 256 (window splits of the 1/8 and 1/4 resolution maps)
+        return synth.make_clip(6, 128, 256, seed=3)
     return synth.make_clip(9, 64, 128, seed=3)
 
 
-def _worker(rank, world, port, case, times, dst_fps, scdet, q):
+def _model(case):
     import oracle
+    from tests import cases
+    if case == "gmfss_union":
+        s = synth.gmfss_union_state_dicts(seed=0)
+        return oracle.gmfss.GmfssUnionOracle(s["flownet"], s["metric"], s["feat"], s["fusion"], s["rife"], 1.0)
+    if case == "gmfss":
+        s = cases.gmfss_state_dicts(seed=0)
+        return oracle.gmfss.GmfssOracle(s["flownet"], s["metric"], s["feat"], s["fusion"], 1.0)
+    return oracle.rife.RifeOracle(synth.ifnet_state_dict(seed=0), 1.0)
+
+
+def _worker(rank, world, port, case, times, dst_fps, scdet, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    model = oracle.rife.RifeOracle(synth.ifnet_state_dict(seed=0), 1.0)
+    model = _model(case)
     frames = _clip(case)
     to_inp, to_out, check = _cpu_hooks()
-    mine = parallel.interpolate_shard(model, frames, 24.0, dst_fps, rank, world, times=times, enable_scdet=scdet,
-                                      to_inp=to_inp, to_out=to_out, check_scene=check)
-    allf = parallel.gather_frames(mine, rank, world)
+    if case in ("cut", "gmfss_union"):  # frames streamed to the writer in rounds of 2 emissions while the shard runs
+        sg = parallel.StreamedGather(rank, world, parallel.emission_counts(len(frames), 24.0, dst_fps, times, world), chunk=2,
+                                     frame_shape=None if case == "cut" else frames[0].shape)
+        rest = parallel.interpolate_shard(model, frames, 24.0, dst_fps, rank, world, times=times, enable_scdet=scdet,
+                                          to_inp=to_inp, to_out=to_out, check_scene=check, sink=sg.push)
+        assert rest == []
+        allf = sg.finish()
+    else:
+        mine = parallel.interpolate_shard(model, frames, 24.0, dst_fps, rank, world, times=times, enable_scdet=scdet,
+                                          to_inp=to_inp, to_out=to_out, check_scene=check)
+        allf = parallel.gather_frames(mine, rank, world)
     if rank == 0:
         io = _IO(frames, 24.0)
         drv.interpolate_stream(model, io, dst_fps, times=times, enable_scdet=scdet, to_inp=to_inp, to_out=to_out,
@@ -74,7 +95,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("case,times,dst_fps,scdet", [("plain", 2, 60, False), ("cut", -1, 60, True)])
+@pytest.mark.parametrize("case,times,dst_fps,scdet", [("plain", 2, 60, False), ("cut", -1, 60, True),
+                                                      ("gmfss", 2, 60, False), ("gmfss_union", -1, 60, False)])
 def test_sharded_equals_sequential_world2(case, times, dst_fps, scdet):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -97,3 +119,62 @@ def test_partition_covers_range():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+class _FakeModel:
+    """Cheap stand-in with the models' call surface whose outputs depend on the carried `reuse` state the way the real
+    ones do (cold and warm steps differ), so a wrong halo / cut state in a shard changes the frames."""
+    scale, pad_size = 1.0, 16
+
+    def calc_flow(self, a, b):
+        return a - b, b - a * 0.5, a * 2.0, b * 3.0
+
+    def inference_ts(self, I0, I1, ts):
+        return [I0 if t == 0 else I1 if t == 1 else (1 - t) * I0 + t * I1 for t in ts]
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False):
+        flow10, _, f1, _ = self.calc_flow(I1, I0) if not reuse else reuse
+        flow12, flow21, f1b, f2 = self.calc_flow(I1, I2)
+        out = []
+        for t in ts:
+            if t in (0, 1, 2):
+                out.append((I0, I1, I2)[int(t)])
+            else:
+                out.append((I1 + 0.1 * flow10 * (1 - t) + 0.05 * flow12 * t + 0.01 * f1).clamp(0, 1))
+        return out, (flow21, flow12, f2, f1b)
+
+
+def _fake_worker(rank, world, port, scdet, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    frames = synth.make_clip(7, 32, 64, seed=5, cut_at=3 if scdet else None)
+    to_inp, to_out, check = _cpu_hooks()
+    model = _FakeModel()
+    sg = parallel.StreamedGather(rank, world, parallel.emission_counts(len(frames), 24.0, 60, -1, world), chunk=2)
+    parallel.interpolate_shard(model, frames, 24.0, 60, rank, world, enable_scdet=scdet, to_inp=to_inp, to_out=to_out,
+                               check_scene=check, sink=sg.push)
+    allf = sg.finish()
+    if rank == 0:
+        io = _IO(frames, 24.0)
+        drv.interpolate_stream(model, io, 60, enable_scdet=scdet, to_inp=to_inp, to_out=to_out, check_scene=check)
+        q.put((len(allf), len(io.written), all(np.array_equal(a.numpy(), b) for a, b in zip(allf, io.written))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scdet", (False, True))
+def test_streamed_gather_uneven_world3(scdet):
+    """7 frames -> 5 loop iterations over 3 ranks (2, 2, 1): ranks have 3 / 2 / 2 emissions, rounds of 2, so the last
+    round is empty for two ranks; the streamed result must equal the sequential driver's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fake_worker, args=(r, 3, port, scdet, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    n_sharded, n_seq, same = q.get(timeout=10)
+    assert n_sharded == n_seq and same
