@@ -1,30 +1,40 @@
 #!/usr/bin/env python3
 """DRBA hot-path benchmark: interpolated frames/s, `rife -t 2`, 1080p (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1080p|4k|480p] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1080p|4k|480p|4k_s1] [--no-cpu-baseline] [--no-extra]
 
-A *step* = one source frame of the driver's steady state: the next uint8 frame (already resident
-in HBM) -> to_inp (u8->fp32 + bilinear resize to the network size) -> warm
-RIFE.inference_ts_drba(I0, I1, I2, ts=[0.75, 1.25], reuse, linear=True) -> to_out for the two
-model-generated frames (resize back + *255 truncation, still on the device).  Decode/encode and
-PCIe are outside the metric.  value = model-generated frames of ALL ranks / max-rank time.
-As in drba_amd.infer.interpolate_stream the loop reads one frame ahead, so the next step's coarse flow runs on a
-side stream under this step's interpolation (`--no-lookahead` disables it); every frame is converted and encoded
-exactly once either way, and the K timed steps contain K coarse-flow computations.
+A *step* = one source frame of the driver's steady state: the next uint8 frame (already resident in HBM) -> to_inp
+(u8 HWC -> fp32 NCHW + bilinear resize to the network size) -> warm RIFE.inference_ts_drba(I0, I1, I2, ts=[0.75, 1.25],
+reuse, linear=True) -> to_out for the two model-generated frames (resize back + *255 truncation, on the device).
+Decode/encode and PCIe are outside the metric; `pcie_inclusive` reports the same loop with the frames
+starting and ending in pinned host memory.  value = model-generated frames of ALL ranks / max-rank time.
+As in drba_amd.infer.interpolate_stream the loop reads one frame ahead, so the next step's coarse flow and
+low-resolution stages run on a side stream under this step's full-resolution stages (`--no-lookahead` disables it);
+every frame is converted and encoded exactly once either way and the K timed steps contain K steps of work.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): frame-level data parallelism, every
-rank interpolates its own contiguous shard of the clip (weak scaling: per-GPU work fixed); the only
-collective in the data path is the RCCL gather of the finished uint8 frames to rank 0 (the writer),
-inside the timed region.
+N = 1: the K-step loop above.
+N > 1 (launched by torch.distributed.run, one rank per GPU): ONE clip of N*K + 2 source frames is sharded with
+drba_amd.parallel.interpolate_shard (contiguous chunks, one-frame halo for the warm `reuse`, weak scaling: K steps per
+GPU), the finished uint8 frames travel to rank 0 (the writer) through StreamedGather -- the only data-path collective,
+RCCL over xGMI, inside the timed region.  `replica_loop` is the N = 1 loop run by every rank on its own clip (no halo,
+no collective) and `config5_sharded` BASELINE.json configs[4]: one FIXED 4K clip (-fps 60, scale 0.5, one planted scene
+cut) sharded over the N ranks (strong scaling).
 
 Extra objects on the JSON line:
-  roofline     the kernel with the largest total time among those that dominate the rocprof trace
-               (profiles/): algorithmic bytes (or FLOPs) per launch / average launch duration from HIP
-               events attached to those launches' dispatch packets on the launch stream during the timed
-               region (the kernel's own execution time, as rocprofv3's kernel trace reports it); peaks from
-               MI355X_MICROARCH.md (HBM 8 TB/s; dense fp32 MFMA 157.3 TFLOP/s).  `others` lists the next ones.
-  cpu_baseline the fp32 CPU oracle (a port validated against the reference) on the same workload,
-               bounded sample, host cores stated.
+  roofline      the kernel SYMBOL with the largest total time over the instrumented steps of the timed region (every
+                `roof_every`-th step runs with the library's kernel trace on: each launch carries an event pair on its
+                own dispatch packet, i.e. the kernel's own execution time as rocprofv3's kernel trace reports it).
+                achieved = sum of the launches' algorithmic FLOPs (or bytes) / sum of their durations; avg_us and
+                algorithmic_per_launch are plain means over the same launches; `by_geometry` splits the symbol by layer
+                shape; `others` = the next symbols; `step_kernels_ms` = all kernel time per step.  Peaks from
+                MI355X_MICROARCH.md (HBM 8 TB/s; dense fp32 MFMA 157.3 TFLOP/s; dense bf16 2500 TFLOP/s).
+                `traffic` = HBM bytes per launch from rocprofv3 --pmc passes (profiles/pmc_traffic.json, keyed by symbol).
+  cpu_baseline  the fp32 CPU oracle (a port pinned bit-for-bit to the reference, tests/golden) on the same workload:
+                bounded sample, all host cores (`value`) and one thread (`single_thread`).
+  max_abs_vs_oracle  max |HIP frame - oracle frame| over the frames of the cpu_baseline sample, same uint8 inputs
+                (fp32 at network size), plus the largest difference of the uint8 outputs in LSB.
+  extra_configs BASELINE.json configs[2], [3], [4] at N = 1 through the real driver loop (interpolate_stream) with the
+                clip resident in HBM, each with its own roofline entry.
 """
 import argparse
 import json
@@ -49,10 +59,10 @@ CONFIGS = {
     "4k_s1": ((2160, 3840), 1.0, "rife -t 2, 4K synthetic (net 2176x3840), scale 1.0"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense; the split-bf16 convolution spends 6 bf16 MFMA products per fp32 multiply
-N_FP32_CONV_CFGS = 14  # drba_conv3x3 cfg ids below this are the fp32 MFMA kernels, the rest the split-bf16 family
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense; the split-bf16 kernels spend 6 bf16 MFMA products per fp32 multiply
 HBM_PEAK_GBS = 8000.0
 TS = np.array([0.75, 1.25])  # what `-t 2` yields every step (infer.py:76-87)
+SRC_FPS = 24.0
 
 
 def parse():
@@ -62,52 +72,197 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--config", default="1080p", choices=sorted(CONFIGS))
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=1)
-    p.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU baseline (capped by affinity)")
+    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = every core the affinity mask allows)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip extra_configs / pcie_inclusive (configs 3-5 at N = 1)")
     p.add_argument("--no-lookahead", action="store_true", help="do not overlap the next step's coarse flow (A/B runs)")
     return p.parse_args()
 
 
-def make_frames_u8(n, h, w, seed):
-    """n distinct uint8 HWC frames; built from a short seeded clip cycled with a roll so the content keeps moving."""
+def make_frames_u8(n, h, w, seed, cut_at=None):
+    """n distinct uint8 HWC frames; built from a short seeded clip cycled with a roll so the content keeps moving.
+    `cut_at`: frames from that index on come from an independently seeded scene (scene-cut configs)."""
     base = synth.make_clip(min(n, 8), h, w, seed=seed)
+    other = synth.make_clip(min(n, 8), h, w, seed=seed + 7919) if cut_at is not None else None
     out = []
     for k in range(n):
-        f = base[k % len(base)]
-        out.append(np.roll(f, (k // len(base)) * 3, axis=1) if k >= len(base) else f)
+        src = other if (cut_at is not None and k >= cut_at) else base
+        f = src[k % len(src)]
+        out.append(np.roll(f, (k // len(src)) * 3, axis=1) if k >= len(src) else f)
     return out
 
 
-def gpu_leg(args, rank, world):
-    import torch.distributed as dist
+class DeviceClip:
+    """make_frames_u8 as a random-access sequence of uint8 HWC tensors resident in HBM (only 8 (+8) base frames are
+    stored; frame k is a view or a roll of one of them), so a rank touches only its own range of a long clip."""
 
+    def __init__(self, n, h, w, seed, dev, cut_at=None):
+        self.n, self.cut_at = n, cut_at
+        self.base = [torch.from_numpy(f).to(dev) for f in synth.make_clip(min(n, 8), h, w, seed=seed)]
+        self.other = ([torch.from_numpy(f).to(dev) for f in synth.make_clip(min(n, 8), h, w, seed=seed + 7919)]
+                      if cut_at is not None else None)
+        self.shape = tuple(self.base[0].shape)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, k):
+        if not 0 <= k < self.n:
+            raise IndexError(k)
+        src = self.other if (self.cut_at is not None and k >= self.cut_at) else self.base
+        f = src[k % len(src)]
+        return torch.roll(f, (k // len(src)) * 3, dims=1) if k >= len(src) else f
+
+
+class _Counting:
+    """Wraps a model: counts the frames it SYNTHESISES (pass-through copies at t in {0, 1, 2} are not model output)."""
+
+    def __init__(self, m):
+        self.m, self.generated = m, 0
+        self.scale, self.pad_size = m.scale, m.pad_size
+        self.supports_lookahead = bool(getattr(m, "supports_lookahead", False))
+
+    def inference_ts(self, I0, I1, ts):
+        self.generated += sum(1 for t in ts if t not in (0, 1))
+        return self.m.inference_ts(I0, I1, ts)
+
+    def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False, **kw):
+        self.generated += sum(1 for t in ts if t not in (0, 1, 2))
+        return self.m.inference_ts_drba(I0, I1, I2, ts, reuse, linear, **kw)
+
+    def warm_reuse(self, a, b):
+        return self.m.warm_reuse(a, b)
+
+
+class _DevIO:
+    """VideoFI_IO's read/write surface over a clip resident in HBM (decode/encode are outside the metric)."""
+
+    def __init__(self, clip, fps):
+        self.src_fps, self.total_frames_count = fps, len(clip)
+        self.clip, self.k, self.written = clip, 0, 0
+        self.last = None
+
+    def read_frame(self):
+        if self.k >= len(self.clip):
+            return None
+        self.k += 1
+        return self.clip[self.k - 1]
+
+    def write_frame(self, x):
+        self.written += 1
+        self.last = x
+
+
+def _dev_hooks():
     from drba_amd import ops
-    from drba_amd.models.rife import RIFE
-    from drba_amd.models.utils import tools
 
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    (H, W), scale, desc = CONFIGS[args.config]
-    model = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=scale, device=dev)
+    def to_inp(frame_u8, dst_size):
+        return ops.to_inp(frame_u8, dst_size)
+
+    def to_out(x, src_size):
+        return ops.to_out(x, src_size)
+
+    return to_inp, to_out
+
+
+# ------------------------------------------------------------------------------------------------- roofline
+def _peak(name, unit):
+    if unit == "byte":
+        return HBM_PEAK_GBS, "GB/s", "hbm", "HBM3E 8 TB/s"
+    if "split" in name:
+        return round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), "TFLOP/s", "mfma", "dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32 multiply"
+    return FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma", "dense fp32 MFMA"
+
+
+def roofline_from_trace(recs, n_steps, traffic=None):
+    """recs: ops.trace_end() records of `n_steps` instrumented steps.  Ranks kernel symbols by total time."""
+    if not recs or n_steps <= 0:
+        return None
+    agg = {}
+    for r in recs:
+        a = agg.setdefault(r["name"], {"ms": 0.0, "n": 0, "work": 0.0, "tagged": 0, "unit": None, "geo": {}})
+        a["ms"] += r["ms"]
+        a["n"] += 1
+        if r["work"] is not None:
+            a["work"] += r["work"]
+            a["tagged"] += 1
+            a["unit"] = r["unit"]
+            g = a["geo"].setdefault(r["label"], [0.0, 0, 0.0])
+            g[0] += r["ms"]
+            g[1] += 1
+            g[2] += r["work"]
+    total_ms = sum(a["ms"] for a in agg.values())
+    ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+
+    def entry(name, a, with_geo):
+        e = {"kernel": name, "launches_per_step": round(a["n"] / n_steps, 2), "avg_us": round(a["ms"] / a["n"] * 1e3, 2),
+             "ms_per_step": round(a["ms"] / n_steps, 4), "share_of_kernel_time": round(a["ms"] / total_ms, 4)}
+        if a["tagged"] == a["n"] and a["ms"] > 0:  # every launch of the symbol carries its algorithmic work
+            peak, unit, bound, basis = _peak(name, a["unit"])
+            ach = a["work"] / (a["ms"] * 1e-3) / (1e9 if a["unit"] == "byte" else 1e12)
+            e.update({"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                      "algorithmic_per_launch": a["work"] / a["n"], "peak_basis": basis,
+                      "traffic": (traffic or {}).get(name)})
+            if with_geo:
+                e["by_geometry"] = [
+                    {"launch": lab, "launches_per_step": round(g[1] / n_steps, 2), "avg_us": round(g[0] / g[1] * 1e3, 2),
+                     "frac": round(g[2] / (g[0] * 1e-3) / (1e9 if a["unit"] == "byte" else 1e12) / peak, 4)}
+                    for lab, g in sorted(a["geo"].items(), key=lambda kv: -kv[1][0])[:6]]
+        else:
+            e.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None})
+        return e
+
+    roof = entry(*ranked[0], True)
+    roof["others"] = [entry(n, a, False) for n, a in ranked[1:5]]
+    roof["step_kernels_ms"] = round(total_ms / n_steps, 3)
+    roof["kernels_per_step"] = round(len(recs) / n_steps, 1)
+    roof["instrumented_steps"] = n_steps
+    return roof
+
+
+def _traffic_table():
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
+    return json.load(open(tpath)) if os.path.exists(tpath) else {}
+
+
+# ------------------------------------------------------------------------------------------------- GPU legs
+def _fence(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False):
+    """The N = 1 loop of the module docstring over `frames` (sequence of uint8 HWC frames: device tensors, or -- with
+    pcie=True -- pinned host tensors with the outputs copied back to pinned host buffers).
+    -> (seconds for args.steps steps, host-side enqueue seconds, trace records, instrumented steps)."""
+    from drba_amd import ops
+    from drba_amd.models.utils import tools
+    H, W = frames[0].shape[:2]
     size = tools.get_valid_net_inp_size(np.zeros((H, W, 3), np.uint8), model.scale, div=model.pad_size)
     src_size, dst_size = size["src_size"], size["dst_size"]
-
-    n_steps = args.warmup + args.steps
-    frames = [torch.from_numpy(f).to(dev) for f in make_frames_u8(min(n_steps + 2, 12), H, W, seed=1234 + rank)]
     nf = len(frames)
+    dev = model.device
+    host_out = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(4)] if pcie else None
 
     def to_inp(k):
-        return ops.resize_bilinear(ops.u8hwc_to_f32nchw(frames[k % nf]), dst_size)
+        f = frames[k % nf]
+        if pcie:
+            f = f.to(dev, non_blocking=True)
+        return ops.to_inp(f, dst_size)
+
+    n_out = [0]
 
     def to_out(x):
-        return ops.f32nchw_to_u8hwc(ops.resize_bilinear(x, src_size))
+        y = ops.to_out(x, src_size)
+        if pcie:
+            host_out[n_out[0] % 4].copy_(y, non_blocking=True)
+            n_out[0] += 1
+        return y
 
-    I0, I1 = to_inp(0), to_inp(1)
-    state = {"I0": I0, "I1": I1, "reuse": None, "k": 2}
-    sink = []
-
+    state = {"I0": to_inp(0), "I1": to_inp(1), "reuse": None, "k": 2}
     lookahead = not args.no_lookahead
 
     def step():
@@ -119,105 +274,188 @@ def gpu_leg(args, rank, world):
         nxt = to_inp(state["k"] + 1) if lookahead else None
         out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True,
                                                       lookahead=None if nxt is None else (nxt, TS))
-        for x in out:
-            sink.append(to_out(x))
+        res = [to_out(x) for x in out]
         state["I0"], state["I1"] = state["I1"], I2
         state["next"] = nxt
         state["k"] += 1
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        return res
 
     for _ in range(args.warmup):
         step()
-    sink.clear()
-    timing = None
-    if not args.no_roofline:
-        # time only the kernels that dominate the rocprof trace: the stage-input gather (HBM-bound) and the large
-        # ResConv layers (MFMA-bound).  The event pair of a timed launch is attached to the launch's own dispatch
-        # packet inside the library (no barrier packets around it), and only every `roof_every`-th step is timed
-        def want(kind, key):
-            if kind == "ifblock_input":
-                return key[0] == 52
-            return kind == "conv3x3" and key[1] == key[2] and key[5] == 1 and key[3] * key[4] >= 30000
-        timing = {"want": want, "records": []}
     roof_every = max(1, min(10, args.steps // 2))
-    fence()
+    traced = 0
+    if trace:
+        ops.trace_begin()
+        ops.trace_pause()
+    _fence(world)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ops.TIMING = timing if (timing is not None and k % roof_every == 0) else None
+        on = trace and k % roof_every == 0
+        if on:
+            ops.trace_resume()
+            traced += 1
         step()
-    ops.TIMING = None
+        if on:
+            ops.trace_pause()
     t_host = time.perf_counter() - t0  # all launches enqueued: the host side of a step (the GPU may still be working)
-    if world > 1:  # the only data-path collective: finished frames -> the writer rank
-        mine = torch.stack(sink)
-        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gathered, dst=0)
-    fence()
+    _fence(world)
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    roof = None
-    if timing and timing["records"]:
-        agg = {}
-        for kind, key, work, unit, slot in timing["records"]:
-            a = agg.setdefault((kind, key), [0.0, 0, work, unit, []])
-            d = ops.timing_ms(slot)
-            a[0] += d
-            a[1] += 1
-            a[4].append(d)
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath))
-
-        def entry(k, v):
-            ms, cnt, work, unit, durs = v
-            # average launch duration over the launches within 1.5x of the median (guards against a preempted launch)
-            med = sorted(durs)[len(durs) // 2]
-            good = [d for d in durs if d <= 1.5 * med] or durs
-            avg_s = sum(good) / len(good) / 1e3
-            extra = {}
-            if unit == "flop":
-                split = k[0] == "conv3x3" and k[1][0] >= N_FP32_CONV_CFGS
-                # algorithmic fp32 flops of the layer against the matrix-core peak of the kernel that ran: fp32 MFMA, or
-                # for the split-bf16 family (six bf16 MFMA products per fp32 product) the dense bf16 peak / 6
-                peak = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if split else FP32_MFMA_PEAK_TFLOPS
-                ach, u, bound = work / avg_s / 1e12, "TFLOP/s", "mfma"
-                kern = "conv_split_mfma" if split else "conv_mfma"
-                name = f"{kern} {k[1][1]}->{k[1][2]}ch {k[1][3]}x{k[1][4]} s{k[1][5]} N{k[1][6]} (ResConv)"
-                extra = {"peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32 multiply" if split
-                         else "dense fp32 MFMA"}
-            else:
-                ach, peak, u, bound = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
-                name = f"ifblock_input_kernel<true> {k[1][0]}ch {k[1][1]}x{k[1][2]} -> {k[1][3]}x{k[1][4]}"
-            return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
-                    "traffic": traffic.get(name), "kernel": name, "launches": cnt, "avg_us": round(avg_s * 1e6, 2),
-                    "algorithmic_per_launch": work, "cfg": k[1][0] if unit == "flop" else None,
-                    "ms_per_step": round(avg_s * 1e3 * cnt / n_instr, 3), **extra}
-
-        n_instr = len(range(0, args.steps, roof_every))  # instrumented steps
-        ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])
-        roof = entry(*ranked[0])
-        roof["others"] = [entry(k, v) for k, v in ranked[1:4]]
-    frames_per_step = len(TS)
-    return {"dt": dt, "host_dt": t_host, "frames": frames_per_step * args.steps * world, "desc": desc, "dst_size": dst_size, "roofline": roof}
+    recs = ops.trace_end() if trace else None
+    return dt, t_host, recs, traced, dst_size
 
 
-def cpu_leg(args):
-    """The CPU baseline: the fp32 oracle (port of the reference, pinned to it by tests/golden) on the same workload.
-    Bounded sample: one untimed warm-up (a calc_flow to build `reuse` + one IFNet pass so oneDNN primitives exist),
-    then `--cpu-steps` timed warm steps including to_inp/to_out."""
+def clip_leg(model, clip, dst_fps, times, scdet, args, label):
+    """One extra config through the real driver loop: drba_amd.infer.interpolate_stream over a clip resident in HBM.
+    The K loop iterations after W warm-up iterations are timed (on_step marks them); every roof_every-th is traced."""
+    from drba_amd import infer as drv
+    from drba_amd import ops
+    cm = _Counting(model)
+    io = _DevIO(clip, SRC_FPS)
+    to_inp, to_out = _dev_hooks()
+    W_, K = args.warmup, args.steps
+    roof_every = max(1, min(10, K // 2))
+    st = {"t0": None, "t1": None, "g0": 0, "g1": 0, "w0": 0, "w1": 0, "traced": 0}
+    ops.trace_begin()
+    ops.trace_pause()
+
+    def on_step(idx):  # idx = loop iterations completed (0 after the head)
+        j = idx - W_
+        ops.trace_pause()
+        if j == 0:
+            torch.cuda.synchronize()
+            st["t0"], st["g0"], st["w0"] = time.perf_counter(), cm.generated, io.written
+        if j == K:
+            torch.cuda.synchronize()
+            st["t1"], st["g1"], st["w1"] = time.perf_counter(), cm.generated, io.written
+        if 0 <= j < K and j % roof_every == 0:
+            ops.trace_resume()
+            st["traced"] += 1
+
+    drv.interpolate_stream(cm, io, dst_fps, times=times, enable_scdet=scdet, to_inp=to_inp, to_out=to_out, on_step=on_step)
+    torch.cuda.synchronize()
+    recs = ops.trace_end()
+    dt = st["t1"] - st["t0"]
+    gen, wr = st["g1"] - st["g0"], st["w1"] - st["w0"]
+    return {"workload": label, "value": round(gen / dt, 3), "unit": "frames/s", "steps": K, "warmup": W_,
+            "ms_per_step": round(dt / K * 1e3, 3), "frames_generated": gen, "frames_written": wr,
+            "roofline": roofline_from_trace(recs, st["traced"], _traffic_table())}
+
+
+def extra_configs(args, dev):
+    """BASELINE.json configs[2], [3], [4] at N = 1 (bounded: K steps each)."""
+    from drba_amd.models.gmfss_union import GMFSS_UNION
+    from drba_amd.models.rife import RIFE
+    n = args.warmup + args.steps + 3
+    out = {}
+    cut = args.warmup + args.steps // 2 + 2
+    m = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=1.0, device=dev)
+    out["config3_rife_fps60_scdet_1080p"] = clip_leg(
+        m, DeviceClip(n, 1080, 1920, 1234, dev, cut_at=cut), 60.0, -1, True, args,
+        f"rife -fps 60 (24 -> 60: ts alternate [0.6,1.0,1.4] / [0.8,1.2]), 1080p (net 1088x1920), scale 1.0, scdet on "
+        f"(threshold 0.3), one planted cut at frame {cut}; driver loop incl. to_inp/to_out/check_scene on device")
+    del m
+    m = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=0.5, device=dev)
+    out["config5_rife_fps60_4k_scale0.5_one_gpu"] = clip_leg(
+        m, DeviceClip(n, 2160, 3840, 1234, dev, cut_at=cut), 60.0, -1, True, args,
+        f"rife -fps 60, 4K (net 2176x3840), scale 0.5, scdet on, one planted cut at frame {cut}: the per-GPU work of the "
+        "frame-sharded config (N = 1)")
+    del m
+    torch.cuda.empty_cache()
+    g = GMFSS_UNION(weights=synth.gmfss_union_state_dicts(seed=0), scale=1.0, device=dev)
+    out["config4_gmfss_union_fps60_1080p"] = clip_leg(
+        g, DeviceClip(n, 1080, 1920, 4321, dev), 60.0, -1, False, args,
+        "gmfss_union -fps 60 (24 -> 60), 1080p (net 1152x1920), scale 1.0 (GMFlow + softsplat + GridNet path)")
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
+def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
+    """One clip sharded over the ranks (drba_amd.parallel), frames streamed to rank 0 -> (seconds max over ranks,
+    generated frames of all ranks, frames on the writer)."""
+    import torch.distributed as dist
+    from drba_amd import parallel
+    cm = _Counting(model)
+    to_inp, to_out = _dev_hooks()
+    counts = parallel.emission_counts(len(clip), SRC_FPS, dst_fps, times, world)
+    _fence(world)
+    t0 = time.perf_counter()
+    sg = parallel.StreamedGather(rank, world, counts, chunk=4, device=dev, frame_shape=clip.shape)
+    parallel.interpolate_shard(cm, clip, SRC_FPS, dst_fps, rank, world, times=times, enable_scdet=scdet,
+                               to_inp=to_inp, to_out=to_out, sink=sg.push)
+    allf = sg.finish()
+    _fence(world)
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(cm.generated)], dtype=torch.float64, device=dev)
+    mx = t.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(mx[0].item()), int(round(float(t[1].item()))), (len(allf) if allf is not None else 0)
+
+
+def gpu_leg(args, rank, world):
+    from drba_amd.models.rife import RIFE
+
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    (H, W), scale, desc = CONFIGS[args.config]
+    model = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=scale, device=dev)
+    n_total = args.warmup + args.steps
+    r = {"desc": desc, "dev": dev, "model": model}
+    clip = DeviceClip(min(n_total + 2, 12), H, W, 1234 + rank, dev)
+    frames = [clip[k] for k in range(len(clip))]
+    dt, t_host, recs, traced, dst = step_loop(model, frames, n_total, args, world, trace=not args.no_roofline)
+    r["dst_size"] = dst
+    r["roofline"] = roofline_from_trace(recs, traced, _traffic_table()) if recs else None
+    if world == 1:
+        r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps})
+        return r
+    # ---- N > 1: the headline is ONE clip sharded over the ranks, K loop iterations per rank (weak scaling)
+    import torch.distributed as dist
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    r["replica_loop"] = {"value": round(len(TS) * args.steps * world / float(t.item()), 3), "unit": "frames/s",
+                         "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "scaling": "weak",
+                         "what": "every rank runs the N = 1 loop on its own clip: no halo, no collective"}
+    big = DeviceClip(world * args.steps + 2, H, W, 1234, dev)
+    sdt, gen, got = sharded_leg(model, big, SRC_FPS * 2, 2, False, rank, world, dev)
+    r.update({"dt": sdt, "host_dt": None, "frames": gen, "writer_frames": got})
+    if not args.no_extra:
+        m5 = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=0.5, device=dev)
+        n5 = 8 * args.steps + 2  # fixed clip whatever N is: strong scaling
+        c5 = DeviceClip(n5, 2160, 3840, 1234, dev, cut_at=n5 // 2)
+        warm = [c5[k] for k in range(min(12, n5))]
+        step_loop(m5, warm, 0, argparse.Namespace(**{**vars(args), "steps": 2, "warmup": 2}), world, trace=False)  # autotune / allocator warm-up
+        sdt5, gen5, got5 = sharded_leg(m5, c5, 60.0, -1, True, rank, world, dev)
+        r["config5_sharded"] = {"value": round(gen5 / sdt5, 3), "unit": "frames/s", "scaling": "strong", "seconds": round(sdt5, 4),
+                                "frames_generated": gen5, "writer_frames": got5, "clip_source_frames": n5,
+                                "workload": "rife -fps 60, 4K (net 2176x3840), scale 0.5, scdet on, one planted cut: ONE clip of "
+                                            f"{n5} source frames sharded over {world} ranks, frames gathered on rank 0"}
+    return r
+
+
+def pcie_leg(args, model):
+    """The N = 1 loop with the clip in pinned host memory and every output copied back to pinned host buffers
+    (async H2D / D2H on the compute stream): what the CLI pays on top of the resident-in-HBM metric."""
+    (H, W), _, _ = CONFIGS[args.config]
+    frames = [torch.from_numpy(f).pin_memory() for f in make_frames_u8(min(args.warmup + args.steps + 2, 12), H, W, seed=1234)]
+    dt, _, _, _, _ = step_loop(model, frames, args.warmup + args.steps, args, 1, trace=False, pcie=True)
+    return {"value": round(len(TS) * args.steps / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "what": "same loop, uint8 frames read from pinned host memory and written back to pinned host memory (PCIe inclusive)"}
+
+
+# ------------------------------------------------------------------------------------------------- CPU leg
+def cpu_leg(args, model):
+    """The CPU baseline: the fp32 oracle (port of the reference, pinned to it by tests/golden) on the same workload, and
+    the parity figure of the metric: the HIP path run on the SAME uint8 frames, max-abs of the synthesised frames.
+    Bounded sample: one untimed warm-up (a calc_flow to build `reuse` + one IFNet pass so oneDNN primitives exist), then
+    `--cpu-steps` timed warm steps including to_inp/to_out on all cores, and one timed step on one thread."""
     import oracle  # the checker, timed here as the reported CPU baseline (never the product path)
+    from drba_amd import ops
     (H, W), scale, _ = CONFIGS[args.config]
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(avail, args.cpu_threads))
-    torch.set_num_threads(cores)
+    cores = avail if args.cpu_threads <= 0 else max(1, min(avail, args.cpu_threads))
     ora = oracle.rife.RifeOracle(synth.ifnet_state_dict(seed=0), scale)
     from drba_amd.models.utils.tools import get_valid_net_inp_size
     dst = get_valid_net_inp_size(np.zeros((H, W, 3), np.uint8), scale, div=64)["dst_size"]
@@ -226,22 +464,49 @@ def cpu_leg(args):
     def to_inp(f):
         return oracle.ops.resize(torch.from_numpy(f.transpose(2, 0, 1)).unsqueeze(0).float() / 255.0, dst)
 
-    I = [to_inp(f) for f in fr]
-    with torch.no_grad():
-        flow12, flow21, f1, f2 = ora.calc_flow(I[1], I[2])  # untimed: what the previous step would have left behind
-        reuse = (flow21, flow12, f2, f1)
-        oracle.ifnet.ifnet(ora.sd, torch.cat((I[1], I[2]), 1), 0.5, ora.scale_list, f0=f1, f1=f2)
-        t0 = time.perf_counter()
-        n = 0
-        for k in range(args.cpu_steps):
-            out, reuse = ora.inference_ts_drba(I[k + 1], I[k + 2], I[k + 3], TS, reuse, True)
-            for x in out:
-                (oracle.ops.resize(x, (H, W))[0].numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
-            n += len(out)
-        dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+    def to_out(x):
+        return (oracle.ops.resize(x, (H, W))[0].numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
+
+    def run(threads, steps, keep):
+        torch.set_num_threads(threads)
+        I = [to_inp(f) for f in fr]
+        with torch.no_grad():
+            flow12, flow21, f1, f2 = ora.calc_flow(I[1], I[2])  # untimed: what the previous step would have left behind
+            reuse = (flow21, flow12, f2, f1)
+            oracle.ifnet.ifnet(ora.sd, torch.cat((I[1], I[2]), 1), 0.5, ora.scale_list, f0=f1, f1=f2)
+            t0 = time.perf_counter()
+            n = 0
+            for k in range(steps):
+                out, reuse = ora.inference_ts_drba(I[k + 1], I[k + 2], I[k + 3], TS, reuse, True)
+                u8 = [to_out(x) for x in out]
+                if keep is not None:
+                    keep.append((out, u8))
+                n += len(out)
+            return n, time.perf_counter() - t0
+
+    kept = []
+    n, dt = run(cores, args.cpu_steps, kept)
+    n1, dt1 = run(1, 1, None)
+    base = {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{args.cpu_steps} warm inference_ts_drba step(s) = {n} frames at {dst[0]}x{dst[1]} incl. to_inp/to_out, after an "
-                      f"untimed warm-up; torch {torch.__version__} CPU fp32, {cores} threads of {avail} available"}
+                      f"untimed warm-up; torch {torch.__version__} CPU fp32, {cores} threads of {avail} available",
+            "single_thread": {"value": round(n1 / dt1, 4), "unit": "frames/s", "cores": 1, "sample": f"1 warm step = {n1} frames"}}
+    # ---- parity on the same frames: HIP path, same uint8 inputs, same step sequence
+    dev = model.device
+    g = [ops.to_inp(torch.from_numpy(f).to(dev), dst) for f in fr]
+    reuse = model.warm_reuse(g[1], g[2])
+    worst, worst_lsb, n_cmp = 0.0, 0, 0
+    for k, (want, want_u8) in enumerate(kept):
+        out, reuse = model.inference_ts_drba(g[k + 1], g[k + 2], g[k + 3], TS, reuse, True)
+        for a, b, bu in zip(out, want, want_u8):
+            worst = max(worst, float((a.cpu() - b).abs().max()))
+            au = ops.to_out(a, (H, W)).cpu().numpy()
+            worst_lsb = max(worst_lsb, int(np.abs(au.astype(np.int32) - bu.astype(np.int32)).max()))
+            n_cmp += 1
+    parity = {"value": worst, "frames": n_cmp, "u8_max_lsb": worst_lsb, "tolerance": 1e-3,
+              "what": "max |HIP - CPU oracle| over the synthesised fp32 frames of the cpu_baseline steps (same uint8 inputs, to_inp "
+                      "on each side); u8_max_lsb = largest difference of the written uint8 frames"}
+    return base, parity
 
 
 def main():
@@ -257,21 +522,37 @@ def main():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         dist.init_process_group(backend="nccl")  # RCCL over xGMI
     r = gpu_leg(args, rank, world)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_leg(args)
+    cpu = parity = extra = pcie = None
+    if rank == 0 and world == 1:
+        if not args.no_extra:
+            pcie = pcie_leg(args, r["model"])
+        if not args.no_cpu_baseline:
+            cpu, parity = cpu_leg(args, r["model"])
+        if not args.no_extra:
+            r["model"] = None
+            torch.cuda.empty_cache()
+            extra = extra_configs(args, r["dev"])
     if rank == 0:
+        wl = r["desc"] + "; warm inference_ts_drba ts=[0.75,1.25] + to_inp/to_out on device"
+        if world > 1:
+            wl += f"; ONE clip of {world * args.steps + 2} source frames sharded over {world} ranks (interpolate_shard), frames gathered on rank 0"
         line = {
             "metric": "interpolated frames/sec @1080p RIFE x2" if args.config == "1080p" else f"interpolated frames/sec @{args.config} RIFE x2",
             "value": round(r["frames"] / r["dt"], 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
-            "host_ms_per_step": round(r["host_dt"] / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": r["desc"] + "; warm inference_ts_drba ts=[0.75,1.25] + to_inp/to_out on device",
-                       "net_size": list(r["dst_size"]), "frames_per_step": len(TS), "weights": "seeded random IFNet 4.26-heavy",
-                       "parallelism": f"frame-sharded dp{world}"},
-            "roofline": r["roofline"], "cpu_baseline": cpu,
+            "host_ms_per_step": None if r["host_dt"] is None else round(r["host_dt"] / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "net_size": list(r["dst_size"]), "frames_per_step": len(TS),
+                       "weights": "seeded random IFNet 4.26-heavy", "parallelism": f"frame-sharded dp{world}"},
+            "max_abs_vs_oracle": parity, "roofline": r["roofline"], "cpu_baseline": cpu,
         }
+        if pcie is not None:
+            line["pcie_inclusive"] = pcie
+        for k in ("replica_loop", "config5_sharded", "writer_frames"):
+            if k in r:
+                line[k] = r[k]
+        if extra is not None:
+            line["extra_configs"] = extra
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

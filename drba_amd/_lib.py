@@ -45,6 +45,8 @@ SIGNATURES = {
     "drba_resize_bilinear": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
     "drba_u8hwc_to_f32nchw": (_i, [_p, _p, _i, _i, _p]),
     "drba_f32nchw_to_u8hwc": (_i, [_p, _p, _i, _i, _p]),
+    "drba_to_inp": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _p]),
+    "drba_to_out": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _i, _p]),
     "drba_ssim3d_32": (_i, [_p, _p, _p, _p]),
     "drba_conv3x3_pick_cfg": (_i, [_i, _i, _i, _i, _i]),
     "drba_conv3x3_num_cfgs": (_i, []),

@@ -12,6 +12,27 @@ using namespace drba;
 
 namespace {
 
+// ---- frame source / sink (tools.py:33-38,59-72): bit-exact with ATen's CPU upsample_bilinear2d --------------------
+// ATen evaluates the source coordinate as fma(scale, dst + 0.5, -0.5) and each 1-D interpolation as
+// fma(w0, a, w1 * b) (its vectorised kernels are compiled with contraction; established by comparing every
+// contraction variant against F.interpolate on the 480p/1080p/4K frame sizes: only this one matches in every bit).
+// hipcc would pick its own contraction, so the operations are spelled out.
+__device__ __forceinline__ Lerp lerp_src_aten(int dst, float scale, int size) {
+  float s = __fmaf_rn(scale, (float)dst + 0.5f, -0.5f);
+  if (s < 0.f) s = 0.f;
+  Lerp l;
+  l.i0 = min((int)s, size - 1);
+  l.i1 = l.i0 + (l.i0 < size - 1 ? 1 : 0);
+  l.w1 = __fsub_rn(s, (float)l.i0);
+  l.w0 = __fsub_rn(1.f, l.w1);
+  return l;
+}
+__device__ __forceinline__ float lerp2_aten(const Lerp &ly, const Lerp &lx, float a, float b, float c, float d) {
+  const float top = __fmaf_rn(lx.w0, a, __fmul_rn(lx.w1, b));
+  const float bot = __fmaf_rn(lx.w0, c, __fmul_rn(lx.w1, d));
+  return __fmaf_rn(ly.w0, top, __fmul_rn(ly.w1, bot));
+}
+
 // F.interpolate(bilinear, align_corners=False): out = wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d)
 // (ATen's separable evaluation order: innermost axis first).
 __global__ void __launch_bounds__(256) resize_bilinear_kernel(const float *__restrict__ in, float *__restrict__ out, int NC, int Hin,
@@ -21,12 +42,44 @@ __global__ void __launch_bounds__(256) resize_bilinear_kernel(const float *__res
     const int ox = (int)(i % Wout);
     const int oy = (int)((i / Wout) % Hout);
     const int c = (int)(i / ((size_t)Wout * Hout));
-    const Lerp ly = lerp_src(oy, sy, Hin), lx = lerp_src(ox, sx, Win);
+    const Lerp ly = lerp_src_aten(oy, sy, Hin), lx = lerp_src_aten(ox, sx, Win);
     const float *p = in + (size_t)c * Hin * Win;
     const float *r0 = p + (size_t)ly.i0 * Win, *r1 = p + (size_t)ly.i1 * Win;
-    const float top = lx.w0 * r0[lx.i0] + lx.w1 * r0[lx.i1];
-    const float bot = lx.w0 * r1[lx.i0] + lx.w1 * r1[lx.i1];
-    out[i] = ly.w0 * top + ly.w1 * bot;
+    out[i] = lerp2_aten(ly, lx, r0[lx.i0], r0[lx.i1], r1[lx.i0], r1[lx.i1]);
+  }
+}
+
+// to_inp = resize(to_tensor(img), dst_size) in ONE pass: uint8 HWC -> /255. -> bilinear -> fp32 [1,3,Hout,Wout].
+// (the reference materialises the full-size fp32 frame in between, tools.py:33-34,59-60)
+__global__ void __launch_bounds__(256) to_inp_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int Hin, int Win,
+                                                     int Hout, int Wout, float sy, float sx) {
+  const Tile2D p = tile_pixel(Wout, Hout);
+  if (!p.valid) return;
+  const Lerp ly = lerp_src_aten(p.y, sy, Hin), lx = lerp_src_aten(p.x, sx, Win);
+  const uint8_t *r0 = in + (size_t)ly.i0 * Win * 3, *r1 = in + (size_t)ly.i1 * Win * 3;
+  const size_t P = (size_t)Hout * Wout, o = (size_t)p.y * Wout + p.x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a = (float)r0[lx.i0 * 3 + c] / 255.f, b = (float)r0[lx.i1 * 3 + c] / 255.f;
+    const float cc = (float)r1[lx.i0 * 3 + c] / 255.f, d = (float)r1[lx.i1 * 3 + c] / 255.f;
+    out[c * P + o] = lerp2_aten(ly, lx, a, b, cc, d);
+  }
+}
+
+// to_out = to_cv2(resize(x, src_size)) in ONE pass: fp32 [1,3,Hin,Win] -> bilinear -> *255. truncated -> uint8 HWC,
+// channels reversed when `rev` (the BGR -> RGB flip of the encoder pipe, tools.py:202, otherwise a host-side copy).
+__global__ void __launch_bounds__(256) to_out_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, int Hin, int Win,
+                                                     int Hout, int Wout, float sy, float sx, int rev) {
+  const Tile2D p = tile_pixel(Wout, Hout);
+  if (!p.valid) return;
+  const Lerp ly = lerp_src_aten(p.y, sy, Hin), lx = lerp_src_aten(p.x, sx, Win);
+  const size_t P = (size_t)Hin * Win;
+  uint8_t *o = out + ((size_t)p.y * Wout + p.x) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float *r0 = in + c * P + (size_t)ly.i0 * Win, *r1 = in + c * P + (size_t)ly.i1 * Win;
+    const float v = __fmul_rn(lerp2_aten(ly, lx, r0[lx.i0], r0[lx.i1], r1[lx.i0], r1[lx.i1]), 255.f);
+    o[rev ? 2 - c : c] = (uint8_t)(int)v;
   }
 }
 
@@ -401,6 +454,24 @@ int drba_u8hwc_to_f32nchw(const uint8_t *in, float *out, int H, int W, void *str
 int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *stream) {
   if (!in || !out || H <= 0 || W <= 0) return DRBA_EINVAL;
   DRBA_LAUNCH(f32_to_u8_kernel, dim3(grid_for((size_t)H * W)), dim3(kBlock), 0, (hipStream_t)stream, in, out, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_to_inp(const uint8_t *img_hwc, float *out, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
+                void *stream) {
+  if (!img_hwc || !out || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
+  DRBA_LAUNCH(to_inp_kernel, dim3(tiles_for(Wout, Hout)), dim3(kBlock), 0, (hipStream_t)stream, img_hwc, out, Hin, Win, Hout,
+              Wout, scale_y, scale_x);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_to_out(const float *in, uint8_t *out_hwc, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
+                int reverse_channels, void *stream) {
+  if (!in || !out_hwc || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
+  DRBA_LAUNCH(to_out_kernel, dim3(tiles_for(Wout, Hout)), dim3(kBlock), 0, (hipStream_t)stream, in, out_hwc, Hin, Win, Hout,
+              Wout, scale_y, scale_x, reverse_channels);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -145,8 +145,12 @@ def inference(model, args):
         step = lambda _i: bar.update(1)  # noqa: E731
     except ImportError:
         bar, step = None, None
+    to_out = None
+    if getattr(video_io, "wants_rgb", False):  # encoder pipe / raw sink: BGR -> RGB inside the to_out kernel, not on the host
+        video_io.frames_are_rgb = True
+        to_out = lambda x, size: _tools.to_out(x, size, rgb=True)  # noqa: E731
     n = interpolate_stream(model, video_io, args.dst_fps, times=args.times, enable_scdet=args.enable_scdet,
-                           scdet_threshold=args.scdet_threshold, on_step=step)
+                           scdet_threshold=args.scdet_threshold, to_out=to_out, on_step=step)
     while not video_io.finish_writing():
         time.sleep(0.01)
     video_io.close()

@@ -5,6 +5,7 @@ import torch
 
 from drba_amd import ops as _ops
 from drba_amd.models.gmflow.gmflow import GMFlow
+from drba_amd.models.lookahead import _tensors
 from drba_amd.models.model_gmfss_union.FeatureNet import FeatureNet
 from drba_amd.models.model_gmfss_union.FusionNet import GridNet
 from drba_amd.models.model_gmfss_union.MetricNet import MetricNet
@@ -48,24 +49,35 @@ class Model:
         ld = lambda n: torch.load(f"{path}/{n}.pkl", map_location="cpu")  # noqa: E731
         self.load_state_dicts(ld("flownet"), ld("metric"), ld("feat"), ld("fusionnet"), device)
 
+    def _cached(self, frame, attr, key, make):
+        """Per-frame cache on the frame tensor, keyed by (this model, key).  The value may have been produced on the
+        lookahead's side stream: the producing event travels with it and the consumer's stream waits on it (a scene cut
+        drops the lookahead RESULT without waiting, but these caches survive), and the allocator is told about the
+        second stream."""
+        key = (id(self), key)
+        c = getattr(frame, attr, None)
+        if c is not None and c[0] == key:
+            if c[2] is not None:
+                cur = torch.cuda.current_stream(frame.device)
+                cur.wait_event(c[2])
+                for t in _tensors(c[1]):
+                    t.record_stream(cur)
+            return c[1]
+        val = make()
+        if frame.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(frame.device))
+            setattr(frame, attr, (key, val, ev))
+        return val
+
     def _features(self, img):
         """FeatureNet pyramid of a frame, computed once per frame tensor (the reference recomputes it for both pairs a
         frame belongs to, GMFSS.py:56-57; same values)."""
-        f = getattr(img, "_drba_feat", None)
-        if f is None:
-            f = self.feat_ext(img)
-            if img.is_cuda:
-                img._drba_feat = f
-        return f
+        return self._cached(img, "_drba_feat", None, lambda: self.feat_ext(img))
 
     def _encoded(self, frame, flow_input, scale):
         """GMFlow's CNN encoding of `flow_input` (the frame at flow resolution), cached on the frame tensor per scale."""
-        c = getattr(frame, "_drba_gmf", None)
-        if c is None or c[0] != scale:
-            c = (scale, self.flownet.encode_frame(flow_input))
-            if frame.is_cuda:
-                frame._drba_gmf = c
-        return c[1]
+        return self._cached(frame, "_drba_gmf", scale, lambda: self.flownet.encode_frame(flow_input))
 
     def reuse(self, img0, img1, scale):
         feat0, feat1 = self._features(img0), self._features(img1)

@@ -19,39 +19,6 @@ from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
 from drba_amd.models.utils.tools import convert
 
 
-class _WarmStepGraph:
-    """One warm DRBA step (calc_flow + per-frame DRM + IFNet) captured as a HIP graph.
-
-    The eager step issues ~170 kernel launches from Python; at 1080p the GPU needs ~6 ms for them, which is
-    about what the host needs to issue them, so the step is replayed as a graph instead (one launch).
-    Static input buffers are refilled before each replay; timesteps live in device memory (`t_dev`), so one
-    graph serves every ts with the same structure (which entries are pass-through / left / right)."""
-
-    def __init__(self, model, I0, I1, I2, flow10, f1, f0, kinds):
-        self.kinds = kinds
-        self.sI = [torch.empty_like(I0) for _ in range(3)]
-        self.s_flow10, self.s_f1, self.s_f0 = torch.empty_like(flow10), torch.empty_like(f1), torch.empty_like(f0)
-        self.t_dev = torch.zeros(max(len(kinds), 1), dtype=torch.float32, device=I0.device)
-        self._fill(I0, I1, I2, flow10, f1, f0, [0.25] * len(kinds))
-        model._warm_step(*self.sI, self.s_flow10, self.s_f1, self.s_f0, kinds, self.t_dev)  # primes autotune/workspaces
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outs, self.reuse = model._warm_step(*self.sI, self.s_flow10, self.s_f1, self.s_f0, kinds, self.t_dev)
-
-    def _fill(self, I0, I1, I2, flow10, f1, f0, tvals):
-        for dst, src in zip(self.sI + [self.s_flow10, self.s_f1, self.s_f0], (I0, I1, I2, flow10, f1, f0)):
-            if dst is not src:
-                dst.copy_(src, non_blocking=True)
-        self.t_dev[:len(tvals)].copy_(torch.tensor(tvals, dtype=torch.float32), non_blocking=True)
-
-    def run(self, I0, I1, I2, flow10, f1, f0, tvals):
-        self._fill(I0, I1, I2, flow10, f1, f0, tvals)
-        self.graph.replay()
-        outs = [None if o is None else o.clone() for o in self.outs]  # fresh tensors: the static ones are overwritten next replay
-        return outs, tuple(r.clone() for r in self.reuse)
-
-
 class RIFE:
     supports_lookahead = True  # inference_ts_drba(..., lookahead=next frame): see prefetch_flow
     _look = None     # models/lookahead.Lookahead, created on first use
@@ -70,8 +37,6 @@ class RIFE:
         self.scale = scale
         self.scale_list = [16 / scale, 8 / scale, 4 / scale, 2 / scale, 1 / scale]
         self.pad_size = 64
-        self.use_graphs = os.environ.get("DRBA_GRAPH", "0") == "1"  # HIP-graph replay of warm DRBA steps (off: GPU-bound today, the buffer refills cost more than the launch gaps)
-        self._graphs = {}
 
     def encode(self, img):
         return self.ifnet.encode(img[:, :3])
@@ -119,46 +84,6 @@ class RIFE:
         """The `reuse` a DRBA step ending on the pair (Ia, Ib) hands to the next step (rife.py:82-85,109)."""
         flow_ab, flow_ba, fa, fb = self.calc_flow(Ia, Ib)
         return (flow_ba, flow_ab, fb, fa)
-
-    def _warm_step(self, I0, I1, I2, flow10, f1, f0, kinds, t_dev):
-        """The steady-state body of inference_ts_drba with linear DRM; timesteps come from device memory."""
-        flow12, flow21, f1, f2 = self.calc_flow(I1, I2, f0=f1)
-        outs, items = [], []
-        for k, kind in enumerate(kinds):
-            if kind == "L":
-                drm = _ops.drm_rife_linear(flow10, flow12, 0.0, 1e-4, t_dev=t_dev[k:k + 1])
-                outs.append(len(items))
-                items.append((I1, I0, drm, f1, f0))
-            elif kind == "R":
-                drm = _ops.drm_rife_linear(flow12, flow10, 0.0, 1e-4, t_dev=t_dev[k:k + 1])
-                outs.append(len(items))
-                items.append((I1, I2, drm, f1, f2))
-            else:
-                outs.append(None)
-        return self._fill(outs, items), (flow21, flow12, f2, f1)
-
-    def _graphed_step(self, I0, I1, I2, ts, reuse):
-        kinds, tvals = [], []
-        for t in ts:
-            if t == 0 or t == 1 or t == 2:
-                kinds.append("c%d" % int(t))
-                tvals.append(0.0)
-            elif 0 < t < 1:
-                kinds.append("L")
-                tvals.append(float(np.float32(1 - t)))
-            elif 1 < t < 2:
-                kinds.append("R")
-                tvals.append(float(np.float32(t - 1)))
-            else:
-                return None
-        key = (tuple(I0.shape), tuple(kinds))
-        flow10, _, f1, f0 = reuse
-        g = self._graphs.get(key)
-        if g is None:
-            g = self._graphs[key] = _WarmStepGraph(self, I0, I1, I2, flow10, f1, f0, tuple(kinds))
-        outs, new_reuse = g.run(I0, I1, I2, flow10, f1, f0, tvals)
-        passthru = {"c0": I0, "c1": I1, "c2": I2}
-        return [passthru[k] if k in passthru else o for k, o in zip(kinds, outs)], new_reuse
 
     SIDE_STAGES = int(os.environ.get("DRBA_SIDE_STAGES", "3"))  # IFNet stages of the NEXT step run by the lookahead
 
@@ -212,10 +137,6 @@ class RIFE:
         or (that frame, the next call's ts).  calc_flow(I2, next) -- and, when the timesteps are known, the DRM maps
         and the first SIDE_STAGES low-resolution IFNet stages of the next step -- run on a side stream under this
         call's full-resolution stages; the next call resumes from there if its arguments match."""
-        if reuse and linear and self.use_graphs and I0.is_cuda:
-            r = self._graphed_step(I0, I1, I2, ts, reuse)
-            if r is not None:
-                return r
         flow10, flow01, f1, f0 = self.calc_flow(I1, I0) if not reuse else reuse
         (flow12, flow21, f1, f2), staged = self._flow_pair(I1, I2, None if reuse is None else reuse[2])
         nxt, ts_nxt = split_lookahead(lookahead)

@@ -60,12 +60,21 @@ def resize(tensor, size):
     return _ops.resize_bilinear(tensor, size)
 
 
-def to_inp(npInp, dst_size):
-    return resize(to_tensor(npInp), dst_size)
+def to_inp(npInp, dst_size, device=None):
+    """resize(to_tensor(npInp), dst_size) (tools.py:59-60) as one kernel on the uploaded uint8 frame (the full-size
+    fp32 frame of the reference is never materialised); bit-exact with the two-step form."""
+    device = _ops.default_device() if device is None else device
+    if torch.is_tensor(npInp):
+        u8 = npInp.to(device, non_blocking=True)
+    else:
+        u8 = torch.from_numpy(np.ascontiguousarray(npInp)).to(device, non_blocking=True)
+    return _ops.to_inp(u8, dst_size)
 
 
-def to_out(tenInp, src_size):
-    return to_cv2(resize(tenInp, src_size))
+def to_out(tenInp, src_size, rgb=False):
+    """to_cv2(resize(tenInp, src_size)) (tools.py:63-64) as one kernel + the D2H copy.  rgb=True returns the frame in RGB
+    order (the flip the reference's writer thread does on the host, tools.py:202, done on the device instead)."""
+    return _ops.to_out(tenInp, src_size, rgb=rgb).cpu().numpy()
 
 
 def distance_calculator(_x):
@@ -171,6 +180,11 @@ class VideoFI_IO:
                 self._ffmpeg = self._spawn_ffmpeg(hwaccel)
             else:
                 self._raw = open(output_path, "wb")
+        # sinks that want RGB bytes (the ffmpeg pipe and the raw file, tools.py:202): the driver can hand over frames that
+        # are already RGB (to_out(..., rgb=True) flips on the device) by setting frames_are_rgb
+        self.wants_rgb = self._sink_frames is None
+        self.frames_are_rgb = False
+        self._sink_error = None
         self.read_buffer = Queue(maxsize=100)
         self.write_buffer = Queue(maxsize=-1)
         self._closed = threading.Event()
@@ -178,14 +192,29 @@ class VideoFI_IO:
         self._writer_thread = threading.Thread(target=self._writer, daemon=True)
         self._writer_thread.start()
 
+    def _ffmpeg_cmd(self, hwaccel):
+        """The reference's pipe (tools.py:176-186): rawvideo rgb24 in, libx264 -qp 16 -preset medium, audio copied from the
+        source container.  -hw selects h264_vaapi (the reference's h264_nvenc has no AMD counterpart), which needs the
+        device + upload filter and takes neither -preset nor a software pixel format.  A .npz/.npy source has no audio
+        stream to map, so the second input is only added for real containers."""
+        container = self._cv2 is not None
+        cmd = ["ffmpeg", "-y"]
+        if hwaccel:
+            cmd += ["-vaapi_device", "/dev/dri/renderD128"]
+        cmd += ["-f", "rawvideo", "-pix_fmt", "rgb24", "-r", f"{self.dst_fps}", "-s", f"{self.width}x{self.height}", "-i", "pipe:0"]
+        if container:
+            cmd += ["-i", self.input_path, "-map", "0:v", "-map", "1:a?"]
+        if hwaccel:
+            cmd += ["-vf", "format=nv12,hwupload", "-c:v", "h264_vaapi", "-qp", "16"]
+        else:
+            cmd += ["-c:v", "libx264", "-pix_fmt", "yuv420p", "-qp", "16", "-preset", "medium"]
+        cmd += ["-movflags", "+faststart"]
+        if container:
+            cmd += ["-c:a", "aac", "-b:a", "320k"]
+        return cmd + [f"{self.output_path}"]
+
     def _spawn_ffmpeg(self, hwaccel):
-        encoder, preset = ("h264_vaapi", "medium") if hwaccel else ("libx264", "medium")
-        cmd = ["ffmpeg", "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-r", f"{self.dst_fps}",
-               "-s", f"{self.width}x{self.height}", "-i", "pipe:0", "-i", self.input_path,
-               "-map", "0:v", "-map", "1:a?", "-c:v", encoder, "-movflags", "+faststart",
-               "-pix_fmt", "yuv420p", "-qp", "16", "-preset", preset, "-c:a", "aac", "-b:a", "320k",
-               f"{self.output_path}"]
-        return subprocess.Popen(cmd, stdin=subprocess.PIPE)
+        return subprocess.Popen(self._ffmpeg_cmd(hwaccel), stdin=subprocess.PIPE)
 
     def _reader(self):
         if self._cv2 is not None:
@@ -205,9 +234,15 @@ class VideoFI_IO:
                 break
             if self._sink_frames is not None:
                 self._sink_frames.append(item)
-            else:
-                rgb = np.ascontiguousarray(item[:, :, ::-1])  # BGR -> RGB, as the reference's pipe
-                (self._ffmpeg.stdin if self._ffmpeg is not None else self._raw).write(rgb)
+            elif self._sink_error is None:
+                # BGR -> RGB as the reference's pipe, unless the driver already flipped on the device
+                rgb = np.ascontiguousarray(item if self.frames_are_rgb else item[:, :, ::-1])
+                try:
+                    if self._ffmpeg is not None and self._ffmpeg.poll() is not None:
+                        raise BrokenPipeError(f"ffmpeg exited with code {self._ffmpeg.returncode}")
+                    (self._ffmpeg.stdin if self._ffmpeg is not None else self._raw).write(rgb)
+                except (BrokenPipeError, OSError) as e:  # keep draining the queue; close() re-raises
+                    self._sink_error = e
         if self._sink_frames is not None:
             arr = np.stack(self._sink_frames) if self._sink_frames else np.zeros((0, self.height, self.width, 3), np.uint8)
             if self.output_path.lower().endswith(".npz"):
@@ -215,8 +250,12 @@ class VideoFI_IO:
             else:
                 np.save(self.output_path, arr)
         elif self._ffmpeg is not None:
-            self._ffmpeg.stdin.close()
-            self._ffmpeg.wait()
+            try:
+                self._ffmpeg.stdin.close()
+            except OSError:
+                pass
+            if self._ffmpeg.wait() != 0 and self._sink_error is None:
+                self._sink_error = RuntimeError(f"ffmpeg exited with code {self._ffmpeg.returncode}")
         else:
             self._raw.close()
         self._closed.set()
@@ -234,6 +273,8 @@ class VideoFI_IO:
         """Flush and close the sink (the reference never terminates its writer thread; this does)."""
         self.write_buffer.put(None)
         self._writer_thread.join()
+        if self._sink_error is not None:
+            raise RuntimeError(f"writing {self.output_path} failed: {self._sink_error}") from self._sink_error
 
 
 def _have_ffmpeg():

@@ -261,6 +261,34 @@ def f32nchw_to_u8hwc(x):
     return out
 
 
+def to_inp(img_u8, dst_size):
+    """tools.to_inp on a device-resident frame: uint8 [H,W,3] -> fp32 [1,3,*dst_size] in [0,1], one kernel."""
+    if not (torch.is_tensor(img_u8) and img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3):
+        raise _lib.DrbaHipError("expected a CUDA uint8 [H,W,3] tensor")
+    img_u8 = img_u8.contiguous()
+    h, w = img_u8.shape[:2]
+    ho, wo = int(dst_size[0]), int(dst_size[1])
+    out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=img_u8.device)
+    sy, sx = float(np.float32(h) / np.float32(ho)), float(np.float32(w) / np.float32(wo))  # ATen: static_cast<float>(in) / out
+    _lib.check(_timed("to_inp", (h, w, ho, wo), 3.0 * min(h * w, 4 * ho * wo) + 12.0 * ho * wo, "byte", lambda: _lib.load().drba_to_inp(
+        _p(img_u8), _p(out), h, w, ho, wo, sy, sx, _stream())), "drba_to_inp")
+    return out
+
+
+def to_out(x, src_size, rgb=False):
+    """tools.to_out without the D2H copy: fp32 [1,3,h,w] -> uint8 [*src_size,3] on the device, one kernel
+    (resize + *255. truncation; rgb=True also flips BGR -> RGB for the encoder pipe)."""
+    x = _f32(x)
+    assert x.shape[0] == 1 and x.shape[1] == 3
+    h, w = x.shape[2:]
+    ho, wo = int(src_size[0]), int(src_size[1])
+    out = torch.empty((ho, wo, 3), dtype=torch.uint8, device=x.device)
+    sy, sx = float(np.float32(h) / np.float32(ho)), float(np.float32(w) / np.float32(wo))
+    _lib.check(_timed("to_out", (h, w, ho, wo), 12.0 * min(h * w, 4 * ho * wo) + 3.0 * ho * wo, "byte", lambda: _lib.load().drba_to_out(
+        _p(x), _p(out), h, w, ho, wo, sy, sx, 1 if rgb else 0, _stream())), "drba_to_out")
+    return out
+
+
 def ssim_thumb32(x1, x2):
     """check_scene's metric: 32x32 bilinear thumbnails -> 3-D gaussian SSIM.  Returns a Python float
     (one D2H read: the driver branches on it, exactly like the reference's `if check_scene(...)`)."""

@@ -95,6 +95,14 @@ int drba_resize_bilinear(const float *in, float *out, int NC, int Hin, int Win, 
                          float scale_y, float scale_x, void *stream);
 int drba_u8hwc_to_f32nchw(const uint8_t *in, float *out, int H, int W, void *stream); /* /255. */
 int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *stream); /* trunc(x*255.) */
+/* to_inp (tools.py:59-60 = resize(to_tensor(img), dst_size)) and to_out (tools.py:63-64 = to_cv2(resize(x, src_size))) as
+ * ONE kernel each: uint8 HWC -> /255. -> bilinear -> fp32 [1,3,Hout,Wout], and fp32 [1,3,Hin,Win] -> bilinear -> *255.
+ * truncated -> uint8 HWC; reverse_channels != 0 also performs the BGR -> RGB flip of the encoder pipe (tools.py:202).
+ * Arithmetic pinned to ATen's CPU kernel (fma(scale, dst+0.5, -0.5); fma(w0, a, w1*b) per axis): bit-exact. */
+int drba_to_inp(const uint8_t *img_hwc, float *out, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
+                void *stream);
+int drba_to_out(const float *in, uint8_t *out_hwc, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
+                int reverse_channels, void *stream);
 
 /* ---- scene-cut metric: tools.py:27-30 + pytorch_msssim/__init__.py:83-136 (ssim_matlab)
  * x1, x2: [1,3,32,32] thumbnails (already resized); out: 1 float on device. */

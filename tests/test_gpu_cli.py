@@ -59,3 +59,59 @@ def test_infer_cli_gmfss_union_npz_roundtrip(tmp_path):
     z = np.load(out)
     assert z["frames"].shape == (10, 96, 160, 3) and z["frames"].dtype == np.uint8
     assert float(z["fps"]) == 60.0
+
+
+def _oracle_clip(frames, fps, dst_fps, times, scdet):
+    """The whole clip through the driver on the CPU: oracle model + the reference's frame conversion (the checker)."""
+    import oracle
+    from drba_amd import infer as drv
+    from tests.clip_common import ListIO, cpu_hooks
+    io = ListIO(list(frames), fps)
+    to_inp, to_out, check = cpu_hooks()
+    drv.interpolate_stream(oracle.rife.RifeOracle(synth.ifnet_state_dict(0), 1.0), io, dst_fps, times=times, enable_scdet=scdet,
+                           to_inp=to_inp, to_out=to_out, check_scene=check)
+    return np.stack(io.written)
+
+
+def _cli_clip(tmp_path, frames, fps, argv):
+    wdir = tmp_path / "w"
+    wdir.mkdir(exist_ok=True)
+    torch.save({"module." + k: v for k, v in synth.ifnet_state_dict(0).items()}, str(wdir / "flownet.pkl"))
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(inp, frames=np.stack(frames), fps=np.float64(fps))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import drba_amd.infer as I\n"
+        "a = I.parse_args(['-m','rife','-i',%r,'-o',%r] + %r)\n"
+        "m = I.load_model(a.model_type, a.scale, weights=%r)\n"
+        "print('written', I.inference(m, a))\n" % (ROOT, inp, out, list(argv), str(wdir)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)["frames"]
+
+
+def _assert_frames_close(got, want):
+    """uint8 frames of the HIP CLI vs the CPU driver run: the fp32 frames agree to ~1e-6, so after *255 truncation a
+    value sitting on an integer boundary may land one LSB apart; nothing may differ by more, and few may differ at all."""
+    assert got.shape == want.shape and got.dtype == np.uint8
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"max diff {d.max()} LSB"
+    assert (d > 0).mean() < 2e-3, f"{(d > 0).mean():.2e} of the bytes differ"
+
+
+def test_cli_whole_clip_config1_matches_cpu_driver(tmp_path):
+    """BASELINE.json configs[0]'s clip (16 frames, 854x480, -t 2, scdet off) through infer.py on the HIP path: all 32
+    written frames within 1 LSB of the same clip run through the driver on the CPU oracle."""
+    frames = synth.make_clip(16, 480, 854, seed=1234)
+    got = _cli_clip(tmp_path, frames, 24.0, ["-t", "2"])
+    assert got.shape == (32, 480, 854, 3)
+    _assert_frames_close(got, _oracle_clip(frames, 24.0, 48.0, 2, False))
+
+
+def test_cli_whole_clip_fps60_scdet_matches_cpu_driver(tmp_path):
+    """-fps 60 -s on a 24 fps clip with a planted cut (configs[2] at 480p): fractional timesteps, DRM, scene-cut branches,
+    reuse reset -- frame for frame against the CPU driver run (same cut decisions, same copies)."""
+    frames = synth.make_clip(12, 480, 854, seed=77, cut_at=6)
+    got = _cli_clip(tmp_path, frames, 24.0, ["-fps", "60", "-s"])
+    want = _oracle_clip(frames, 24.0, 60.0, -1, True)
+    _assert_frames_close(got, want)

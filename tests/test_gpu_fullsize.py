@@ -94,20 +94,21 @@ def test_rife_4k_half_scale_bench_loop_parity(hip_backend, oracle_backend):
 
 
 def test_to_inp_to_out_fullsize_bit_exact(hip_backend):
-    """to_inp / to_out at 1080p -> 1088x1920 and back (tools.py:33-38,59-72): fp32 values within 1 ulp of the oracle's
-    resize, uint8 frames within 1 LSB (truncation of a value 1 ulp below an integer)."""
+    """to_inp / to_out (one fused kernel each) at 1080p <-> 1088x1920, 4K <-> 2176x3840 and 1080p <-> 1152x1920
+    (tools.py:33-38,59-72): every fp32 value and every uint8 byte equal to the oracle's (= ATen's CPU kernels)."""
     import bench
     import oracle
     from drba_amd.models.utils import tools
-    f = bench.make_frames_u8(1, 1080, 1920, seed=1234)[0]
-    x = torch.from_numpy(f.transpose(2, 0, 1)).unsqueeze(0).float() / 255.0
-    want = oracle.ops.resize(x, (1088, 1920))
-    got = tools.to_inp(f, (1088, 1920))
-    assert float((got.cpu() - want).abs().max()) <= 2e-7
-    back = tools.to_out(got, (1080, 1920))
-    ref = (oracle.ops.resize(want, (1080, 1920))[0].numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
-    d = np.abs(back.astype(np.int32) - ref.astype(np.int32))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())
+    for (src, net) in (((1080, 1920), (1088, 1920)), ((2160, 3840), (2176, 3840)), ((1080, 1920), (1152, 1920))):
+        f = bench.make_frames_u8(1, src[0], src[1], seed=1234)[0]
+        x = torch.from_numpy(f.transpose(2, 0, 1)).unsqueeze(0).float() / 255.0
+        want = oracle.ops.resize(x, net)
+        got = tools.to_inp(f, net)
+        assert torch.equal(got.cpu(), want), (src, net, float((got.cpu() - want).abs().max()))
+        back = tools.to_out(got, src)
+        ref = (oracle.ops.resize(want, src)[0].numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
+        assert np.array_equal(back, ref), (src, net, int(np.abs(back.astype(np.int32) - ref.astype(np.int32)).max()))
+        assert np.array_equal(tools.to_out(got, src, rgb=True), ref[:, :, ::-1])
 
 
 def test_gmfss_union_1080p_warm_step_parity(hip_backend, oracle_backend):
@@ -129,11 +130,13 @@ def test_gmfss_union_1080p_warm_step_parity(hip_backend, oracle_backend):
     with torch.no_grad():
         g = run(hip_backend, frames)
         o = run(oracle_backend, frames)
-        gen = torch.Generator().manual_seed(99)
-        o2 = run(oracle_backend, [f + (torch.rand(f.shape, generator=gen) - 0.5) * 2e-7 for f in frames])
+        o2 = None
+        if any(gpu_checks._diff(g[k], o[k]) > 1e-3 for k in o):  # the conditioning floor costs a second oracle run
+            gen = torch.Generator().manual_seed(99)
+            o2 = run(oracle_backend, [f + (torch.rand(f.shape, generator=gen) - 0.5) * 2e-7 for f in frames])
     rows = []
     for k in o:
-        d, floor = gpu_checks._diff(g[k], o[k]), gpu_checks._diff(o2[k], o[k])
+        d, floor = gpu_checks._diff(g[k], o[k]), (gpu_checks._diff(o2[k], o[k]) if o2 is not None else 0.0)
         tk = max(1e-3, 4.0 * floor)
         n_out, n = gpu_checks._outliers(g[k], o[k], tk)
         ok = n_out <= n // 1000 and d <= 5e-2
@@ -152,7 +155,7 @@ def test_split_conv_configs_on_many_tile_shapes(hip_backend):
     g = torch.Generator().manual_seed(321)
     rows = []
     for (nb, cin, cout, h, w, kind) in ((2, 32, 32, 272, 480, "res"), (2, 64, 64, 136, 240, "res"), (2, 96, 96, 68, 120, "res"),
-                                        (1, 32, 16, 544, 960, "conv"), (1, 64, 64, 576, 960, "pre")):
+                                        (1, 32, 16, 544, 960, "conv"), (1, 64, 64, 288, 960, "pre")):
         x = torch.randn(nb, cin, h, w, generator=g) * 2.0
         wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
         b = torch.randn(cout, generator=g) * 0.1
@@ -178,7 +181,7 @@ def test_split_conv_configs_on_many_tile_shapes(hip_backend):
                 got = ops.Conv3x3(wt, b, 1, True, None, device=dev, cfg=cfg)(xg)
             rows.append((f"conv split cfg{cfg} {kind} [{nb}x{cin}->{cout} {h}x{w}]", gpu_checks._diff(got, ref),
                          5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
-    for (nb, cin, cout, h, w, ps) in ((2, 32, 52, 272, 480, True), (2, 64, 52, 136, 240, True), (1, 96, 64, 288, 480, False)):
+    for (nb, cin, cout, h, w, ps) in ((2, 32, 52, 272, 480, True), (2, 64, 52, 136, 240, True), (1, 96, 64, 192, 480, False)):
         x = torch.randn(nb, cin, h, w, generator=g) * 2.0
         wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
         b = torch.randn(cout, generator=g) * 0.1
