@@ -83,7 +83,9 @@ SIGNATURES = {
     "drba_linear_split_cat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "drba_linear_split_layernorm": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "drba_softmax_rows": (_i, [_p, _p, _z, _i, _i, _i, _f, _p]),
-    "drba_softmax_expect2": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
+    "drba_global_expect2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
+    "drba_global_expect2_ws_floats": (_z, [_i]),
+    "drba_bmm": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "drba_local_corr_flow": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "drba_local_attn_flow": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "drba_convex_upsample": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -33,7 +33,11 @@ const std::string &kernel_name(const void *host_fn, const char *fallback, hipStr
     char *dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
     nm = (status == 0 && dem) ? dem : mangled;
     std::free(dem);
-    // rocprofv3 prints "name(args)"; keep the name part so that records group like its kernel-name column minus arguments
+    // rocprofv3 prints "void ns::name<...>(args)"; keep "ns::name<...>" (no return type, anonymous-namespace tag or
+    // argument list) so that records group like its kernel-name column
+    if (nm.rfind("void ", 0) == 0) nm.erase(0, 5);
+    const std::string anon = "(anonymous namespace)::";
+    for (size_t p = nm.find(anon); p != std::string::npos; p = nm.find(anon)) nm.erase(p, anon.size());
     int depth = 0;
     for (size_t i = 0; i < nm.size(); ++i) {
       if (nm[i] == '<') ++depth;
@@ -43,7 +47,6 @@ const std::string &kernel_name(const void *host_fn, const char *fallback, hipStr
         break;
       }
     }
-    if (nm.rfind("void ", 0) == 0) nm.erase(0, 5);
   } else {
     nm = fallback;
   }
@@ -75,6 +78,12 @@ extern "C" {
 int drba_abi_version(void) { return 1; }
 
 int drba_trace_begin(void) {
+  // events are created here, outside any timed region (hipEventCreate costs tens of microseconds each)
+  for (int i = 0; i < 2048; ++i) {
+    if (g_ev_made[i]) continue;
+    if (hipEventCreate(&g_ev[i][0]) != hipSuccess || hipEventCreate(&g_ev[i][1]) != hipSuccess) return DRBA_ELAUNCH;
+    g_ev_made[i] = true;
+  }
   g_recs.clear();
   drba::g_trace_on = true;
   return DRBA_OK;

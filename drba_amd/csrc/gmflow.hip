@@ -246,41 +246,6 @@ softmax_rows_long_kernel(float *__restrict__ x, const float *__restrict__ mask, 
   for (int c = threadIdx.x; c < cols; c += 256) p[c] = p[c] / s;
 }
 
-// Row softmax of scores/scale followed by the expectation of a 2-vector per column, fused:
-//   vals == NULL: column j carries its pixel coordinate (j % w, j / w) and the row's own coordinate is
-//                 subtracted -> global correlation flow (matching.py:7-38)
-//   vals != NULL: [2][cols] planar values (the flow) -> global self-attention propagation (transformer.py:355-372)
-__global__ void __launch_bounds__(256)
-softmax_expect2_kernel(const float *__restrict__ scores, const float *__restrict__ vals, float *__restrict__ out,
-                       int rows, int cols, int w, float scale) {
-  __shared__ float red[4];
-  const int row = blockIdx.x;
-  const float *p = scores + (size_t)row * cols;
-  float mx = -INFINITY;
-  for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, p[c] / scale);
-  mx = block_max256(mx, red);
-  float s = 0.f, ax = 0.f, ay = 0.f;
-  for (int c = threadIdx.x; c < cols; c += 256) {
-    const float e = expf(p[c] / scale - mx);
-    s += e;
-    const float vx = vals ? vals[c] : (float)(c % w), vy = vals ? vals[cols + c] : (float)(c / w);
-    ax += e * vx;
-    ay += e * vy;
-  }
-  s = block_sum256(s, red);
-  ax = block_sum256(ax, red);
-  ay = block_sum256(ay, red);
-  if (threadIdx.x == 0) {
-    float ox = ax / s, oy = ay / s;
-    if (!vals) {
-      ox -= (float)(row % w);
-      oy -= (float)(row / w);
-    }
-    out[row] = ox;
-    out[rows + row] = oy;
-  }
-}
-
 // matching.py:41-89 with local_radius r: for every pixel, correlation of feature0 with feature1 at the (2r+1)^2
 // integer offsets (zeros outside the image, those taps get -1e4), softmax, expected offset.
 // One lane per pixel with the (2r+1)^2 running dot products in registers: the channel loop reads feature0 once and
@@ -554,15 +519,6 @@ int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int ro
     DRBA_LAUNCH(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(kBlock), 0, s, x, mask, cols, rows_per_mat, nm,
                        scale);
 #undef DRBA_SOFTMAX
-  DRBA_CHECK_LAUNCH();
-  return DRBA_OK;
-}
-
-int drba_softmax_expect2(const float *scores, const float *vals, float *out, int rows, int cols, int w, float scale,
-                         void *stream) {
-  if (!scores || !out || rows <= 0 || cols <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
-  DRBA_LAUNCH(softmax_expect2_kernel, dim3(rows), dim3(kBlock), 0, (hipStream_t)stream, scores, vals, out, rows,
-                     cols, w, scale);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -1,14 +1,14 @@
 """GMFlow on the MI355X (reference models/gmflow/{gmflow,backbone,trident_conv,transformer,matching,geometry,utils,
 position}.py, same state-dict keys; configuration used by DRBA: 2 scales, swin attention, 6 layers, 1 head).
 
-Division of labour: the 3x3 convolutions run on the fp32-MFMA implicit-GEMM kernel; the 7x7 / 1x1 convolutions, the
-norms, GELU, masked softmax, correlation-softmax -> flow expectations, local-window propagation, convex upsampling
-and warps are hand-written HIP kernels (drba_amd/csrc/gmflow.hip); the plain GEMMs (linear projections, QK^T, PV)
-go to the vendor BLAS through torch.matmul, and window split / merge / roll are pure data movement done with torch
-views.  No arithmetic other than those GEMMs happens in torch.
+Division of labour: the 3x3 convolutions run on the MFMA implicit-GEMM kernels; the 7x7 / 1x1 convolutions, the norms,
+local-window correlation / propagation, convex upsampling and warps are hand-written HIP kernels
+(drba_amd/csrc/gmflow.hip); every linear layer is drba_linear_split (three-term bf16 MFMA, fp32-level error), the
+window attention is one fused kernel (window_attn.hip) and the global correlation / propagation softmaxes are a
+flash-style kernel that never forms the L x L score matrix (global_corr.hip).  torch does views, cat and nothing else:
+no arithmetic and no vendor BLAS.
 """
 import math
-import os
 
 import torch
 
@@ -18,11 +18,8 @@ C = 128
 _MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
-def _linear(x, w, b=None):
-    if isinstance(w, _ops.LinearSplit):
-        return w(x)
-    y = torch.matmul(x, w.t())
-    return y if b is None else torch.add(y, b)  # bias add of the two flow-attention projections (128 floats)
+def _linear(x, w):
+    return w(x)  # _ops.LinearSplit
 
 
 class _ResBlock:
@@ -78,21 +75,20 @@ class GMFlow:
                 # fused projections: self-attention projects one tensor three times, cross-attention its target twice
                 d["qkv_proj"] = torch.cat((d["q_proj"], d["k_proj"], d["v_proj"]), 0).contiguous()
                 d["kv_proj"] = torch.cat((d["k_proj"], d["v_proj"]), 0).contiguous()
-                if self.SPLIT_LINEAR:  # drba_linear_split (three-term bf16 MFMA, fp32-level error) instead of the BLAS
-                    for n in ("qkv_proj", "kv_proj", "q_proj", "merge"):
-                        d[n] = _ops.LinearSplit(d[n], device=dev)
+                for n in ("qkv_proj", "kv_proj", "q_proj", "merge"):
+                    d[n] = _ops.LinearSplit(d[n], device=dev)
+                del d["k_proj"], d["v_proj"]
                 d["n1w"], d["n1b"] = g(p + "norm1.weight"), g(p + "norm1.bias")
                 if ffn:
-                    d["mlp0"], d["mlp2"] = g(p + "mlp.0.weight"), g(p + "mlp.2.weight")
-                    if self.SPLIT_LINEAR:
-                        d["mlp0"] = _ops.LinearSplit(d["mlp0"], gelu=True, device=dev)  # GELU in the epilogue
-                        d["mlp2"] = _ops.LinearSplit(d["mlp2"], device=dev)
+                    d["mlp0"] = _ops.LinearSplit(g(p + "mlp.0.weight"), gelu=True, device=dev)  # GELU in the epilogue
+                    d["mlp2"] = _ops.LinearSplit(g(p + "mlp.2.weight"), device=dev)
                     d["n2w"], d["n2b"] = g(p + "norm2.weight"), g(p + "norm2.bias")
                 lay[part] = d
             self.layers.append(lay)
-        self.ffa = {k: g(f"feature_flow_attn.{k}") for k in ("q_proj.weight", "q_proj.bias", "k_proj.weight", "k_proj.bias")}
+        self.ffa_q = _ops.LinearSplit(g("feature_flow_attn.q_proj.weight"), g("feature_flow_attn.q_proj.bias"), device=dev)
+        self.ffa_k = _ops.LinearSplit(g("feature_flow_attn.k_proj.weight"), g("feature_flow_attn.k_proj.bias"), device=dev)
         self.up0 = _ops.Conv3x3(sd["upsampler.0.weight"], sd["upsampler.0.bias"], stride=1, act="relu", device=dev)
-        self.up2 = (g("upsampler.2.weight").view(144, 256), g("upsampler.2.bias"))
+        self.up2 = (g("upsampler.2.weight").view(144, 256, 1, 1), g("upsampler.2.bias"))
         self._pos, self._mask = {}, {}
         return self
 
@@ -141,64 +137,43 @@ class GMFlow:
         return self._mask[key]
 
     # ---------------------------------------------------------------- transformer (transformer.py)
-    FUSED_ATTENTION = os.environ.get("DRBA_FUSED_ATTENTION", "1") != "0"
-    SPLIT_LINEAR = os.environ.get("DRBA_LINEAR_SPLIT", "1") != "0"  # 0: the transformer's linears through the vendor BLAS
-
     def _attention(self, q, k, v, h, w, splits, shift):
         b, _, c = q.shape
-        scale = c ** 0.5
         k_ = max(splits, 1)
         shifted = bool(shift) and splits > 1
-        degenerate = shifted and (h // k_ < 2 or w // k_ < 2)  # the reference's mask table is ill-formed there: keep it
-        if self.FUSED_ATTENTION and c == C and not degenerate:
-            return _ops.window_attention(q, k, v, h, w, k_, shifted, scale)
-        return self._attention_unfused(q, k, v, h, w, splits, shift)
+        if shifted and (h // k_ < 2 or w // k_ < 2):
+            return self._attention_degenerate(q, k, v, h, w, splits)
+        return _ops.window_attention(q, k, v, h, w, k_, shifted, c ** 0.5)
 
-    def _attention_unfused(self, q, k, v, h, w, splits, shift):
-        """The reference's formulation step by step (BLAS GEMMs + masked softmax kernel); kept as the cross-check."""
+    def _attention_degenerate(self, q, k, v, h, w, splits):
+        """Shifted windows one pixel wide or high (feature maps below 16 px, i.e. frames below 128 px): the reference's
+        mask table is built with slice(-0, None) there (transformer.py:28-36), which the fused kernel's coordinate rule
+        does not reproduce, so the reference's steps are replayed with the host-built table: roll, split, plain fp32
+        products (drba_bmm), masked softmax kernel, merge, roll back."""
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()  # column slices of a fused projection output
         b, _, c = q.shape
-        scale = c ** 0.5
-        if splits <= 1:
-            scores = torch.matmul(q, k.transpose(1, 2)).contiguous()
-            _ops.softmax_rows_(scores, scale)
-            return torch.matmul(scores, v)
         bn, wh, ww = b * splits * splits, h // splits, w // splits
-        q, k, v = q.view(b, h, w, c), k.view(b, h, w, c), v.view(b, h, w, c)
-        if shift:
-            sh, sw = wh // 2, ww // 2
-            q, k, v = [torch.roll(t, shifts=(-sh, -sw), dims=(1, 2)) for t in (q, k, v)]
-        q, k, v = [_split(t, splits, True).reshape(bn, -1, c) for t in (q, k, v)]
-        scores = torch.matmul(q, k.transpose(1, 2)).contiguous()
-        _ops.softmax_rows_(scores, scale, self._shift_mask(h, w, splits) if shift else None)
-        out = _merge(torch.matmul(scores, v).view(bn, wh, ww, c), splits, True)
-        if shift:
-            out = torch.roll(out, shifts=(sh, sw), dims=(1, 2))
-        return out.reshape(b, -1, c)
+        sh, sw = wh // 2, ww // 2
+        q, k, v = [torch.roll(t.view(b, h, w, c), shifts=(-sh, -sw), dims=(1, 2)) for t in (q, k, v)]
+        q, k, v = [_split(t, splits, True).reshape(bn, -1, c).contiguous() for t in (q, k, v)]
+        scores = _ops.bmm(q, k, trans_b=True)
+        _ops.softmax_rows_(scores, c ** 0.5, self._shift_mask(h, w, splits))
+        out = _merge(_ops.bmm(scores, v, trans_b=False).view(bn, wh, ww, c), splits, True)
+        return torch.roll(out, shifts=(sh, sw), dims=(1, 2)).reshape(b, -1, c)
 
     def _layer(self, d, source, target, h, w, splits, shift, ffn):
-        if self.FUSED_ATTENTION and source is target:  # one [tokens, 3C] GEMM; the attention kernel reads column slices
+        if source is target:  # one [tokens, 3C] GEMM; the attention kernel reads column slices
             qkv = _linear(source, d["qkv_proj"])
             q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-        elif self.FUSED_ATTENTION:
+        else:
             q, kv = _linear(source, d["q_proj"]), _linear(target, d["kv_proj"])
             k, v = kv[..., :C], kv[..., C:]
-        else:
-            q, k, v = _linear(source, d["q_proj"]), _linear(target, d["k_proj"]), _linear(target, d["v_proj"])
         att = self._attention(q, k, v, h, w, splits, shift)
-        fused_ln = isinstance(d["merge"], _ops.LinearSplit)  # LayerNorm (+ residual) in the GEMM's epilogue
-        if not ffn:
-            if fused_ln:
-                return d["merge"].layernorm(att, d["n1w"], d["n1b"], residual=source)
-            return _ops.layernorm(_linear(att, d["merge"]), d["n1w"], d["n1b"], residual=source)
-        msg = d["merge"].layernorm(att, d["n1w"], d["n1b"]) if fused_ln else _ops.layernorm(_linear(att, d["merge"]), d["n1w"], d["n1b"])
-        if isinstance(d["mlp0"], _ops.LinearSplit):  # reads cat(source, msg) in place; GELU in the epilogue
-            hid = d["mlp0"].cat(source, msg)
-        else:
-            hid = _ops.gelu(_linear(torch.cat([source, msg], dim=-1), d["mlp0"]))
-        if isinstance(d["mlp2"], _ops.LinearSplit):
-            return d["mlp2"].layernorm(hid, d["n2w"], d["n2b"], residual=source)
-        return _ops.layernorm(_linear(hid, d["mlp2"]), d["n2w"], d["n2b"], residual=source)
+        if not ffn:  # LayerNorm (+ residual) in the GEMM's epilogue
+            return d["merge"].layernorm(att, d["n1w"], d["n1b"], residual=source)
+        msg = d["merge"].layernorm(att, d["n1w"], d["n1b"])
+        hid = d["mlp0"].cat(source, msg)  # reads cat(source, msg) in place; GELU in the epilogue
+        return d["mlp2"].layernorm(hid, d["n2w"], d["n2b"], residual=source)
 
     def transformer(self, f0, f1, splits):
         b, c, h, w = f0.shape
@@ -211,6 +186,7 @@ class GMFlow:
             c0 = self._layer(lay["cross_attn_ffn"], c0, c1, h, w, splits, shift, True)
             c1 = torch.cat(c0.chunk(2, 0)[::-1], 0).contiguous()
         t0, t1 = c0.chunk(2, 0)
+        self._tokens = (t0.reshape(h * w, c), t1.reshape(h * w, c))  # token-major views of the outputs (global matching reads them)
         return (t0.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous(),
                 t1.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous())
 
@@ -223,36 +199,37 @@ class GMFlow:
         pos = self._position(f0.shape[0], f0.shape[2], f0.shape[3])
         return _ops.add_act(f0, pos), _ops.add_act(f1, pos)
 
-    def _propagate(self, f0, flow, local, radius):
-        """FeatureFlowAttention (transformer.py:325-409)."""
+    def _propagate(self, f0, flow, local, radius, tok=None):
+        """FeatureFlowAttention (transformer.py:325-409).  `tok`: f0 token-major ([h*w, C]) if the caller has it."""
         b, c, h, w = f0.shape
-        tok = f0.view(b, c, h * w).permute(0, 2, 1).contiguous()
-        q = _linear(tok, self.ffa["q_proj.weight"], self.ffa["q_proj.bias"])
+        if tok is None:
+            tok = f0.view(c, h * w).t().contiguous()
+        q = self.ffa_q(tok)
         if not local:
-            k = _linear(q, self.ffa["k_proj.weight"], self.ffa["k_proj.bias"])  # key from the projected query, as written
-            scores = torch.matmul(q[0], k[0].t()).contiguous()
-            return _ops.softmax_expect2(scores, flow.view(2, h * w), w, c ** 0.5).view(1, 2, h, w)
-        k = _linear(tok, self.ffa["k_proj.weight"], self.ffa["k_proj.bias"])
-        return _ops.local_attn_flow(q[0].contiguous(), k[0].contiguous(), flow, radius)
+            k = self.ffa_k(q)  # key from the projected query, as written (transformer.py:361-364)
+            return _ops.global_expect2(q, k, flow.view(2, h * w), w, c ** 0.5).view(1, 2, h, w)
+        k = self.ffa_k(tok)
+        return _ops.local_attn_flow(q, k, flow, radius)
 
     # ---------------------------------------------------------------- forward (gmflow.py:92-185)
-    def _match(self, f0, f1, flow, corr_r, prop_r):
-        """Correlation softmax (global or local) + flow propagation of one direction at one scale."""
+    def _match(self, f0, f1, flow, corr_r, prop_r, tok0=None, tok1=None):
+        """Correlation softmax (global or local) + flow propagation of one direction at one scale.  tok0 / tok1: the
+        token-major ([h*w, C]) form of f0 / f1 when the caller has it (the transformer's own layout)."""
         _, c, h, w = f0.shape
         if corr_r == -1:
-            scores = torch.matmul(f0.view(c, h * w).t(), f1.view(c, h * w)).contiguous()
-            pred = _ops.softmax_expect2(scores, None, w, c ** 0.5).view(1, 2, h, w)
+            if tok0 is None:
+                tok0, tok1 = f0.view(c, h * w).t().contiguous(), f1.view(c, h * w).t().contiguous()
+            pred = _ops.global_expect2(tok0, tok1, None, w, c ** 0.5).view(1, 2, h, w)
         else:
             pred = _ops.local_corr_flow(f0, f1, corr_r)
         flow = pred if flow is None else _ops.add_act(flow, pred)
-        return self._propagate(f0, flow, local=prop_r > 0, radius=prop_r)
+        return self._propagate(f0, flow, local=prop_r > 0, radius=prop_r, tok=tok0)
 
     def _upsample(self, flow, f0):
         """learned convex upsampling x4 (gmflow.py:67-90)"""
         m = self.up0(torch.cat((flow, f0), 1))
-        _, _, h, w = flow.shape
-        m = torch.add(torch.matmul(self.up2[0], m.view(256, h * w)), self.up2[1].view(144, 1))  # 1x1 conv = plain GEMM
-        return _ops.convex_upsample(m.view(1, 144, h, w), flow, 4)
+        m = _ops.conv_direct(m, self.up2[0], self.up2[1], 1, 0)  # 1x1 conv 256 -> 144 (9 x 16 convex weights)
+        return _ops.convex_upsample(m, flow, 4)
 
     def _refine(self, fa, fb, flow, splits, corr_r, prop_r):
         """One finer scale of one direction: warp the other frame's features by the upsampled flow, transformer, match."""
@@ -261,7 +238,8 @@ class GMFlow:
         fb = _ops.flow_warp(fb, flow)
         fa, fb = self._add_position(fa, fb, splits)
         fa, fb = self.transformer(fa, fb, splits)
-        return self._match(fa, fb, flow, corr_r, prop_r), fa
+        ta, tb = self._tokens
+        return self._match(fa, fb, flow, corr_r, prop_r, ta, tb), fa
 
     def __call__(self, img0, img1, attn_splits_list=(2, 8), corr_radius_list=(-1, 4), prop_radius_list=(-1, 1), **kw):
         x = _ops.channel_normalize3(torch.cat((img0, img1), 0).contiguous(), _MEAN, _STD)
@@ -274,7 +252,7 @@ class GMFlow:
             else:
                 f0, f1 = self._add_position(f0, f1, splits)
                 f0, f1 = self.transformer(f0, f1, splits)
-                flow = self._match(f0, f1, None, corr_r, prop_r)
+                flow = self._match(f0, f1, None, corr_r, prop_r, *self._tokens)
         return self._upsample(flow, f0)
 
     def encode_frame(self, img):
@@ -300,8 +278,9 @@ class GMFlow:
             (c0, h0), (c1, h1) = feats
         t0, t1 = self._add_position(c0, c1, attn_splits_list[0])
         t0, t1 = self.transformer(t0, t1, attn_splits_list[0])
-        flow_a = self._match(t0, t1, None, corr_radius_list[0], prop_radius_list[0])
-        flow_b = self._match(t1, t0, None, corr_radius_list[0], prop_radius_list[0])
+        k0, k1 = self._tokens
+        flow_a = self._match(t0, t1, None, corr_radius_list[0], prop_radius_list[0], k0, k1)
+        flow_b = self._match(t1, t0, None, corr_radius_list[0], prop_radius_list[0], k1, k0)
         flow_a, fa = self._refine(h0, h1, flow_a, attn_splits_list[1], corr_radius_list[1], prop_radius_list[1])
         flow_b, fb = self._refine(h1, h0, flow_b, attn_splits_list[1], corr_radius_list[1], prop_radius_list[1])
         return self._upsample(flow_a, fa), self._upsample(flow_b, fb)

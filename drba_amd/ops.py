@@ -816,14 +816,36 @@ def softmax_rows_(scores, scale, mask=None):
     return scores
 
 
-def softmax_expect2(scores, vals, w, scale):
-    """scores [rows, cols]; vals None (pixel coordinates, own coordinate subtracted) or [2, cols] -> [2, rows]."""
-    scores = _f32(scores)
-    rows, cols = scores.shape
-    out = torch.empty((2, rows), dtype=torch.float32, device=scores.device)
+def global_expect2(q_tok, k_tok, vals, w, scale):
+    """softmax(q k^T / scale) . vals without the score matrix: q_tok, k_tok [L, 128] token-major (row-strided column
+    slices allowed), vals None (pixel coordinates, own coordinate subtracted: the correlation flow) or [2, L] -> [2, L]."""
+    def rows(t):
+        ok = (t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda and t.stride(1) == 1 and t.stride(0) % 4 == 0
+              and t.data_ptr() % 16 == 0)
+        t = t if ok else _f32(t.reshape(-1, t.shape[-1]))
+        return t, t.stride(0)
+    (q, ldq), (k, ldk) = rows(q_tok), rows(k_tok)
+    L, c = q.shape
+    assert k.shape == (L, c)
     v = None if vals is None else _f32(vals)
-    _lib.check(_lib.load().drba_softmax_expect2(_p(scores), _p(v), _p(out), rows, cols, int(w), float(scale), _stream()),
-               "drba_softmax_expect2")
+    if v is not None:
+        assert v.numel() == 2 * L
+    out = torch.empty((2, L), dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    nws = lib.drba_global_expect2_ws_floats(L)
+    ws = _workspace(q.device, nws) if nws else None
+    _lib.check(_timed("global_expect2", (L, c), 2.0 * L * L * c, "flop", lambda: lib.drba_global_expect2(
+        _p(q), _p(k), _p(v), _p(out), _p(ws), L, c, int(w), float(scale), ldq, ldk, _stream())), "drba_global_expect2")
+    return out
+
+
+def bmm(a, b, trans_b):
+    """[B, M, K] x ([B, N, K]^T if trans_b else [B, K, N]) -> [B, M, N]; plain fp32 kernel for the degenerate attention case."""
+    a, b = _f32(a), _f32(b)
+    bsz, m, kk = a.shape
+    n = b.shape[1] if trans_b else b.shape[2]
+    out = torch.empty((bsz, m, n), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().drba_bmm(_p(a), _p(b), _p(out), bsz, m, n, kk, 1 if trans_b else 0, _stream()), "drba_bmm")
     return out
 
 

@@ -242,11 +242,17 @@ int drba_linear_split_layernorm(const float *x, const float *packed_w, const flo
 /* in-place row softmax of x/scale + mask[(row/rows_per_mat) % n_masks][row % rows_per_mat] (transformer.py:91-96) */
 int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks,
                       float scale, void *stream);
-/* fused softmax(scores/scale) . values per row -> out [2, rows].  vals NULL: global-correlation flow
- * (matching.py:7-38; column j = pixel (j % w, j / w), own coordinate subtracted); else vals [2, cols]
- * (global flow propagation, transformer.py:355-372) */
-int drba_softmax_expect2(const float *scores, const float *vals, float *out, int rows, int cols, int w,
-                         float scale, void *stream);
+/* Global correlation / global flow propagation WITHOUT the L x L score matrix (matching.py:7-38 global_correlation_softmax;
+ * transformer.py:355-372, FeatureFlowAttention's global branch): out[2][L] = softmax_j(<q_i, k_j> / scale) . val_j, flash
+ * style on the fp32 matrix cores.  q, k: token-major [L][ldq / ldk] rows of C = 128 features.  vals == NULL: val_j = pixel
+ * coordinate (j % w, j / w) and the query's own coordinate is subtracted (the correlation flow); else vals = [2][L] planes
+ * (the flow to propagate).  ws: drba_global_expect2_ws_floats(L) floats (NULL: no key split). */
+int drba_global_expect2(const float *q, const float *k, const float *vals, float *out, float *ws, int L, int C, int w,
+                        float scale, int ldq, int ldk, void *stream);
+size_t drba_global_expect2_ws_floats(int L);
+/* plain batched fp32 matrix product C[b] = A[b] B[b]^T (trans_b) or A[b] B[b]: only the degenerate shifted-window case of
+ * transformer.py:46-113 (windows one pixel wide, frames below 128 px) uses it; everything else is fused */
+int drba_bmm(const float *a, const float *b, float *c, int batch, int M, int N, int K, int trans_b, void *stream);
 /* matching.py:41-89: local correlation softmax flow, radius r, features NCHW */
 int drba_local_corr_flow(const float *f0, const float *f1, float *out, int C, int H, int W, int radius, void *stream);
 /* transformer.py:374-409: local-window flow propagation; q_tok / k_tok token-major [H*W, C], flow [2,H,W] */

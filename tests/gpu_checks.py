@@ -470,6 +470,45 @@ def check_window_attention(dev):
     return rows
 
 
+def check_global_expect2(dev):
+    """drba_global_expect2 (flash-style global correlation / propagation, no L x L matrix) against the oracle's
+    formulation (oracle/gmflow.py global_correlation_softmax = matching.py:7-38) and an fp64 softmax expectation: L not a
+    multiple of the 64-key chunk, L below one query tile, the 1080p size (8640 tokens, key-split path), row-strided
+    inputs; and the degenerate shifted-window attention (windows one pixel high) that takes the plain drba_bmm path."""
+    from drba_amd import ops
+    from drba_amd.models.gmflow.gmflow import GMFlow
+    from oracle import gmflow as ogm
+    rows = []
+    for idx, (h, w) in enumerate(((5, 9), (13, 45), (36, 60), (72, 120))):
+        L = h * w
+        f0, f1 = cases.rnd((1, 128, h, w), 300 + idx, 0.9), cases.rnd((1, 128, h, w), 310 + idx, 0.9)
+        want = ogm.global_correlation_softmax(f0, f1)[0].reshape(2, L)
+        t0, t1 = f0.view(128, L).t().contiguous().to(dev), f1.view(128, L).t().contiguous().to(dev)
+        got = ops.global_expect2(t0, t1, None, w, 128 ** 0.5)
+        ref64 = ogm.global_correlation_softmax(f0.double(), f1.double())[0].reshape(2, L).float()
+        floor = _diff(want, ref64)
+        rows.append((f"global_expect2 coords {h}x{w} (L={L})", _diff(got, ref64), max(2e-5, 3.0 * floor) * max(1.0, w / 16.0),
+                     f"fp32_oracle_vs_fp64={floor:.2e}"))
+        if L >= 8192:
+            assert ops._lib.load().drba_global_expect2_ws_floats(L) > 0  # the key-split path is what ran
+        # values = a flow field; q / k as column slices of a wider tensor (row stride 256)
+        flow = cases.rnd((2, L), 320 + idx, 5.0)
+        wide = torch.cat((t0, t1), 1)
+        got = ops.global_expect2(wide[:, :128], wide[:, 128:], flow.to(dev), w, 128 ** 0.5)
+        p = torch.softmax((t0.double().cpu() @ t1.double().cpu().t()) / 128 ** 0.5, -1)
+        rows.append((f"global_expect2 values {h}x{w} strided", _diff(got, (p @ flow.double().t()).t().float()), 5e-5, ""))
+    # degenerate shifted window: 8 x 16 map, 8 splits -> windows 1 x 2 (sh = 0): reference mask table via slice(-0, None)
+    net = GMFlow.__new__(GMFlow)
+    net.device, net._mask = dev, {}
+    h, w, splits = 8, 16, 8
+    q, k, v = [cases.rnd((2, h * w, 128), 340 + j, 1.2) for j in range(3)]
+    mask = ogm.shift_window_mask(h, w, 1, 2, 0, 1)
+    want = ogm.window_attention(q, k, v, splits, True, h, w, mask)
+    got = net._attention(q.to(dev), k.to(dev), v.to(dev), h, w, splits, True)
+    rows.append(("window attention, degenerate 1x2 windows (drba_bmm path)", _diff(got, want), 2e-5, ""))
+    return rows
+
+
 # ----------------------------------------------------------------------------------------- split-bf16 linear
 def check_linear_split(dev):
     """drba_linear_split against an fp64 nn.Linear: ragged token counts, N not a multiple of the 128-feature tile, a

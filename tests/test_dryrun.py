@@ -121,7 +121,7 @@ def test_gmfss_union_pipeline_plumbing(dry, monkeypatch, scale, size):
     r = m.inference_ts(I[0], I[1], np.array([0.0, 0.5, 1.0]))
     assert r[0] is I[0] and r[2] is I[1] and r[1].shape == (1, 3, H, W)
     for k in ("drba_conv_direct", "drba_instance_norm", "drba_linear_split_layernorm", "drba_linear_split", "drba_window_attention",
-              "drba_softmax_expect2", "drba_local_corr_flow", "drba_local_attn_flow", "drba_convex_upsample",
+              "drba_global_expect2", "drba_local_corr_flow", "drba_local_attn_flow", "drba_convex_upsample",
               "drba_flow_warp", "drba_resize_bilinear_ac", "drba_metric_input", "drba_pixel_shuffle2",
               "drba_timestep_fix", "drba_swap_select", "drba_clamp", "drba_channel_normalize3", "drba_add_act"):
         assert dry.calls.get(k, 0) > 0, k

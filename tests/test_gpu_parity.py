@@ -172,6 +172,11 @@ def test_window_attention(hip_backend):
 
 
 @pytest.mark.gpu
+def test_global_expect2(hip_backend):
+    _assert_rows(gpu_checks.check_global_expect2(hip_backend.dev))
+
+
+@pytest.mark.gpu
 def test_linear_split(hip_backend):
     _assert_rows(gpu_checks.check_linear_split(hip_backend.dev))
 
