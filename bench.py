@@ -296,7 +296,13 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
     roof_every = max(1, min(10, args.steps // 2))
     traced = 0
     if trace:
+        # one traced and one plain step before the timed region: the first plain launch after the first traced ones
+        # costs ~40 ms once (the runtime switches the queue's profiling mode; tools/exp/trace_overhead.py)
         ops.trace_begin()
+        step()
+        ops.trace_pause()
+        step()
+        ops.trace_begin()  # clears the records of the untimed step
         ops.trace_pause()
     _fence(world)
     t0 = time.perf_counter()

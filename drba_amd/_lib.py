@@ -61,6 +61,8 @@ SIGNATURES = {
     "drba_conv_chain": (_i, [_p, _p, _p, _p, C.POINTER(ConvLayer), _i, _i, _i, _i, _p]),
     "drba_deconv4x4s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_ifblock_input_lds": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_warp_blend_fold": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
     "drba_pair_interleave": (_i, [_p, _p, _i, _i, _i, _p]),
     "drba_ifblock_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "drba_metric_input": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),

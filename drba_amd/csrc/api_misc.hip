@@ -15,7 +15,8 @@
 namespace {
 constexpr int kTraceSlots = 16384;
 struct Rec {
-  const std::string *name;
+  const void *fn;        // host stub of the kernel: its symbol name is looked up when the record is READ (drba_trace_get),
+  const char *fallback;  // never inside the traced region
   unsigned gx, gy, gz;
 };
 hipEvent_t g_ev[kTraceSlots][2];
@@ -23,7 +24,8 @@ bool g_ev_made[kTraceSlots];
 std::vector<Rec> g_recs;
 std::unordered_map<const void *, std::string> g_names;
 
-const std::string &kernel_name(const void *host_fn, const char *fallback, hipStream_t stream) {
+const std::string &kernel_name(const void *host_fn, const char *fallback) {
+  hipStream_t stream = nullptr;
   auto it = g_names.find(host_fn);
   if (it != g_names.end()) return it->second;
   std::string nm;
@@ -66,7 +68,8 @@ TimedLaunch trace_launch(const void *host_fn, const char *fallback, dim3 grid, h
     if (hipEventCreate(&g_ev[slot][0]) != hipSuccess || hipEventCreate(&g_ev[slot][1]) != hipSuccess) return t;
     g_ev_made[slot] = true;
   }
-  g_recs.push_back(Rec{&kernel_name(host_fn, fallback, stream), grid.x, grid.y, grid.z});
+  (void)stream;
+  g_recs.push_back(Rec{host_fn, fallback, grid.x, grid.y, grid.z});
   t.start = g_ev[slot][0];
   t.stop = g_ev[slot][1];
   return t;
@@ -105,7 +108,7 @@ int drba_trace_get(int i, const char **name, unsigned *grid3, float *ms) {
   if (i < 0 || (size_t)i >= g_recs.size() || !name || !grid3 || !ms) return DRBA_EINVAL;
   if (hipEventSynchronize(g_ev[i][1]) != hipSuccess) return DRBA_ELAUNCH;
   if (hipEventElapsedTime(ms, g_ev[i][0], g_ev[i][1]) != hipSuccess) return DRBA_ELAUNCH;
-  *name = g_recs[i].name->c_str();
+  *name = kernel_name(g_recs[i].fn, g_recs[i].fallback).c_str();
   grid3[0] = g_recs[i].gx;
   grid3[1] = g_recs[i].gy;
   grid3[2] = g_recs[i].gz;

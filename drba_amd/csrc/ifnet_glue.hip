@@ -365,6 +365,181 @@ ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ i
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Warped stage input with the previous head output staged through LDS, optionally with the previous stage's flow
+// update folded in (IFNet_HDv3.py:85-95,146-160).
+//
+// The kernels above evaluate mask / feat (x s_prev upsample of tmp_prev's channels 4..12) with 36 scattered global
+// loads per sample point; they are bound by the NUMBER of vector-memory instructions (TA busy 86-98 %).  A workgroup's
+// sample points cover a 32 x 8 (scale 1, 2) or 16s x 4s full-resolution block, whose footprint in tmp_prev is at most
+// 18 x 6 pixels: the 13-channel footprint (<= 5.6 KB) is staged once per workgroup and the taps become LDS reads.
+// With FOLD the running flow is not read as the finished sum: flow = flow_prev + up(tmp_prev[0:4]) * s_prev is formed
+// here from the same LDS tile (ifblock_update's arithmetic), written to flow_out and used for the warps.  That needs
+// every full-resolution pixel to be a sample point exactly once, i.e. scale <= 2 (the two full-resolution stages of
+// the 1080p path): one 8P-byte read-modify-write pass and one launch per sample and stage disappear.
+constexpr int kPrevRW = 20, kPrevRH = 6;  // LDS footprint capacity (columns padded to 20)
+template <bool SINGLE, bool FOLD>
+__global__ void __launch_bounds__(256)
+ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
+                  const float *__restrict__ f1, const float *__restrict__ f0p, const float *__restrict__ f1p,
+                  const float *__restrict__ tmap, float tscalar, const float *__restrict__ flow,
+                  const float *__restrict__ tmp_prev, int hp, int wp, float inv_prev_scale, float prev_scale,
+                  float *__restrict__ flow_out, float *__restrict__ out, int H, int W, int h, int w, float scale) {
+  __shared__ float prev[13][kPrevRH][kPrevRW];
+  constexpr int LPO = SINGLE ? 1 : 4;
+  constexpr int TWo = SINGLE ? 32 : 16, THo = SINGLE ? 8 : 4;
+  constexpr int C0 = FOLD ? 0 : 4;  // first channel of tmp_prev that is needed
+  const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
+  const int tiles_x = (w + TWo - 1) / TWo;
+  const int t = xcd_band(blockIdx.x, gridDim.x);
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  // footprint of this workgroup's sample points in tmp_prev (same for every lane: computed from the tile corners)
+  const int ox_a = tx * TWo, oy_a = ty * THo;
+  const int ox_b = min(ox_a + TWo - 1, w - 1), oy_b = min(oy_a + THo - 1, h - 1);
+  const int Xa = lerp_src(ox_a, scale, W).i0, Ya = lerp_src(oy_a, scale, H).i0;
+  const int Xb = SINGLE ? ox_b : lerp_src(ox_b, scale, W).i1, Yb = SINGLE ? oy_b : lerp_src(oy_b, scale, H).i1;
+  const int rx0 = lerp_src(Xa, inv_prev_scale, wp).i0, ry0 = lerp_src(Ya, inv_prev_scale, hp).i0;
+  const int rw = lerp_src(Xb, inv_prev_scale, wp).i1 - rx0 + 1, rh = lerp_src(Yb, inv_prev_scale, hp).i1 - ry0 + 1;
+  for (int i = threadIdx.x; i < (13 - C0) * rh * rw; i += 256) {
+    const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
+    prev[C0 + c][r][col] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
+  }
+  __syncthreads();
+
+  const int lo = threadIdx.x / LPO;
+  const int ox_raw = ox_a + (lo % TWo), oy_raw = oy_a + (lo / TWo);
+  const bool valid = ox_raw < w && oy_raw < h;
+  const int ox = min(ox_raw, w - 1), oy = min(oy_raw, h - 1);
+  const size_t o = (size_t)oy * w + ox;
+  const int sub = (int)(threadIdx.x % LPO), sj = sub >> 1, si = sub & 1;
+  const Lerp ly = lerp_src(oy, scale, H), lx = lerp_src(ox, scale, W);
+  const int X = si ? lx.i1 : lx.i0, Y = sj ? ly.i1 : ly.i0;
+  const float wx = si ? lx.w1 : lx.w0, wy = sj ? ly.w1 : ly.w0;
+  const size_t q = (size_t)Y * W + X;
+  auto comb = [&](float v) -> float {
+    if (SINGLE) return ly.w0 * (lx.w0 * v + lx.w1 * 0.f) + ly.w1 * 0.f;
+    const float a = wx * v;
+    const float row = a + __shfl_xor(a, 1, 64);
+    const float b = wy * row;
+    return b + __shfl_xor(b, 2, 64);
+  };
+  const bool writer = valid && sub == 0;
+  float *dst = out + o;
+  // taps of the previous head output's upsample at (X, Y), relative to the staged footprint
+  const Lerp a = lerp_src(Y, inv_prev_scale, hp), b = lerp_src(X, inv_prev_scale, wp);
+  const int r0 = a.i0 - ry0, r1 = a.i1 - ry0, c0 = b.i0 - rx0, c1 = b.i1 - rx0;
+  auto prev_up = [&](int c) -> float {
+    const float top = b.w0 * prev[c][r0][c0] + b.w1 * prev[c][r0][c1];
+    const float bot = b.w0 * prev[c][r1][c0] + b.w1 * prev[c][r1][c1];
+    return a.w0 * top + a.w1 * bot;
+  };
+  float fls[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (FOLD) {
+      const float fd = prev_up(c) * prev_scale;  // ifblock_update: flow_in + up(tmp) * scale
+      fls[c] = flow ? flow[(size_t)c * P + q] + fd : fd;
+      if (valid) flow_out[(size_t)c * P + q] = fls[c];  // scale <= 2: the sample points are the full-resolution pixels
+    } else {
+      fls[c] = flow[(size_t)c * P + q];
+    }
+  }
+  const Taps t0 = taps_border(warp_coord(X, W, fls[0]), warp_coord(Y, H, fls[1]), W, H);
+  const Taps t1 = taps_border(warp_coord(X, W, fls[2]), warp_coord(Y, H, fls[3]), W, H);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v0 = comb(sample(img0 + (size_t)c * P, W, t0)), v1 = comb(sample(img1 + (size_t)c * P, W, t1));
+    if (writer) {
+      dst[(size_t)c * p_lo] = v0;
+      dst[(size_t)(3 + c) * p_lo] = v1;
+    }
+  }
+  if (f0p) {
+#pragma unroll 1
+    for (int c2 = 0; c2 < 8; ++c2) {
+      float a0, a1, b0, b1;
+      sample_pair(f0p + (size_t)c2 * 2 * P, W, t0, a0, a1);
+      sample_pair(f1p + (size_t)c2 * 2 * P, W, t1, b0, b1);
+      a0 = comb(a0), a1 = comb(a1), b0 = comb(b0), b1 = comb(b1);
+      if (writer) {
+        dst[(size_t)(6 + 2 * c2) * p_lo] = a0;
+        dst[(size_t)(7 + 2 * c2) * p_lo] = a1;
+        dst[(size_t)(22 + 2 * c2) * p_lo] = b0;
+        dst[(size_t)(23 + 2 * c2) * p_lo] = b1;
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < 16; ++c) {
+      const float v0 = comb(sample(f0 + (size_t)c * P, W, t0)), v1 = comb(sample(f1 + (size_t)c * P, W, t1));
+      if (writer) {
+        dst[(size_t)(6 + c) * p_lo] = v0;
+        dst[(size_t)(22 + c) * p_lo] = v1;
+      }
+    }
+  }
+  {
+    const float v = comb(tmap ? tmap[q] : tscalar);
+    if (writer) dst[(size_t)38 * p_lo] = v;
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {  // mask (tmp[4]) and feat (tmp[5:13])
+    const float v = comb(prev_up(4 + c));
+    if (writer) dst[(size_t)(39 + c) * p_lo] = v;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float v = comb(fls[c]);
+    if (writer) dst[(size_t)(48 + c) * p_lo] = (v * 1.f) / scale;  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
+  }
+}
+
+// warp_blend with the LAST stage's flow update folded in: flow = flow_prev + up(tmp[0:4]) * scale is formed per pixel
+// (never stored: nothing reads the final flow), the mask is tmp's channel 4; tmp's footprint is staged through LDS.
+__global__ void __launch_bounds__(256)
+warp_blend_fold_kernel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ flow,
+                       const float *__restrict__ tmp, int h, int w, float inv_scale, float scale, float *__restrict__ out,
+                       int H, int W) {
+  __shared__ float prev[5][10][36];
+  const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
+  const int tiles_x = (W + kTileW - 1) / kTileW;
+  const int t = xcd_band(blockIdx.x, gridDim.x);
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int Xa = tx * kTileW, Ya = ty * kTileH, Xb = min(Xa + kTileW - 1, W - 1), Yb = min(Ya + kTileH - 1, H - 1);
+  const int rx0 = lerp_src(Xa, inv_scale, w).i0, ry0 = lerp_src(Ya, inv_scale, h).i0;
+  const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
+  for (int i = threadIdx.x; i < 5 * rh * rw; i += 256) {
+    const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
+    prev[c][r][col] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
+  }
+  __syncthreads();
+  const int x = Xa + (threadIdx.x & (kTileW - 1)), y = Ya + (threadIdx.x >> 5);
+  if (x >= W || y >= H) return;
+  const size_t p = (size_t)y * W + x;
+  const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
+  const int r0 = ly.i0 - ry0, r1 = ly.i1 - ry0, c0 = lx.i0 - rx0, c1 = lx.i1 - rx0;
+  auto up = [&](int c) -> float {
+    const float top = lx.w0 * prev[c][r0][c0] + lx.w1 * prev[c][r0][c1];
+    const float bot = lx.w0 * prev[c][r1][c0] + lx.w1 * prev[c][r1][c1];
+    return ly.w0 * top + ly.w1 * bot;
+  };
+  float fl[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float fd = up(c) * scale;
+    fl[c] = flow ? flow[(size_t)c * P + p] + fd : fd;
+  }
+  const Taps t0 = taps_border(warp_coord(x, W, fl[0]), warp_coord(y, H, fl[1]), W, H);
+  const Taps t1 = taps_border(warp_coord(x, W, fl[2]), warp_coord(y, H, fl[3]), W, H);
+  const float mk = up(4);
+  const float m = 1.f / (1.f + expf(-mk));
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a = sample(img0 + (size_t)c * P, W, t0), b = sample(img1 + (size_t)c * P, W, t1);
+    out[(size_t)c * P + p] = a * m + b * (1.f - m);
+  }
+}
+
 // IFNet_HDv3.py:92-95 + :160: tmp [13,h,w] -> x`scale` bilinear; flow_out = flow_in + tmp[:4]*scale.
 // mask / feat are written only when requested (the fused pipeline re-derives them from tmp on the fly).
 __global__ void __launch_bounds__(256)
@@ -514,6 +689,45 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
   }
 #undef DRBA_ARGS
 #undef DRBA_IFIN
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0, const float *f1, const float *f0_pair,
+                           const float *f1_pair, const float *timestep_map, float timestep_scalar, const float *flow,
+                           const float *tmp_prev, int hp, int wp, float prev_scale, float *flow_out, float *out, int H,
+                           int W, int h, int w, float scale, void *stream) {
+  if (!img0 || !img1 || !f0 || !f1 || !out || !tmp_prev || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
+  if (hp <= 0 || wp <= 0 || !(prev_scale > 0.f)) return DRBA_EINVAL;
+  if ((f0_pair == nullptr) != (f1_pair == nullptr)) return DRBA_EINVAL;
+  if (!flow_out && !flow) return DRBA_EINVAL;              // without the fold the finished flow must be given
+  if (flow_out && scale > 2.f) return DRBA_EUNSUPPORTED;   // the fold needs every full-resolution pixel sampled once
+  if (scale != 1.f && scale != 2.f && scale != 4.f && scale != 8.f && scale != 16.f && scale != 32.f) return DRBA_EUNSUPPORTED;
+  if (prev_scale != 2.f * scale) return DRBA_EUNSUPPORTED;  // IFNet's pyramid; bounds the staged footprint to 18 x 6 pixels
+  const bool single = scale == 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  const float ips = (float)(1.0 / (double)prev_scale);
+  const int tiles = single ? tiles_for(w, h) : ((w + 15) / 16) * ((h + 3) / 4);
+#define DRBA_IFL(SG, FO)                                                                                                  \
+  DRBA_LAUNCH((ifblock_input_lds<SG, FO>), dim3(tiles), dim3(kBlock), 0, s, img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, \
+              timestep_scalar, flow, tmp_prev, hp, wp, ips, prev_scale, flow_out, out, H, W, h, w, scale)
+  if (flow_out) {
+    if (single) DRBA_IFL(true, true);
+    else DRBA_IFL(false, true);
+  } else {
+    if (single) DRBA_IFL(true, false);
+    else DRBA_IFL(false, false);
+  }
+#undef DRBA_IFL
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_warp_blend_fold(const float *img0, const float *img1, const float *flow, const float *tmp_last, int h, int w,
+                         float scale, float *out, int H, int W, void *stream) {
+  if (!img0 || !img1 || !tmp_last || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale >= 1.f)) return DRBA_EINVAL;
+  DRBA_LAUNCH(warp_blend_fold_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1, flow, tmp_last, h,
+              w, (float)(1.0 / (double)scale), scale, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

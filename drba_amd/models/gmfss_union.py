@@ -41,7 +41,7 @@ class GMFSS_UNION:
             else:
                 if I0s is None:
                     I0s, I1s = _half(I0), _half(I1)
-                rife = self.ifnet.forward_pair(I0s, I1s, float(t), self.scale_list)[0]
+                rife = self.ifnet.forward_pair(I0s, I1s, float(t), self.scale_list, want_flows=False)[0]
                 output.append(self.model.inference(I0, I1, reuse, timestep0=float(t), timestep1=float(1 - t), rife=rife))
         return output
 
@@ -88,10 +88,10 @@ class GMFSS_UNION:
                 dr = calc_drm_rife_auxiliary(tt, flow10, flow12, metric10, metric12, linear)
                 dr = {k: resize(v, I0s.shape[2:]) for k, v in dr.items()}
                 if left:
-                    rife = self.ifnet.forward_pair(I1s, I0s, dr["drm_t1_t01"], self.scale_list)[0]
+                    rife = self.ifnet.forward_pair(I1s, I0s, dr["drm_t1_t01"], self.scale_list, want_flows=False)[0]
                     output.append(self.model.inference(I1, I0, reuseI1I0, dg["drm1t_t01"], dg["drm0t_t01"], rife))
                 else:
-                    rife = self.ifnet.forward_pair(I1s, I2s, dr["drm_t1_t12"], self.scale_list)[0]
+                    rife = self.ifnet.forward_pair(I1s, I2s, dr["drm_t1_t12"], self.scale_list, want_flows=False)[0]
                     output.append(self.model.inference(I1, I2, reuseI1I2, dg["drm1t_t12"], dg["drm2t_t12"], rife))
         # next step's (I1, I0) state = this step's (I1, I2) state with the roles swapped (gmfss_union.py:95-98)
         new_reuse = [v for pair in zip(reuseI1I2[1::2], reuseI1I2[0::2]) for v in pair]

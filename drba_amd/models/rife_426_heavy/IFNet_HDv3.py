@@ -97,11 +97,15 @@ class IFNet:
         self.encode = Head(sd, "encode.", dev)
         return self
 
-    def forward_pair(self, img0, img1, timestep=0.5, scale_list=(8, 4, 2, 1), f0=None, f1=None):
-        """IFNet.forward (IFNet_HDv3.py:126-177) on separate frames (no 6-channel concat)."""
+    def forward_pair(self, img0, img1, timestep=0.5, scale_list=(8, 4, 2, 1), f0=None, f1=None, want_flows=True):
+        """IFNet.forward (IFNet_HDv3.py:126-177) on separate frames (no 6-channel concat) -> (frame, per-stage flows).
+        want_flows=False: only the frame is needed -> the pipeline of forward_pairs (flow updates folded into their
+        consumers, the per-stage full-resolution flows are not all materialised); returns (frame, None)."""
         _, _, H, W = img0.shape
         f0 = self.encode(img0) if f0 is None else f0
         f1 = self.encode(img1) if f1 is None else f1
+        if not want_flows:
+            return self.forward_pairs([(img0, img1, timestep, f0, f1)], scale_list)[0], None
         flow = tmp = None
         s_prev = 1.0
         flow_list = []
@@ -114,34 +118,56 @@ class IFNet:
             s_prev = s
         return _ops.warp_blend(img0, img1, flow, tmp, s_prev), flow_list
 
+    @staticmethod
+    def _lds_ok(s, s_prev):
+        return _ops.LDS_STAGE_INPUT and s_prev == 2 * s and s in (1, 2, 4, 8, 16, 32)
+
     def forward_pairs(self, items, scale_list=(8, 4, 2, 1), first=0, last=5, state=None):
         """Several interpolations of one frame size in one pass: items = [(img0, img1, timestep, f0, f1), ...].
         The samples are independent (IFNet_HDv3.py:126-177 applied to each); stacking them makes every
         convolution of a stage one launch over the batch, which fills the 256 CUs better than the 1/16..1/64
         resolution maps of a single 1080p frame do and halves the launch count of a `-t 2` step.
-        Stages [first, last) are run; last < 5 returns the carried state (per-sample flows, head output, its scale)
-        instead of frames, and `state` resumes from it (models/rife.py runs the low-resolution stages of the NEXT
-        step on a side stream)."""
+        Stages [first, last) are run; last < 5 returns the carried state (per-sample flows, head output, its scale,
+        pending) instead of frames, and `state` resumes from it (models/rife.py runs the low-resolution stages of the
+        NEXT step on a side stream).
+        `pending`: the flow update of the last stage run (flow += up(tmp[:4]) * s, IFNet_HDv3.py:92-95,160) has not been
+        applied to `flows` yet -- it is folded into the consumer where that one visits every full-resolution pixel
+        exactly once (next stage's input kernel at scale <= 2, the final warp_blend): no separate read-modify-write
+        pass over the full-resolution flow for the two full-resolution stages."""
         B = len(items)
-        if B == 1 and first == 0 and last == 5:
-            img0, img1, t, f0, f1 = items[0]
-            return [self.forward_pair(img0, img1, t, scale_list, f0, f1)[0]]
         _, _, H, W = items[0][0].shape
-        flows, tmp, s_prev = state if state is not None else ([None] * B, None, 1.0)
+        flows, tmp, s_prev, pending = state if state is not None else ([None] * B, None, 1.0, False)
         flows = list(flows)
+        dev = items[0][0].device
         for i in range(first, last):
             s = scale_list[i]
             h, w = int(np.floor(H * (1.0 / s))), int(np.floor(W * (1.0 / s)))
-            xin = torch.empty((B, 52 if i else 39, h, w), dtype=torch.float32, device=items[0][0].device)
+            xin = torch.empty((B, 52 if i else 39, h, w), dtype=torch.float32, device=dev)
+            lds = i > 0 and self._lds_ok(s, s_prev)
+            fold = pending and lds and s <= 2
             for k, (img0, img1, t, f0, f1) in enumerate(items):
-                _ops.ifblock_input(img0, img1, f0, f1, t, flows[k], None if tmp is None else tmp[k:k + 1], s_prev, s,
-                                   out=xin[k:k + 1])
-            tmp = self.block[i].core(xin)  # [B,13,H/s,W/s]
-            for k in range(B):
-                flows[k] = _ops.ifblock_update(tmp[k:k + 1], flows[k], H, W, s)
+                if pending and not fold:
+                    flows[k] = _ops.ifblock_update(tmp[k:k + 1], flows[k], H, W, s_prev)
+                if fold:
+                    _, flows[k] = _ops.ifblock_input_lds(img0, img1, f0, f1, t, flows[k], tmp[k:k + 1], s_prev, s,
+                                                         out=xin[k:k + 1], fold=True)
+                elif lds:
+                    _ops.ifblock_input_lds(img0, img1, f0, f1, t, flows[k], tmp[k:k + 1], s_prev, s, out=xin[k:k + 1])
+                else:
+                    _ops.ifblock_input(img0, img1, f0, f1, t, flows[k], None if tmp is None else tmp[k:k + 1], s_prev, s,
+                                       out=xin[k:k + 1])
+            tmp = self.block[i].core(xin)  # [B,13,H/s,W/s]: flow delta (4), mask (1), feat (8)
             s_prev = s
+            # leave the update to the consumer if that one can fold it
+            nxt_folds = (i + 1 < 5 and self._lds_ok(scale_list[i + 1], s) and scale_list[i + 1] <= 2) or i + 1 == 5
+            pending = bool(nxt_folds)
+            if not pending:
+                for k in range(B):
+                    flows[k] = _ops.ifblock_update(tmp[k:k + 1], flows[k], H, W, s)
         if last < 5:
-            return flows, tmp, s_prev
+            return flows, tmp, s_prev, pending
+        if pending:
+            return [_ops.warp_blend_fold(it[0], it[1], flows[k], tmp[k:k + 1], s_prev) for k, it in enumerate(items)]
         return [_ops.warp_blend(it[0], it[1], flows[k], tmp[k:k + 1], s_prev) for k, it in enumerate(items)]
 
     def __call__(self, x, timestep=0.5, scale_list=(8, 4, 2, 1), training=False, fastmode=True, ensemble=False,

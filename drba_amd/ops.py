@@ -579,6 +579,49 @@ def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scal
     return out
 
 
+LDS_STAGE_INPUT = True  # warped stage inputs through drba_ifblock_input_lds (tmp_prev's footprint staged in LDS)
+
+
+def ifblock_input_lds(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scale, out=None, fold=False):
+    """Warped stage input like ifblock_input(flow != None), previous head output staged through LDS.  fold=True: `flow` is
+    the running flow BEFORE the previous stage's update (or None); the update flow + up(tmp_prev[:4]) * prev_scale is
+    formed inside the kernel (scale <= 2 only) and returned as the second value."""
+    img0, img1, f0, f1, tmp_prev = _f32(img0), _f32(img1), _f32(f0), _f32(f1), _f32(tmp_prev)
+    _, _, H, W = img0.shape
+    h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
+    tmap, tsc = (None, float(timestep)) if not torch.is_tensor(timestep) else (_f32(timestep), 0.0)
+    if out is None:
+        out = torch.empty((1, 52, h, w), dtype=torch.float32, device=img0.device)
+    elif tuple(out.shape) != (1, 52, h, w) or not out.is_contiguous():
+        raise _lib.DrbaHipError(f"ifblock_input_lds: out must be a contiguous [1,52,{h},{w}] tensor")
+    flow = None if flow is None else _f32(flow)
+    flow_out = torch.empty((1, 4, H, W), dtype=torch.float32, device=img0.device) if fold else None
+    hp, wp = tmp_prev.shape[2], tmp_prev.shape[3]
+    pts = H * W if scale <= 2 else 4 * h * w
+    nbytes = 4.0 * (43 * pts + 52 * h * w + (4 * pts if fold else 0))
+    f0p = f1p = None
+    if PAIR_FEATURES and f0.shape[1] == 16:
+        f0p, f1p = pair_interleaved(f0), pair_interleaved(f1)
+    lib = _lib.load()
+    _lib.check(_timed("ifblock_input_lds" + ("+fold" if fold else ""), (52, H, W, h, w), nbytes, "byte", lambda: lib.drba_ifblock_input_lds(
+        _p(img0), _p(img1), _p(f0), _p(f1), _p(f0p), _p(f1p), _p(tmap), tsc, _p(flow), _p(tmp_prev), hp, wp, float(prev_scale),
+        _p(flow_out), _p(out), H, W, h, w, float(scale), _stream())), "drba_ifblock_input_lds")
+    return (out, flow_out) if fold else out
+
+
+def warp_blend_fold(img0, img1, flow_prev, tmp_last, scale):
+    """Final frame with the last stage's flow update folded in (flow_prev: running flow before it, or None)."""
+    img0, img1, tmp_last = _f32(img0), _f32(img1), _f32(tmp_last)
+    flow_prev = None if flow_prev is None else _f32(flow_prev)
+    _, _, H, W = img0.shape
+    h, w = tmp_last.shape[2], tmp_last.shape[3]
+    out = torch.empty((1, 3, H, W), dtype=torch.float32, device=img0.device)
+    nbytes = 4.0 * ((6 + 4 + 3) * H * W + 5 * h * w)
+    _lib.check(_timed("warp_blend_fold", (H, W), nbytes, "byte", lambda: _lib.load().drba_warp_blend_fold(
+        _p(img0), _p(img1), _p(flow_prev), _p(tmp_last), h, w, float(scale), _p(out), H, W, _stream())), "drba_warp_blend_fold")
+    return out
+
+
 def ifblock_update(tmp, flow_in, H, W, scale, want_mask_feat=False):
     """flow (and optionally mask, feat) at full resolution from the 13-channel head output at 1/scale."""
     tmp = _f32(tmp)

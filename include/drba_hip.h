@@ -164,6 +164,17 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
                        const float *timestep_map, float timestep_scalar, const float *flow,
                        const float *tmp_prev, int hp, int wp, float prev_scale, float *out,
                        int H, int W, int h, int w, float scale, void *stream);
+/* The warped stage input (flow != NULL form of drba_ifblock_input) with tmp_prev's footprint staged through LDS, and --
+ * when flow_out != NULL -- with the PREVIOUS stage's flow update (IFNet_HDv3.py:92-95,160) folded in:
+ *   flow_new = (flow ? flow : 0) + up(tmp_prev[0:4]) * prev_scale   is formed per sample point, written to flow_out
+ *   [4,H,W] and used for the warps (flow = the running flow BEFORE that update; drba_ifblock_update is then not called).
+ * The fold requires scale <= 2 (every full-resolution pixel is a sample point exactly once).  flow_out == NULL: `flow` is
+ * the finished running flow, as in drba_ifblock_input.  scale in {1,2,4,...,32}, prev_scale == 2*scale (IFNet's pyramid). */
+int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0, const float *f1,
+                           const float *f0_pair, const float *f1_pair, const float *timestep_map,
+                           float timestep_scalar, const float *flow, const float *tmp_prev, int hp, int wp,
+                           float prev_scale, float *flow_out, float *out, int H, int W, int h, int w, float scale,
+                           void *stream);
 /* [C,H,W] -> [C/2,H,W,2] (C even): channel pairs interleaved per pixel. */
 int drba_pair_interleave(const float *in, float *out, int C, int H, int W, void *stream);
 /* Upsample the 13-channel head output by `scale` and fold it into the running flow:
@@ -175,6 +186,10 @@ int drba_ifblock_update(const float *tmp, const float *flow_in, float *flow_out,
  * m = x scale bilinear upsample of mask_lo [h, w] (channel 4 of the last head output). */
 int drba_warp_blend(const float *img0, const float *img1, const float *flow, const float *mask_lo,
                     int h, int w, float scale, float *out, int H, int W, void *stream);
+/* drba_warp_blend with the LAST stage's flow update folded in: flow = (flow_prev ? flow_prev : 0) + up(tmp_last[0:4]) * scale
+ * per pixel (not stored), mask = channel 4 of tmp_last [13,h,w]. */
+int drba_warp_blend_fold(const float *img0, const float *img1, const float *flow_prev, const float *tmp_last, int h, int w,
+                         float scale, float *out, int H, int W, void *stream);
 
 /* ---- GMFSS / GMFSS_UNION glue (models/model_gmfss_union: MetricNet.py, FusionNet.py, GMFSS.py) ---
  * MetricNet.forward input (MetricNet.py:45-60, geometry.py:87-108), 14 channels at the half-res size:

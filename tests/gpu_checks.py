@@ -231,6 +231,19 @@ def check_glue(dev):
         ref = torch.cat((x, fl), 1)
         got = ops.ifblock_input(D(img0), D(img1), D(f0), D(f1), D(tmap), D(flow), D(tprev), sp, s)
         rows.append((f"ifblock_input warped s={s}", _diff(got, ref), 5e-5, ""))
+        got = ops.ifblock_input_lds(D(img0), D(img1), D(f0), D(f1), D(tmap), D(flow), D(tprev), sp, s)
+        rows.append((f"ifblock_input_lds (tmp_prev staged in LDS) s={s}", _diff(got, ref), 5e-5, ""))
+        if s <= 2:  # previous stage's flow update folded in: flow = flow_prev + up(tprev[:4]) * sp
+            for fprev in (flow * 0.5, None):
+                fl2 = upp[:, :4] * sp if fprev is None else fprev + upp[:, :4] * sp
+                w0, w1 = oracle.ops.backwarp(img0, fl2[:, :2]), oracle.ops.backwarp(img1, fl2[:, 2:4])
+                wf0, wf1 = oracle.ops.backwarp(f0, fl2[:, :2]), oracle.ops.backwarp(f1, fl2[:, 2:4])
+                x2 = F.interpolate(torch.cat((w0, w1, wf0, wf1, tmap, mask, feat), 1), scale_factor=1.0 / s, mode="bilinear", align_corners=False)
+                ref2 = torch.cat((x2, F.interpolate(fl2, scale_factor=1.0 / s, mode="bilinear", align_corners=False) * 1.0 / s), 1)
+                got2, fo = ops.ifblock_input_lds(D(img0), D(img1), D(f0), D(f1), D(tmap), None if fprev is None else D(fprev), D(tprev), sp, s, fold=True)
+                tag = "no prior flow" if fprev is None else "prior flow"
+                rows.append((f"ifblock_input_lds + folded update s={s} ({tag}): flow_out", _diff(fo, fl2), 1e-5 * sp, ""))
+                rows.append((f"ifblock_input_lds + folded update s={s} ({tag}): stage input", _diff(got2, ref2), 1e-4, ""))
         # update
         h, w = int(H / s), int(W / s)
         tmp = torch.randn(1, 13, h, w, generator=g)
@@ -272,6 +285,10 @@ def check_glue(dev):
         m = torch.sigmoid(F.interpolate(tl, scale_factor=sl, mode="bilinear", align_corners=False)[:, 4:5])
         ref = oracle.ops.backwarp(img0, flow[:, :2]) * m + oracle.ops.backwarp(img1, flow[:, 2:4]) * (1 - m)
         rows.append((f"warp_blend s={sl}", _diff(ops.warp_blend(D(img0), D(img1), D(flow), D(tl), sl), ref), 1e-5, ""))
+        upl = F.interpolate(tl, scale_factor=sl, mode="bilinear", align_corners=False)
+        flf = flow * 0.5 + upl[:, :4] * sl
+        ref = oracle.ops.backwarp(img0, flf[:, :2]) * m + oracle.ops.backwarp(img1, flf[:, 2:4]) * (1 - m)
+        rows.append((f"warp_blend_fold s={sl}", _diff(ops.warp_blend_fold(D(img0), D(img1), D(flow * 0.5), D(tl), sl), ref), 2e-5, ""))
     # frame conversion round trip (tools.py:33-38)
     u8 = torch.randint(0, 256, (37, 53, 3), dtype=torch.uint8, generator=g)
     f = ops.u8hwc_to_f32nchw(D(u8))
