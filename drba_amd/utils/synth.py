@@ -187,8 +187,9 @@ def gridnet_shapes(in_channels=9, head0="head0"):
     return sh
 
 
-def seeded_state_dict(shapes, seed=0, tag=""):
-    """Generic seeded weights: conv/linear ~ N(0, (g/sqrt(fan_in))^2), PReLU slopes ~ U(0.1, 0.4), norm weights ~ 1, biases small."""
+def seeded_state_dict(shapes, seed=0, tag="", damp_transformer=True):
+    """Generic seeded weights: conv/linear ~ N(0, (g/sqrt(fan_in))^2), PReLU slopes ~ U(0.1, 0.4), norm weights ~ 1, biases small.
+    damp_transformer=False keeps the transformer's LayerNorm gains at ~1 (the ill-conditioned variant, see below)."""
     sd = {}
     for key, shape in shapes.items():
         g = _gen(tag + key, seed)
@@ -198,7 +199,7 @@ def seeded_state_dict(shapes, seed=0, tag=""):
             t = torch.randn(shape, generator=g) * 0.02
         elif len(shape) == 1:  # LayerNorm weight
             t = 1.0 + torch.randn(shape, generator=g) * 0.05
-            if key.startswith("transformer."):
+            if key.startswith("transformer.") and damp_transformer:
                 # damped attention / FFN messages keep the matching features close to the CNN features, so the
                 # correlation softmax is peaked as in a trained network; with unit gains the random transformer
                 # makes it diffuse and a 1-ulp input change moves the reference's own flow by > 1e-2

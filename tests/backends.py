@@ -30,6 +30,15 @@ class OracleBackend:
     def make_gmfss(self, sds, scale):
         return self._o.gmfss.GmfssOracle(sds["flownet"], sds["metric"], sds["feat"], sds["fusion"], scale)
 
+    def featurenet(self, sd, x):
+        return self._o.gmfss.featurenet(sd, x)
+
+    def metricnet(self, sd, h0, h1, f01, f10, union=True):
+        return self._o.gmfss.metricnet(sd, h0, h1, f01, f10, union)
+
+    def gmflow(self, sd, a, b):
+        return self._o.gmflow.gmflow(sd, a, b)
+
 
 class HipBackend:
     """The product: drba_amd's reference-named call surface running on the HIP library."""
@@ -63,3 +72,15 @@ class HipBackend:
     def make_gmfss(self, sds, scale):
         from drba_amd.models.gmfss import GMFSS
         return GMFSS(weights=sds, scale=scale, device=self.dev)
+
+    def featurenet(self, sd, x):
+        from drba_amd.models.model_gmfss_union.FeatureNet import FeatureNet
+        return FeatureNet(sd, self.dev)(x)
+
+    def metricnet(self, sd, h0, h1, f01, f10, union=True):
+        from drba_amd.models.model_gmfss_union.MetricNet import MetricNet
+        return MetricNet(sd, self.dev, tanh10=union)(h0, h1, f01, f10)
+
+    def gmflow(self, sd, a, b):
+        from drba_amd.models.gmflow.gmflow import GMFlow
+        return GMFlow(sd, self.dev)(a, b)

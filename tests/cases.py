@@ -243,6 +243,63 @@ def gmfss_run(b, sds, scale, H, W):
     return out
 
 
+# ------------------------------------------------------------------------------------------ trained weights
+TRAINED_NPZ = "trained_union_weights.npz"  # FeatureNet / MetricNet of the reference's weights/train_log_gmfss_union (data)
+
+
+def trained_state_dicts(golden_dir, seed=0):
+    """GMFSS_UNION weight set whose FeatureNet and MetricNet are the TRAINED ones shipped in the reference mount
+    (weights/train_log_gmfss_union/{feat,metric}.pkl, CUDA-tagged pickles re-saved as plain fp32 arrays by
+    tests/golden/make_golden.py trained); GMFlow, GridNet and the auxiliary RIFE stay seeded (the mount has none)."""
+    import os
+    z = np.load(os.path.join(golden_dir, TRAINED_NPZ))
+    sds = dict(synth.gmfss_union_state_dicts(seed))
+    for net in ("feat", "metric"):
+        sds[net] = {k[len(net) + 1:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(net + "/")}
+    return sds
+
+
+def trained_run(b, sds, H=128, W=256):
+    """Trained FeatureNet / MetricNet in isolation (MetricNet on seeded smooth flows) and inside one cold + one warm
+    GMFSS_UNION step.  Backends expose featurenet(sd, x) and metricnet(sd, h0, h1, f01, f10, union)."""
+    import torch.nn.functional as F
+    I0, I1, I2, I3 = [f.to(b.dev) for f in gmfss_frames(H, W)]
+    h0 = F.interpolate(I0, scale_factor=0.5, mode="bilinear", align_corners=False)
+    h1 = F.interpolate(I1, scale_factor=0.5, mode="bilinear", align_corners=False)
+    f01 = ((synth._smooth_field(2, H // 2, W // 2, 71) - 0.5) * 12.0).to(b.dev)
+    f10 = ((synth._smooth_field(2, H // 2, W // 2, 72) - 0.5) * 12.0).to(b.dev)
+    out = {}
+    for k, t in enumerate(b.featurenet(sds["feat"], I0)):
+        out[f"featurenet_{k}"] = t
+    for k, t in enumerate(b.metricnet(sds["metric"], h0, h1, f01, f10, True)):
+        out[f"metricnet_{k}"] = t
+    m = b.make_gmfss_union(sds, 1.0)
+    ts = np.array([0.75, 1.25])
+    r, reuse = m.inference_ts_drba(I0, I1, I2, ts, None, True)
+    out["drba_cold_0"], out["drba_cold_1"] = r
+    out["reuse_metric2"], out["reuse_feat2_0"] = reuse[2], reuse[4][0]
+    r2, _ = m.inference_ts_drba(I1, I2, I3, ts, reuse, True)
+    out["drba_warm_0"], out["drba_warm_1"] = r2
+    return out
+
+
+def undamped_gmflow_sd(seed=0):
+    """GMFlow weights with the transformer's LayerNorm gains at ~1 instead of the damped 0.1 of the main fixtures: the
+    random attention/FFN messages swamp the CNN features, the correlation softmax is diffuse and the flow is
+    ill-conditioned -- the case that documents how far the 1e-3 bar holds."""
+    return synth.seeded_state_dict(synth.gmflow_shapes(), seed, "gmflow.", damp_transformer=False)
+
+
+def undamped_gmflow_run(b, H=128, W=256, ulp_noise=False):
+    import torch.nn.functional as F
+    fr = gmfss_frames(H, W)[:2]
+    if ulp_noise:
+        g = torch.Generator().manual_seed(99)
+        fr = [f + (torch.rand(f.shape, generator=g) - 0.5) * 2e-7 for f in fr]
+    h0, h1 = [F.interpolate(f, scale_factor=0.5, mode="bilinear", align_corners=False).to(b.dev) for f in fr]
+    return {"flow01": b.gmflow(undamped_gmflow_sd(), h0, h1)}
+
+
 # ------------------------------------------------------------------------------------------ fixture packing
 MAX_FULL = 1 << 15
 

@@ -419,7 +419,50 @@ def golden_gmfss_plain():
     save("gmfss.npz", out)
 
 
+def _load(mod, sd):
+    mod.load_state_dict(sd)
+    return mod.eval()
+
+
+ReferenceBackend.featurenet = staticmethod(lambda sd, x: _load(RefFeatureNet(), sd)(x))
+ReferenceBackend.metricnet = staticmethod(lambda sd, h0, h1, f01, f10, union=True: _load(RefMetricNet(), sd)(h0, h1, f01, f10))
+ReferenceBackend.gmflow = staticmethod(lambda sd, a, b: _load(RefGMFlow(), sd)(a, b))
+
+
+def golden_trained():
+    """The only trained weights in the reference mount, weights/train_log_gmfss_union/{feat,metric}.pkl (CUDA-tagged:
+    map_location), as data + the reference modules' outputs with them; and GMFlow with un-damped LayerNorm gains."""
+    d = os.path.join(REF, "weights", "train_log_gmfss_union")
+    w = {}
+    for net, shapes in (("feat", synth.featurenet_shapes()), ("metric", synth.metricnet_shapes())):
+        sd = torch.load(os.path.join(d, net + ".pkl"), map_location="cpu", weights_only=True)
+        assert list(sd) == list(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd), net
+        for k, v in sd.items():
+            assert v.dtype == torch.float32
+            w[f"{net}/{k}"] = v.numpy()
+    path = os.path.join(HERE, cases.TRAINED_NPZ)
+    np.savez_compressed(path, **w)
+    print(f"wrote {cases.TRAINED_NPZ}: {os.path.getsize(path) / 1024:.0f} KiB")
+    sds = cases.trained_state_dicts(HERE)
+    out = {}
+    with torch.inference_mode():
+        r, o = cases.trained_run(REFB, sds), cases.trained_run(ORAB, sds)
+        assert list(r) == list(o)
+        for k in r:
+            same(o[k], r[k], "trained " + k)
+            out[k] = cases.pack(r[k])
+        r, o = cases.undamped_gmflow_run(REFB), cases.undamped_gmflow_run(ORAB)
+        same(o["flow01"], r["flow01"], "undamped gmflow")
+        out["undamped_flow01"] = cases.pack(r["flow01"])
+        n = cases.undamped_gmflow_run(REFB, ulp_noise=True)
+        floor = float((n["flow01"] - r["flow01"]).abs().max())
+    out["_meta"] = {"weights_sum": np.float64(sum(float(v.astype(np.float64).sum()) for v in w.values())),
+                    "undamped_ulp_noise_floor": np.float64(floor)}
+    save("trained_union.npz", out)
+    print("undamped GMFlow: reference flow moves by", floor, "under a 1e-7 input perturbation; |flow| max", float(r["flow01"].abs().max()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "drm", "scdet", "schedule", "rife", "gmfss", "gmfss_plain"]
+    which = sys.argv[1:] or ["ops", "drm", "scdet", "schedule", "rife", "gmfss", "gmfss_plain", "trained"]
     for w in which:
         globals()["golden_" + w]()

@@ -460,6 +460,26 @@ def check_gmfss_plain(hip, ora, golden, tol=1e-3):
     return rows
 
 
+def check_trained(hip, ora, golden, golden_dir, tol=1e-3):
+    """Trained FeatureNet / MetricNet (tests/golden/trained_union_weights.npz) on the HIP path: the subnets alone at the
+    per-layer bar, the GMFSS_UNION frames they feed at the 1e-3 bar, vs the oracle and the reference fixture; GMFlow with
+    un-damped LayerNorm gains against max(1e-3, 4 x the reference's own movement under a 1e-7 input perturbation)."""
+    sds = cases.trained_state_dicts(golden_dir)
+    rows = []
+    with torch.no_grad():
+        g, o = cases.trained_run(hip, sds), cases.trained_run(ora, sds)
+        for k in o:
+            t = tol if k.startswith("drba") else 1e-4 * max(1.0, float(o[k].abs().max()))
+            fx, fx_out, fx_n = cases.compare_to_fixture(golden, k, g[k], count_above=t)
+            rows.append((f"trained {k}", _diff(g[k], o[k]), t, f"ref_absmax={float(o[k].abs().max()):.3g} vs_fixture={fx:.2e} ({fx_out}/{fx_n} above)"))
+        floor = float(golden["_meta/undamped_ulp_noise_floor"])
+        gu, ou = cases.undamped_gmflow_run(hip)["flow01"], cases.undamped_gmflow_run(ora)["flow01"]
+        rows.append(("undamped gmflow flow01", _diff(gu, ou), max(tol, 4.0 * floor),
+                     f"ref_absmax={float(ou.abs().max()):.3g} reference_ulp_noise_floor={floor:.2e} "
+                     f"vs_fixture={cases.compare_to_fixture(golden, 'undamped_flow01', gu):.2e}"))
+    return rows
+
+
 # ----------------------------------------------------------------------------------------- fused window attention
 def check_window_attention(dev):
     """drba_window_attention against the oracle's step-by-step formulation (oracle/gmflow.py window_attention =

@@ -92,6 +92,12 @@ def test_gmfss_plain_end_to_end_parity(hip_backend, oracle_backend, golden_dir):
         assert float(extra.split("vs_fixture=")[1]) <= tol, f"{name}: {extra}"
 
 
+def test_trained_weights_parity(hip_backend, oracle_backend, golden_dir):
+    """FeatureNet / MetricNet with the reference's trained weights, and GMFlow with un-damped LayerNorm gains."""
+    _assert_rows(gpu_checks.check_trained(hip_backend, oracle_backend, np.load(os.path.join(golden_dir, "trained_union.npz")),
+                                          golden_dir))
+
+
 @pytest.mark.parametrize("mode", ("frame", "frame+ts", "frame+ts f3", "frame+other ts"))
 def test_lookahead_flow_matches_inline(hip_backend, mode):
     """inference_ts_drba(..., lookahead=...) computes the next step's coarse flow (and, when the next timesteps are

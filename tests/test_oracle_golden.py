@@ -115,3 +115,37 @@ def test_gmfss_plain_end_to_end_against_reference_fixture(oracle_backend, golden
     for k, t in out.items():
         d = cases.compare_to_fixture(z, k, t)
         assert d <= 2e-4, f"{k}: {d}"
+
+
+def test_trained_featurenet_metricnet_against_reference_fixture(oracle_backend, golden_dir):
+    """The reference mount's only trained weights (weights/train_log_gmfss_union/{feat,metric}.pkl, committed as plain
+    arrays): FeatureNet / MetricNet alone and inside a cold + warm GMFSS_UNION step, oracle vs the reference's outputs;
+    and GMFlow with un-damped transformer LayerNorm gains (the ill-conditioned variant)."""
+    z = np.load(os.path.join(golden_dir, "trained_union.npz"))
+    sds = cases.trained_state_dicts(golden_dir)
+    wsum = sum(float(v.double().sum()) for net in ("feat", "metric") for v in sds[net].values())
+    assert abs(wsum - float(z["_meta/weights_sum"])) < 1e-4
+    with torch.no_grad():
+        out = cases.trained_run(oracle_backend, sds)
+        for k, t in out.items():
+            d = cases.compare_to_fixture(z, k, t)
+            assert d <= 2e-4, f"{k}: {d}"
+        # a 1e-7 input perturbation moves the REFERENCE's own un-damped flow by ~4e-4 (recorded): hosts may differ by that
+        floor = float(z["_meta/undamped_ulp_noise_floor"])
+        assert 1e-5 < floor < 1e-2
+        d = cases.compare_to_fixture(z, "undamped_flow01", cases.undamped_gmflow_run(oracle_backend)["flow01"])
+        assert d <= 10 * floor, d
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/weights/train_log_gmfss_union"), reason="build container only")
+def test_real_pickles_load_and_equal_committed_arrays(golden_dir):
+    """The CUDA-tagged pickles themselves: load with map_location (the reference's loader has none, GMFSS.py:50-53),
+    keys / shapes are what FeatureNet / MetricNet expect, values equal the committed arrays."""
+    sds = cases.trained_state_dicts(golden_dir)
+    for net, shapes in (("feat", synth.featurenet_shapes()), ("metric", synth.metricnet_shapes())):
+        for d in ("train_log_gmfss_union", "train_log_gmfss"):
+            sd = torch.load(f"/root/reference/weights/{d}/{net}.pkl", map_location="cpu", weights_only=True)
+            assert list(sd) == list(shapes)
+            assert all(tuple(sd[k].shape) == tuple(shapes[k]) and sd[k].dtype == torch.float32 for k in sd)
+            if d == "train_log_gmfss_union":
+                assert all(torch.equal(sd[k], sds[net][k]) for k in sd)
