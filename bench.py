@@ -37,6 +37,7 @@ Extra objects on the JSON line:
                 clip resident in HBM, each with its own roofline entry.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -245,6 +246,14 @@ def _fence(world):
     torch.cuda.synchronize()
 
 
+def _quiet_gc():
+    """Before a timed region: collect now and move everything alive to the permanent generation, so that a full
+    (generation 2) collection of the interpreter -- 40-80 ms with torch loaded, triggered once the trace bookkeeping has
+    allocated enough containers (tools/exp/trace_stall.py) -- does not land inside it."""
+    gc.collect()
+    gc.freeze()
+
+
 def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False):
     """The N = 1 loop of the module docstring over `frames` (sequence of uint8 HWC frames: device tensors, or -- with
     pcie=True -- pinned host tensors with the outputs copied back to pinned host buffers).
@@ -304,8 +313,10 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
         step()
         ops.trace_begin()  # clears the records of the untimed step
         ops.trace_pause()
+    _quiet_gc()
     _fence(world)
     t0 = time.perf_counter()
+    per_step = []
     for k in range(args.steps):
         on = trace and k % roof_every == 0
         if on:
@@ -314,10 +325,13 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
         step()
         if on:
             ops.trace_pause()
+        per_step.append(time.perf_counter())
     t_host = time.perf_counter() - t0  # all launches enqueued: the host side of a step (the GPU may still be working)
     _fence(world)
     dt = time.perf_counter() - t0
     recs = ops.trace_end() if trace else None
+    if os.environ.get("DRBA_BENCH_STEPLOG"):  # host-side enqueue time of every step (diagnostic)
+        log("host ms per step: " + " ".join(f"{(b - a) * 1e3:.2f}" for a, b in zip([t0] + per_step, per_step)))
     return dt, t_host, recs, traced, dst_size
 
 
@@ -339,6 +353,7 @@ def clip_leg(model, clip, dst_fps, times, scdet, args, label):
         j = idx - W_
         ops.trace_pause()
         if j == 0:
+            _quiet_gc()
             torch.cuda.synchronize()
             st["t0"], st["g0"], st["w0"] = time.perf_counter(), cm.generated, io.written
         if j == K:
@@ -398,6 +413,7 @@ def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
     cm = _Counting(model)
     to_inp, to_out = _dev_hooks()
     counts = parallel.emission_counts(len(clip), SRC_FPS, dst_fps, times, world)
+    _quiet_gc()
     _fence(world)
     t0 = time.perf_counter()
     sg = parallel.StreamedGather(rank, world, counts, chunk=4, device=dev, frame_shape=clip.shape)
