@@ -30,6 +30,7 @@ SIGNATURES = {
     "drba_trace_resume": (_i, []),
     "drba_trace_count": (_i, []),
     "drba_trace_get": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.POINTER(C.c_float)]),
+    "drba_trace_get_start": (_i, [_i, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]),
     "drba_error_string": (C.c_char_p, [_i]),
     "drba_softsplat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "drba_softsplat_ws_floats": (_z, [_i, _i, _i, _i]),

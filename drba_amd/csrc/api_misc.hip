@@ -18,6 +18,7 @@ struct Rec {
   const void *fn;        // host stub of the kernel: its symbol name is looked up when the record is READ (drba_trace_get),
   const char *fallback;  // never inside the traced region
   unsigned gx, gy, gz;
+  hipStream_t stream;
 };
 hipEvent_t g_ev[kTraceSlots][2];
 bool g_ev_made[kTraceSlots];
@@ -68,8 +69,7 @@ TimedLaunch trace_launch(const void *host_fn, const char *fallback, dim3 grid, h
     if (hipEventCreate(&g_ev[slot][0]) != hipSuccess || hipEventCreate(&g_ev[slot][1]) != hipSuccess) return t;
     g_ev_made[slot] = true;
   }
-  (void)stream;
-  g_recs.push_back(Rec{host_fn, fallback, grid.x, grid.y, grid.z});
+  g_recs.push_back(Rec{host_fn, fallback, grid.x, grid.y, grid.z, stream});
   t.start = g_ev[slot][0];
   t.stop = g_ev[slot][1];
   return t;
@@ -112,6 +112,15 @@ int drba_trace_get(int i, const char **name, unsigned *grid3, float *ms) {
   grid3[0] = g_recs[i].gx;
   grid3[1] = g_recs[i].gy;
   grid3[2] = g_recs[i].gz;
+  return DRBA_OK;
+}
+
+int drba_trace_get_start(int i, float *ms_since_first, unsigned long long *stream) {
+  if (i < 0 || (size_t)i >= g_recs.size() || !ms_since_first || !stream) return DRBA_EINVAL;
+  if (hipEventSynchronize(g_ev[i][0]) != hipSuccess) return DRBA_ELAUNCH;
+  *ms_since_first = 0.f;
+  if (i > 0 && hipEventElapsedTime(ms_since_first, g_ev[0][0], g_ev[i][0]) != hipSuccess) return DRBA_ELAUNCH;
+  *stream = (unsigned long long)(uintptr_t)g_recs[i].stream;
   return DRBA_OK;
 }
 

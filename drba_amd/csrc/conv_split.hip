@@ -71,11 +71,34 @@ struct TileCtx {
   int x0, y0, cz, n, py;
 };
 
+// Experiment builds only (tools/exp/conv_split_phases.hip defines DRBA_PHASE_CLOCKS): clocks spent per phase, summed over
+// the waves' first lanes -- [0] waiting for the previous readers + staging (incl. the wait for the fetched data),
+// [1] the MFMA phase, [2] the epilogue, [3] tiles, [4] first-fetch issue to first stage done.
+#ifdef DRBA_PHASE_CLOCKS
+__device__ long long g_phase[1024 * 4 * 4];  // [workgroup][wave][slot]: written once per wave at the end (no atomics)
+#define DRBA_CLK(var) const long long var = (long long)__builtin_readcyclecounter()
+#define DRBA_CLK_ADD(slot, a, b) clk_acc[slot] += (b) - (a)
+#define DRBA_CLK_INIT long long clk_acc[4] = {0, 0, 0, 0}
+#define DRBA_CLK_FLUSH                                                                     \
+  if (lane == 0 && blockIdx.x < 1024) {                                                    \
+    for (int k_ = 0; k_ < 4; ++k_) g_phase[(blockIdx.x * 4 + wave) * 4 + k_] += clk_acc[k_]; \
+  }
+#else
+#define DRBA_CLK(var)
+#define DRBA_CLK_ADD(slot, a, b)
+#define DRBA_CLK_INIT
+#define DRBA_CLK_FLUSH
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global-memory queue
 // (s_waitcnt vmcnt(0)): here that would expose, once per tile, the latency of the epilogue stores just issued.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <class Cfg, bool PRE>
+// RL ("residual from LDS", MODE 0, 32-cout tiles, residual == input, Cin == Cout): the residual of a ResConv IS the input
+// tile, and x = h + m + l holds exactly (8 + 8 + 8 mantissa bits, each remainder exact), so the epilogue rebuilds it from
+// the three bf16 planes the tile's LAST chunk left in LDS instead of reading it from HBM again.  The chunks of a tile
+// are therefore taken in rotated order so that the last one is the chunk of the tile's own 32 output channels.
+template <class Cfg, bool PRE, bool RL = false>
 __global__ void __launch_bounds__(256, 2)  // at least two workgroups per CU: <= 256 registers
 conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                 const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
@@ -167,8 +190,10 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 
   int work = blockIdx.x;
   if (work >= total) return;
+  DRBA_CLK_INIT;
   TileCtx ctx = decode(work);
-  fetch(ctx, 0);
+  auto first_chunk = [&](const TileCtx &c) -> int { return RL ? (c.cz + 1 == nchunks ? 0 : c.cz + 1) : 0; };
+  fetch(ctx, first_chunk(ctx));
   while (true) {
     f32x4 acc[NPX][RW][MW][NT];
 #pragma unroll
@@ -183,15 +208,24 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     TileCtx nctx = ctx;
     if (next < total) nctx = decode(next);
     // per-channel epilogue constants: fetched here so that their latency sits under the tile's MFMAs
-    float bs[NT], bt[NT];
+    // (MODE 0 with W % 4 == 0 stores in the regrouped layout of the epilogue: lane -> couts (lane >> 3) and + 8 of a tile)
+    const bool regroup = MODE == 0 && vec;
+    float bs[NT], bt[NT], bs2[NT], bt2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
+      const int co = ctx.cz * Cfg::NTC + nt * 16 + (regroup ? (lane >> 3) : m), co2 = co + 8;
       bs[nt] = (bias && co < Cout) ? bias[co] : 0.f;
       bt[nt] = (beta && co < Cout) ? beta[co] : 0.f;
+      bs2[nt] = (regroup && bias && co2 < Cout) ? bias[co2] : 0.f;
+      bt2[nt] = (regroup && beta && co2 < Cout) ? beta[co2] : 0.f;
     }
 
-    for (int q = 0; q < nchunks; ++q) {
+    for (int qi = 0; qi < nchunks; ++qi) {
+      int q = qi;  // the chunk worked on (RL: rotated so that the tile's own channels come last)
+      if (RL) {
+        q = qi + first_chunk(ctx);
+        if (q >= nchunks) q -= nchunks;
+      }
       // Weight fragments are fetched D steps (a step = one tap of one cout tile: RW*MW*6 MFMAs) ahead of their use: a
       // chunk's fragments (27 KB per cout tile) do not stay in the 32 KB L1 next to the activations, so a fetch is
       // an L2 round trip.  The first D are independent of LDS and stay in flight across the staging barriers.
@@ -209,32 +243,35 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bw[d][pl] = wload(d, pl);
+      DRBA_CLK(c_s0);
       lds_barrier();  // every wave is done reading the previous chunk
       stage();
       lds_barrier();
-      if (q + 1 < nchunks) fetch(ctx, q + 1);
-      else if (next < total) fetch(nctx, 0);
+      DRBA_CLK(c_s1);
+      DRBA_CLK_ADD(0, c_s0, c_s1);
+      if (qi + 1 < nchunks) fetch(ctx, q + 1 == nchunks ? 0 : q + 1);
+      else if (next < total) fetch(nctx, first_chunk(nctx));
 
-      // activation fragments: one tap slot ahead.  Transposed conv, tap = 2a + b: window row rw + dro[a] with
-      // dro = {1, 0} (py = 0) / {2, 1} (py = 1), window column x + dco[px][b] with dco = {{1, 0}, {2, 1}} (conv.hip).
-      u32x4 af[2][RW][MW][3];
-      auto load_a = [&](int ts, int slot_) {
+      // activation fragments: ONE buffer; the fragment of (rw, mw) for the next tap slot is read from LDS right after the
+      // last MFMAs of the current slot that use it (nt = NT - 1), i.e. RW*MW*6 MFMAs (>= 200 clocks) before its first use
+      // -- half the registers of a whole-slot double buffer (48 instead of 96 for the 8x32 tile, which spilled).
+      // Transposed conv, tap = 2a + b: window row rw + dro[a] with dro = {1, 0} (py = 0) / {2, 1} (py = 1), window
+      // column x + dco[px][b] with dco = {{1, 0}, {2, 1}} (conv.hip).
+      u32x4 af[RW][MW][3];
+      auto load_piece = [&](int ts, int rw, int mw) {
         const int p = ts / NTAP, tap = ts - p * NTAP;
         const int ro = MODE == 0 ? tap / 3 : ((tap >> 1) ? 0 : 1) + ctx.py;
         const int co = MODE == 0 ? tap % 3 : ((tap & 1) ? 0 : 1) + p;
+        const int slot = kq * NPIXP + (row0 + rw + ro) * TC + mw * 16 + m + co;
 #pragma unroll
-        for (int rw = 0; rw < RW; ++rw)
-#pragma unroll
-          for (int mw = 0; mw < MW; ++mw) {
-            const int slot = kq * NPIXP + (row0 + rw + ro) * TC + mw * 16 + m + co;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[slot_][rw][mw][pl] = tile[4 * pl * NPIXP + slot];
-          }
+        for (int pl = 0; pl < 3; ++pl) af[rw][mw][pl] = tile[4 * pl * NPIXP + slot];
       };
-      load_a(0, 0);
+#pragma unroll
+      for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+        for (int mw = 0; mw < MW; ++mw) load_piece(0, rw, mw);
 #pragma unroll
       for (int ts = 0; ts < NTS; ++ts) {
-        if (ts + 1 < NTS) load_a(ts + 1, (ts + 1) & 1);
         const int p = ts / NTAP;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -246,9 +283,9 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
           for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
             for (int mw = 0; mw < MW; ++mw) {
-              const bf16x8 ah = __builtin_bit_cast(bf16x8, af[ts & 1][rw][mw][0]);
-              const bf16x8 am = __builtin_bit_cast(bf16x8, af[ts & 1][rw][mw][1]);
-              const bf16x8 al = __builtin_bit_cast(bf16x8, af[ts & 1][rw][mw][2]);
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, af[rw][mw][0]);
+              const bf16x8 am = __builtin_bit_cast(bf16x8, af[rw][mw][1]);
+              const bf16x8 al = __builtin_bit_cast(bf16x8, af[rw][mw][2]);
               f32x4 c = acc[p][rw][mw][nt];
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);  // smallest terms first
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
@@ -257,6 +294,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
               acc[p][rw][mw][nt] = c;
+              if (nt == NT - 1 && ts + 1 < NTS) load_piece(ts + 1, rw, mw);
             }
           if (step + D < STEPS) {
 #pragma unroll
@@ -265,7 +303,10 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
           __builtin_amdgcn_sched_barrier(0);  // keep the fetch distances as written
         }
       }
+      DRBA_CLK(c_m1);
+      DRBA_CLK_ADD(1, c_s1, c_m1);
     }
+    DRBA_CLK(c_e0);
 
     // ---- epilogue (conv.hip MODE 0): y = acc + bias; ResConv: y = y*beta + res; otherwise y += res (+ res2); then
     // the post activation: act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10.  The activation is
@@ -273,36 +314,144 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     // expansion to jump over) made the epilogue 10k instructions and as slow as the tile's MFMAs.
     if constexpr (MODE == 0) {
       const size_t img = (size_t)ctx.n * Cout * HW;
-      auto epilogue = [&](auto post) {
-        // column tiles innermost: the 64-byte halves of a 128-byte row segment are stored back to back (merged in L2)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+      if (vec) {
+        // Whole-line stores and residual reads.  The accumulator leaves lane (m, kq) with 4 consecutive x of ONE cout:
+        // stored as it is, a wave instruction touches 16 couts x 64 bytes and no two neighbouring lanes are
+        // neighbours in memory (measured: WRITE_SIZE 1.45x the output, the store queue back-pressuring at 64-byte
+        // pieces).  Two column blocks (mw = 2j, 2j+1) of a (row, cout tile) are regrouped across lanes -- the halves
+        // of each 16-lane row swap one block (couts 0-7 keep block 2j and receive block 2j+1 of the same cout from
+        // lane ^ 8, couts 8-15 the other way round), then a lane permutation puts the 8 lanes of a (cout, row) next
+        // to each other -- so that lanes 8c..8c+7 hold the 32 consecutive pixels of cout c: every store / residual load
+        // instruction moves 8 whole 128-byte row segments, first couts 0-7 of the tile (A), then couts 8-15 (B).
+        // (the lane-derived indices are formed here, from an opaque copy of the lane id: hoisted out of the tile loop
+        // they would stay live across the MFMA loop, where every register counts)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int c8 = ln >> 3, blk = (ln >> 2) & 1, q4 = ln & 3;
+        const int src = q4 * 16 + blk * 8 + c8;  // lane holding (cout c8 | c8 + 8, block blk, pixel group q4) after the swap
+        const bool hi = (ln & 8) != 0;
+        // Residual loads and stores go through buffer descriptors: a lane outside the image (or past Cout) gets an offset
+        // beyond num_records -- its load returns 0, its store is dropped -- so the epilogue is straight-line code and the
+        // compiler's s_waitcnt placement is exact.  With branches around them every path merge forced s_waitcnt vmcnt(0),
+        // i.e. each store's full round trip was waited for before the next piece (vmcnt counts loads AND stores in issue
+        // order); for the same reason pass 1 issues every residual load of the tile before pass 2 issues the first store.
+        const unsigned obytes = (unsigned)((size_t)Cout * HW * 4);
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(out + img), 0, obytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)((res ? res : out) + img), 0, res ? obytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r2rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)((res2 ? res2 : out) + img), 0, res2 ? obytes : 0u, 0x00020000);
+        auto offs = [&](int nt, int rw, int j, unsigned &oa, unsigned &ob) {
+          const int coA = ctx.cz * Cfg::NTC + nt * 16 + c8;
+          const int y = ctx.y0 + row0 + rw;
+          const int xb = ctx.x0 + (2 * j + blk) * 16 + q4 * 4;
+          const bool in_img = y < H && xb < W;
+          const unsigned base = (unsigned)(((coA * H + y) * W + xb) * 4);
+          oa = (in_img && coA < Cout) ? base : 0xffffffffu;
+          ob = (in_img && coA + 8 < Cout) ? base + 8u * (unsigned)HW * 4u : 0xffffffffu;
+        };
+        // residual pieces of cout tile nt + 1 are requested before the stores of tile nt are issued (ring of two)
+        u32x4 ra[2][RW][MW / 2], rb[2][RW][MW / 2];  // (a second residual, GridNet's lateral sums, is read in pass 2)
+        auto load_res = [&](int nt) {
 #pragma unroll
           for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-            for (int mw = 0; mw < MW; ++mw) {
-              f32x4 v = acc[0][rw][mw][nt];
-              const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
-              const int y = ctx.y0 + row0 + rw;
-              const int xb = ctx.x0 + mw * 16 + kq * 4;
-              if (co >= Cout || y >= H || xb >= W) continue;
-              const size_t idx = img + ((size_t)co * H + y) * W + xb;
-              if (vec) {
-                f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (res) r = *reinterpret_cast<const f32x4 *>(res + idx);
-                if (res2) r2 = *reinterpret_cast<const f32x4 *>(res2 + idx);
+            for (int j = 0; j < MW / 2; ++j) {
+              unsigned oa, ob;
+              offs(nt, rw, j, oa, ob);
+              ra[nt & 1][rw][j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, oa, 0, 0);
+              rb[nt & 1][rw][j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ob, 0, 0);
+            }
+        };
+        if (!RL && res) load_res(0);
+        auto epilogue = [&](auto post) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float bsA = bs[nt], bsB = bs2[nt], btA = bt[nt], btB = bt2[nt];
+            if (!RL && res && nt + 1 < NT) load_res(nt + 1);
+#pragma unroll
+            for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+              for (int j = 0; j < MW / 2; ++j) {
+                const f32x4 v0 = acc[0][rw][2 * j][nt], v1 = acc[0][rw][2 * j + 1][nt];
+                f32x4 a, b;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                  float u = v[k] + bs[nt];
-                  if (beta) u = u * bt[nt] + r[k];
-                  else {
-                    if (res) u = u + r[k];
-                    if (res2) u = u + r2[k];
-                  }
-                  v[k] = post(u);
+                  const float got = __shfl_xor(hi ? v0[k] : v1[k], 8, 64);
+                  a[k] = __shfl(hi ? got : v0[k], src, 64);
+                  b[k] = __shfl(hi ? v1[k] : got, src, 64);
                 }
-                *reinterpret_cast<f32x4 *>(out + idx) = v;
-              } else {
+                unsigned oa, ob;
+                offs(nt, rw, j, oa, ob);
+                f32x4 xa = (f32x4){0.f, 0.f, 0.f, 0.f}, xb_ = xa, xa2 = xa, xb2 = xa;
+                if (!RL && res) {
+                  xa = __builtin_bit_cast(f32x4, ra[nt & 1][rw][j]);
+                  xb_ = __builtin_bit_cast(f32x4, rb[nt & 1][rw][j]);
+                }
+                if (!RL && res2) {
+                  xa2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2rsrc, oa, 0, 0));
+                  xb2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2rsrc, ob, 0, 0));
+                }
+                if (RL) {
+                  // channel nt*16 + c8 (A) / + 8 (B) of the chunk in LDS = group 2*nt (A) / 2*nt + 1 (B), element c8;
+                  // the pixel's slot in the haloed window is (row + 1, column + 1)
+                  const unsigned short *pl = reinterpret_cast<const unsigned short *>(tile);
+                  const int px0 = (row0 + rw + 1) * TC + (2 * j + blk) * 16 + q4 * 4 + 1;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) {
+                    const int sa = ((2 * nt) * NPIXP + px0 + k) * 8 + c8, sb = sa + NPIXP * 8;
+                    const float ha = __uint_as_float((unsigned)pl[sa] << 16), hb = __uint_as_float((unsigned)pl[sb] << 16);
+                    const float ma = __uint_as_float((unsigned)pl[4 * NPIXP * 8 + sa] << 16);
+                    const float mb = __uint_as_float((unsigned)pl[4 * NPIXP * 8 + sb] << 16);
+                    const float la = __uint_as_float((unsigned)pl[8 * NPIXP * 8 + sa] << 16);
+                    const float lb = __uint_as_float((unsigned)pl[8 * NPIXP * 8 + sb] << 16);
+                    xa[k] = ha + (ma + la);
+                    xb_[k] = hb + (mb + lb);
+                  }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  float ua = a[k] + bsA, ub = b[k] + bsB;
+                  if (beta) {
+                    ua = ua * btA + xa[k];
+                    ub = ub * btB + xb_[k];
+                  } else {
+                    if (RL || res) ua = ua + xa[k], ub = ub + xb_[k];
+                    if (!RL && res2) ua = ua + xa2[k], ub = ub + xb2[k];
+                  }
+                  a[k] = post(ua);
+                  b[k] = post(ub);
+                }
+#ifdef DRBA_EXP_NOSTORE  // experiment: the stores are compiled in but never executed (H is never negative)
+                if (H >= 0) continue;
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), orsrc, oa, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), orsrc, ob, 0, 0);
+              }
+          }
+        };
+        switch (act) {
+          case 1: epilogue([](float v) { return lrelu02(v); }); break;
+          case 2: epilogue([post_slope](float v) { return v > 0.f ? v : post_slope * v; }); break;
+          case 3: epilogue([](float v) { return fmaxf(v, 0.f); }); break;
+          case 4: epilogue([](float v) { return tanhf(v) * 10.f; }); break;
+          default: epilogue([](float v) { return v; }); break;
+        }
+      } else {
+        // W not a multiple of 4: element-wise stores from the accumulator layout (lane = cout m, pixels 4*kq..+3)
+        auto epilogue = [&](auto post) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+              for (int mw = 0; mw < MW; ++mw) {
+                const f32x4 v = acc[0][rw][mw][nt];
+                const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
+                const int y = ctx.y0 + row0 + rw;
+                const int xb = ctx.x0 + mw * 16 + kq * 4;
+                if (co >= Cout || y >= H || xb >= W) continue;
+                const size_t idx = img + ((size_t)co * H + y) * W + xb;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                   if (xb + k >= W) continue;
@@ -315,14 +464,14 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
                   out[idx + k] = post(u);
                 }
               }
-            }
-      };
-      switch (act) {
-        case 1: epilogue([](float v) { return lrelu02(v); }); break;
-        case 2: epilogue([post_slope](float v) { return v > 0.f ? v : post_slope * v; }); break;
-        case 3: epilogue([](float v) { return fmaxf(v, 0.f); }); break;
-        case 4: epilogue([](float v) { return tanhf(v) * 10.f; }); break;
-        default: epilogue([](float v) { return v; }); break;
+        };
+        switch (act) {
+          case 1: epilogue([](float v) { return lrelu02(v); }); break;
+          case 2: epilogue([post_slope](float v) { return v > 0.f ? v : post_slope * v; }); break;
+          case 3: epilogue([](float v) { return fmaxf(v, 0.f); }); break;
+          case 4: epilogue([](float v) { return tanhf(v) * 10.f; }); break;
+          default: epilogue([](float v) { return v; }); break;
+        }
       }
     } else {
       // transposed conv, row phase py, both column phases: lane (cout m, column group kq) holds the input columns
@@ -382,7 +531,13 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
             }
           }
     }
-    if (next >= total) break;
+    DRBA_CLK(c_e1);
+    DRBA_CLK_ADD(2, c_e0, c_e1);
+    DRBA_CLK_ADD(3, 0, 1);
+    if (next >= total) {
+      DRBA_CLK_FLUSH;
+      break;
+    }
     work = next;
     ctx = nctx;
   }
@@ -410,10 +565,10 @@ constexpr Info info() {
 const Info kInfo[kNum] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>()};
 const Info kInfoT[kNumT] = {info<T0>(), info<T1>()};
 
-template <class Cfg, bool PRE>
+template <class Cfg, bool PRE, bool RL = false>
 hipError_t lds_limit() {
   if (Cfg::LDS_BYTES <= 64 * 1024) return hipSuccess;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_split_mfma<Cfg, PRE>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_split_mfma<Cfg, PRE, RL>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
   return e;
 }
@@ -439,8 +594,15 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
                       post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle);
     return DRBA_OK;
   };
-  const int rc = pre_act ? go(conv_split_mfma<Cfg, true>, lds_limit<Cfg, true>())
-                         : go(conv_split_mfma<Cfg, false>, lds_limit<Cfg, false>());
+  int rc;
+  if constexpr (Cfg::MODE == 0 && Cfg::NTC == CK) {
+    // ResConv shape (the residual is the layer's own input): rebuilt from the bf16 planes in LDS, no second read
+    const bool rl = res && res == in && !res2 && !pre_act && Cin == Cout && (W & 3) == 0;
+    rc = rl ? go(conv_split_mfma<Cfg, false, true>, lds_limit<Cfg, false, true>())
+            : (pre_act ? go(conv_split_mfma<Cfg, true>, lds_limit<Cfg, true>()) : go(conv_split_mfma<Cfg, false>, lds_limit<Cfg, false>()));
+  } else {
+    rc = pre_act ? go(conv_split_mfma<Cfg, true>, lds_limit<Cfg, true>()) : go(conv_split_mfma<Cfg, false>, lds_limit<Cfg, false>());
+  }
   if (rc != DRBA_OK) return rc;
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -515,6 +677,7 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
   using namespace drba_conv_split;
   if (!conv_split_supports(Cin, Cout, id)) return DRBA_EUNSUPPORTED;
   if ((size_t)Cin * H * W * 4 >= (1ull << 31)) return DRBA_EUNSUPPORTED;  // 32-bit byte offsets inside an image
+  if ((size_t)Cout * H * W * 4 >= (1ull << 31)) return DRBA_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
 #define DRBA_CASE(ID, T) \
   case ID:               \

@@ -83,11 +83,12 @@ def trace_end():
     _lib.check(lib.drba_trace_end(), "drba_trace_end")
     tags, TRACE = TRACE or [], None
     recs = []
-    name, grid, ms = C.c_char_p(), (C.c_uint * 3)(), C.c_float()
+    name, grid, ms, t0, st = C.c_char_p(), (C.c_uint * 3)(), C.c_float(), C.c_float(), C.c_ulonglong()
     for i in range(lib.drba_trace_count()):
         _lib.check(lib.drba_trace_get(i, C.byref(name), grid, C.byref(ms)), "drba_trace_get")
+        _lib.check(lib.drba_trace_get_start(i, C.byref(t0), C.byref(st)), "drba_trace_get_start")
         recs.append({"name": name.value.decode(), "grid": tuple(grid), "ms": float(ms.value), "work": None, "unit": None,
-                     "label": None})
+                     "label": None, "start_ms": float(t0.value), "stream": int(st.value)})
     for first, items in tags:
         for k, it in enumerate(items):
             if it is not None and first + k < len(recs):

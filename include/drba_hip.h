@@ -42,6 +42,8 @@ int drba_trace_end(void);
 int drba_trace_resume(void);
 int drba_trace_count(void);
 int drba_trace_get(int i, const char **name, unsigned *grid3, float *ms);
+/* start of launch i relative to the start of launch 0 (ms, from the same event pairs) and the stream it was issued on */
+int drba_trace_get_start(int i, float *ms_since_first, unsigned long long *stream);
 
 /* ---- forward splat ----------------------------------------------------------------------
  * replaces: models/softsplat/softsplat.py:248-293 (softsplat) + :306-367 (kernel softsplat_out)

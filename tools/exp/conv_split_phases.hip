@@ -1,0 +1,53 @@
+// Where does a split-bf16 convolution tile spend its clocks?  Builds conv_split.hip with per-phase cycle counters
+// (DRBA_PHASE_CLOCKS) and runs one ResConv layer shape.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics tools/exp/conv_split_phases.hip drba_amd/csrc/api_misc.hip -o /tmp/csp
+//   /tmp/csp <cfg 0-4> N C H W
+#define DRBA_PHASE_CLOCKS 1
+#include "../../drba_amd/csrc/conv_split.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+int main(int argc, char **argv) {
+  const int cfg = argc > 1 ? atoi(argv[1]) : 4, N = argc > 2 ? atoi(argv[2]) : 2, C = argc > 3 ? atoi(argv[3]) : 32;
+  const int H = argc > 4 ? atoi(argv[4]) : 272, W = argc > 5 ? atoi(argv[5]) : 480;
+  const size_t n = (size_t)N * C * H * W;
+  std::vector<float> hx(n), hw((size_t)C * C * 9), hb(C, 0.1f), hbeta(C, 1.0f);
+  srand(1);
+  for (auto &v : hx) v = (float)rand() / RAND_MAX - 0.5f;
+  for (auto &v : hw) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+  const size_t pf = drba::conv_split_packed_floats(C, C, cfg);
+  std::vector<float> hp(pf);
+  if (drba::conv_split_pack(hw.data(), hp.data(), C, C, cfg) != DRBA_OK) return 1;
+  float *x, *y, *p, *b, *beta;
+  hipMalloc(&x, n * 4), hipMalloc(&y, n * 4), hipMalloc(&p, pf * 4), hipMalloc(&b, C * 4), hipMalloc(&beta, C * 4);
+  hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
+  hipMemcpy(p, hp.data(), pf * 4, hipMemcpyHostToDevice);
+  hipMemcpy(b, hb.data(), C * 4, hipMemcpyHostToDevice);
+  hipMemcpy(beta, hbeta.data(), C * 4, hipMemcpyHostToDevice);
+  auto run = [&]() { return drba::conv_split_launch(cfg, x, p, b, beta, x, nullptr, y, N, C, H, W, C, 1, 0.f, 0, 0.f, nullptr); };
+  for (int i = 0; i < 3; ++i)
+    if (run() != DRBA_OK) return 2;
+  hipDeviceSynchronize();
+  static long long buf[1024 * 4 * 4];
+  hipMemcpyToSymbol(HIP_SYMBOL(drba_conv_split::g_phase), buf, sizeof(buf));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
+  const int reps = 10;
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) run();
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipMemcpyFromSymbol(buf, HIP_SYMBOL(drba_conv_split::g_phase), sizeof(buf));
+  long long ph[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 1024 * 4; ++i)
+    for (int k = 0; k < 4; ++k) ph[k] += buf[i * 4 + k];
+  const double tiles = (double)ph[3] / 4.0;  // 4 waves count each tile
+  printf("cfg %d N%d C%d %dx%d: %.1f us/launch (with counters), %.0f tiles/launch\n", cfg, N, C, H, W, ms / reps * 1e3, tiles / reps);
+  printf("  per tile per wave: stage(+wait) %.0f clk, mfma phase %.0f clk, epilogue %.0f clk\n", ph[0] / (double)ph[3],
+         ph[1] / (double)ph[3], ph[2] / (double)ph[3]);
+  return 0;
+}

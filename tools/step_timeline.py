@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Timeline of traced steady-state bench steps from the library's own kernel trace (event pairs on the dispatch packets):
+per stream, every launch with its start, duration and the idle gap before it.  Traced steps run slower than plain ones
+(profiled dispatches), so read the structure -- which stream waits for which -- not the absolute step time.
+    python tools/step_timeline.py [--steps 2] [--config 1080p] [--brief]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from drba_amd import ops  # noqa: E402
+from drba_amd.models.rife import RIFE  # noqa: E402
+from drba_amd.utils import synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--config", default="1080p")
+ap.add_argument("--brief", action="store_true")
+a = ap.parse_args()
+(H, W), scale, _ = bench.CONFIGS[a.config]
+dev = torch.device("cuda:0")
+m = RIFE(weights=synth.ifnet_state_dict(0), scale=scale, device=dev)
+from drba_amd.models.utils import tools  # noqa: E402
+size = tools.get_valid_net_inp_size(np.zeros((H, W, 3), np.uint8), scale, div=64)
+clip = bench.DeviceClip(12, H, W, 1234, dev)
+TS = bench.TS
+state = {"I0": ops.to_inp(clip[0], size["dst_size"]), "I1": ops.to_inp(clip[1], size["dst_size"]), "reuse": None, "k": 2, "next": None}
+
+
+def step():
+    I2 = state["next"] if state["next"] is not None else ops.to_inp(clip[state["k"] % 12], size["dst_size"])
+    nxt = ops.to_inp(clip[(state["k"] + 1) % 12], size["dst_size"])
+    out, state["reuse"] = m.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], True, lookahead=(nxt, TS))
+    res = [ops.to_out(x, size["src_size"]) for x in out]
+    state["I0"], state["I1"], state["next"] = state["I1"], I2, nxt
+    state["k"] += 1
+    return res
+
+
+for _ in range(6):
+    step()
+torch.cuda.synchronize()
+ops.trace_begin()
+for _ in range(a.steps):
+    step()
+torch.cuda.synchronize()
+recs = ops.trace_end()
+streams = sorted({r["stream"] for r in recs})
+names = {s: f"s{i}" for i, s in enumerate(streams)}
+t_end = max(r["start_ms"] + r["ms"] for r in recs)
+print(f"{a.steps} traced steps: {len(recs)} launches, span {t_end:.3f} ms = {t_end / a.steps:.3f} ms/step (traced)")
+busy = {s: sum(r["ms"] for r in recs if r["stream"] == s) for s in streams}
+for s in streams:
+    print(f"  stream {names[s]}: {sum(1 for r in recs if r['stream'] == s)} launches, {busy[s]:.3f} ms of kernels")
+last = {}
+for r in sorted(recs, key=lambda r: r["start_ms"]):
+    s = r["stream"]
+    gap = r["start_ms"] - last.get(s, r["start_ms"])
+    last[s] = r["start_ms"] + r["ms"]
+    nm = r["name"].replace("drba_conv_split::", "").replace("drba_conv::", "")
+    if a.brief and gap < 0.02 and r["ms"] < 0.06:
+        continue
+    print(f"{names[s]} t={r['start_ms'] * 1e3:8.1f} dur={r['ms'] * 1e3:7.1f} gap={gap * 1e3:7.1f}  {nm[:58]} {r['label'] or ''}")
