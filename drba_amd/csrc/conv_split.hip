@@ -51,6 +51,11 @@ struct SplitCfg {
   static constexpr int LIT = (ITEMS + 255) / 256;        // per thread
   static constexpr int FRAG_U4 = NTAP * NT * 3 * 64;     // 16-byte units of packed weights per (cout tile[, phase], chunk)
   static constexpr int BDEPTH = (RW * MW >= 4) ? 2 : 4;  // weight fetch distance in steps (>= ~700 cycles of MFMAs)
+#ifndef DRBA_SPLIT_MINB3
+#define DRBA_SPLIT_MINB3 1
+#endif
+  // workgroups per CU the register allocation aims at: the 4x32x32 tile needs 170 registers, two short of three per CU
+  static constexpr int MINB = (DRBA_SPLIT_MINB3 && MODE == 0 && RW * MW * NT <= 4) ? 3 : 2;
 };
 
 // fp32 -> (h, m, l) bf16 with round-to-nearest-even at every step; returns the three terms of 2 values packed
@@ -99,7 +104,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // the three bf16 planes the tile's LAST chunk left in LDS instead of reading it from HBM again.  The chunks of a tile
 // are therefore taken in rotated order so that the last one is the chunk of the tile's own 32 output channels.
 template <class Cfg, bool PRE, bool RL = false>
-__global__ void __launch_bounds__(256, 2)  // at least two workgroups per CU: <= 256 registers
+__global__ void __launch_bounds__(256, Cfg::MINB)  // at least two workgroups per CU: <= 256 registers
 conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                 const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
                 float *__restrict__ out, int Cin, int H, int W, int Cout, int act, float post_slope, float pre_slope,

@@ -378,7 +378,14 @@ ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ i
 // every full-resolution pixel to be a sample point exactly once, i.e. scale <= 2 (the two full-resolution stages of
 // the 1080p path): one 8P-byte read-modify-write pass and one launch per sample and stage disappear.
 constexpr int kPrevRW = 20, kPrevRH = 6;  // LDS footprint capacity (columns padded to 20)
-template <bool SINGLE, bool FOLD>
+// VS ("vector stores", taken when the output is a whole number of tiles and rows are 16-byte aligned): a lane computes
+// one value per channel, so stored directly a wave instruction writes 64 (scale 1) or only 16 (scale >= 2, one writer lane
+// per 2 x 2 sample quad) floats of ONE channel -- 52 (+4) store instructions per wave on kernels that are bound by the
+// number of vector-memory instructions.  Instead the values are parked in a wave-private LDS strip and written back
+// as 16 bytes per lane: scale 1: 4 channels x (32 x 2 pixels) per store, 14 stores; scale >= 2: all 52 channels x 16
+// pixels in 4 stores; the folded flow update (a 32 x 2 full-resolution block per wave either way) in one.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+template <bool SINGLE, bool FOLD, bool VS>
 __global__ void __launch_bounds__(256)
 ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
                   const float *__restrict__ f1, const float *__restrict__ f0p, const float *__restrict__ f1p,
@@ -386,6 +393,8 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
                   const float *__restrict__ tmp_prev, int hp, int wp, float inv_prev_scale, float prev_scale,
                   float *__restrict__ flow_out, float *__restrict__ out, int H, int W, int h, int w, float scale) {
   __shared__ float prev[13][kPrevRH][kPrevRW];
+  constexpr int STG = VS ? (SINGLE ? 4 * 64 : 52 * 16 + 4 * 64) : 1;  // floats per wave
+  __shared__ __attribute__((aligned(16))) float stg_all[4 * STG];
   constexpr int LPO = SINGLE ? 1 : 4;
   constexpr int TWo = SINGLE ? 32 : 16, THo = SINGLE ? 8 : 4;
   constexpr int C0 = FOLD ? 0 : 4;  // first channel of tmp_prev that is needed
@@ -406,6 +415,8 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
   }
   __syncthreads();
 
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *ws = stg_all + wave * STG;
   const int lo = threadIdx.x / LPO;
   const int ox_raw = ox_a + (lo % TWo), oy_raw = oy_a + (lo / TWo);
   const bool valid = ox_raw < w && oy_raw < h;
@@ -425,6 +436,24 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
   };
   const bool writer = valid && sub == 0;
   float *dst = out + o;
+  // ---- VS plumbing.  A 32 x 2 block (scale 1: the wave's output pixels; FOLD at scale 2: its full-resolution sample
+  // points) is parked as [4 slots][64] and written by lane l as the 16 bytes of slot l >> 4, pixels 4*(l & 15)..+3.
+  const int g4 = lane >> 4, qd = lane & 15;
+  auto flush32x2 = [&](const float *strip, float *base, size_t plane, int width, int x0, int y0, int ch) {
+    const f32x4a v = *reinterpret_cast<const f32x4a *>(strip + g4 * 64 + qd * 4);
+    *reinterpret_cast<f32x4a *>(base + (size_t)ch * plane + (size_t)(y0 + (qd >> 3)) * width + x0 + (qd & 7) * 4) = v;
+  };
+  // scale 1: emit(slot, v) parks channel values, flush(ch of this lane's 16-lane group) writes 4 channels at once
+  auto park = [&](int slot, float v) { ws[slot * 64 + lane] = v; };
+  auto flush_out = [&](int ch) { flush32x2(ws, out, p_lo, w, ox_a, oy_a + 2 * wave, ch); };
+  // scale >= 2: channel values of the wave's 16 output pixels parked as [52][16]
+  auto emit = [&](int ch, float v) {
+    if (VS) {
+      if (!SINGLE && sub == 0) ws[ch * 16 + (lo & 15)] = v;
+    } else if (writer) {
+      dst[(size_t)ch * p_lo] = v;
+    }
+  };
   // taps of the previous head output's upsample at (X, Y), relative to the staged footprint
   const Lerp a = lerp_src(Y, inv_prev_scale, hp), b = lerp_src(X, inv_prev_scale, wp);
   const int r0 = a.i0 - ry0, r1 = a.i1 - ry0, c0 = b.i0 - rx0, c1 = b.i1 - rx0;
@@ -439,20 +468,63 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
     if (FOLD) {
       const float fd = prev_up(c) * prev_scale;  // ifblock_update: flow_in + up(tmp) * scale
       fls[c] = flow ? flow[(size_t)c * P + q] + fd : fd;
-      if (valid) flow_out[(size_t)c * P + q] = fls[c];  // scale <= 2: the sample points are the full-resolution pixels
+      // scale <= 2: the sample points are the full-resolution pixels, each exactly once
+      if (VS) {
+        if (SINGLE) park(c, fls[c]);
+        else ws[52 * 16 + c * 64 + sj * 32 + (lo & 15) * 2 + si] = fls[c];
+      } else if (valid) {
+        flow_out[(size_t)c * P + q] = fls[c];
+      }
     } else {
       fls[c] = flow[(size_t)c * P + q];
     }
   }
+  if (VS && FOLD) {
+    if (SINGLE) flush32x2(ws, flow_out, P, W, ox_a, oy_a + 2 * wave, g4);
+    else flush32x2(ws + 52 * 16, flow_out, P, W, 2 * ox_a, 2 * (oy_a + wave), g4);  // scale 2: rows 2y, 2y+1, columns 2x..
+  }
   const Taps t0 = taps_border(warp_coord(X, W, fls[0]), warp_coord(Y, H, fls[1]), W, H);
   const Taps t1 = taps_border(warp_coord(X, W, fls[2]), warp_coord(Y, H, fls[3]), W, H);
+  const float tmv = comb(tmap ? tmap[q] : tscalar);
+  if (VS && SINGLE) {
+    // batches of four channels: {img0 0..2, timestep}, {img1 0..2, mask}, 8 x {f0 pair, f1 pair}, feat 0..3, feat 4..7, flow
+#pragma unroll
+    for (int c = 0; c < 3; ++c) park(c, comb(sample(img0 + (size_t)c * P, W, t0)));
+    park(3, tmv);
+    flush_out(g4 < 3 ? g4 : 38);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) park(c, comb(sample(img1 + (size_t)c * P, W, t1)));
+    park(3, comb(prev_up(4)));
+    flush_out(g4 < 3 ? 3 + g4 : 39);
+#pragma unroll 1
+    for (int c2 = 0; c2 < 8; ++c2) {
+      float a0, a1, b0, b1;
+      if (f0p) {
+        sample_pair(f0p + (size_t)c2 * 2 * P, W, t0, a0, a1);
+        sample_pair(f1p + (size_t)c2 * 2 * P, W, t1, b0, b1);
+      } else {
+        a0 = sample(f0 + (size_t)(2 * c2) * P, W, t0), a1 = sample(f0 + (size_t)(2 * c2 + 1) * P, W, t0);
+        b0 = sample(f1 + (size_t)(2 * c2) * P, W, t1), b1 = sample(f1 + (size_t)(2 * c2 + 1) * P, W, t1);
+      }
+      park(0, comb(a0)), park(1, comb(a1)), park(2, comb(b0)), park(3, comb(b1));
+      flush_out(6 + 2 * c2 + (g4 & 1) + (g4 >> 1) * 16);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) park(c, comb(prev_up(5 + 4 * half + c)));
+      flush_out(40 + 4 * half + g4);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) park(c, (comb(fls[c]) * 1.f) / scale);  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
+    flush_out(48 + g4);
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float v0 = comb(sample(img0 + (size_t)c * P, W, t0)), v1 = comb(sample(img1 + (size_t)c * P, W, t1));
-    if (writer) {
-      dst[(size_t)c * p_lo] = v0;
-      dst[(size_t)(3 + c) * p_lo] = v1;
-    }
+    emit(c, v0);
+    emit(3 + c, v1);
   }
   if (f0p) {
 #pragma unroll 1
@@ -461,36 +533,34 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
       sample_pair(f0p + (size_t)c2 * 2 * P, W, t0, a0, a1);
       sample_pair(f1p + (size_t)c2 * 2 * P, W, t1, b0, b1);
       a0 = comb(a0), a1 = comb(a1), b0 = comb(b0), b1 = comb(b1);
-      if (writer) {
-        dst[(size_t)(6 + 2 * c2) * p_lo] = a0;
-        dst[(size_t)(7 + 2 * c2) * p_lo] = a1;
-        dst[(size_t)(22 + 2 * c2) * p_lo] = b0;
-        dst[(size_t)(23 + 2 * c2) * p_lo] = b1;
-      }
+      emit(6 + 2 * c2, a0);
+      emit(7 + 2 * c2, a1);
+      emit(22 + 2 * c2, b0);
+      emit(23 + 2 * c2, b1);
     }
   } else {
 #pragma unroll 1
     for (int c = 0; c < 16; ++c) {
       const float v0 = comb(sample(f0 + (size_t)c * P, W, t0)), v1 = comb(sample(f1 + (size_t)c * P, W, t1));
-      if (writer) {
-        dst[(size_t)(6 + c) * p_lo] = v0;
-        dst[(size_t)(22 + c) * p_lo] = v1;
-      }
+      emit(6 + c, v0);
+      emit(22 + c, v1);
     }
   }
-  {
-    const float v = comb(tmap ? tmap[q] : tscalar);
-    if (writer) dst[(size_t)38 * p_lo] = v;
-  }
+  emit(38, tmv);
 #pragma unroll
-  for (int c = 0; c < 9; ++c) {  // mask (tmp[4]) and feat (tmp[5:13])
-    const float v = comb(prev_up(4 + c));
-    if (writer) dst[(size_t)(39 + c) * p_lo] = v;
-  }
+  for (int c = 0; c < 9; ++c) emit(39 + c, comb(prev_up(4 + c)));  // mask (tmp[4]) and feat (tmp[5:13])
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float v = comb(fls[c]);
-    if (writer) dst[(size_t)(48 + c) * p_lo] = (v * 1.f) / scale;  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
+  for (int c = 0; c < 4; ++c) emit(48 + c, (comb(fls[c]) * 1.f) / scale);  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
+  if (VS && !SINGLE) {
+    // [52][16] -> lane l of pass i writes the 16 bytes of channel (64 i + l) >> 2, pixels 4 * (l & 3)..+3 of the wave's row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = i * 64 + lane, ch = idx >> 2, qq = idx & 3;
+      if (ch < 52) {
+        const f32x4a v = *reinterpret_cast<const f32x4a *>(ws + ch * 16 + qq * 4);
+        *reinterpret_cast<f32x4a *>(out + (size_t)ch * p_lo + (size_t)(oy_a + wave) * w + ox_a + qq * 4) = v;
+      }
+    }
   }
 }
 
@@ -708,16 +778,27 @@ int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0
   hipStream_t s = (hipStream_t)stream;
   const float ips = (float)(1.0 / (double)prev_scale);
   const int tiles = single ? tiles_for(w, h) : ((w + 15) / 16) * ((h + 3) / 4);
-#define DRBA_IFL(SG, FO)                                                                                                  \
-  DRBA_LAUNCH((ifblock_input_lds<SG, FO>), dim3(tiles), dim3(kBlock), 0, s, img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, \
+  // vector-store form: whole tiles only, 16-byte aligned rows and planes (DRBA_IFIN_VS=0 forces the scalar stores: A/B runs)
+  static const bool vs_allowed = !(getenv("DRBA_IFIN_VS") && atoi(getenv("DRBA_IFIN_VS")) == 0);
+  const int two = single ? 32 : 16, tho = single ? 8 : 4;
+  const bool vs = vs_allowed && w % two == 0 && h % tho == 0 && (W & 3) == 0 && ((uintptr_t)out & 15) == 0 &&
+                  (!flow_out || (((uintptr_t)flow_out & 15) == 0 && (single || (W == 2 * w && H == 2 * h))));
+#define DRBA_IFL(SG, FO, VS_)                                                                                                  \
+  DRBA_LAUNCH((ifblock_input_lds<SG, FO, VS_>), dim3(tiles), dim3(kBlock), 0, s, img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, \
               timestep_scalar, flow, tmp_prev, hp, wp, ips, prev_scale, flow_out, out, H, W, h, w, scale)
+#define DRBA_IFL2(SG, FO) \
+  do {                    \
+    if (vs) DRBA_IFL(SG, FO, true); \
+    else DRBA_IFL(SG, FO, false);   \
+  } while (0)
   if (flow_out) {
-    if (single) DRBA_IFL(true, true);
-    else DRBA_IFL(false, true);
+    if (single) DRBA_IFL2(true, true);
+    else DRBA_IFL2(false, true);
   } else {
-    if (single) DRBA_IFL(true, false);
-    else DRBA_IFL(false, false);
+    if (single) DRBA_IFL2(true, false);
+    else DRBA_IFL2(false, false);
   }
+#undef DRBA_IFL2
 #undef DRBA_IFL
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;

@@ -194,19 +194,17 @@ def check_conv_layers(dev):
 
 
 # ----------------------------------------------------------------------------------------- glue kernels
-def check_glue(dev):
+def _glue_stage_rows(dev, g, D, H, W, scales):
     import oracle
     from drba_amd import ops
     rows = []
-    g = torch.Generator().manual_seed(7)
-    H, W = 64, 128
+    sz = f" [{H}x{W}]"
     img0, img1 = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 3, H, W, generator=g)
     f0, f1 = torch.randn(1, 16, H, W, generator=g), torch.randn(1, 16, H, W, generator=g)
     tmap = torch.rand(1, 1, H, W, generator=g)
     flow = torch.randn(1, 4, H, W, generator=g) * 3
     mask, feat = torch.randn(1, 1, H, W, generator=g), torch.randn(1, 8, H, W, generator=g)
-    D = lambda t: t.to(dev)  # noqa: E731
-    for s in (16.0, 8.0, 4.0, 2.0, 1.0, 32.0):
+    for s in scales:
         if H / s < 1:
             continue
         # first stage (no flow)
@@ -253,6 +251,23 @@ def check_glue(dev):
         rows.append((f"ifblock_update mask/feat s={s}", max(_diff(gm, up[:, 4:5]), _diff(gfe, up[:, 5:])), 1e-5, ""))
         gf = ops.ifblock_update(D(tmp), None, H, W, s)
         rows.append((f"ifblock_update noflow s={s}", _diff(gf, up[:, :4] * s), 1e-5 * max(1.0, s), ""))
+    return [(n + sz, e, t, x) for n, e, t, x in rows]
+
+
+def check_glue(dev):
+    import oracle
+    from drba_amd import ops
+    rows = []
+    g = torch.Generator().manual_seed(7)
+    D = lambda t: t.to(dev)  # noqa: E731
+    # 64x128: whole tiles at every scale down to 1/8 -> the vector-store form of ifblock_input_lds; 72x136: ragged tiles ->
+    # the element-wise stores
+    for (H, W), scales in (((64, 128), (16.0, 8.0, 4.0, 2.0, 1.0, 32.0)), ((72, 136), (4.0, 2.0, 1.0))):
+        rows += _glue_stage_rows(dev, g, D, H, W, scales)
+    H, W = 64, 128
+    img0, img1 = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 3, H, W, generator=g)
+    flow = torch.randn(1, 4, H, W, generator=g) * 3
+
     # fused splat pipelines (flow reversal, linear DRM) on flows that exercise every path of the sorted tile kernel:
     # smooth, longer than the 16-px tile halo, NaN/inf, and a 4x zoom-out that overflows the tile's LDS record space
     Hs, Ws = 70, 150
