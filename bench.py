@@ -28,7 +28,9 @@ Extra objects on the JSON line:
                 algorithmic_per_launch are plain means over the same launches; `by_geometry` splits the symbol by layer
                 shape; `others` = the next symbols; `step_kernels_ms` = all kernel time per step.  Peaks from
                 MI355X_MICROARCH.md (HBM 8 TB/s; dense fp32 MFMA 157.3 TFLOP/s; dense bf16 2500 TFLOP/s).
-                `traffic` = HBM bytes per launch from rocprofv3 --pmc passes (profiles/pmc_traffic.json, keyed by symbol).
+                `traffic` = HBM bytes per launch from rocprofv3 --pmc passes (profiles/pmc_traffic.json, keyed by symbol
+                and launch label; tools/pmc_targets.py + tools/pmc_traffic.py regenerate it), null where a geometry the
+                symbol ran with was not measured.
   cpu_baseline  the fp32 CPU oracle (a port pinned bit-for-bit to the reference, tests/golden) on the same workload:
                 bounded sample, all host cores (`value`) and one thread (`single_thread`).
   max_abs_vs_oracle  max |HIP frame - oracle frame| over the frames of the cpu_baseline sample, same uint8 inputs
@@ -213,13 +215,18 @@ def roofline_from_trace(recs, n_steps, traffic=None):
         if a["tagged"] == a["n"] and a["ms"] > 0:  # every launch of the symbol carries its algorithmic work
             peak, unit, bound, basis = _peak(name, a["unit"])
             ach = a["work"] / (a["ms"] * 1e-3) / (1e9 if a["unit"] == "byte" else 1e12)
+            # HBM bytes per launch from the PMC passes: {label: bytes} for this symbol; the symbol's figure is the mean over
+            # its launches when every geometry it ran was measured
+            tr = (traffic or {}).get(name) or {}
+            known = all(lab in tr for lab in a["geo"])
             e.update({"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                       "algorithmic_per_launch": a["work"] / a["n"], "peak_basis": basis,
-                      "traffic": (traffic or {}).get(name)})
+                      "traffic": (round(sum(tr[lab] * g[1] for lab, g in a["geo"].items()) / a["n"]) if known and tr else None)})
             if with_geo:
                 e["by_geometry"] = [
                     {"launch": lab, "launches_per_step": round(g[1] / n_steps, 2), "avg_us": round(g[0] / g[1] * 1e3, 2),
-                     "frac": round(g[2] / (g[0] * 1e-3) / (1e9 if a["unit"] == "byte" else 1e12) / peak, 4)}
+                     "frac": round(g[2] / (g[0] * 1e-3) / (1e9 if a["unit"] == "byte" else 1e12) / peak, 4),
+                     "algorithmic_per_launch": g[2] / g[1], "traffic": tr.get(lab)}
                     for lab, g in sorted(a["geo"].items(), key=lambda kv: -kv[1][0])[:6]]
         else:
             e.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None})

@@ -50,7 +50,10 @@ struct SplitCfg {
   static constexpr int ITEMS = NPIX * 4;                 // (pixel, channel group) staging items per chunk
   static constexpr int LIT = (ITEMS + 255) / 256;        // per thread
   static constexpr int FRAG_U4 = NTAP * NT * 3 * 64;     // 16-byte units of packed weights per (cout tile[, phase], chunk)
-  static constexpr int BDEPTH = (RW * MW >= 4) ? 2 : 4;  // weight fetch distance in steps (>= ~700 cycles of MFMAs)
+#ifndef DRBA_SPLIT_BDEPTH_BIG
+#define DRBA_SPLIT_BDEPTH_BIG 2
+#endif
+  static constexpr int BDEPTH = (RW * MW >= 4) ? DRBA_SPLIT_BDEPTH_BIG : 4;  // weight fetch distance in steps (>= ~700 cycles of MFMAs)
 #ifndef DRBA_SPLIT_MINB3
 #define DRBA_SPLIT_MINB3 1
 #endif
@@ -196,6 +199,15 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   int work = blockIdx.x;
   if (work >= total) return;
   DRBA_CLK_INIT;
+#ifdef DRBA_SPLIT_STAGGER  // experiment: put the co-resident workgroups of a CU out of phase
+  {
+    const int b = blockIdx.x;
+    const bool late = DRBA_SPLIT_STAGGER == 1 ? (b & 1) : DRBA_SPLIT_STAGGER == 2 ? (b >= (int)gridDim.x / 2) : ((b >> 3) & 1);
+    if (late) {
+      for (int i = 0; i < DRBA_SPLIT_STAGGER_N; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+#endif
   TileCtx ctx = decode(work);
   auto first_chunk = [&](const TileCtx &c) -> int { return RL ? (c.cz + 1 == nchunks ? 0 : c.cz + 1) : 0; };
   fetch(ctx, first_chunk(ctx));
@@ -254,8 +266,14 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       lds_barrier();
       DRBA_CLK(c_s1);
       DRBA_CLK_ADD(0, c_s0, c_s1);
+      // (measured, tools/exp/conv_split_phases.hip: without this request the MFMA phase of the 8x32 tile takes 9.8k clocks
+      // instead of 15.9k -- vmcnt retires in issue order, so the weight fragments requested after it wait behind these HBM
+      // loads, and the streaming traffic lengthens the L2 round trip of the fragments; issuing it behind the chunk's
+      // last weight fetch brought 14.3k and the spills back, a fetch distance of 3 nothing)
+#ifndef DRBA_EXP_NOFETCH
       if (qi + 1 < nchunks) fetch(ctx, q + 1 == nchunks ? 0 : q + 1);
       else if (next < total) fetch(nctx, first_chunk(nctx));
+#endif
 
       // activation fragments: ONE buffer; the fragment of (rw, mw) for the next tap slot is read from LDS right after the
       // last MFMAs of the current slot that use it (nt = NT - 1), i.e. RW*MW*6 MFMAs (>= 200 clocks) before its first use
@@ -299,12 +317,17 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
               acc[p][rw][mw][nt] = c;
+#ifndef DRBA_EXP_NOALOAD
               if (nt == NT - 1 && ts + 1 < NTS) load_piece(ts + 1, rw, mw);
+#endif
             }
+#ifndef DRBA_EXP_NOWLOAD
           if (step + D < STEPS) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bw[step % D][pl] = wload(step + D, pl);
           }
+#endif
+
           __builtin_amdgcn_sched_barrier(0);  // keep the fetch distances as written
         }
       }

@@ -2,7 +2,9 @@
 """Launch the roofline-target kernels of bench.py three times each (for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)
 and write the launch manifest tools/pmc_traffic.py needs.  A plain elementwise kernel with a known byte count
 (drba_affine on 64 Mi floats: 256 MiB read + 256 MiB written, 4 B per lane like the targets) calibrates the counters,
-as MI355X_MICROARCH.md 'HBM' prescribes.  Names are the ones bench.py prints in `roofline.kernel`."""
+as MI355X_MICROARCH.md 'HBM' prescribes.  Every target is first run once under the library's own kernel trace, which
+yields the exact kernel symbol and the launch label bench.py prints in `roofline.kernel` / `by_geometry[].launch`:
+profiles/pmc_traffic.json is keyed {symbol: {label: bytes per launch}}."""
 import json
 import os
 import sys
@@ -17,44 +19,51 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 H, W = 1088, 1920
 REPS = 3
-manifest = []  # (name, substring of the kernel symbol, launches), in launch order
-
-
+manifest = []  # {name, symbol, label, launches, algorithmic}, in launch order
 marker = torch.zeros(256, device=dev)
 
 
-def target(name, sym, fn):
+def target(name, fn, pick=-1):
     """A 256-element affine launch marks the start of each target's segment in the dispatch order; the target's
     counted launches are the last REPS dispatches of its symbol in the segment (autotune launches come before them)."""
-    ops.affine(marker, 1.0, 0.0)
-    fn()  # warm / autotune
+    fn()  # warm / autotune, outside any segment that matters (its launches precede the marker)
     torch.cuda.synchronize()
+    ops.trace_begin()
+    fn()
+    rec = ops.trace_end()[pick]  # the kernel of interest is the last launch of the call unless told otherwise
+    ops.affine(marker, 1.0, 0.0)
     for _ in range(REPS):
         fn()
-    manifest.append({"name": name, "symbol": sym, "launches": REPS})
+    torch.cuda.synchronize()
+    manifest.append({"name": name, "symbol": rec["name"], "label": rec["label"], "launches": REPS, "algorithmic": rec["work"],
+                     "unit": rec["unit"]})
 
 
 a = torch.randn(64 << 20, generator=g).to(dev)
-target("calibration affine 64Mi floats (256 MiB read, 256 MiB written)", "affine_kernel", lambda: ops.affine(a, 1.5, 0.25))
+target("calibration affine 64Mi floats (256 MiB read, 256 MiB written)", lambda: ops.affine(a, 1.5, 0.25))
 img0, img1 = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 3, H, W, generator=g).to(dev)
 f0, f1 = torch.randn(1, 16, H, W, generator=g).to(dev), torch.randn(1, 16, H, W, generator=g).to(dev)
 flow = torch.nn.functional.interpolate(torch.randn(1, 4, H // 32, W // 32, generator=g) * 6, size=(H, W), mode="bilinear").to(dev).contiguous()
 tmap = torch.rand(1, 1, H, W, generator=g).to(dev)
+ops.pair_interleaved(f0), ops.pair_interleaved(f1)  # made once, as in the pipeline (calc_flow)
 for s in (1.0, 2.0):
     tprev = torch.randn(1, 13, int(H / (2 * s)), int(W / (2 * s)), generator=g).to(dev)
-    h, w = int(H / s), int(W / s)
-    target(f"ifblock_input_kernel<true> 52ch {H}x{W} -> {h}x{w}", "ifblock_input",
-           lambda: ops.ifblock_input(img0, img1, f0, f1, tmap, flow, tprev, 2 * s, s))
-convs = []
-for (c, h, w, n) in ((64, 136, 240, 2), (32, 272, 480, 2)):
+    target(f"stage input s={s:.0f} with the folded flow update",
+           lambda: ops.ifblock_input_lds(img0, img1, f0, f1, tmap, flow, tprev, 2 * s, s, fold=True))
+tprev = torch.randn(1, 13, H // 8, W // 8, generator=g).to(dev)
+target("stage input s=4", lambda: ops.ifblock_input_lds(img0, img1, f0, f1, tmap, flow, tprev, 8.0, 4.0))
+for (c, h, w, n) in ((64, 136, 240, 2), (32, 272, 480, 2), (96, 68, 120, 2), (128, 34, 60, 2)):
     x = torch.randn(n, c, h, w, generator=g).to(dev)
     layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, True, torch.ones(1, c, 1, 1), device=dev)
     out = torch.empty_like(x)
-    layer(x, residual=x, out=out)  # autotune (before any conv segment starts: its launches carry the same symbols)
-    kern = "conv_split_mfma" if ops._tuned[("conv3x3", n, c, c, h, w, 1)] >= 14 else "conv_mfma"
-    convs.append((f"{kern} {c}->{c}ch {h}x{w} s1 N{n} (ResConv)", kern, layer, x, out))
-for name, kern, layer, x, out in convs:
-    target(name, kern, lambda: layer(x, residual=x, out=out))
+    target(f"ResConv {c}->{c}ch {h}x{w} N{n}", lambda: layer(x, residual=x, out=out))
+x52 = torch.randn(2, 52, H, W, generator=g).to(dev)
+conv00 = ops.Conv3x3(torch.randn(16, 52, 3, 3, generator=g) * 0.05, torch.zeros(16), 2, True, None, device=dev)
+target("block4 conv0.0 52->16 s2 1088x1920 N2", lambda: conv00(x52))
+x32 = torch.randn(2, 32, 272, 480, generator=g).to(dev)
+last = ops.Deconv4x4(torch.randn(32, 52, 4, 4, generator=g) * 0.05, torch.zeros(52), pixel_shuffle=True, device=dev)
+target("block4 lastconv 32->52 deconv + PixelShuffle 272x480 N2", lambda: last(x32))
 torch.cuda.synchronize()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(manifest, open(os.path.join(ROOT, "gpurun_out", "pmc_manifest.json"), "w"), indent=1)
+print(json.dumps(manifest, indent=1))

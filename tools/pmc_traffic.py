@@ -1,49 +1,85 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_targets.py -> profiles/pmc_traffic.json (+ a table).
-    python tools/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv gpurun_out/pmc_manifest.json
+    python tools/pmc_traffic.py FETCH.csv|FETCH.db WRITE.csv|WRITE.db gpurun_out/pmc_manifest.json [table.md]
 Counter unit: KiB.  gfx950 corrections (MI355X_MICROARCH.md 'HBM', re-checked by the calibration kernel in the same
-run): FETCH_SIZE reports half of the bytes read (x2), WRITE_SIZE is exact.  traffic = 2*FETCH + WRITE per launch."""
+run): FETCH_SIZE reports half of the bytes read (x2), WRITE_SIZE is exact.  traffic = 2*FETCH + WRITE per launch.
+Output: {kernel symbol: {launch label: bytes per launch}} -- the keys bench.py's roofline object uses."""
 import csv
 import json
 import os
+import re
+import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def per_target(path, manifest, counter):
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def rows_of(path, counter):
+    """[(dispatch id, kernel name, grid size, value)] for one counter, from a counter_collection CSV or a rocpd database."""
+    if path.endswith(".db"):
+        db = sqlite3.connect(path)
+        cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+        q = "select dispatch_id, kernel_name, grid_size_x, counter_name, value from counters_collection" if "grid_size_x" in cols else \
+            "select dispatch_id, kernel_name, grid_size, counter_name, value from counters_collection"
+        acc = {}
+        for d, k, gsz, c, v in db.execute(q):
+            if c == counter:
+                key = (int(d), k, int(gsz))
+                acc[key] = acc.get(key, 0.0) + float(v)
+        return sorted((d, k, gsz, v) for (d, k, gsz), v in acc.items())
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return sorted((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"])) for r in rows)
+
+
+def per_target(path, manifest, counter):
     segments, cur = [], None
-    for r in rows:
-        if "affine_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) == 256:  # segment marker
+    for _, kname, gsz, val in rows_of(path, counter):
+        if "affine_kernel" in kname and gsz == 256:  # segment marker
             cur = []
             segments.append(cur)
         elif cur is not None:
-            cur.append(r)
+            cur.append((kname, val))
     assert len(segments) == len(manifest), (len(segments), len(manifest))
-    out = {}
+    out = []
     for m, seg in zip(manifest, segments):
-        vals = [float(r["Counter_Value"]) for r in seg if m["symbol"] in r["Kernel_Name"]][-m["launches"]:]
-        out[m["name"]] = sum(vals) / max(1, len(vals))
+        vals = [v for k, v in seg if short(k) == m["symbol"]][-m["launches"]:]
+        assert vals, (m["symbol"], sorted({short(k) for k, _ in seg}))
+        out.append(sum(vals) / len(vals))
     return out
 
 
 def main():
-    fetch_csv, write_csv, man = sys.argv[1:4]
+    fetch_p, write_p, man = sys.argv[1:4]
     manifest = json.load(open(man))
-    f, w = per_target(fetch_csv, manifest, "FETCH_SIZE"), per_target(write_csv, manifest, "WRITE_SIZE")
-    cal = [n for n in f if n.startswith("calibration")][0]
-    print(f"calibration: FETCH_SIZE {f[cal]:.0f} KiB for 262144 KiB read (x{262144 / f[cal]:.3f}), WRITE_SIZE {w[cal]:.0f} KiB for 262144 KiB written (x{262144 / w[cal]:.3f})")
+    f, w = per_target(fetch_p, manifest, "FETCH_SIZE"), per_target(write_p, manifest, "WRITE_SIZE")
+    lines = [f"calibration: FETCH_SIZE {f[0]:.0f} KiB for 262144 KiB read (x{262144 / f[0]:.3f}), WRITE_SIZE {w[0]:.0f} KiB for "
+             f"262144 KiB written (x{262144 / w[0]:.3f})", "",
+             "| target | kernel | launch | FETCH_SIZE KiB | WRITE_SIZE KiB | corrected traffic MB | algorithmic MB | ratio |", "|---|---|---|---|---|---|---|---|"]
     traffic = {}
-    print("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | corrected traffic MB |")
-    print("|---|---|---|---|")
-    for n in f:
-        if n == cal:
-            continue
-        traffic[n] = int((2.0 * f[n] + w[n]) * 1024)
-        print(f"| {n} | {f[n]:.0f} | {w[n]:.0f} | {traffic[n] / 1e6:.1f} |")
+    for m, fv, wv in zip(manifest[1:], f[1:], w[1:]):
+        t = int((2.0 * fv + wv) * 1024)
+        traffic.setdefault(m["symbol"], {})[m["label"]] = t
+        alg = m["algorithmic"] if m["unit"] == "byte" else None
+        lines.append(f"| {m['name']} | `{m['symbol']}` | {m['label']} | {fv:.0f} | {wv:.0f} | {t / 1e6:.1f} | "
+                     f"{'' if alg is None else f'{alg / 1e6:.1f}'} | {'' if alg is None else f'{t / alg:.2f}'} |")
+    print("\n".join(lines))
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    if len(sys.argv) > 4:
+        open(sys.argv[4], "w").write("\n".join(lines) + "\n")
 
 
 if __name__ == "__main__":
