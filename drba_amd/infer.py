@@ -159,12 +159,66 @@ def inference(model, args):
     return n
 
 
+def inference_sharded(model, args, rank, world, to_inp=None, to_out=None, check_scene=None, device=None, chunk=4):
+    """ONE clip frame-sharded over the ranks of a torch.distributed job (not in the reference, which has no parallelism;
+    BASELINE.json configs[4]).  Every rank opens the clip (random access: .npz / .npy sources), runs its contiguous share
+    of the driver loop with the one-frame halo of drba_amd.parallel.interpolate_shard, and the finished uint8 frames
+    stream to rank 0 -- the writer -- through StreamedGather (the only collective: RCCL over xGMI on the GPUs).  The file
+    rank 0 writes equals the single-process run's.  Returns the number of frames written (rank 0), 0 elsewhere."""
+    import numpy as np
+
+    from drba_amd import parallel
+    ext = os.path.splitext(args.input)[1].lower()
+    if ext == ".npz":
+        z = np.load(args.input)
+        frames, fps = z["frames"], (float(z["fps"]) if "fps" in z.files else 24.0)
+    elif ext == ".npy":
+        frames = np.load(args.input, mmap_mode="r")
+        side = os.path.splitext(args.input)[0] + ".json"
+        fps = 24.0
+        if os.path.exists(side):
+            import json
+            fps = float(json.load(open(side))["fps"])
+    else:
+        raise RuntimeError("the frame-sharded run needs random access to the clip: use a .npz / .npy source")
+    counts = parallel.emission_counts(len(frames), fps, args.dst_fps, args.times, world)
+    sg = parallel.StreamedGather(rank, world, counts, chunk=chunk, device=device, frame_shape=tuple(frames[0].shape))
+    parallel.interpolate_shard(model, frames, fps, args.dst_fps, rank, world, times=args.times, enable_scdet=args.enable_scdet,
+                               scdet_threshold=args.scdet_threshold, to_inp=to_inp, to_out=to_out, check_scene=check_scene,
+                               sink=sg.push)
+    allf = sg.finish()
+    if rank != 0:
+        return 0
+    video_io = _tools.VideoFI_IO(args.input, args.output, dst_fps=args.dst_fps, times=args.times, hwaccel=args.hwaccel)
+    for f in allf:
+        video_io.write_frame(f.cpu().numpy() if hasattr(f, "cpu") else f)
+    while not video_io.finish_writing():
+        time.sleep(0.01)
+    video_io.close()
+    return len(allf)
+
+
 def main(argv=None):
+    """`python infer.py ...` = the reference CLI.  Under torch.distributed.run (WORLD_SIZE > 1, one rank per GPU) the same
+    command line shards the clip over the ranks: `python -m torch.distributed.run --nproc-per-node 8 infer.py -m rife ...`."""
     args = parse_args(argv)
     if not os.path.exists(args.input):
         raise FileNotFoundError(f"can't find the video file {args.input}")
-    model = load_model(args.model_type, scale=args.scale)
-    return inference(model, args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        model = load_model(args.model_type, scale=args.scale)
+        return inference(model, args)
+    import torch
+    import torch.distributed as dist
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl")  # RCCL over xGMI
+    try:
+        model = load_model(args.model_type, scale=args.scale, device=torch.device("cuda", local))
+        return inference_sharded(model, args, rank, world, device=torch.device("cuda", local))
+    finally:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -178,3 +178,41 @@ def test_streamed_gather_uneven_world3(scdet):
         assert p.exitcode == 0
     n_sharded, n_seq, same = q.get(timeout=10)
     assert n_sharded == n_seq and same
+
+
+def _cli_worker(rank, world, port, tmp, q):
+    """drba_amd.infer.inference_sharded (what `torchrun infer.py` runs per rank) with the oracle model and CPU hooks."""
+    import argparse
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    model = _model("cut")
+    to_inp, to_out, check = _cpu_hooks()
+    args = argparse.Namespace(input=os.path.join(tmp, "in.npz"), output=os.path.join(tmp, "sharded.npz"), dst_fps=60.0, times=-1,
+                              enable_scdet=True, scdet_threshold=0.3, hwaccel=False)
+    n = drv.inference_sharded(model, args, rank, world, to_inp=to_inp, to_out=to_out, check_scene=check, chunk=2)
+    if rank == 0:
+        frames = _clip("cut")
+        io = _IO(frames, 24.0)
+        drv.interpolate_stream(model, io, 60.0, times=-1, enable_scdet=True, to_inp=to_inp, to_out=to_out, check_scene=check)
+        z = np.load(args.output)
+        ok = n == len(io.written) and z["frames"].shape[0] == n and all(np.array_equal(a, b) for a, b in zip(z["frames"], io.written))
+        q.put((ok, n, len(io.written), float(z["fps"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cli_sharded_run_writes_the_sequential_file(tmp_path):
+    """The CLI's frame-sharded path (WORLD_SIZE > 1): rank 0's output file == the single-process driver's frames."""
+    np.savez(os.path.join(tmp_path, "in.npz"), frames=np.stack(_clip("cut")), fps=np.float64(24.0))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, n, n_seq, fps = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert ok, (n, n_seq)
+    assert fps == 60.0
