@@ -25,7 +25,8 @@ marker = torch.zeros(256, device=dev)
 
 def target(name, fn, pick=-1):
     """A 256-element affine launch marks the start of each target's segment in the dispatch order; the target's
-    counted launches are the last REPS dispatches of its symbol in the segment (autotune launches come before them)."""
+    counted launches are the FIRST REPS dispatches of its symbol after the marker (the next target's warm-up and autotune
+    launches follow them in the same segment)."""
     fn()  # warm / autotune, outside any segment that matters (its launches precede the marker)
     torch.cuda.synchronize()
     ops.trace_begin()

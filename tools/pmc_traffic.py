@@ -56,7 +56,8 @@ def per_target(path, manifest, counter):
     assert len(segments) == len(manifest), (len(segments), len(manifest))
     out = []
     for m, seg in zip(manifest, segments):
-        vals = [v for k, v in seg if short(k) == m["symbol"]][-m["launches"]:]
+        vals = [v for k, v in seg if short(k) == m["symbol"]][:m["launches"]]  # the reps follow the marker directly; what comes
+        # after them in the segment is the NEXT target's warm-up / autotune (possibly the same symbol on another layer)
         assert vals, (m["symbol"], sorted({short(k) for k, _ in seg}))
         out.append(sum(vals) / len(vals))
     return out
