@@ -260,8 +260,8 @@ ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ i
   constexpr int TWo = SINGLE ? 32 : 16, THo = SINGLE ? 8 : 4;
   {
     const int tiles_x = (w + TWo - 1) / TWo;
-    const int t = xcd_band(blockIdx.x, gridDim.x);
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    int tx, ty;
+    xcd_strip_tile(blockIdx.x, gridDim.x, tiles_x, tx, ty);
     const int lo = threadIdx.x / LPO;
     const int ox_raw = tx * TWo + (lo % TWo), oy_raw = ty * THo + (lo / TWo);
     const bool valid = ox_raw < w && oy_raw < h;
@@ -400,8 +400,8 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
   constexpr int C0 = FOLD ? 0 : 4;  // first channel of tmp_prev that is needed
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
   const int tiles_x = (w + TWo - 1) / TWo;
-  const int t = xcd_band(blockIdx.x, gridDim.x);
-  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  int tx, ty;
+  xcd_strip_tile(blockIdx.x, gridDim.x, tiles_x, tx, ty);
   // footprint of this workgroup's sample points in tmp_prev (same for every lane: computed from the tile corners)
   const int ox_a = tx * TWo, oy_a = ty * THo;
   const int ox_b = min(ox_a + TWo - 1, w - 1), oy_b = min(oy_a + THo - 1, h - 1);
@@ -573,8 +573,8 @@ warp_blend_fold_kernel(const float *__restrict__ img0, const float *__restrict__
   __shared__ float prev[5][10][36];
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
   const int tiles_x = (W + kTileW - 1) / kTileW;
-  const int t = xcd_band(blockIdx.x, gridDim.x);
-  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  int tx, ty;
+  xcd_strip_tile(blockIdx.x, gridDim.x, tiles_x, tx, ty);
   const int Xa = tx * kTileW, Ya = ty * kTileH, Xb = min(Xa + kTileW - 1, W - 1), Yb = min(Ya + kTileH - 1, H - 1);
   const int rx0 = lerp_src(Xa, inv_scale, w).i0, ry0 = lerp_src(Ya, inv_scale, h).i0;
   const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
