@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/drba_hip.h"
 
@@ -36,6 +37,18 @@ TimedLaunch trace_launch(const void *host_fn, const char *fallback_name, dim3 gr
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                         \
   } while (0)
 #define DRBA_LAUNCH_TIMED DRBA_LAUNCH
+
+// Environment switches select between kernel variants of THIS library for A/B measurements (never another backend).  The
+// release build -- the Makefile's default -- compiles them out: env_int() returns the default without reading the
+// environment; `make TUNING=1` (-DDRBA_TUNING_SWITCHES) builds the measuring library the tools/ scripts may use.
+#ifdef DRBA_TUNING_SWITCHES
+static inline int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#else
+static inline int env_int(const char *, int dflt) { return dflt; }
+#endif
 
 constexpr int kBlock = 256;      // 4 waves: one per SIMD of a CU
 constexpr int kMaxBlocks = 2048; // 256 CUs x 8: grid-stride beyond this (guide G11)

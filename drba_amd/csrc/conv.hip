@@ -526,10 +526,8 @@ size_t packed_floats(const CfgInfo &c, int Cin, int Cout, int phases) {
   return n_ct * phases * nch * c.per_chunk;
 }
 
-int env_override(const char *name, int ntab) {
-  const char *ov = getenv(name);
-  if (!ov) return -1;
-  const int id = atoi(ov);
+int env_override(const char *name, int ntab) {  // (compiled out of the release build: common.hpp env_int)
+  const int id = env_int(name, -1);
   return (id >= 0 && id < ntab) ? id : -1;
 }
 
@@ -538,9 +536,9 @@ int env_override(const char *name, int ntab) {
 extern "C" {
 
 // cfg ids: 0..kNumConvCfg-1 the fp32 MFMA table above, then the split-bf16 family of conv_split.hip (stride 1, Cin a
-// multiple of 32; drba_conv3x3_packed_floats returns 0 for a layer a config cannot run).  DRBA_CONV_SPLIT=0 hides it.
+// multiple of 32; drba_conv3x3_packed_floats returns 0 for a layer a config cannot run).  DRBA_CONV_SPLIT=0 hides it (TUNING builds only).
 static bool split_enabled() {
-  static const bool on = !(getenv("DRBA_CONV_SPLIT") && atoi(getenv("DRBA_CONV_SPLIT")) == 0);
+  static const bool on = env_int("DRBA_CONV_SPLIT", 1) != 0;
   return on;
 }
 int drba_conv3x3_num_cfgs(void) { return kNumConvCfg + (split_enabled() ? conv_split_num_cfgs() : 0); }

@@ -733,8 +733,8 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
   hipStream_t s = (hipStream_t)stream;
   const float ips = flow ? (float)(1.0 / (double)prev_scale) : 1.f;
   // variant: 0 = lane per output pixel; 1 = lane per sample point; 2 = lane per sample point, channel loops unrolled x4.
-  // DRBA_IFIN_VARIANT overrides the default (A/B experiments only).
-  static const int forced = getenv("DRBA_IFIN_VARIANT") ? atoi(getenv("DRBA_IFIN_VARIANT")) : -1;
+  // DRBA_IFIN_VARIANT overrides the default (A/B experiments, TUNING builds only).
+  static const int forced = env_int("DRBA_IFIN_VARIANT", -1);
   const int var = forced >= 0 ? forced : (single ? 0 : 1);
   dim3 b(kBlock);
   const int quad_tiles = single ? tiles_for(w, h) : ((w + 15) / 16) * ((h + 3) / 4);
@@ -778,8 +778,8 @@ int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0
   hipStream_t s = (hipStream_t)stream;
   const float ips = (float)(1.0 / (double)prev_scale);
   const int tiles = single ? tiles_for(w, h) : ((w + 15) / 16) * ((h + 3) / 4);
-  // vector-store form: whole tiles only, 16-byte aligned rows and planes (DRBA_IFIN_VS=0 forces the scalar stores: A/B runs)
-  static const bool vs_allowed = !(getenv("DRBA_IFIN_VS") && atoi(getenv("DRBA_IFIN_VS")) == 0);
+  // vector-store form: whole tiles only, 16-byte aligned rows and planes (DRBA_IFIN_VS=0 forces the scalar stores: A/B runs, TUNING builds)
+  static const bool vs_allowed = env_int("DRBA_IFIN_VS", 1) != 0;
   const int two = single ? 32 : 16, tho = single ? 8 : 4;
   const bool vs = vs_allowed && w % two == 0 && h % tho == 0 && (W & 3) == 0 && ((uintptr_t)out & 15) == 0 &&
                   (!flow_out || (((uintptr_t)flow_out & 15) == 0 && (single || (W == 2 * w && H == 2 * h))));

@@ -294,7 +294,7 @@ static int attn_ksplit(int nwin, int L) {
   const int qtiles = (L + drba_attn::kRows - 1) / drba_attn::kRows, chunks = (L + drba_attn::kKeys - 1) / drba_attn::kKeys;
   const long long wgs = (long long)((nwin + 7) / 8) * 8 * qtiles;
   if (wgs >= 2 * 256 || chunks < 8) return 1;  // two workgroups per CU already, or too few chunks to share out
-  static const int force = getenv("DRBA_ATTN_KSPLIT") ? atoi(getenv("DRBA_ATTN_KSPLIT")) : 0;
+  static const int force = env_int("DRBA_ATTN_KSPLIT", 0);  // (TUNING builds only)
   if (force > 0) return force;
   return chunks >= 16 ? 4 : 2;  // measured on 8 windows x 2160 tokens: 349 us unsplit, 287 us in two runs, 260 us in four
 }

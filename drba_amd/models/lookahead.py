@@ -6,8 +6,6 @@ frame it can be computed while the current step's frames are synthesised.  Those
 (hundreds of launches on 1/4..1/16-resolution maps for GMFlow), the synthesis kernels are large: overlapping them on
 two streams fills the chip.  The result is handed to the next call by frame identity; a scene cut or any other call
 pattern simply leaves it unused."""
-import os
-
 import torch
 
 
@@ -41,7 +39,7 @@ class Lookahead:
             return
         main = torch.cuda.current_stream(a.device)
         if self.side is None:
-            self.side = torch.cuda.Stream(device=a.device, priority=int(os.environ.get("DRBA_SIDE_PRIORITY", "0")))
+            self.side = torch.cuda.Stream(device=a.device)  # (stream priorities measured: no effect on the step)
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(self.side):

@@ -85,7 +85,7 @@ class RIFE:
         flow_ab, flow_ba, fa, fb = self.calc_flow(Ia, Ib)
         return (flow_ba, flow_ab, fb, fa)
 
-    SIDE_STAGES = int(os.environ.get("DRBA_SIDE_STAGES", "3"))  # IFNet stages of the NEXT step run by the lookahead
+    SIDE_STAGES = 3  # IFNet stages of the NEXT step run by the lookahead on the side stream (class attribute: A/B runs set it)
 
     def _items(self, I0, I1, I2, ts, linear, flow10, flow12, f0, f1, f2):
         """DRM maps and the (img0, img1, timestep, f0, f1) work items of one step; output holds pass-through frames
