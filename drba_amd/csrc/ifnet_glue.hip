@@ -428,7 +428,7 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
   const float wx = si ? lx.w1 : lx.w0, wy = sj ? ly.w1 : ly.w0;
   const size_t q = (size_t)Y * W + X;
   auto comb = [&](float v) -> float {
-    if (SINGLE) return ly.w0 * (lx.w0 * v + lx.w1 * 0.f) + ly.w1 * 0.f;
+    if (SINGLE) return v;  // scale 1: the "downsample" has weights (1, 0) x (1, 0) -- v * 1 + 0 * 0 + 0 * 0, the identity
     const float a = wx * v;
     const float row = a + __shfl_xor(a, 1, 64);
     const float b = wy * row;
@@ -485,26 +485,53 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
   }
   const Taps t0 = taps_border(warp_coord(X, W, fls[0]), warp_coord(Y, H, fls[1]), W, H);
   const Taps t1 = taps_border(warp_coord(X, W, fls[2]), warp_coord(Y, H, fls[3]), W, H);
+  // sample() / sample_pair() of common.hpp with everything that does not depend on the channel taken out of the channel
+  // loops: 32-bit element offsets of the two tap rows, and the right-border case (x0 == W-1: the pair is loaded one
+  // column to the left and its SECOND element is the left tap) folded into the four weights instead of four selects per
+  // sample.  Same products, same order, same zeros added: bit-identical to the helpers for finite inputs.
+  struct TapW {
+    int o0, o1;
+    float w00, w01, w10, w11;
+  };
+  auto tapw = [&](const Taps &t) -> TapW {
+    const int xb = min(t.x0, W - 2);
+    const bool edge = t.x0 != xb;
+    TapW k;
+    k.o0 = t.y0 * W + xb, k.o1 = t.y1 * W + xb;
+    k.w00 = edge ? 0.f : t.wnw, k.w01 = edge ? t.wnw : t.wne;
+    k.w10 = edge ? 0.f : t.wsw, k.w11 = edge ? t.wsw : t.wse;
+    return k;
+  };
+  const TapW k0 = tapw(t0), k1 = tapw(t1);
+  auto sample = [&](const float *__restrict__ p, int, const TapW &k) -> float {
+    const f32x2u a = *reinterpret_cast<const f32x2u *>(p + k.o0), b = *reinterpret_cast<const f32x2u *>(p + k.o1);
+    return a.x * k.w00 + a.y * k.w01 + b.x * k.w10 + b.y * k.w11;
+  };
+  auto sample_pair = [&](const float *__restrict__ pp, int, const TapW &k, float &v0, float &v1) {
+    const f32x4u a = *reinterpret_cast<const f32x4u *>(pp + 2 * k.o0), b = *reinterpret_cast<const f32x4u *>(pp + 2 * k.o1);
+    v0 = a.x * k.w00 + a.z * k.w01 + b.x * k.w10 + b.z * k.w11;
+    v1 = a.y * k.w00 + a.w * k.w01 + b.y * k.w10 + b.w * k.w11;
+  };
   const float tmv = comb(tmap ? tmap[q] : tscalar);
   if (VS && SINGLE) {
     // batches of four channels: {img0 0..2, timestep}, {img1 0..2, mask}, 8 x {f0 pair, f1 pair}, feat 0..3, feat 4..7, flow
 #pragma unroll
-    for (int c = 0; c < 3; ++c) park(c, comb(sample(img0 + (size_t)c * P, W, t0)));
+    for (int c = 0; c < 3; ++c) park(c, comb(sample(img0 + (size_t)c * P, W, k0)));
     park(3, tmv);
     flush_out(g4 < 3 ? g4 : 38);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) park(c, comb(sample(img1 + (size_t)c * P, W, t1)));
+    for (int c = 0; c < 3; ++c) park(c, comb(sample(img1 + (size_t)c * P, W, k1)));
     park(3, comb(prev_up(4)));
     flush_out(g4 < 3 ? 3 + g4 : 39);
 #pragma unroll 1
     for (int c2 = 0; c2 < 8; ++c2) {
       float a0, a1, b0, b1;
       if (f0p) {
-        sample_pair(f0p + (size_t)c2 * 2 * P, W, t0, a0, a1);
-        sample_pair(f1p + (size_t)c2 * 2 * P, W, t1, b0, b1);
+        sample_pair(f0p + (size_t)c2 * 2 * P, W, k0, a0, a1);
+        sample_pair(f1p + (size_t)c2 * 2 * P, W, k1, b0, b1);
       } else {
-        a0 = sample(f0 + (size_t)(2 * c2) * P, W, t0), a1 = sample(f0 + (size_t)(2 * c2 + 1) * P, W, t0);
-        b0 = sample(f1 + (size_t)(2 * c2) * P, W, t1), b1 = sample(f1 + (size_t)(2 * c2 + 1) * P, W, t1);
+        a0 = sample(f0 + (size_t)(2 * c2) * P, W, k0), a1 = sample(f0 + (size_t)(2 * c2 + 1) * P, W, k0);
+        b0 = sample(f1 + (size_t)(2 * c2) * P, W, k1), b1 = sample(f1 + (size_t)(2 * c2 + 1) * P, W, k1);
       }
       park(0, comb(a0)), park(1, comb(a1)), park(2, comb(b0)), park(3, comb(b1));
       flush_out(6 + 2 * c2 + (g4 & 1) + (g4 >> 1) * 16);
@@ -522,7 +549,7 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float v0 = comb(sample(img0 + (size_t)c * P, W, t0)), v1 = comb(sample(img1 + (size_t)c * P, W, t1));
+    const float v0 = comb(sample(img0 + (size_t)c * P, W, k0)), v1 = comb(sample(img1 + (size_t)c * P, W, k1));
     emit(c, v0);
     emit(3 + c, v1);
   }
@@ -530,8 +557,8 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
 #pragma unroll 1
     for (int c2 = 0; c2 < 8; ++c2) {
       float a0, a1, b0, b1;
-      sample_pair(f0p + (size_t)c2 * 2 * P, W, t0, a0, a1);
-      sample_pair(f1p + (size_t)c2 * 2 * P, W, t1, b0, b1);
+      sample_pair(f0p + (size_t)c2 * 2 * P, W, k0, a0, a1);
+      sample_pair(f1p + (size_t)c2 * 2 * P, W, k1, b0, b1);
       a0 = comb(a0), a1 = comb(a1), b0 = comb(b0), b1 = comb(b1);
       emit(6 + 2 * c2, a0);
       emit(7 + 2 * c2, a1);
@@ -541,7 +568,7 @@ ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1
   } else {
 #pragma unroll 1
     for (int c = 0; c < 16; ++c) {
-      const float v0 = comb(sample(f0 + (size_t)c * P, W, t0)), v1 = comb(sample(f1 + (size_t)c * P, W, t1));
+      const float v0 = comb(sample(f0 + (size_t)c * P, W, k0)), v1 = comb(sample(f1 + (size_t)c * P, W, k1));
       emit(6 + c, v0);
       emit(22 + c, v1);
     }
