@@ -5,7 +5,7 @@ This package restates, in plain fp32 CPU torch, the algorithm of the reference
 Every function cites the reference file:line it follows.  It is the checker the
 HIP path is compared against and the `cpu_baseline` timed by bench.py.
 
-Rules (enforced by tests/test_layout.py):
+Rules (enforced by tests/test_abi.py::test_oracle_is_not_imported_by_the_product):
   * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import it;
   * nothing under drba_amd/ (the product) imports or falls back to it;
   * it never touches a GPU and never reads /root/reference at run time.

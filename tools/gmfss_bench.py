@@ -43,7 +43,7 @@ def main():
     size = tools.get_valid_net_inp_size(np.zeros((H, W, 3), np.uint8), model.scale, div=model.pad_size)
     src_size, dst_size = size["src_size"], size["dst_size"]
     frames = [torch.from_numpy(f).to(dev) for f in synth.make_clip(6, H, W, seed=7)]
-    to_inp = lambda k: ops.resize_bilinear(ops.u8hwc_to_f32nchw(frames[k % 6]), dst_size)  # noqa: E731
+    to_inp = lambda k: ops.to_inp(frames[k % 6], dst_size)  # noqa: E731
     I0, I1, reuse, k = to_inp(0), to_inp(1), None, 2
     ts = np.array([0.75, 1.25])
     sink = []
@@ -55,7 +55,7 @@ def main():
         I2 = nxt if nxt is not None else to_inp(k)
         nxt = None if a.no_lookahead else to_inp(k + 1)  # the driver reads one frame ahead (drba_amd/infer.py)
         out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, True, lookahead=nxt)
-        sink = [ops.f32nchw_to_u8hwc(ops.resize_bilinear(x, src_size)) for x in out]
+        sink = [ops.to_out(x, src_size) for x in out]
         I0, I1, k = I1, I2, k + 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
