@@ -84,9 +84,9 @@ def parse():
     p.add_argument("--config", default="1080p", choices=sorted(CONFIGS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=2)
-    p.add_argument("--cpu-threads", type=int, default=32,
-                   help="threads of the multi-core CPU leg (capped by the affinity mask; 0 = all).  8-32 threads are the fastest "
-                        "settings on the 256-thread GPU box (0.40-0.42 frames/s; 1 thread 0.21, 128 threads 0.15, 256 threads "
+    p.add_argument("--cpu-threads", type=int, default=16,
+                   help="threads of the multi-core CPU leg (capped by the affinity mask; 0 = all).  16 threads are the fastest setting "
+                        "on the 256-thread GPU box (0.42 frames/s; 8: 0.40, 32: 0.38, 1 thread 0.21, 128 threads 0.15, 256 threads "
                         "< 0.013: oneDNN/OpenMP oversubscription), profiles/r02_cpu_threads.txt (tools/cpu_threads.py)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip extra_configs / pcie_inclusive (configs 3-5 at N = 1)")
