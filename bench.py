@@ -91,6 +91,9 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip extra_configs / pcie_inclusive (configs 3-5 at N = 1)")
     p.add_argument("--no-lookahead", action="store_true", help="do not overlap the next step's coarse flow (A/B runs)")
+    p.add_argument("--selftest-sharded", action="store_true",
+                   help="N = 1 only: run the N > 1 legs' code (sharded warm-up + sharded run of the headline clip and of the "
+                        "config-5 clip) on one GPU without a process group and print their rates; not the metric")
     return p.parse_args()
 
 
@@ -415,7 +418,6 @@ def extra_configs(args, dev):
 def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
     """One clip sharded over the ranks (drba_amd.parallel), frames streamed to rank 0 -> (seconds max over ranks,
     generated frames of all ranks, frames on the writer)."""
-    import torch.distributed as dist
     from drba_amd import parallel
     cm = _Counting(model)
     to_inp, to_out = _dev_hooks()
@@ -429,11 +431,23 @@ def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
     allf = sg.finish()
     _fence(world)
     dt = time.perf_counter() - t0
+    if world == 1:  # (--selftest-sharded: the same code on one GPU, no process group)
+        return dt, cm.generated, (len(allf) if allf is not None else 0)
+    import torch.distributed as dist
     t = torch.tensor([dt, float(cm.generated)], dtype=torch.float64, device=dev)
     mx = t.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(mx[0].item()), int(round(float(t[1].item()))), (len(allf) if allf is not None else 0)
+
+
+def sharded_warmup(model, H, W, dst_fps, times, scdet, rank, world, dev, cut=False):
+    """Untimed: the sharded run on a short clip of the same frame size, so that everything a shard touches OUTSIDE the
+    steady-state loop -- the head / tail `inference_ts` calls (batch 1), the halo's `warm_reuse`, a scene-cut step, the
+    gather's buffers -- has been autotuned / allocated on every rank before the timed run."""
+    n = 4 * world + 2
+    clip = DeviceClip(n, H, W, 4321, dev, cut_at=(n // 2 if cut else None))
+    sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev)
 
 
 def gpu_leg(args, rank, world):
@@ -462,6 +476,7 @@ def gpu_leg(args, rank, world):
                          "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "scaling": "weak",
                          "what": "every rank runs the N = 1 loop on its own clip: no halo, no collective"}
     big = DeviceClip(world * args.steps + 2, H, W, 1234, dev)
+    sharded_warmup(model, H, W, SRC_FPS * 2, 2, False, rank, world, dev)
     sdt, gen, got = sharded_leg(model, big, SRC_FPS * 2, 2, False, rank, world, dev)
     r.update({"dt": sdt, "host_dt": None, "frames": gen, "writer_frames": got})
     if not args.no_extra:
@@ -470,6 +485,7 @@ def gpu_leg(args, rank, world):
         c5 = DeviceClip(n5, 2160, 3840, 1234, dev, cut_at=n5 // 2)
         warm = [c5[k] for k in range(min(12, n5))]
         step_loop(m5, warm, 0, argparse.Namespace(**{**vars(args), "steps": 2, "warmup": 2}), world, trace=False)  # autotune / allocator warm-up
+        sharded_warmup(m5, 2160, 3840, 60.0, -1, True, rank, world, dev, cut=True)
         sdt5, gen5, got5 = sharded_leg(m5, c5, 60.0, -1, True, rank, world, dev)
         r["config5_sharded"] = {"value": round(gen5 / sdt5, 3), "unit": "frames/s", "scaling": "strong", "seconds": round(sdt5, 4),
                                 "frames_generated": gen5, "writer_frames": got5, "clip_source_frames": n5,
@@ -570,6 +586,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         dist.init_process_group(backend="nccl")  # RCCL over xGMI
+    if args.selftest_sharded:
+        from drba_amd.models.rife import RIFE
+        dev = torch.device("cuda", 0)
+        (H, W), scale, _ = CONFIGS[args.config]
+        model = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=scale, device=dev)
+        sharded_warmup(model, H, W, SRC_FPS * 2, 2, False, 0, 1, dev)
+        dt, gen, got = sharded_leg(model, DeviceClip(args.steps + 2, H, W, 1234, dev), SRC_FPS * 2, 2, False, 0, 1, dev)
+        out = {"selftest": "sharded legs at world 1", "headline_clip": {"frames_generated": gen, "writer_frames": got, "frames_per_s": round(gen / dt, 2)}}
+        m5 = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=0.5, device=dev)
+        n5 = args.steps + 2
+        sharded_warmup(m5, 2160, 3840, 60.0, -1, True, 0, 1, dev, cut=True)
+        dt5, gen5, got5 = sharded_leg(m5, DeviceClip(n5, 2160, 3840, 1234, dev, cut_at=n5 // 2), 60.0, -1, True, 0, 1, dev)
+        out["config5_clip"] = {"frames_generated": gen5, "writer_frames": got5, "frames_per_s": round(gen5 / dt5, 2)}
+        print(json.dumps(out))
+        return
     r = gpu_leg(args, rank, world)
     log(f"gpu leg done: {r['frames'] / r['dt']:.1f} frames/s")
     cpu = parity = extra = pcie = None

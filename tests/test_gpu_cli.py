@@ -115,3 +115,19 @@ def test_cli_whole_clip_fps60_scdet_matches_cpu_driver(tmp_path):
     got = _cli_clip(tmp_path, frames, 24.0, ["-fps", "60", "-s"])
     want = _oracle_clip(frames, 24.0, 60.0, -1, True)
     _assert_frames_close(got, want)
+
+
+def test_bench_sharded_legs_run_at_world_1():
+    """bench.py's N > 1 legs (untimed sharded warm-up, then interpolate_shard + StreamedGather over the headline clip and
+    over the 4K config-5 clip with its planted cut) cannot be launched on the one-GPU box; --selftest-sharded runs the
+    same functions at world 1 (no process group): they must execute on the HIP model and count what the schedule says."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-sharded", "--steps", "4", "--config", "480p"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    h, c5 = d["headline_clip"], d["config5_clip"]
+    # -t 2 over 6 source frames: head (1 synthesised, 1 copy) + 4 DRBA steps x 2 + tail (1): 12 written, 10 generated
+    assert (h["frames_generated"], h["writer_frames"]) == (10, 12), h
+    # 24 -> 60 fps over 6 source frames with a cut: every written frame is accounted for, copies replace synthesised ones
+    assert c5["writer_frames"] >= c5["frames_generated"] > 0, c5
