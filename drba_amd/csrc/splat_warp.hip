@@ -321,17 +321,23 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
       }
     }
     const size_t p = (size_t)y * W + x;
-    const float *g = gacc + p * (NV + 1);
-    sw += g[NV];
+    float *g = gacc + p * (NV + 1);
+    const float g0 = g[0], g1 = NV == 2 ? g[1] : 0.f, gw = g[NV];
+    if (g0 != 0.f || g1 != 0.f || gw != 0.f) {  // self-cleaning accumulator: zero on entry, zero again on return
+      g[0] = 0.f;                               // (no memset launch per call; nothing is written in the usual case)
+      if (NV == 2) g[1] = 0.f;
+      g[NV] = 0.f;
+    }
+    sw += gw;
     const float nrm = sw + 0.0000001f;
     const bool gap = (sw / nrm) < 0.999f;
     if (MODE == 0) {
-      a0 += g[0];
-      a1 += g[1];
+      a0 += g0;
+      a1 += g1;
       out[p] = (gap ? fill : -1.f * (a0 / nrm)) * 2.f;
       out[P + p] = (gap ? fill : -1.f * (a1 / nrm)) * 2.f;
     } else {
-      a0 += g[0];
+      a0 += g0;
       const SplatSrc<MODE> sp = splat_source<MODE>(fs, fo, P, p, x, y, t, eps);  // the unaligned value for holes
       out[p] = gap ? sp.v[0] : a0 / nrm;
     }
@@ -703,7 +709,6 @@ int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, in
   if (!flow || !out || !ws || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
-  if (hipMemsetAsync(ws, 0, (size_t)N * P * 3 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
   DRBA_LAUNCH(splat_long_prepass<0>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f,
                      (const float *)nullptr, 0.f, ws, H, W);
   dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);
@@ -718,7 +723,6 @@ int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float 
   if (!flow_self || !flow_other || !out || !ws || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
-  if (hipMemsetAsync(ws, 0, (size_t)N * P * 2 * sizeof(float), s) != hipSuccess) return DRBA_ELAUNCH;
   DRBA_LAUNCH(splat_long_prepass<1>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev,
                      eps, ws, H, W);
   dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);

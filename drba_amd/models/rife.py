@@ -73,8 +73,9 @@ class RIFE:
         s = self.scale_list[0]
         xin = _ops.ifblock_input(a, b, f0, f1, 0.5, None, None, 1.0, s)
         flow = _ops.ifblock_update(self.ifnet.block[0].core(xin), None, H, W, s)
-        flow01 = _ops.flow_reverse(flow[:, :2])   # 2 * (-splat_avg(flow50)), holes -> 2*max(H, W)
-        flow10 = _ops.flow_reverse(flow[:, 2:])
+        # 2 * (-splat_avg(flow50)), holes -> 2*max(H, W); both directions in one launch pair: [1,4,H,W] is [2,2,H,W]
+        rev = _ops.flow_reverse(flow.reshape(2, 2, H, W))
+        flow01, flow10 = rev[0:1], rev[1:2]
         if _ops.PAIR_FEATURES and f0.is_cuda:  # the stages' pair-interleaved copies, made where the features are made
             _ops.pair_interleaved(f0)          # (with a lookahead this runs on the side stream, off the critical path)
             _ops.pair_interleaved(f1)

@@ -52,6 +52,20 @@ def _workspace(device, nfloats):
     return buf
 
 
+_zero_ws_cache = {}
+
+
+def _zero_workspace(device, nfloats):
+    """Zero-initialised scratch per (device, stream) for the fused splats (drba_flow_reverse / drba_drm_rife_linear):
+    their kernels return the accumulator zeroed, so it is cleared once at allocation and never again."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _zero_ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.zeros(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+        _zero_ws_cache[key] = buf
+    return buf
+
+
 # Optional kernel trace (bench.py's roofline leg).  While TRACE is a list, the library times EVERY kernel it launches
 # (drba_trace_begin: an event pair on each launch's own dispatch packet, so a record is the kernel's own execution time,
 # as rocprofv3's kernel trace reports it -- an event recorded on the stream before/after a launch adds a barrier packet
@@ -156,7 +170,7 @@ def flow_reverse(flow):
     flow = _f32(flow, "flow")
     n, _, h, w = flow.shape
     out = torch.empty_like(flow)
-    ws = _workspace(flow.device, n * h * w * 3)
+    ws = _zero_workspace(flow.device, n * h * w * 3)
     first = _trace_pos()
     _lib.check(_lib.load().drba_flow_reverse(_p(flow), _p(out), _p(ws), n, h, w, _stream()), "drba_flow_reverse")
     _tag(first, [None, (16.0 * n * h * w, "byte", f"flow_reverse {(n, h, w)}")])  # long-flow prepass, then the tiled splat
@@ -168,7 +182,7 @@ def drm_rife_linear(flow_self, flow_other, t, eps=1e-4, t_dev=None):
     a, b = _f32(flow_self, "flow_self"), _f32(flow_other, "flow_other")
     n, _, h, w = a.shape
     out = torch.empty((n, 1, h, w), dtype=torch.float32, device=a.device)
-    ws = _workspace(a.device, n * h * w * 2)
+    ws = _zero_workspace(a.device, n * h * w * 2)
     first = _trace_pos()
     _lib.check(_lib.load().drba_drm_rife_linear(_p(a), _p(b), float(t), _p(t_dev), float(eps), _p(out), _p(ws), n, h,
                                                 w, _stream()), "drba_drm_rife_linear")

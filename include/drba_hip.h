@@ -65,13 +65,16 @@ int drba_backwarp(const float *in, const float *flow, float *out, int N, int C, 
 int drba_flow_distance(const float *flow, float *out, int N, int H, int W, void *stream);
 
 /* ---- fused flow reversal: models/rife.py:59-73 (calc_flow tail)
- * out = 2 * where(splat_avg(1, f) < 0.999, max(H,W), -splat_avg(f, f)).  ws: N*H*W*3 floats. */
+ * out = 2 * where(splat_avg(1, f) < 0.999, max(H,W), -splat_avg(f, f)).  ws: N*H*W*3 floats that are ZERO on entry
+ * (the accumulator of the rare long / converging sources); the kernel reads every entry once and writes the non-zero
+ * ones back to zero, so the buffer is zero again on return: allocate it zeroed once and keep it for these two entry
+ * points (no memset per call). */
 int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, int W, void *stream);
 
 /* ---- fused linear DRM, one direction: models/drm.py:65-107 with linear=True
  * u = d_other/(d_self+d_other) * t * 2 with d = |flow| + eps; out = splat_avg(u, self*u) with
  * uncovered pixels (ones-splat < 0.999) keeping u.  drm_t1_t01 = (self=flow10, other=flow12),
- * drm_t1_t12 = (self=flow12, other=flow10).  ws: N*H*W*2 floats.  If t_dev != NULL the timestep
+ * drm_t1_t12 = (self=flow12, other=flow10).  ws: N*H*W*2 floats, zero on entry and on return (as above).  If t_dev != NULL the timestep
  * is read from that device float instead of `t` (so a captured HIP graph can be replayed for any t). */
 int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float t, const float *t_dev,
                          float eps, float *out, float *ws, int N, int H, int W, void *stream);

@@ -295,6 +295,18 @@ def check_glue(dev):
             gotd = ops.drm_rife_linear(D(fl.contiguous()), D(other.contiguous()), tt, 1e-4)
             n_out, n_all = _outliers(torch.nan_to_num(gotd.cpu()), torch.nan_to_num(refd), 2e-5)
             rows.append((f"drm_rife_linear {fname} t={tt}", 0.0 if n_out <= 3 else _diff(gotd, refd), 2e-5, f"outliers {n_out}/{n_all}"))
+    # both directions of calc_flow's reversal in one launch pair ([1,4,H,W] viewed as [2,2,H,W]) == two calls, and the
+    # self-cleaning accumulator is zero again after flows that used it (long / converging sources)
+    both = torch.cat((smooth, other), 1).contiguous()  # short flows (the order of a key's records in LDS, hence of its sum, is not fixed)
+    got2 = ops.flow_reverse(D(both).reshape(2, 2, Hs, Ws))
+    one = torch.cat((ops.flow_reverse(D(smooth.contiguous())), ops.flow_reverse(D(other.contiguous()))), 0)
+    rows.append(("flow_reverse N=2 vs two N=1 calls", _diff(got2, one.cpu()), 2e-5, ""))
+    both = torch.cat((longf, pinch), 1).contiguous()   # long / converging sources: global float atomics (order-dependent sums)
+    got2 = ops.flow_reverse(D(both).reshape(2, 2, Hs, Ws))
+    one = torch.cat((ops.flow_reverse(D(longf.contiguous())), ops.flow_reverse(D(pinch.contiguous()))), 0)
+    rows.append(("flow_reverse N=2 vs two N=1 calls, atomics path", _diff(got2, one.cpu()), 2e-4, ""))
+    zws = ops._zero_workspace(dev, 1)
+    rows.append(("fused splats leave their accumulator zeroed", float(zws.abs().max()), 0.0, ""))
     for sl in (1.0, 2.0):
         tl = torch.randn(1, 13, int(H / sl), int(W / sl), generator=g)
         m = torch.sigmoid(F.interpolate(tl, scale_factor=sl, mode="bilinear", align_corners=False)[:, 4:5])
