@@ -8,9 +8,10 @@ A *step* = one source frame of the driver's steady state: the next uint8 frame (
 reuse, linear=True) -> to_out for the two model-generated frames (resize back + *255 truncation, on the device).
 Decode/encode and PCIe are outside the metric; `pcie_inclusive` reports the same loop with the frames
 starting and ending in pinned host memory.  value = model-generated frames of ALL ranks / max-rank time.
-As in drba_amd.infer.interpolate_stream the loop reads one frame ahead, so the next step's coarse flow and
-low-resolution stages run on a side stream under this step's full-resolution stages (`--no-lookahead` disables it);
-every frame is converted and encoded exactly once either way and the K timed steps contain K steps of work.
+As in drba_amd.infer.interpolate_stream the loop reads two frames ahead: the next step's coarse flow and
+low-resolution stages run on a side stream under this step's full-resolution stages, and the frame after that has its
+context encoder started on a third stream (`--no-lookahead` disables both); every frame is converted and encoded exactly
+once either way, one new frame per step, and the K timed steps contain K steps of work.
 
 N = 1: the K-step loop above.
 N > 1 (launched by torch.distributed.run, one rank per GPU): ONE clip of N*K + 2 source frames is sharded with
@@ -150,6 +151,11 @@ class _Counting:
 
     def warm_reuse(self, a, b):
         return self.m.warm_reuse(a, b)
+
+    def __getattr__(self, name):  # optional driver hooks (prefetch_frame): present only if the model has them
+        if name == "prefetch_frame":
+            return getattr(self.m, name)
+        raise AttributeError(name)
 
 
 class _DevIO:
@@ -295,13 +301,21 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
     state = {"I0": to_inp(0), "I1": to_inp(1), "reuse": None, "k": 2}
     lookahead = not args.no_lookahead
 
+    prefetch = getattr(model, "prefetch_frame", None) if lookahead else None
+
     def step():
-        # the driver reads one frame ahead (as drba_amd.infer.interpolate_stream does): the next step's coarse flow
-        # overlaps this step's interpolation on a side stream; every frame is still converted / encoded exactly once
+        # the driver reads ahead (as drba_amd.infer.interpolate_stream does): the next step's coarse flow and
+        # low-resolution stages overlap this step's interpolation on a side stream, and the frame after that has its
+        # context encoder started on a third one; every frame is still converted / encoded exactly once, one per step
         I2 = state.pop("next", None)
         if I2 is None:
             I2 = to_inp(state["k"])
-        nxt = to_inp(state["k"] + 1) if lookahead else None
+        nxt = state.pop("next2", None)
+        if nxt is None and lookahead:
+            nxt = to_inp(state["k"] + 1)
+        if prefetch is not None:
+            state["next2"] = to_inp(state["k"] + 2)
+            prefetch(state["next2"])
         out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True,
                                                       lookahead=None if nxt is None else (nxt, TS))
         res = [to_out(x) for x in out]

@@ -97,11 +97,26 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
     # (same frames, same order, same outputs): a model that supports it starts the next step's coarse flow on a side
     # stream while this step's frames are synthesised (RIFE.inference_ts_drba(..., lookahead=)).
     can_look = bool(getattr(model, "supports_lookahead", False))
-    i2 = video_io.read_frame()
-    I2 = to_inp(i2, dst_size) if i2 is not None else None
+    prefetch = getattr(model, "prefetch_frame", None) if can_look else None
+
+    eof = [False]
+
+    def read():  # -> (raw frame, network input); a model that can starts the new frame's encoder right away
+        raw = None if eof[0] else video_io.read_frame()  # (the source is not asked again once it has ended)
+        if raw is None:
+            eof[0] = True
+            return None, None
+        x = to_inp(raw, dst_size)
+        if prefetch is not None:
+            prefetch(x)
+        return raw, x
+
+    # with prefetch_frame the loop reads TWO frames ahead (same frames, same order, same outputs): (i3, I3) is the
+    # lookahead frame of this iteration, (i4, I4) only has its encoder started
+    i2, I2 = read()
+    i3, I3 = read() if i2 is not None else (None, None)
     while i2 is not None:
-        i3 = video_io.read_frame()
-        I3 = to_inp(i3, dst_size) if i3 is not None else None
+        i4, I4 = read() if (prefetch is not None and i3 is not None) else (None, None)
         ts = _tools.calc_t(idx, times, mapper)
         cut_right = bool(check_scene(I1, I2, scdet_threshold)) if enable_scdet else False
         if cut_left and cut_right:
@@ -122,6 +137,7 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
         emit(out, src_size)
         I0, I1 = I1, I2
         i2, I2 = i3, I3
+        i3, I3 = (i4, I4) if prefetch is not None else read()
         cut_left = cut_right
         idx += 1
         if on_step:

@@ -68,8 +68,8 @@ class RIFE:
         """Coarse bidirectional flow from block0 at t=0.5, reversed to the frame's own time by a
         forward splat (reference rife.py:41-75); one fused kernel pair per direction."""
         _, _, H, W = a.shape
-        f0 = self.ifnet.encode(a) if f0 is None else f0
-        f1 = self.ifnet.encode(b) if f1 is None else f1
+        f0 = self._encoded(a) if f0 is None else f0
+        f1 = self._encoded(b) if f1 is None else f1
         s = self.scale_list[0]
         xin = _ops.ifblock_input(a, b, f0, f1, 0.5, None, None, 1.0, s)
         flow = _ops.ifblock_update(self.ifnet.block[0].core(xin), None, H, W, s)
@@ -80,6 +80,43 @@ class RIFE:
             _ops.pair_interleaved(f0)          # (with a lookahead this runs on the side stream, off the critical path)
             _ops.pair_interleaved(f1)
         return flow01, flow10, f0, f1
+
+    def prefetch_frame(self, I):
+        """Optional (not in the reference): start the context encoder of a frame the driver has just read -- it depends on
+        nothing but the frame -- on its own HIP stream.  The lookahead's serial chain (encoder -> block0 -> flow reversal ->
+        DRM -> low-resolution stages) is the critical path of a step; with the driver reading two frames ahead the
+        encoder (4 full-chip launches + the pair-interleaved copy) leaves that chain and runs beside it.  calc_flow picks
+        the result up by frame identity; without a prefetch it encodes in place as before."""
+        if not I.is_cuda or getattr(I, "_drba_enc", None) is not None:
+            return
+        dev = I.device
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_enc_stream", None) is None:
+            self._enc_stream = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(main)  # the frame was produced (to_inp) on the caller's stream
+        with torch.cuda.stream(self._enc_stream):
+            self._enc_stream.wait_event(ready)
+            I.record_stream(self._enc_stream)
+            f = self.ifnet.encode(I)
+            if _ops.PAIR_FEATURES:
+                _ops.pair_interleaved(f)
+            done = torch.cuda.Event()
+            done.record(self._enc_stream)
+        I._drba_enc = (f, done, id(self))
+
+    def _encoded(self, I):
+        """encode(I), from prefetch_frame's stream if it was started there (the consumer's stream waits for it)."""
+        c = getattr(I, "_drba_enc", None)
+        if c is not None and c[2] == id(self):
+            cur = torch.cuda.current_stream(I.device)
+            cur.wait_event(c[1])
+            c[0].record_stream(cur)
+            fp = getattr(c[0], "_drba_pair", None)
+            if fp is not None:
+                fp.record_stream(cur)
+            return c[0]
+        return self.ifnet.encode(I)
 
     def warm_reuse(self, Ia, Ib):
         """The `reuse` a DRBA step ending on the pair (Ia, Ib) hands to the next step (rife.py:82-85,109)."""

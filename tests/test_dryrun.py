@@ -44,6 +44,7 @@ def dry(monkeypatch):
     monkeypatch.setattr(ops, "_stream", lambda: C.c_void_p(0))
     monkeypatch.setattr(ops, "default_device", lambda: torch.device("cpu"))
     monkeypatch.setattr(ops, "_workspace", lambda dev, n: torch.empty(int(n), dtype=torch.float32))
+    monkeypatch.setattr(ops, "_zero_workspace", lambda dev, n: torch.zeros(int(n), dtype=torch.float32))
     return stub
 
 

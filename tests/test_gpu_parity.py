@@ -135,6 +135,39 @@ def test_lookahead_flow_matches_inline(hip_backend, mode):
         assert float((x - y).abs().max()) <= 2e-6
 
 
+def test_prefetched_encoder_matches_inline(hip_backend):
+    """RIFE.prefetch_frame starts a frame's context encoder on its own stream as soon as the driver has read it (two
+    frames ahead of its use as I2); calc_flow must pick those features up and every frame and the reuse state must
+    equal the run without prefetching (same kernels, other stream; the splats' sums are order-dependent: 2e-6)."""
+    from drba_amd.utils import synth
+    sd = synth.ifnet_state_dict(seed=0)
+    fr = [f.to(hip_backend.dev) for f in cases.rife_frames(128, 192)]
+    ts = np.array([0.75, 1.25])
+
+    def run(prefetch):
+        m = hip_backend.make_rife(sd, 1.0)
+        frames = [f.clone() for f in fr]  # fresh tensor objects: the prefetch is keyed by frame identity
+        outs, reuse = [], None
+        if prefetch:
+            m.prefetch_frame(frames[2])
+            m.prefetch_frame(frames[3])
+        for k in range(2):
+            if prefetch and k + 4 < len(frames):
+                m.prefetch_frame(frames[k + 4])
+            nxt = (frames[k + 3], ts) if k + 3 < len(frames) else None
+            o, reuse = m.inference_ts_drba(frames[k], frames[k + 1], frames[k + 2], ts, reuse, True, lookahead=nxt)
+            outs += o
+        torch.cuda.synchronize()
+        if prefetch:
+            assert getattr(frames[3], "_drba_enc", None) is not None and frames[3]._drba_enc[0] is reuse[2]  # f of the last I2
+        return outs, reuse
+
+    a, ra = run(True)
+    b, rb = run(False)
+    for x, y in zip(a + list(ra), b + list(rb)):
+        assert float((x - y).abs().max()) <= 2e-6
+
+
 def test_gmfss_union_lookahead_matches_inline(hip_backend):
     """Same for GMFSS_UNION: the pair state model.reuse(I2, next) prefetched on the side stream (and the per-frame
     FeatureNet cache) must give the frames of the inline computation."""
