@@ -63,6 +63,9 @@ SIGNATURES = {
     "drba_deconv4x4s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "drba_ifblock_input": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _i, _i, _i, _i, _f, _p]),
     "drba_ifblock_input_lds": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "drba_ifblock_input_batch": (_i, [_p, _i, _i, _i, _f, _i, _i, _i, _i, _f, _p]),
+    "drba_ifblock_input_lds_batch": (_i, [_p, _i, _i, _i, _f, _i, _i, _i, _i, _f, _p]),
+    "drba_ifblock_update_batch": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "drba_warp_blend_fold": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
     "drba_pair_interleave": (_i, [_p, _p, _i, _i, _i, _p]),
     "drba_ifblock_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
@@ -96,6 +99,15 @@ SIGNATURES = {
     "drba_resize_bilinear_ac": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "drba_warp_blend": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
 }
+
+class StageItem(C.Structure):
+    """include/drba_hip.h: drba_stage_item_t"""
+    _fields_ = [("img0", C.c_void_p), ("img1", C.c_void_p), ("f0", C.c_void_p), ("f1", C.c_void_p), ("f0_pair", C.c_void_p),
+                ("f1_pair", C.c_void_p), ("timestep_map", C.c_void_p), ("timestep_scalar", C.c_float), ("flow", C.c_void_p),
+                ("tmp_prev", C.c_void_p), ("flow_out", C.c_void_p), ("out", C.c_void_p)]
+
+
+MAX_STAGE_ITEMS = 4  # DRBA_MAX_STAGE_ITEMS
 
 _lib = None
 

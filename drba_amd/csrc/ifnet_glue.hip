@@ -6,6 +6,8 @@
 // plus bilinear resize and the uint8<->fp32 frame conversions used by to_inp/to_out.
 #include "common.hpp"
 
+#include <string.h>
+
 #include <stdlib.h>
 
 using namespace drba;
@@ -107,6 +109,29 @@ __global__ void __launch_bounds__(256) f32_to_u8_kernel(const float *__restrict_
   }
 }
 
+// The interpolations of one step (`-t 2`: two frames) are independent until their convolutions are stacked along N: the
+// stage-input and flow-update kernels of ALL items of a stage are one launch (blockIdx.y = item).  On the small maps of
+// the first stages these kernels are latency-bound, and every launch also costs the ~5.5 us a dependent dispatch waits
+// for its predecessor -- a step's serial chains are bound by exactly that.
+constexpr int kMaxItems = DRBA_MAX_STAGE_ITEMS;
+struct StageItems {
+  drba_stage_item_t it[kMaxItems];
+};
+struct UpdateItems {
+  const float *tmp[kMaxItems];
+  const float *flow_in[kMaxItems];
+  float *flow_out[kMaxItems];
+};
+// the kernels' bodies keep their single-item names
+#define DRBA_UNPACK_STAGE_ITEM(items)                                                                             \
+  const drba_stage_item_t &item_ = (items).it[blockIdx.y];                                                        \
+  const float *__restrict__ img0 = item_.img0, *__restrict__ img1 = item_.img1, *__restrict__ f0 = item_.f0,      \
+                           *__restrict__ f1 = item_.f1, *__restrict__ f0p = item_.f0_pair,                        \
+                           *__restrict__ f1p = item_.f1_pair, *__restrict__ tmap = item_.timestep_map,            \
+                           *__restrict__ flow = item_.flow, *__restrict__ tmp_prev = item_.tmp_prev;             \
+  const float tscalar = item_.timestep_scalar;                                                                    \
+  float *__restrict__ out = item_.out
+
 // [C, H, W] -> [C/2, H, W, 2]: the layout the stage-input gathers read the encoder features in (see sample_pair)
 __global__ void __launch_bounds__(256) pair_interleave_kernel(const float *__restrict__ in, float *__restrict__ out, int C2, size_t P) {
   const size_t total = (size_t)C2 * P;
@@ -131,11 +156,8 @@ __global__ void __launch_bounds__(256) pair_interleave_kernel(const float *__res
 // Variant 0: one lane per OUTPUT pixel holding all (up to 4) sample points.
 template <bool HAS_FLOW, bool SINGLE>
 __global__ void __launch_bounds__(256)
-ifblock_input_pixel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
-                    const float *__restrict__ f1, const float *__restrict__ f0p, const float *__restrict__ f1p,
-                    const float *__restrict__ tmap, float tscalar,
-                    const float *__restrict__ flow, const float *__restrict__ tmp_prev, int hp, int wp,
-                    float inv_prev_scale, float *__restrict__ out, int H, int W, int h, int w, float scale) {
+ifblock_input_pixel(const StageItems items, int hp, int wp, float inv_prev_scale, int H, int W, int h, int w, float scale) {
+  DRBA_UNPACK_STAGE_ITEM(items);
   constexpr int NS = SINGLE ? 1 : 2;
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
   const Tile2D tp_ = tile_pixel(w, h);  // 32 x 8 output tile per workgroup, XCD-banded
@@ -248,11 +270,8 @@ ifblock_input_pixel(const float *__restrict__ img0, const float *__restrict__ im
 // small low-resolution stages 4x more lanes in flight.
 template <bool HAS_FLOW, bool SINGLE, int UNR>
 __global__ void __launch_bounds__(256)
-ifblock_input_kernel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
-                     const float *__restrict__ f1, const float *__restrict__ f0p, const float *__restrict__ f1p,
-                     const float *__restrict__ tmap, float tscalar,
-                     const float *__restrict__ flow, const float *__restrict__ tmp_prev, int hp, int wp,
-                     float inv_prev_scale, float *__restrict__ out, int H, int W, int h, int w, float scale) {
+ifblock_input_kernel(const StageItems items, int hp, int wp, float inv_prev_scale, int H, int W, int h, int w, float scale) {
+  DRBA_UNPACK_STAGE_ITEM(items);
   constexpr int LPO = SINGLE ? 1 : 4;  // lanes per output pixel
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
   // workgroup = XCD-banded output tile: 32 x 8 px (SINGLE) or 16 x 4 px x 4 sample lanes; every lane runs
@@ -387,11 +406,10 @@ constexpr int kPrevRW = 20, kPrevRH = 6;  // LDS footprint capacity (columns pad
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 template <bool SINGLE, bool FOLD, bool VS>
 __global__ void __launch_bounds__(256)
-ifblock_input_lds(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ f0,
-                  const float *__restrict__ f1, const float *__restrict__ f0p, const float *__restrict__ f1p,
-                  const float *__restrict__ tmap, float tscalar, const float *__restrict__ flow,
-                  const float *__restrict__ tmp_prev, int hp, int wp, float inv_prev_scale, float prev_scale,
-                  float *__restrict__ flow_out, float *__restrict__ out, int H, int W, int h, int w, float scale) {
+ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, float prev_scale, int H, int W, int h, int w,
+                  float scale) {
+  DRBA_UNPACK_STAGE_ITEM(items);
+  float *__restrict__ flow_out = item_.flow_out;
   __shared__ float prev[13][kPrevRH][kPrevRW];
   constexpr int STG = VS ? (SINGLE ? 4 * 64 : 52 * 16 + 4 * 64) : 1;  // floats per wave
   __shared__ __attribute__((aligned(16))) float stg_all[4 * STG];
@@ -640,8 +658,11 @@ warp_blend_fold_kernel(const float *__restrict__ img0, const float *__restrict__
 // IFNet_HDv3.py:92-95 + :160: tmp [13,h,w] -> x`scale` bilinear; flow_out = flow_in + tmp[:4]*scale.
 // mask / feat are written only when requested (the fused pipeline re-derives them from tmp on the fly).
 __global__ void __launch_bounds__(256)
-ifblock_update_kernel(const float *__restrict__ tmp, const float *flow_in, float *flow_out, float *__restrict__ mask,
-                      float *__restrict__ feat, int h, int w, int H, int W, float scale, float inv_scale) {
+ifblock_update_kernel(const UpdateItems items, float *__restrict__ mask, float *__restrict__ feat, int h, int w, int H, int W,
+                      float scale, float inv_scale) {
+  const float *__restrict__ tmp = items.tmp[blockIdx.y];
+  const float *flow_in = items.flow_in[blockIdx.y];
+  float *flow_out = items.flow_out[blockIdx.y];
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
   const int nch = (mask || feat) ? 13 : 4;
   const Tile2D tp_ = tile_pixel(W, H);
@@ -748,36 +769,53 @@ int drba_to_out(const float *in, uint8_t *out_hwc, int Hin, int Win, int Hout, i
   return DRBA_OK;
 }
 
-int drba_ifblock_input(const float *img0, const float *img1, const float *f0, const float *f1, const float *f0_pair,
-                       const float *f1_pair, const float *timestep_map, float timestep_scalar, const float *flow,
-                       const float *tmp_prev,
-                       int hp, int wp, float prev_scale, float *out, int H, int W, int h, int w, float scale,
-                       void *stream) {
-  if (!img0 || !img1 || !f0 || !f1 || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
-  if (flow && (!tmp_prev || hp <= 0 || wp <= 0 || !(prev_scale > 0.f))) return DRBA_EINVAL;
-  if ((f0_pair == nullptr) != (f1_pair == nullptr)) return DRBA_EINVAL;
+static int stage_items_ok(const drba_stage_item_t *items, int n, bool lds) {
+  if (!items || n <= 0 || n > kMaxItems) return DRBA_EINVAL;
+  for (int k = 0; k < n; ++k) {
+    const drba_stage_item_t &I = items[k];
+    if (!I.img0 || !I.img1 || !I.f0 || !I.f1 || !I.out) return DRBA_EINVAL;
+    if ((I.f0_pair == nullptr) != (I.f1_pair == nullptr)) return DRBA_EINVAL;
+    // one kernel instantiation serves the batch: the items agree on what is optional
+    if ((I.flow == nullptr) != (items[0].flow == nullptr) || (I.flow_out == nullptr) != (items[0].flow_out == nullptr) ||
+        (I.f0_pair == nullptr) != (items[0].f0_pair == nullptr) || (I.tmp_prev == nullptr) != (items[0].tmp_prev == nullptr))
+      return DRBA_EINVAL;
+    if (lds && !I.tmp_prev) return DRBA_EINVAL;
+    if (lds && !I.flow_out && !I.flow) return DRBA_EINVAL;  // without the fold the finished flow must be given
+  }
+  return DRBA_OK;
+}
+
+int drba_ifblock_input_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W, int h,
+                             int w, float scale, void *stream) {
+  const int rc = stage_items_ok(items, n_items, false);
+  if (rc != DRBA_OK) return rc;
+  if (H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
+  const bool has_flow = items[0].flow != nullptr;
+  if (has_flow && (!items[0].tmp_prev || hp <= 0 || wp <= 0 || !(prev_scale > 0.f))) return DRBA_EINVAL;
+  StageItems its;
+  memset(&its, 0, sizeof(its));
+  for (int k = 0; k < n_items; ++k) its.it[k] = items[k];
   const bool single = scale == 1.f;
   hipStream_t s = (hipStream_t)stream;
-  const float ips = flow ? (float)(1.0 / (double)prev_scale) : 1.f;
+  const float ips = has_flow ? (float)(1.0 / (double)prev_scale) : 1.f;
   // variant: 0 = lane per output pixel; 1 = lane per sample point; 2 = lane per sample point, channel loops unrolled x4.
   // DRBA_IFIN_VARIANT overrides the default (A/B experiments, TUNING builds only).
   static const int forced = env_int("DRBA_IFIN_VARIANT", -1);
   const int var = forced >= 0 ? forced : (single ? 0 : 1);
   dim3 b(kBlock);
   const int quad_tiles = single ? tiles_for(w, h) : ((w + 15) / 16) * ((h + 3) / 4);
-#define DRBA_ARGS \
-  img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, timestep_scalar, flow, tmp_prev, hp, wp, ips, out, H, W, h, w, scale
-#define DRBA_IFIN(HF, SG)                                                                                            \
+#define DRBA_ARGS its, hp, wp, ips, H, W, h, w, scale
+#define DRBA_IFIN(HF, SG)                                                                                          \
   do {                                                                                                             \
     if (var == 0) {                                                                                                \
-      DRBA_LAUNCH((ifblock_input_pixel<HF, SG>), dim3(tiles_for(w, h)), b, 0, s, DRBA_ARGS);                 \
+      DRBA_LAUNCH((ifblock_input_pixel<HF, SG>), dim3(tiles_for(w, h), n_items), b, 0, s, DRBA_ARGS);              \
     } else if (var == 1) {                                                                                         \
-      DRBA_LAUNCH((ifblock_input_kernel<HF, SG, 1>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                  \
+      DRBA_LAUNCH((ifblock_input_kernel<HF, SG, 1>), dim3(quad_tiles, n_items), b, 0, s, DRBA_ARGS);               \
     } else {                                                                                                       \
-      DRBA_LAUNCH((ifblock_input_kernel<HF, SG, 4>), dim3(quad_tiles), b, 0, s, DRBA_ARGS);                  \
+      DRBA_LAUNCH((ifblock_input_kernel<HF, SG, 4>), dim3(quad_tiles, n_items), b, 0, s, DRBA_ARGS);               \
     }                                                                                                              \
   } while (0)
-  if (flow) {
+  if (has_flow) {
     if (single) DRBA_IFIN(true, true);
     else DRBA_IFIN(true, false);
   } else {
@@ -790,17 +828,28 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
   return DRBA_OK;
 }
 
-int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0, const float *f1, const float *f0_pair,
-                           const float *f1_pair, const float *timestep_map, float timestep_scalar, const float *flow,
-                           const float *tmp_prev, int hp, int wp, float prev_scale, float *flow_out, float *out, int H,
-                           int W, int h, int w, float scale, void *stream) {
-  if (!img0 || !img1 || !f0 || !f1 || !out || !tmp_prev || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
+int drba_ifblock_input(const float *img0, const float *img1, const float *f0, const float *f1, const float *f0_pair,
+                       const float *f1_pair, const float *timestep_map, float timestep_scalar, const float *flow,
+                       const float *tmp_prev,
+                       int hp, int wp, float prev_scale, float *out, int H, int W, int h, int w, float scale,
+                       void *stream) {
+  const drba_stage_item_t it = {img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, timestep_scalar, flow, tmp_prev, nullptr, out};
+  return drba_ifblock_input_batch(&it, 1, hp, wp, prev_scale, H, W, h, w, scale, stream);
+}
+
+int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
+                                 int h, int w, float scale, void *stream) {
+  const int rc = stage_items_ok(items, n_items, true);
+  if (rc != DRBA_OK) return rc;
+  if (H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
   if (hp <= 0 || wp <= 0 || !(prev_scale > 0.f)) return DRBA_EINVAL;
-  if ((f0_pair == nullptr) != (f1_pair == nullptr)) return DRBA_EINVAL;
-  if (!flow_out && !flow) return DRBA_EINVAL;              // without the fold the finished flow must be given
-  if (flow_out && scale > 2.f) return DRBA_EUNSUPPORTED;   // the fold needs every full-resolution pixel sampled once
+  const bool fold = items[0].flow_out != nullptr;
+  if (fold && scale > 2.f) return DRBA_EUNSUPPORTED;   // the fold needs every full-resolution pixel sampled once
   if (scale != 1.f && scale != 2.f && scale != 4.f && scale != 8.f && scale != 16.f && scale != 32.f) return DRBA_EUNSUPPORTED;
   if (prev_scale != 2.f * scale) return DRBA_EUNSUPPORTED;  // IFNet's pyramid; bounds the staged footprint to 18 x 6 pixels
+  StageItems its;
+  memset(&its, 0, sizeof(its));
+  for (int k = 0; k < n_items; ++k) its.it[k] = items[k];
   const bool single = scale == 1.f;
   hipStream_t s = (hipStream_t)stream;
   const float ips = (float)(1.0 / (double)prev_scale);
@@ -808,17 +857,18 @@ int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0
   // vector-store form: whole tiles only, 16-byte aligned rows and planes (DRBA_IFIN_VS=0 forces the scalar stores: A/B runs, TUNING builds)
   static const bool vs_allowed = env_int("DRBA_IFIN_VS", 1) != 0;
   const int two = single ? 32 : 16, tho = single ? 8 : 4;
-  const bool vs = vs_allowed && w % two == 0 && h % tho == 0 && (W & 3) == 0 && ((uintptr_t)out & 15) == 0 &&
-                  (!flow_out || (((uintptr_t)flow_out & 15) == 0 && (single || (W == 2 * w && H == 2 * h))));
-#define DRBA_IFL(SG, FO, VS_)                                                                                                  \
-  DRBA_LAUNCH((ifblock_input_lds<SG, FO, VS_>), dim3(tiles), dim3(kBlock), 0, s, img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, \
-              timestep_scalar, flow, tmp_prev, hp, wp, ips, prev_scale, flow_out, out, H, W, h, w, scale)
+  bool vs = vs_allowed && w % two == 0 && h % tho == 0 && (W & 3) == 0;
+  for (int k = 0; k < n_items; ++k)
+    vs = vs && ((uintptr_t)items[k].out & 15) == 0 &&
+         (!fold || (((uintptr_t)items[k].flow_out & 15) == 0 && (single || (W == 2 * w && H == 2 * h))));
+#define DRBA_IFL(SG, FO, VS_) \
+  DRBA_LAUNCH((ifblock_input_lds<SG, FO, VS_>), dim3(tiles, n_items), dim3(kBlock), 0, s, its, hp, wp, ips, prev_scale, H, W, h, w, scale)
 #define DRBA_IFL2(SG, FO) \
   do {                    \
     if (vs) DRBA_IFL(SG, FO, true); \
     else DRBA_IFL(SG, FO, false);   \
   } while (0)
-  if (flow_out) {
+  if (fold) {
     if (single) DRBA_IFL2(true, true);
     else DRBA_IFL2(false, true);
   } else {
@@ -831,6 +881,14 @@ int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0
   return DRBA_OK;
 }
 
+int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0, const float *f1, const float *f0_pair,
+                           const float *f1_pair, const float *timestep_map, float timestep_scalar, const float *flow,
+                           const float *tmp_prev, int hp, int wp, float prev_scale, float *flow_out, float *out, int H,
+                           int W, int h, int w, float scale, void *stream) {
+  const drba_stage_item_t it = {img0, img1, f0, f1, f0_pair, f1_pair, timestep_map, timestep_scalar, flow, tmp_prev, flow_out, out};
+  return drba_ifblock_input_lds_batch(&it, 1, hp, wp, prev_scale, H, W, h, w, scale, stream);
+}
+
 int drba_warp_blend_fold(const float *img0, const float *img1, const float *flow, const float *tmp_last, int h, int w,
                          float scale, float *out, int H, int W, void *stream) {
   if (!img0 || !img1 || !tmp_last || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale >= 1.f)) return DRBA_EINVAL;
@@ -840,11 +898,30 @@ int drba_warp_blend_fold(const float *img0, const float *img1, const float *flow
   return DRBA_OK;
 }
 
+int drba_ifblock_update_batch(const float *const *tmp, const float *const *flow_in, float *const *flow_out, int n_items, int h,
+                              int w, int H, int W, float scale, void *stream) {
+  if (!tmp || !flow_out || n_items <= 0 || n_items > kMaxItems || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(scale > 0.f))
+    return DRBA_EINVAL;
+  UpdateItems its;
+  memset(&its, 0, sizeof(its));
+  for (int k = 0; k < n_items; ++k) {
+    if (!tmp[k] || !flow_out[k]) return DRBA_EINVAL;
+    its.tmp[k] = tmp[k], its.flow_in[k] = flow_in ? flow_in[k] : nullptr, its.flow_out[k] = flow_out[k];
+  }
+  DRBA_LAUNCH(ifblock_update_kernel, dim3(tiles_for(W, H), n_items), dim3(kBlock), 0, (hipStream_t)stream, its, (float *)nullptr,
+              (float *)nullptr, h, w, H, W, scale, (float)(1.0 / (double)scale));
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
 int drba_ifblock_update(const float *tmp, const float *flow_in, float *flow_out, float *mask, float *feat, int h,
                         int w, int H, int W, float scale, void *stream) {
   if (!tmp || !flow_out || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
-  DRBA_LAUNCH(ifblock_update_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, tmp,
-                     flow_in, flow_out, mask, feat, h, w, H, W, scale, (float)(1.0 / (double)scale));
+  UpdateItems its;
+  memset(&its, 0, sizeof(its));
+  its.tmp[0] = tmp, its.flow_in[0] = flow_in, its.flow_out[0] = flow_out;
+  DRBA_LAUNCH(ifblock_update_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, its, mask, feat, h, w, H, W,
+              scale, (float)(1.0 / (double)scale));
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

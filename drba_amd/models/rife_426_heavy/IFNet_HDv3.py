@@ -145,25 +145,23 @@ class IFNet:
             xin = torch.empty((B, 52 if i else 39, h, w), dtype=torch.float32, device=dev)
             lds = i > 0 and self._lds_ok(s, s_prev)
             fold = pending and lds and s <= 2
-            for k, (img0, img1, t, f0, f1) in enumerate(items):
-                if pending and not fold:
-                    flows[k] = _ops.ifblock_update(tmp[k:k + 1], flows[k], H, W, s_prev)
-                if fold:
-                    _, flows[k] = _ops.ifblock_input_lds(img0, img1, f0, f1, t, flows[k], tmp[k:k + 1], s_prev, s,
-                                                         out=xin[k:k + 1], fold=True)
-                elif lds:
-                    _ops.ifblock_input_lds(img0, img1, f0, f1, t, flows[k], tmp[k:k + 1], s_prev, s, out=xin[k:k + 1])
-                else:
-                    _ops.ifblock_input(img0, img1, f0, f1, t, flows[k], None if tmp is None else tmp[k:k + 1], s_prev, s,
-                                       out=xin[k:k + 1])
+            # every item's glue kernel of a stage is ONE launch (blockIdx.y = item): these launches are latency-bound on the
+            # small maps, and each one costs the gap a dependent dispatch waits for its predecessor
+            if pending and not fold:
+                flows = _ops.flow_updates(tmp, flows, H, W, s_prev)
+            if fold:
+                flows = _ops.stage_inputs(items, flows, tmp, s_prev, s, xin, fold=True)
+            elif lds:
+                _ops.stage_inputs(items, flows, tmp, s_prev, s, xin)
+            else:
+                _ops.stage_inputs(items, flows, tmp, s_prev, s, xin, lds=False)
             tmp = self.block[i].core(xin)  # [B,13,H/s,W/s]: flow delta (4), mask (1), feat (8)
             s_prev = s
             # leave the update to the consumer if that one can fold it
             nxt_folds = (i + 1 < 5 and self._lds_ok(scale_list[i + 1], s) and scale_list[i + 1] <= 2) or i + 1 == 5
             pending = bool(nxt_folds)
             if not pending:
-                for k in range(B):
-                    flows[k] = _ops.ifblock_update(tmp[k:k + 1], flows[k], H, W, s)
+                flows = _ops.flow_updates(tmp, flows, H, W, s)
         if last < 5:
             return flows, tmp, s_prev, pending
         if pending:

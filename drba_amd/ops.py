@@ -624,6 +624,79 @@ def ifblock_input_lds(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, 
     return (out, flow_out) if fold else out
 
 
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds=True):
+    """The stage input of EVERY item of a stage in one launch (drba_ifblock_input[_lds]_batch).
+    items: [(img0, img1, timestep, f0, f1), ...]; flows: per-item running flow (or None); tmp_prev: the previous stage's
+    stacked head output [B,13,hp,wp] (or None at the first stage); out: the stacked [B,nch,h,w] stage input.
+    fold=True (lds only): returns the list of folded running flows (slices of one new [B,4,H,W] tensor)."""
+    B = len(items)
+    if B > _lib.MAX_STAGE_ITEMS:
+        raise _lib.DrbaHipError(f"stage_inputs: at most {_lib.MAX_STAGE_ITEMS} items per launch")
+    img0 = _f32(items[0][0])
+    _, _, H, W = img0.shape
+    h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
+    has_flow = flows is not None and flows[0] is not None
+    nch = 52 if (has_flow or lds) else 39
+    if tuple(out.shape) != (B, nch, h, w) or not out.is_contiguous():
+        raise _lib.DrbaHipError(f"stage_inputs: out must be a contiguous [{B},{nch},{h},{w}] tensor")
+    flow_out = torch.empty((B, 4, H, W), dtype=torch.float32, device=img0.device) if fold else None
+    hp = wp = 0
+    ps = 1.0
+    if tmp_prev is not None:
+        tmp_prev = _f32(tmp_prev)
+        hp, wp, ps = tmp_prev.shape[2], tmp_prev.shape[3], float(prev_scale)
+    arr = (_lib.StageItem * B)()
+    keep = []
+    for k, (i0, i1, t, f0, f1) in enumerate(items):
+        i0, i1, f0, f1 = _f32(i0), _f32(i1), _f32(f0), _f32(f1)
+        tmap, tsc = (None, float(t)) if not torch.is_tensor(t) else (_f32(t), 0.0)
+        fl = None if (flows is None or flows[k] is None) else _f32(flows[k])
+        f0p = f1p = None
+        if (lds or has_flow) and PAIR_FEATURES and f0.shape[1] == 16:
+            f0p, f1p = pair_interleaved(f0), pair_interleaved(f1)
+        keep += [i0, i1, f0, f1, tmap, fl, f0p, f1p]
+        a = arr[k]
+        a.img0, a.img1, a.f0, a.f1, a.f0_pair, a.f1_pair = _ptr(i0), _ptr(i1), _ptr(f0), _ptr(f1), _ptr(f0p), _ptr(f1p)
+        a.timestep_map, a.timestep_scalar, a.flow = _ptr(tmap), tsc, _ptr(fl)
+        a.tmp_prev = None if tmp_prev is None else tmp_prev[k].data_ptr()
+        a.flow_out = None if flow_out is None else flow_out[k].data_ptr()
+        a.out = out[k].data_ptr()
+    pts = H * W if scale <= 2 else 4 * h * w
+    lib = _lib.load()
+    if lds:
+        nbytes = B * 4.0 * (43 * pts + 52 * h * w + (4 * pts if fold else 0))
+        _lib.check(_timed("ifblock_input_lds" + ("+fold" if fold else ""), (52, H, W, h, w, B), nbytes, "byte",
+                          lambda: lib.drba_ifblock_input_lds_batch(C.cast(arr, C.c_void_p), B, hp, wp, ps, H, W, h, w, float(scale),
+                                                                   _stream())), "drba_ifblock_input_lds_batch")
+    else:
+        nbytes = B * 4.0 * ((nch - (9 if has_flow else 0)) * pts + nch * h * w)
+        _lib.check(_timed("ifblock_input", (nch, H, W, h, w, B), nbytes, "byte",
+                          lambda: lib.drba_ifblock_input_batch(C.cast(arr, C.c_void_p), B, hp, wp, ps, H, W, h, w, float(scale),
+                                                               _stream())), "drba_ifblock_input_batch")
+    return [flow_out[k:k + 1] for k in range(B)] if fold else None
+
+
+def flow_updates(tmp, flows, H, W, scale):
+    """flow_k + up(tmp[k][:4]) * scale for every item of a stage in one launch -> list of [1,4,H,W] (slices of one tensor)."""
+    tmp = _f32(tmp)
+    B, c, h, w = tmp.shape
+    out = torch.empty((B, 4, H, W), dtype=torch.float32, device=tmp.device)
+    fin = [None if f is None else _f32(f) for f in flows]
+    P3 = C.c_void_p * B
+    a_tmp = P3(*[tmp[k].data_ptr() for k in range(B)])
+    a_in = P3(*[_ptr(f) for f in fin])
+    a_out = P3(*[out[k].data_ptr() for k in range(B)])
+    _lib.check(_timed("ifblock_update", (h, w, H, W, B), B * 4.0 * (8.0 * H * W + 4.0 * h * w), "byte",
+                      lambda: _lib.load().drba_ifblock_update_batch(C.cast(a_tmp, C.c_void_p), C.cast(a_in, C.c_void_p),
+                                                                    C.cast(a_out, C.c_void_p), B, h, w, H, W, float(scale),
+                                                                    _stream())), "drba_ifblock_update_batch")
+    return [out[k:k + 1] for k in range(B)]
+
+
 def warp_blend_fold(img0, img1, flow_prev, tmp_last, scale):
     """Final frame with the last stage's flow update folded in (flow_prev: running flow before it, or None)."""
     img0, img1, tmp_last = _f32(img0), _f32(img1), _f32(tmp_last)

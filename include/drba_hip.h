@@ -180,6 +180,24 @@ int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0
                            float timestep_scalar, const float *flow, const float *tmp_prev, int hp, int wp,
                            float prev_scale, float *flow_out, float *out, int H, int W, int h, int w, float scale,
                            void *stream);
+/* Batched forms: the items of one stage (the interpolations of one step: `-t 2` -> 2) in ONE launch per kernel.  Each item
+ * names its own frames / features / timestep / flow / previous head output / outputs (the fields have the meaning of the
+ * arguments above; flow_out != NULL requests the fold); the items agree on which optional pointers are given.
+ * n_items <= DRBA_MAX_STAGE_ITEMS. */
+#define DRBA_MAX_STAGE_ITEMS 4
+typedef struct drba_stage_item {
+  const float *img0, *img1, *f0, *f1, *f0_pair, *f1_pair, *timestep_map;
+  float timestep_scalar;
+  const float *flow, *tmp_prev;
+  float *flow_out, *out;
+} drba_stage_item_t;
+int drba_ifblock_input_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
+                             int h, int w, float scale, void *stream);
+int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
+                                 int h, int w, float scale, void *stream);
+/* drba_ifblock_update for several items (arrays of n_items device pointers; flow_in may be NULL or hold NULLs). */
+int drba_ifblock_update_batch(const float *const *tmp, const float *const *flow_in, float *const *flow_out, int n_items,
+                              int h, int w, int H, int W, float scale, void *stream);
 /* [C,H,W] -> [C/2,H,W,2] (C even): channel pairs interleaved per pixel. */
 int drba_pair_interleave(const float *in, float *out, int C, int H, int W, void *stream);
 /* Upsample the 13-channel head output by `scale` and fold it into the running flow:

@@ -64,8 +64,9 @@ def test_rife_pipeline_plumbing(dry, monkeypatch):
     assert out2[0].shape == (1, 3, 64, 128)
     r = m.inference_ts(I[0], I[1], np.array([0.0, 0.5, 1.0]))
     assert r[0] is I[0] and r[2] is I[1]
-    for k in ("drba_conv3x3", "drba_deconv4x4s2", "drba_ifblock_input", "drba_ifblock_input_lds", "drba_ifblock_update",
-              "drba_warp_blend_fold", "drba_flow_reverse", "drba_drm_rife_linear", "drba_softsplat", "drba_drm_retime"):
+    for k in ("drba_conv3x3", "drba_deconv4x4s2", "drba_ifblock_input", "drba_ifblock_input_batch", "drba_ifblock_input_lds_batch",
+              "drba_ifblock_update", "drba_ifblock_update_batch", "drba_warp_blend_fold", "drba_flow_reverse",
+              "drba_drm_rife_linear", "drba_softsplat", "drba_drm_retime"):
         assert dry.calls.get(k, 0) > 0, k
 
 

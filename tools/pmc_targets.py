@@ -47,12 +47,20 @@ f0, f1 = torch.randn(1, 16, H, W, generator=g).to(dev), torch.randn(1, 16, H, W,
 flow = torch.nn.functional.interpolate(torch.randn(1, 4, H // 32, W // 32, generator=g) * 6, size=(H, W), mode="bilinear").to(dev).contiguous()
 tmap = torch.rand(1, 1, H, W, generator=g).to(dev)
 ops.pair_interleaved(f0), ops.pair_interleaved(f1)  # made once, as in the pipeline (calc_flow)
+# the pipeline launches a stage's input kernel once for BOTH frames of a `-t 2` step (blockIdx.y = item): same here
+img2 = torch.rand(1, 3, H, W, generator=g).to(dev)
+f2 = torch.randn(1, 16, H, W, generator=g).to(dev)
+ops.pair_interleaved(f2)
+items = [(img1, img0, tmap, f1, f0), (img1, img2, tmap, f1, f2)]
+flows2 = [flow, (flow * 0.9).contiguous()]
 for s in (1.0, 2.0):
-    tprev = torch.randn(1, 13, int(H / (2 * s)), int(W / (2 * s)), generator=g).to(dev)
-    target(f"stage input s={s:.0f} with the folded flow update",
-           lambda: ops.ifblock_input_lds(img0, img1, f0, f1, tmap, flow, tprev, 2 * s, s, fold=True))
-tprev = torch.randn(1, 13, H // 8, W // 8, generator=g).to(dev)
-target("stage input s=4", lambda: ops.ifblock_input_lds(img0, img1, f0, f1, tmap, flow, tprev, 8.0, 4.0))
+    tprev = torch.randn(2, 13, int(H / (2 * s)), int(W / (2 * s)), generator=g).to(dev)
+    xin = torch.empty(2, 52, int(H / s), int(W / s), device=dev)
+    target(f"stage input s={s:.0f} with the folded flow update, both frames of a step",
+           lambda: ops.stage_inputs(items, flows2, tprev, 2 * s, s, xin, fold=True))
+tprev = torch.randn(2, 13, H // 8, W // 8, generator=g).to(dev)
+xin4 = torch.empty(2, 52, H // 4, W // 4, device=dev)
+target("stage input s=4, both frames of a step", lambda: ops.stage_inputs(items, flows2, tprev, 8.0, 4.0, xin4))
 for (c, h, w, n) in ((64, 136, 240, 2), (32, 272, 480, 2), (96, 68, 120, 2), (128, 34, 60, 2)):
     x = torch.randn(n, c, h, w, generator=g).to(dev)
     layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, True, torch.ones(1, c, 1, 1), device=dev)
