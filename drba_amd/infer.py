@@ -99,16 +99,20 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
     can_look = bool(getattr(model, "supports_lookahead", False))
     prefetch = getattr(model, "prefetch_frame", None) if can_look else None
 
-    eof = [False]
+    prefetch_pair = getattr(model, "prefetch_pair", None) if prefetch is not None else None
+    eof, last = [False], [I1]
 
-    def read():  # -> (raw frame, network input); a model that can starts the new frame's encoder right away
-        raw = None if eof[0] else video_io.read_frame()  # (the source is not asked again once it has ended)
-        if raw is None:
+    def read():  # -> (raw frame, network input); a model that can starts the new frame's encoder (and the coarse flow
+        raw = None if eof[0] else video_io.read_frame()  # of the pair it forms with the frame before it) right away
+        if raw is None:  # (the source is not asked again once it has ended)
             eof[0] = True
             return None, None
         x = to_inp(raw, dst_size)
         if prefetch is not None:
             prefetch(x)
+            if prefetch_pair is not None:
+                prefetch_pair(last[0], x)
+        last[0] = x
         return raw, x
 
     # with prefetch_frame the loop reads TWO frames ahead (same frames, same order, same outputs): (i3, I3) is the

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from drba_amd import ops as _ops
-from drba_amd.models.lookahead import Lookahead
+from drba_amd.models.lookahead import Lookahead, shared_stream
 from drba_amd.models.lookahead import split as split_lookahead
 from drba_amd.models.drm import calc_drm_rife
 from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
@@ -92,7 +92,7 @@ class RIFE:
         dev = I.device
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_enc_stream", None) is None:
-            self._enc_stream = torch.cuda.Stream(device=dev)
+            self._enc_stream = shared_stream(dev, "prefetch")
         ready = torch.cuda.Event()
         ready.record(main)  # the frame was produced (to_inp) on the caller's stream
         with torch.cuda.stream(self._enc_stream):
@@ -104,6 +104,34 @@ class RIFE:
             done = torch.cuda.Event()
             done.record(self._enc_stream)
         I._drba_enc = (f, done, id(self))
+
+    def prefetch_pair(self, a, b):
+        """Optional: calc_flow(a, b) -- block0 on the 1/16-resolution map and the flow reversal, ~25 serial launches -- on
+        the prefetch stream, behind the two frames' encoders.  With the driver reading two frames ahead this is the pair
+        the NEXT call's lookahead starts from, so the lookahead stream's chain begins at the DRM maps."""
+        if not a.is_cuda or getattr(b, "_drba_pairflow", None) is not None:
+            return
+        self.prefetch_frame(a)
+        self.prefetch_frame(b)
+        with torch.cuda.stream(self._enc_stream):
+            res = self.calc_flow(a, b, f0=self._encoded(a), f1=self._encoded(b))
+            done = torch.cuda.Event()
+            done.record(self._enc_stream)
+        b._drba_pairflow = (a, res, done, id(self))
+
+    def _pair_flow(self, a, b, fa=None):
+        """calc_flow(a, b), from prefetch_pair if it was started there (the consumer's stream waits for it)."""
+        c = getattr(b, "_drba_pairflow", None)
+        if c is not None and c[0] is a and c[3] == id(self):
+            cur = torch.cuda.current_stream(a.device)
+            cur.wait_event(c[2])
+            for t in c[1]:
+                t.record_stream(cur)
+                fp = getattr(t, "_drba_pair", None)
+                if fp is not None:
+                    fp.record_stream(cur)
+            return c[1]
+        return self.calc_flow(a, b, f0=fa)
 
     def _encoded(self, I):
         """encode(I), from prefetch_frame's stream if it was started there (the consumer's stream waits for it)."""
@@ -161,14 +189,14 @@ class RIFE:
             self._look = Lookahead()
 
         def work():
-            res = self.calc_flow(a, b, f0=fa)
+            res = self._pair_flow(a, b, fa)
             return res, (then(res) if then is not None else None)
         self._look.start(a, b, work, inputs=tuple(t for t in (fa,) + tuple(also_reads) if t is not None))
 
     def _flow_pair(self, a, b, fa):
         """(calc_flow(a, b), staged low-resolution stages or None), from a matching lookahead if there is one."""
         got = self._look.take(a, b) if self._look is not None else None
-        return got if got is not None else (self.calc_flow(a, b, f0=fa), None)
+        return got if got is not None else (self._pair_flow(a, b, fa), None)
 
     def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False, lookahead=None):
         """reference rife.py:77-109.  `lookahead` (not in the reference): the frame that will be I2 of the next call,

@@ -151,6 +151,7 @@ def test_prefetched_encoder_matches_inline(hip_backend):
         if prefetch:
             m.prefetch_frame(frames[2])
             m.prefetch_frame(frames[3])
+            m.prefetch_pair(frames[2], frames[3])  # the pair the first call's lookahead starts from
         for k in range(2):
             if prefetch and k + 4 < len(frames):
                 m.prefetch_frame(frames[k + 4])
@@ -160,6 +161,7 @@ def test_prefetched_encoder_matches_inline(hip_backend):
         torch.cuda.synchronize()
         if prefetch:
             assert getattr(frames[3], "_drba_enc", None) is not None and frames[3]._drba_enc[0] is reuse[2]  # f of the last I2
+            assert frames[3]._drba_pairflow[1][1] is reuse[0]  # flow21 of the last call came from prefetch_pair
         return outs, reuse
 
     a, ra = run(True)
