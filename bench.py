@@ -22,12 +22,16 @@ no collective) and `config5_sharded` BASELINE.json configs[4]: one FIXED 4K clip
 cut) sharded over the N ranks (strong scaling).
 
 Extra objects on the JSON line:
-  roofline      the kernel SYMBOL with the largest total time over the instrumented steps of the timed region (every
-                `roof_every`-th step runs with the library's kernel trace on: each launch carries an event pair on its
-                own dispatch packet, i.e. the kernel's own execution time as rocprofv3's kernel trace reports it).
+  roofline      the kernel SYMBOL with the largest total time over the instrumented steps: 4 consecutive steps of the same
+                loop, run right after the timed region with the library's kernel trace on for every launch (each launch
+                carries an event pair on its own dispatch packet, i.e. the kernel's own execution time as rocprofv3's
+                kernel trace reports it; 3 traced steps before them settle the streams' interleaving).
                 achieved = sum of the launches' algorithmic FLOPs (or bytes) / sum of their durations; avg_us and
                 algorithmic_per_launch are plain means over the same launches; `by_geometry` splits the symbol by layer
-                shape; `others` = the next symbols; `step_kernels_ms` = all kernel time per step.  Peaks from
+                shape; `others` = the next symbols; `step_kernels_ms` = all kernel time per step, `traced_ms_per_step` the
+                wall time of a traced step and `avg_concurrency` their ratio: how many kernels (three streams) share the
+                chip on average -- a kernel's duration, hence `frac`, is that of the shared execution, about
+                avg_concurrency times its stand-alone duration.  Peaks from
                 MI355X_MICROARCH.md (HBM 8 TB/s; dense fp32 MFMA 157.3 TFLOP/s; dense bf16 2500 TFLOP/s).
                 `traffic` = HBM bytes per launch from rocprofv3 --pmc passes (profiles/pmc_traffic.json, keyed by symbol
                 and launch label; tools/pmc_targets.py + tools/pmc_traffic.py regenerate it), null where a geometry the
@@ -66,6 +70,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense; the split-bf16 kernels spend 6 bf16 MFMA products per fp32 multiply
 HBM_PEAK_GBS = 8000.0
 TS = np.array([0.75, 1.25])  # what `-t 2` yields every step (infer.py:76-87)
+# The roofline object's kernel durations come from a block of consecutive fully traced steps run right AFTER the timed
+# region (kTraceWarm to settle, kTraceKeep kept), so the timed steps run untraced.  What the records mean with three
+# streams: a step's kernels sum to ~6.9 ms inside a ~3.0 ms step, i.e. 2.3 kernels share the chip on average and each
+# reads about twice its stand-alone duration (32-channel ResConv: 68 us here, 35 us alone in tools/resconv_bench.py).
+# rocprofv3's kernel trace of the same command runs the loop 13 % slower and less overlapped (4.35 ms of kernels in a
+# 3.35 ms step) and reads 36 us for that layer; tracing only the main stream's launches does not change the 68 us
+# (tools/exp/trace_settle.py).  `roofline.frac` is therefore the fraction under the step's real concurrency.
+kTraceWarm, kTraceKeep = 3, 4
 SRC_FPS = 24.0
 
 
@@ -244,6 +256,11 @@ def roofline_from_trace(recs, n_steps, traffic=None):
     roof = entry(*ranked[0], True)
     roof["others"] = [entry(n, a, False) for n, a in ranked[1:5]]
     roof["step_kernels_ms"] = round(total_ms / n_steps, 3)
+    if all("start_ms" in r for r in recs):  # how many kernels share the chip on average while these durations were taken
+        span = max(r["start_ms"] + r["ms"] for r in recs) - min(r["start_ms"] for r in recs)
+        if span > 0:
+            roof["traced_ms_per_step"] = round(span / n_steps, 3)
+            roof["avg_concurrency"] = round(total_ms / span, 2)
     roof["kernels_per_step"] = round(len(recs) / n_steps, 1)
     roof["instrumented_steps"] = n_steps
     return roof
@@ -329,34 +346,29 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
 
     for _ in range(args.warmup):
         step()
-    roof_every = max(1, min(10, args.steps // 2))
-    traced = 0
-    if trace:
-        # one traced and one plain step before the timed region: the first plain launch after the first traced ones
-        # costs ~40 ms once (the runtime switches the queue's profiling mode; tools/exp/trace_overhead.py)
-        ops.trace_begin()
-        step()
-        ops.trace_pause()
-        step()
-        ops.trace_begin()  # clears the records of the untimed step
-        ops.trace_pause()
     _quiet_gc()
     _fence(world)
     t0 = time.perf_counter()
     per_step = []
     for k in range(args.steps):
-        on = trace and k % roof_every == 0
-        if on:
-            ops.trace_resume()
-            traced += 1
         step()
-        if on:
-            ops.trace_pause()
         per_step.append(time.perf_counter())
     t_host = time.perf_counter() - t0  # all launches enqueued: the host side of a step (the GPU may still be working)
     _fence(world)
     dt = time.perf_counter() - t0
-    recs = ops.trace_end() if trace else None
+    recs, traced = None, 0
+    if trace:  # the roofline block: same loop, same state, every launch traced
+        ops.trace_begin()
+        for _ in range(kTraceWarm):
+            step()
+        first = ops._trace_pos()
+        for _ in range(kTraceKeep):
+            step()
+        last = ops._trace_pos()
+        torch.cuda.synchronize()
+        recs, traced = ops.trace_end()[first:last], kTraceKeep
+        step()  # the first untraced launches after traced ones pay a one-time mode switch: not in anybody's timed region
+        torch.cuda.synchronize()
     if os.environ.get("DRBA_BENCH_STEPLOG"):  # host-side enqueue time of every step (diagnostic)
         log("host ms per step: " + " ".join(f"{(b - a) * 1e3:.2f}" for a, b in zip([t0] + per_step, per_step)))
     return dt, t_host, recs, traced, dst_size
@@ -364,47 +376,49 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
 
 def clip_leg(model, clip, dst_fps, times, scdet, args, label):
     """One extra config through the real driver loop: drba_amd.infer.interpolate_stream over a clip resident in HBM.
-    The K loop iterations after W warm-up iterations are timed (on_step marks them); every roof_every-th is traced."""
+    The K loop iterations after W warm-up iterations are timed (on_step marks them); the iterations after them are the traced roofline block (see kTraceWarm)."""
     from drba_amd import infer as drv
     from drba_amd import ops
     cm = _Counting(model)
     io = _DevIO(clip, SRC_FPS)
     to_inp, to_out = _dev_hooks()
     W_, K = args.warmup, args.steps
-    roof_every = max(1, min(10, K // 2))
-    st = {"t0": None, "t1": None, "g0": 0, "g1": 0, "w0": 0, "w1": 0, "traced": 0}
+    st = {"t0": None, "t1": None, "g0": 0, "g1": 0, "w0": 0, "w1": 0, "first": None, "last": None}
     ops.trace_begin()
     ops.trace_pause()
 
-    def on_step(idx):  # idx = loop iterations completed (0 after the head)
+    def on_step(idx):  # idx = loop iterations completed (0 after the head); called before iteration j = idx - W_ runs
         j = idx - W_
-        ops.trace_pause()
         if j == 0:
             _quiet_gc()
             torch.cuda.synchronize()
             st["t0"], st["g0"], st["w0"] = time.perf_counter(), cm.generated, io.written
-        if j == K:
+        if j == K:  # the timed iterations are done; the clip's remaining iterations are the roofline block (all traced)
             torch.cuda.synchronize()
             st["t1"], st["g1"], st["w1"] = time.perf_counter(), cm.generated, io.written
-        if 0 <= j < K and j % roof_every == 0:
             ops.trace_resume()
-            st["traced"] += 1
+        if j == K + kTraceWarm:
+            st["first"] = ops._trace_pos()
+        if j == K + kTraceWarm + kTraceKeep:
+            st["last"] = ops._trace_pos()
+            ops.trace_pause()
 
     drv.interpolate_stream(cm, io, dst_fps, times=times, enable_scdet=scdet, to_inp=to_inp, to_out=to_out, on_step=on_step)
     torch.cuda.synchronize()
     recs = ops.trace_end()
+    recs = recs[st["first"]:st["last"]] if st["last"] is not None else []
     dt = st["t1"] - st["t0"]
     gen, wr = st["g1"] - st["g0"], st["w1"] - st["w0"]
     return {"workload": label, "value": round(gen / dt, 3), "unit": "frames/s", "steps": K, "warmup": W_,
             "ms_per_step": round(dt / K * 1e3, 3), "frames_generated": gen, "frames_written": wr,
-            "roofline": roofline_from_trace(recs, st["traced"], _traffic_table())}
+            "roofline": roofline_from_trace(recs, kTraceKeep, _traffic_table())}
 
 
 def extra_configs(args, dev):
     """BASELINE.json configs[2], [3], [4] at N = 1 (bounded: K steps each)."""
     from drba_amd.models.gmfss_union import GMFSS_UNION
     from drba_amd.models.rife import RIFE
-    n = args.warmup + args.steps + 3
+    n = args.warmup + args.steps + 3 + kTraceWarm + kTraceKeep + 1  # + the traced iterations of the roofline block
     out = {}
     cut = args.warmup + args.steps // 2 + 2
     m = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=1.0, device=dev)

@@ -112,6 +112,8 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
 
     # ---- loop iterations [a, b): infer.py:112-156 with idx == k
     can_look = bool(getattr(model, "supports_lookahead", False))
+    prefetch = getattr(model, "prefetch_frame", None) if can_look else None
+    prefetch_pair = getattr(model, "prefetch_pair", None) if can_look else None
     for k in range(a, b):
         I0, I1, I2 = inp(k), inp(k + 1), inp(k + 2)
         ts = _tools.calc_t(k, times, mapper)
@@ -125,7 +127,13 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
             reuse = None
             res = list(model.inference_ts(I0, I1, ts[ts <= 1])) + [I1 for _ in ts[ts > 1] - 1]
         elif can_look and k + 1 < b and k + 3 < n:
-            # one-frame lookahead inside the shard (drba_amd/models/lookahead.py): frame k+3 is I2 of iteration k+1
+            # one-frame lookahead inside the shard (drba_amd/models/lookahead.py): frame k+3 is I2 of iteration k+1; the
+            # frame after it has its encoder and the coarse flow of the pair (k+3, k+4) -- what iteration k+1's lookahead
+            # starts from -- put on the prefetch stream, as the sequential driver does by reading two frames ahead
+            if prefetch is not None and k + 2 < b and k + 4 < n:
+                prefetch(inp(k + 4))
+                if prefetch_pair is not None:
+                    prefetch_pair(inp(k + 3), inp(k + 4))
             res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=(inp(k + 3), _tools.calc_t(k + 1, times, mapper)))
         else:
             res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)
