@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $OUT/trace_4k -o rife4k -- python $REPO/bench.py --config 4k --no-extra --no-cpu-baseline > $OUT/bench_4k_under_rocprof.json 2> $OUT/rocprof_4k.err; echo "rocprof 4k exit $?")
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $OUT/trace_4k -o rife4k -- python $REPO/bench.py --config 4k --no-extra --no-cpu-baseline --no-roofline > $OUT/bench_4k_under_rocprof.json 2> $OUT/rocprof_4k.err; echo "rocprof 4k exit $?")
 DB=$(ls $OUT/trace_4k/*_results.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocpd_steady.py $DB 10 $OUT/steady_state_4k_s0.5.csv --rows 12
 [ -n "$DB" ] && python tools/rocpd_steady.py $DB 10 $OUT/steady_state_4k_s0.5_by_grid.csv --by-grid --by-queue --rows 0 > /dev/null

@@ -18,7 +18,7 @@ done
 python tools/step_timeline.py --steps 2 > $OUT/timeline_1080p.txt 2>/dev/null
 export TMPDIR=/tmp
 REPO=$(pwd)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $OUT/trace -o rife1080 -- python $REPO/bench.py --no-extra --no-cpu-baseline > $OUT/bench_1080p_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?")
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $OUT/trace -o rife1080 -- python $REPO/bench.py --no-extra --no-cpu-baseline --no-roofline > $OUT/bench_1080p_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?")
 ls $OUT/trace | head
 DB=$(ls $OUT/trace/*_results.db 2>/dev/null | head -1)
 if [ -n "$DB" ]; then
