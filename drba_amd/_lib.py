@@ -121,6 +121,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own libamdhip64 / libhsa-runtime64, the library links the image's /opt/rocm copies
+    # under the same sonames.  Whichever is mapped first serves both; with the library's copy mapped first torch's streams
+    # and allocations belong to a runtime it was not built against and every launch fails (hipGetLastError after the
+    # launch: __graft_entry__.build() followed by smoke() in one process did exactly that).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DrbaHipError(
             f"{LIB_PATH} not found: the HIP kernel library is not built. "

@@ -148,3 +148,16 @@ def test_oracle_is_not_imported_by_the_product():
         if os.path.exists(p) and re.search(r"^\s*(from|import)\s+oracle\b", open(p).read(), flags=re.M):
             offenders.append(p)
     assert not offenders, offenders
+
+
+def test_library_is_mapped_after_torch():
+    """torch's wheel bundles its own HIP runtime under the sonames the library links against /opt/rocm; the library must
+    never be the one that brings a HIP runtime into the process first (every launch fails then): load() imports torch."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from drba_amd import _lib\n"
+            "assert 'torch' not in sys.modules\n"
+            "_lib.load()\n"
+            "assert 'torch' in sys.modules\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
