@@ -154,6 +154,7 @@ def test_library_is_mapped_after_torch():
     """torch's wheel bundles its own HIP runtime under the sonames the library links against /opt/rocm; the library must
     never be the one that brings a HIP runtime into the process first (every launch fails then): load() imports torch."""
     import subprocess
+    import sys
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from drba_amd import _lib\n"
             "assert 'torch' not in sys.modules\n"
