@@ -31,7 +31,8 @@ Extra objects on the JSON line:
                 shape; `others` = the next symbols; `step_kernels_ms` = all kernel time per step, `traced_ms_per_step` the
                 wall time of a traced step and `avg_concurrency` their ratio: how many kernels (three streams) share the
                 chip on average -- a kernel's duration, hence `frac`, is that of the shared execution, about
-                avg_concurrency times its stand-alone duration.  Peaks from
+                avg_concurrency times its stand-alone duration; `standalone` = the heaviest geometry of the symbol launched
+                back to back on the idle GPU right after (stride-1 conv layers).  Peaks from
                 MI355X_MICROARCH.md (HBM 8 TB/s; dense fp32 MFMA 157.3 TFLOP/s; dense bf16 2500 TFLOP/s).
                 `traffic` = HBM bytes per launch from rocprofv3 --pmc passes (profiles/pmc_traffic.json, keyed by symbol
                 and launch label; tools/pmc_targets.py + tools/pmc_traffic.py regenerate it), null where a geometry the
@@ -266,6 +267,44 @@ def roofline_from_trace(recs, n_steps, traffic=None):
     return roof
 
 
+def standalone_of(roof, dev, reps=30):
+    """The dominant symbol's heaviest geometry launched back to back on an otherwise idle GPU (stride-1 conv layers only):
+    the kernel's own quality, next to the in-step figure that is taken while ~2 other kernels share the chip."""
+    import re
+    geo = sorted((roof or {}).get("by_geometry") or [], key=lambda g: -g["algorithmic_per_launch"])  # most work first
+    for g in geo:
+        m = re.match(r"conv3x3 \((\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)$", g["launch"])
+        if not m:
+            continue
+        cfg, cin, cout, ho, wo, stride, n = (int(v) for v in m.groups())
+        if stride != 1:
+            continue
+        from drba_amd import ops
+        gen = torch.Generator().manual_seed(0)
+        x = torch.randn(n, cin, ho, wo, generator=gen).to(dev)
+        res = cin == cout  # ResConv: lrelu(conv(x) * beta + x), the residual rebuilt from the staged input
+        layer = ops.Conv3x3(torch.randn(cout, cin, 3, 3, generator=gen) / (cin * 9) ** 0.5, torch.zeros(cout), 1, True,
+                            torch.ones(1, cout, 1, 1) if res else None, device=dev, cfg=cfg)
+        out = torch.empty(n, cout, ho, wo, device=dev)
+        run = (lambda: layer(x, residual=x, out=out)) if res else (lambda: layer(x, out=out))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        flop = 2.0 * cout * cin * 9 * ho * wo * n
+        return {"launch": g["launch"], "avg_us": round(us, 2), "achieved": round(flop / us / 1e6, 2), "unit": "TFLOP/s",
+                "frac": round(flop / us / 1e6 / roof["peak"], 4),
+                "what": f"{reps} back-to-back launches of this layer alone (events around the run: includes the ~5 us between "
+                        "dependent launches)"}
+    return None
+
+
 def _traffic_table():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
     return json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -498,6 +537,9 @@ def gpu_leg(args, rank, world):
     r["roofline"] = roofline_from_trace(recs, traced, _traffic_table()) if recs else None
     if world == 1:
         r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps})
+        if r["roofline"] and r["roofline"].get("bound") == "mfma":
+            torch.cuda.synchronize()
+            r["roofline"]["standalone"] = standalone_of(r["roofline"], dev)
         return r
     # ---- N > 1: the headline is ONE clip sharded over the ranks, K loop iterations per rank (weak scaling)
     import torch.distributed as dist
