@@ -7,6 +7,7 @@ Everything runs in fp32 (the reference's CPU autocast path is bf16 and deviates 
 its own fp32 evaluation; parity is against the fp32 evaluation).
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -117,12 +118,14 @@ class RIFE:
             res = self.calc_flow(a, b, f0=self._encoded(a), f1=self._encoded(b))
             done = torch.cuda.Event()
             done.record(self._enc_stream)
-        b._drba_pairflow = (a, res, done, id(self))
+        # (a weak reference to `a`: a strong one would chain every frame -- with its features -- to its successor for the
+        # length of the clip)
+        b._drba_pairflow = (weakref.ref(a), res, done, id(self))
 
     def _pair_flow(self, a, b, fa=None):
         """calc_flow(a, b), from prefetch_pair if it was started there (the consumer's stream waits for it)."""
         c = getattr(b, "_drba_pairflow", None)
-        if c is not None and c[0] is a and c[3] == id(self):
+        if c is not None and c[0]() is a and c[3] == id(self):
             cur = torch.cuda.current_stream(a.device)
             cur.wait_event(c[2])
             for t in c[1]:

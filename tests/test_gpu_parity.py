@@ -170,6 +170,40 @@ def test_prefetched_encoder_matches_inline(hip_backend):
         assert float((x - y).abs().max()) <= 2e-6
 
 
+def test_prefetch_does_not_retain_frames(hip_backend):
+    """The prefetch caches hang on the frame tensors (encoder output on the frame, coarse flow on the pair's second frame);
+    nothing may keep a frame -- with its 16-channel features -- alive once the driver has dropped it: memory is flat over a
+    long run of the two-frames-ahead loop."""
+    import gc
+    from drba_amd.utils import synth
+    m = hip_backend.make_rife(synth.ifnet_state_dict(seed=0), 1.0)
+    dev = hip_backend.dev
+    g = torch.Generator().manual_seed(5)
+    base = [torch.rand(1, 3, 128, 192, generator=g).to(dev) for _ in range(4)]
+    ts = np.array([0.75, 1.25])
+
+    def frame(k):
+        return torch.roll(base[k % 4], k // 4, dims=3).contiguous()  # a fresh tensor object per source frame
+
+    win = [frame(k) for k in range(5)]  # I0, I1, I2, next, next2
+    for x in win[2:]:
+        m.prefetch_frame(x)
+    m.prefetch_pair(win[2], win[3])
+    m.prefetch_pair(win[3], win[4])
+    reuse, marks = None, {}
+    for k in range(60):
+        _, reuse = m.inference_ts_drba(win[0], win[1], win[2], ts, reuse, True, lookahead=(win[3], ts))
+        nxt2 = frame(k + 5)
+        m.prefetch_frame(nxt2)
+        m.prefetch_pair(win[4], nxt2)
+        win = win[1:] + [nxt2]
+        if k in (19, 59):
+            torch.cuda.synchronize()
+            gc.collect()
+            marks[k] = torch.cuda.memory_allocated(dev)
+    assert marks[59] <= marks[19] + (1 << 20), marks  # 40 more steps: not one frame's worth (0.3 MB + 3.1 MB features) each
+
+
 def test_gmfss_union_lookahead_matches_inline(hip_backend):
     """Same for GMFSS_UNION: the pair state model.reuse(I2, next) prefetched on the side stream (and the per-frame
     FeatureNet cache) must give the frames of the inline computation."""
