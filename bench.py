@@ -311,6 +311,25 @@ def _traffic_table():
 
 
 # ------------------------------------------------------------------------------------------------- GPU legs
+# DRBA_BENCH_BACKEND=gloo is a REHEARSAL switch, not a mode of the benchmark: the one-GPU build box cannot run RCCL with
+# two ranks, so `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with it lets both ranks share cuda:0 and
+# carries the collectives over gloo on host tensors -- every barrier, gather round and reduction of the N > 1 legs
+# executes (tests/test_gpu_cli.py); its rates mean nothing.
+BACKEND = os.environ.get("DRBA_BENCH_BACKEND", "nccl")
+
+
+def _local_device():
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if BACKEND != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
+    return local
+
+
+def _coll_device(dev):
+    """Where the collectives' tensors live: the GPU for RCCL, the host for the gloo rehearsal."""
+    return dev if BACKEND == "nccl" else torch.device("cpu")
+
+
 def _fence(world):
     if world > 1:
         import torch.distributed as dist
@@ -495,7 +514,7 @@ def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
     _quiet_gc()
     _fence(world)
     t0 = time.perf_counter()
-    sg = parallel.StreamedGather(rank, world, counts, chunk=4, device=dev, frame_shape=clip.shape)
+    sg = parallel.StreamedGather(rank, world, counts, chunk=4, device=_coll_device(dev), frame_shape=clip.shape)
     parallel.interpolate_shard(cm, clip, SRC_FPS, dst_fps, rank, world, times=times, enable_scdet=scdet,
                                to_inp=to_inp, to_out=to_out, sink=sg.push)
     allf = sg.finish()
@@ -504,7 +523,7 @@ def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
     if world == 1:  # (--selftest-sharded: the same code on one GPU, no process group)
         return dt, cm.generated, (len(allf) if allf is not None else 0)
     import torch.distributed as dist
-    t = torch.tensor([dt, float(cm.generated)], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, float(cm.generated)], dtype=torch.float64, device=_coll_device(dev))
     mx = t.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -523,7 +542,7 @@ def sharded_warmup(model, H, W, dst_fps, times, scdet, rank, world, dev, cut=Fal
 def gpu_leg(args, rank, world):
     from drba_amd.models.rife import RIFE
 
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = _local_device()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     (H, W), scale, desc = CONFIGS[args.config]
@@ -543,7 +562,7 @@ def gpu_leg(args, rank, world):
         return r
     # ---- N > 1: the headline is ONE clip sharded over the ranks, K loop iterations per rank (weak scaling)
     import torch.distributed as dist
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=_coll_device(dev))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     r["replica_loop"] = {"value": round(len(TS) * args.steps * world / float(t.item()), 3), "unit": "frames/s",
                          "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "scaling": "weak",
@@ -657,8 +676,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group(backend="nccl")  # RCCL over xGMI
+        torch.cuda.set_device(_local_device())
+        dist.init_process_group(backend=BACKEND)  # "nccl" = RCCL over xGMI
     if args.selftest_sharded:
         from drba_amd.models.rife import RIFE
         dev = torch.device("cuda", 0)
