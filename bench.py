@@ -79,6 +79,8 @@ TS = np.array([0.75, 1.25])  # what `-t 2` yields every step (infer.py:76-87)
 # 3.35 ms step) and reads 36 us for that layer; tracing only the main stream's launches does not change the 68 us
 # (tools/exp/trace_settle.py).  `roofline.frac` is therefore the fraction under the step's real concurrency.
 kTraceWarm, kTraceKeep = 3, 4
+kSettleSeconds = 0.5  # untimed steps after the W warm-up steps (step_loop) / minimum warm-up iterations of the clip legs
+kClipWarmup = 24
 SRC_FPS = 24.0
 
 
@@ -404,6 +406,17 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
 
     for _ in range(args.warmup):
         step()
+    # W is the minimum.  With three streams (per-stream allocator pools, the lookahead state two frames deep) and on a box
+    # whose first GPU process this is, three steps do not reach the steady state: the first ~30 steps enqueue at 3.5 ms
+    # each instead of 1.0 ms (allocator growth, first touches) and a 20-step timed region started there reads 508 instead
+    # of 670 frames/s (profiles/README.md).  So the untimed warm-up goes on for kSettleSeconds of steps.
+    t_settle, settled = time.perf_counter() + kSettleSeconds, 0
+    while time.perf_counter() < t_settle:
+        step()
+        settled += 1
+        if settled % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
     _quiet_gc()
     _fence(world)
     t0 = time.perf_counter()
@@ -476,6 +489,7 @@ def extra_configs(args, dev):
     """BASELINE.json configs[2], [3], [4] at N = 1 (bounded: K steps each)."""
     from drba_amd.models.gmfss_union import GMFSS_UNION
     from drba_amd.models.rife import RIFE
+    args = argparse.Namespace(**{**vars(args), "warmup": max(args.warmup, kClipWarmup)})  # see step_loop: W is the minimum
     n = args.warmup + args.steps + 3 + kTraceWarm + kTraceKeep + 1  # + the traced iterations of the roofline block
     out = {}
     cut = args.warmup + args.steps // 2 + 2
