@@ -457,8 +457,18 @@ ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, 
   // ---- VS plumbing.  A 32 x 2 block (scale 1: the wave's output pixels; FOLD at scale 2: its full-resolution sample
   // points) is parked as [4 slots][64] and written by lane l as the 16 bytes of slot l >> 4, pixels 4*(l & 15)..+3.
   const int g4 = lane >> 4, qd = lane & 15;
+  // The strip is exchanged between the lanes of ONE wave: LDS operations of a wave retire in order, so no s_barrier is
+  // needed, but the compiler must keep the parked writes in front of the other lanes' reads and the reads in front of
+  // the next round's writes -- wavefront-scope fences + wave barriers pin that order (they emit no instruction).
+  auto strip_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   auto flush32x2 = [&](const float *strip, float *base, size_t plane, int width, int x0, int y0, int ch) {
+    strip_sync();
     const f32x4a v = *reinterpret_cast<const f32x4a *>(strip + g4 * 64 + qd * 4);
+    strip_sync();
     *reinterpret_cast<f32x4a *>(base + (size_t)ch * plane + (size_t)(y0 + (qd >> 3)) * width + x0 + (qd & 7) * 4) = v;
   };
   // scale 1: emit(slot, v) parks channel values, flush(ch of this lane's 16-lane group) writes 4 channels at once
@@ -598,6 +608,7 @@ ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, 
   for (int c = 0; c < 4; ++c) emit(48 + c, (comb(fls[c]) * 1.f) / scale);  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
   if (VS && !SINGLE) {
     // [52][16] -> lane l of pass i writes the 16 bytes of channel (64 i + l) >> 2, pixels 4 * (l & 3)..+3 of the wave's row
+    strip_sync();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = i * 64 + lane, ch = idx >> 2, qq = idx & 3;

@@ -203,6 +203,11 @@ def inference_sharded(model, args, rank, world, to_inp=None, to_out=None, check_
         raise RuntimeError("the frame-sharded run needs random access to the clip: use a .npz / .npy source")
     counts = parallel.emission_counts(len(frames), fps, args.dst_fps, args.times, world)
     sg = parallel.StreamedGather(rank, world, counts, chunk=chunk, device=device, frame_shape=tuple(frames[0].shape))
+    if to_out is None and world > 1 and device is not None and device.type == "cuda":
+        # finished frames stay on the device until the gather has moved them (tools.to_out would copy each one to the
+        # host only for StreamedGather to copy it back): the uint8 frame is written straight into the send path
+        from drba_amd import ops as _ops
+        to_out = lambda x, size: _ops.to_out(x, size)  # noqa: E731
     parallel.interpolate_shard(model, frames, fps, args.dst_fps, rank, world, times=args.times, enable_scdet=args.enable_scdet,
                                scdet_threshold=args.scdet_threshold, to_inp=to_inp, to_out=to_out, check_scene=check_scene,
                                sink=sg.push)

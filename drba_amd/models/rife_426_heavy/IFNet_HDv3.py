@@ -14,6 +14,7 @@ convolutions is fused into three glue kernels (drba_amd/csrc/ifnet_glue.hip):
 import numpy as np
 import torch
 
+from drba_amd import _lib
 from drba_amd import ops as _ops
 
 BLOCK_C = (192, 128, 96, 64, 32)
@@ -135,6 +136,18 @@ class IFNet:
         exactly once (next stage's input kernel at scale <= 2, the final warp_blend): no separate read-modify-write
         pass over the full-resolution flow for the two full-resolution stages."""
         B = len(items)
+        M = _lib.MAX_STAGE_ITEMS
+        if B > M:
+            # the batched glue launches take at most M items (drba_hip.h DRBA_MAX_STAGE_ITEMS): a step with more frames to
+            # synthesise (`-t 6`, 24 -> 144 fps, ...) runs as independent groups of M -- the samples do not interact
+            parts = []
+            for a in range(0, B, M):
+                st = None if state is None else (list(state[0][a:a + M]), None if state[1] is None else state[1][a:a + M],
+                                                 state[2], state[3])
+                parts.append(self.forward_pairs(items[a:a + M], scale_list, first, last, st))
+            if last < 5:
+                return ([f for p in parts for f in p[0]], torch.cat([p[1] for p in parts], 0), parts[0][2], parts[0][3])
+            return [f for p in parts for f in p]
         _, _, H, W = items[0][0].shape
         flows, tmp, s_prev, pending = state if state is not None else ([None] * B, None, 1.0, False)
         flows = list(flows)
@@ -158,7 +171,10 @@ class IFNet:
             tmp = self.block[i].core(xin)  # [B,13,H/s,W/s]: flow delta (4), mask (1), feat (8)
             s_prev = s
             # leave the update to the consumer if that one can fold it
-            nxt_folds = (i + 1 < 5 and self._lds_ok(scale_list[i + 1], s) and scale_list[i + 1] <= 2) or i + 1 == 5
+            # (the final warp_blend_fold takes scale >= 1 only: with a model scale > 1 the last stage runs at s < 1 and
+            # the plain update + warp_blend pair finishes the frame)
+            nxt_folds = ((i + 1 < 5 and self._lds_ok(scale_list[i + 1], s) and scale_list[i + 1] <= 2)
+                         or (i + 1 == 5 and s >= 1))
             pending = bool(nxt_folds)
             if not pending:
                 flows = _ops.flow_updates(tmp, flows, H, W, s)

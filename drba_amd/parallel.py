@@ -165,9 +165,14 @@ class StreamedGather:
     padded buffer to an ASYNCHRONOUS dist.gather (RCCL runs it on its own stream, under the next steps' kernels).  All
     sizes follow from emission_counts(), which every rank computes locally, so ranks with fewer emissions (no head /
     tail) still take part in every round and the collectives are issued in the same order everywhere.
-    finish() returns the ordered frame list on rank 0 (None elsewhere)."""
+    Device memory stays bounded: at most `in_flight` rounds keep their send / receive buffers on the GPU; older rounds
+    are retired as later ones are issued -- every rank drops its send buffer, the writer copies the round's received
+    frames into pinned host memory on a drain stream of its own (a 10-minute 1080p60 clip is > 200 GB of uint8 frames:
+    it cannot wait on the GPU for finish()).  `on_round(j, frames_by_rank)`, if given, receives the writer's host
+    frames of round j as soon as they have landed (list over ranks of lists of HWC uint8 tensors).
+    finish() returns the ordered frame list on rank 0 (host tensors; None elsewhere)."""
 
-    def __init__(self, rank, world, counts, chunk=4, device=None, group=None, frame_shape=None):
+    def __init__(self, rank, world, counts, chunk=4, device=None, group=None, frame_shape=None, in_flight=2, on_round=None):
         self.rank, self.world, self.group, self.chunk = rank, world, group, max(1, int(chunk))
         self.dev = device if device is not None else (_default_device(group) if world > 1 else None)
         self.counts = counts
@@ -179,6 +184,11 @@ class StreamedGather:
         self.handles, self.recv, self.keep = [], [], []
         self.shape = None if frame_shape is None else tuple(frame_shape)  # (H, W, 3) of an output frame, if known
         self.local = []  # world == 1: plain accumulation
+        self.in_flight, self.on_round = max(1, int(in_flight)), on_round
+        self.retired = 0            # rounds [0, retired) no longer hold device buffers
+        self.host = []              # writer: per retired round, per rank, the received frames in host memory
+        self._drain, self._landed = None, []  # writer on a GPU: the D2H stream and one event per retired round
+        self.peak_device_rounds = 0  # (tests) most rounds that held device buffers at any time
 
     def _tensor(self, f):
         t = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
@@ -203,6 +213,45 @@ class StreamedGather:
         self.keep.append(buf)
         self.pending = []
         self.round += 1
+        self.peak_device_rounds = max(self.peak_device_rounds, self.round - self.retired)
+        while self.round - self.retired > self.in_flight:
+            self._retire()
+
+    def _retire(self):
+        """Round self.retired leaves the device: wait for its gather, (writer) copy what it received to host memory."""
+        j = self.retired
+        h = self.handles[j]
+        on_gpu = self.dev is not None and torch.device(self.dev).type == "cuda"
+        if self.rank != 0:
+            h.wait()  # (RCCL: orders the current stream behind the collective; gloo: blocks the host)
+        elif not on_gpu:
+            h.wait()
+            self.host.append([[self.recv[j][r][k] for k in range(self.per_round[r][j])] for r in range(self.world)])
+        else:
+            if self._drain is None:
+                self._drain = torch.cuda.Stream(device=self.dev)
+            with torch.cuda.stream(self._drain):
+                h.wait()  # the drain stream, not the compute stream, waits for the collective
+                rows = []
+                for r in range(self.world):
+                    n = self.per_round[r][j]
+                    src = self.recv[j][r]
+                    src.record_stream(self._drain)
+                    dst = torch.empty((n,) + tuple(src.shape[1:]), dtype=torch.uint8, pin_memory=True)
+                    if n:
+                        dst.copy_(src[:n], non_blocking=True)
+                    rows.append([dst[k] for k in range(n)])
+                ev = torch.cuda.Event()
+                ev.record(self._drain)
+            self.keep[j].record_stream(self._drain)
+            self._landed.append(ev)
+            self.host.append(rows)
+        self.recv[j] = self.keep[j] = None  # device buffers back to the allocator
+        self.retired += 1
+        if self.rank == 0 and self.on_round is not None:
+            if self._landed:
+                self._landed[-1].synchronize()
+            self.on_round(j, self.host[j])
 
     def push(self, frames):
         """One emission of this rank (a list of uint8 HWC frames)."""
@@ -220,14 +269,16 @@ class StreamedGather:
         assert self.emissions == len(self.counts[self.rank]), "every emission must be pushed before finish()"
         while self.round < self.n_rounds:  # ranks with fewer emissions: empty contributions to the remaining rounds
             self._issue()
-        for h in self.handles:
-            h.wait()
+        while self.retired < self.n_rounds:
+            self._retire()
         if self.rank != 0:
             return None
+        for ev in self._landed:
+            ev.synchronize()
         out = []
         for r in range(self.world):
             for j in range(self.n_rounds):
-                out.extend(self.recv[j][r][k] for k in range(self.per_round[r][j]))
+                out.extend(self.host[j][r])
         return out
 
 

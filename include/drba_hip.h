@@ -27,6 +27,9 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
+/* ABI version.  2 (round 2 of this tree): drba_timing_* and drba_softmax_expect2 removed; drba_flow_reverse and
+ * drba_drm_rife_linear take a workspace that must be ZERO on entry (they leave it zero on return: self-cleaning
+ * accumulator) instead of clearing it themselves; batched stage entry points added.  1: the first release. */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in include/drba_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in drba_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.drba_abi_version() == 1
+    assert lib.drba_abi_version() == 2
     assert lib.drba_error_string(-1) == b"invalid argument"
 
 

@@ -142,3 +142,30 @@ def test_gmfss_pipeline_plumbing(dry):
     out, reuse = m.inference_ts_drba(I[0], I[1], I[2], np.array([0.75, 1.25]), None, True)
     assert out[0].shape == (1, 3, 128, 256) and len(reuse) == 6
     assert m.inference_ts(I[0], I[1], np.array([0.5]))[0].shape == (1, 3, 128, 256)
+
+
+@pytest.mark.parametrize("scale,n_items", ((1.0, 7), (2.0, 2), (0.5, 9)))
+def test_rife_many_items_and_scale_plumbing(dry, scale, n_items):
+    """More synthesised frames per step than one batched glue launch takes (DRBA_MAX_STAGE_ITEMS) run as groups, also when
+    the step is split at a stage boundary (the lookahead's carried state); model scale 2 ends on a stage above the frame
+    resolution, which must take the plain update + warp_blend pair (drba_warp_blend_fold refuses scale < 1)."""
+    from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
+    net = IFNet().to(torch.device("cpu")).eval()
+    net.load_state_dict(synth.ifnet_state_dict(0))
+    sl = [16 / scale, 8 / scale, 4 / scale, 2 / scale, 1 / scale]
+    H, W = 128, 128
+    img = [torch.rand(1, 3, H, W) for _ in range(2)]
+    f = [torch.rand(1, 16, H, W) for _ in range(2)]
+    items = [(img[0], img[1], 0.1 * (k + 1), f[0], f[1]) for k in range(n_items)]
+    frames = net.forward_pairs(items, sl)
+    assert len(frames) == n_items and all(x.shape == (1, 3, H, W) for x in frames)
+    state = net.forward_pairs(items, sl, 0, 3)
+    assert len(state[0]) == n_items and state[1].shape[0] == n_items
+    frames = net.forward_pairs(items, sl, 3, 5, state)
+    assert len(frames) == n_items
+    if n_items > _lib.MAX_STAGE_ITEMS:
+        assert dry.calls["drba_ifblock_input_batch"] >= 2 * -(-n_items // _lib.MAX_STAGE_ITEMS)
+    if scale > 1:
+        assert dry.calls.get("drba_warp_blend", 0) == 2 * n_items and dry.calls.get("drba_warp_blend_fold", 0) == 0
+    else:
+        assert dry.calls.get("drba_warp_blend_fold", 0) == 2 * n_items

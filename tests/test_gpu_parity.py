@@ -23,7 +23,7 @@ def test_native_library_is_what_runs():
     """The product must be the HIP library: it is loaded from the tree and there is no fallback."""
     from drba_amd import _lib
     lib = _lib.load()
-    assert lib.drba_abi_version() == 1
+    assert lib.drba_abi_version() == 2
     with open("/proc/self/maps") as f:
         assert "libdrba_hip.so" in f.read()
 
@@ -259,3 +259,29 @@ def test_linear_split(hip_backend):
 @pytest.mark.gpu
 def test_feature_splat_quad_source(hip_backend):
     _assert_rows(gpu_checks.check_splat_quad(hip_backend.dev))
+
+
+@pytest.mark.parametrize("scale,n_ts", [(1.0, 7), (2.0, 2), (2.0, 5)])
+def test_rife_many_timesteps_and_model_scale_above_one(hip_backend, oracle_backend, scale, n_ts):
+    """A step with more frames to synthesise than one batched glue launch takes (DRBA_MAX_STAGE_ITEMS = 4: `-t 8` has 7)
+    runs as independent groups, and with a model scale > 1 (scale_list ends at 0.5: the last stage runs ABOVE the frame
+    resolution) the frame is finished by the plain flow update + warp_blend pair; both against the oracle at 1e-3, cold
+    and warm step (reference rife.py:77-109 takes any number of timesteps and any scale)."""
+    from drba_amd.utils import synth
+    sd = synth.ifnet_state_dict(seed=0)
+    fr = cases.rife_frames(128, 192)
+    ts = np.linspace(0.5, 1.5, n_ts + 2)[1:-1]
+    ts = ts[ts != 1.0] if n_ts % 2 == 0 else ts  # an odd count keeps t = 1 (pass-through frame)
+    hip, ora = hip_backend.make_rife(sd, scale), oracle_backend.make_rife(sd, scale)
+    dev = hip_backend.dev
+    g = [f.to(dev) for f in fr]
+    out, reuse = hip.inference_ts_drba(g[0], g[1], g[2], ts, None, True)
+    out2, _ = hip.inference_ts_drba(g[1], g[2], g[3], ts, reuse, True)
+    ref, rre = ora.inference_ts_drba(fr[0], fr[1], fr[2], ts, None, True)
+    ref2, _ = ora.inference_ts_drba(fr[1], fr[2], fr[3], ts, rre, True)
+    assert len(out + out2) == len(ref + ref2) == 2 * len(ts)
+    errs = [float((a.cpu() - b).abs().max()) for a, b in zip(out + out2, ref + ref2)]
+    assert max(errs) <= 1e-3, errs
+    plain = hip.inference_ts(g[0], g[1], list(np.linspace(0, 1, n_ts + 2)))
+    pref = ora.inference_ts(fr[0], fr[1], list(np.linspace(0, 1, n_ts + 2)))
+    assert max(float((a.cpu() - b).abs().max()) for a, b in zip(plain, pref)) <= 1e-3

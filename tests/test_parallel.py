@@ -151,10 +151,18 @@ def _fake_worker(rank, world, port, scdet, q):
     frames = synth.make_clip(7, 32, 64, seed=5, cut_at=3 if scdet else None)
     to_inp, to_out, check = _cpu_hooks()
     model = _FakeModel()
-    sg = parallel.StreamedGather(rank, world, parallel.emission_counts(len(frames), 24.0, 60, -1, world), chunk=2)
+    seen = []
+    sg = parallel.StreamedGather(rank, world, parallel.emission_counts(len(frames), 24.0, 60, -1, world), chunk=1, in_flight=1,
+                                 on_round=lambda j, rows: seen.append((j, [len(r) for r in rows])))
     parallel.interpolate_shard(model, frames, 24.0, 60, rank, world, enable_scdet=scdet, to_inp=to_inp, to_out=to_out,
                                check_scene=check, sink=sg.push)
     allf = sg.finish()
+    # bounded buffering: rounds are retired (send / receive buffers dropped, the writer's frames handed on) as later ones
+    # are issued, never more than in_flight + the one being issued alive at a time
+    assert sg.n_rounds >= 3 and sg.peak_device_rounds <= 2 and all(b is None for b in sg.keep) and all(r is None for r in sg.recv)
+    if rank == 0:
+        assert [j for j, _ in seen] == list(range(sg.n_rounds))
+        assert [c for _, c in seen] == [[sg.per_round[r][j] for r in range(world)] for j in range(sg.n_rounds)]
     if rank == 0:
         io = _IO(frames, 24.0)
         drv.interpolate_stream(model, io, 60, enable_scdet=scdet, to_inp=to_inp, to_out=to_out, check_scene=check)
