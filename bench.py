@@ -85,6 +85,8 @@ SRC_FPS = 24.0
 
 
 _T0 = time.perf_counter()
+LAST_SHARD = {"rank_dt": None}  # this rank's own wall time of the last sharded_leg (the line reports every rank's)
+LAST_SETTLE = {"steps": 0}  # untimed settling steps the last step_loop ran after its W warm-up steps (reported on the line)
 
 
 def log(msg):
@@ -417,6 +419,7 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
         if settled % 8 == 0:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
+    LAST_SETTLE["steps"] = settled
     _quiet_gc()
     _fence(world)
     t0 = time.perf_counter()
@@ -534,6 +537,7 @@ def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
     allf = sg.finish()
     _fence(world)
     dt = time.perf_counter() - t0
+    LAST_SHARD["rank_dt"] = dt
     if world == 1:  # (--selftest-sharded: the same code on one GPU, no process group)
         return dt, cm.generated, (len(allf) if allf is not None else 0)
     import torch.distributed as dist
@@ -567,6 +571,7 @@ def gpu_leg(args, rank, world):
     frames = [clip[k] for k in range(len(clip))]
     dt, t_host, recs, traced, dst = step_loop(model, frames, n_total, args, world, trace=not args.no_roofline)
     r["dst_size"] = dst
+    r["settle_steps"] = LAST_SETTLE["steps"]
     r["roofline"] = roofline_from_trace(recs, traced, _traffic_table()) if recs else None
     if world == 1:
         r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps})
@@ -584,7 +589,7 @@ def gpu_leg(args, rank, world):
     big = DeviceClip(world * args.steps + 2, H, W, 1234, dev)
     sharded_warmup(model, H, W, SRC_FPS * 2, 2, False, rank, world, dev)
     sdt, gen, got = sharded_leg(model, big, SRC_FPS * 2, 2, False, rank, world, dev)
-    r.update({"dt": sdt, "host_dt": None, "frames": gen, "writer_frames": got})
+    r.update({"dt": sdt, "host_dt": None, "frames": gen, "writer_frames": got, "rank_dt": LAST_SHARD["rank_dt"]})
     if not args.no_extra:
         m5 = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=0.5, device=dev)
         n5 = 8 * args.steps + 2  # fixed clip whatever N is: strong scaling
@@ -680,12 +685,50 @@ def cpu_leg(args, model):
     return base, parity
 
 
+def describe_job(rank, world, r):
+    """What torch.distributed saw: backend, world size, the device of every rank, the RCCL version, every rank's time for
+    the timed sharded run -- so that a scaling record can be checked for "did RCCL run with N ranks on N GPUs"."""
+    dev = r["dev"]
+    prop = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", 0)), "device": f"cuda:{dev.index}", "name": prop.name,
+          "arch": getattr(prop, "gcnArchName", None), "pci_bus_id": getattr(prop, "pci_bus_id", None),
+          "uuid": str(getattr(prop, "uuid", "")) or None, "pid": os.getpid(),
+          "rank_seconds": None if r.get("rank_dt") is None else round(r["rank_dt"], 5)}
+    info = {"backend": "none (single process)", "world_size": 1, "devices": [me], "rccl_version": None,
+            "visible_gpus": torch.cuda.device_count()}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001  (a torch build without the binding: reported as null)
+        pass
+    if world > 1:
+        import torch.distributed as dist
+        rows = [None] * world
+        dist.all_gather_object(rows, me)
+        info.update({"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (rehearsal, not a benchmark)"),
+                     "world_size": dist.get_world_size(), "devices": rows,
+                     "distinct_devices": len({(d["device"], d["uuid"], d["pci_bus_id"]) for d in rows})})
+    return info
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed without a launcher (`python bench.py --gpus 8`): start the ranks ourselves, one process per GPU, exactly
+        # as the driver's command line does; rank 0's JSON line is the only thing on stdout either way
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("self-launch: " + " ".join(cmd))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        os.execv(sys.executable, cmd)
+    if args.gpus != world:
+        print(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     if world > 1:
         import torch.distributed as dist
@@ -709,6 +752,7 @@ def main():
         return
     r = gpu_leg(args, rank, world)
     log(f"gpu leg done: {r['frames'] / r['dt']:.1f} frames/s")
+    dist_info = describe_job(rank, world, r)
     cpu = parity = extra = pcie = None
     if rank == 0 and world == 1:
         if not args.no_extra:
@@ -728,13 +772,14 @@ def main():
         line = {
             "metric": "interpolated frames/sec @1080p RIFE x2" if args.config == "1080p" else f"interpolated frames/sec @{args.config} RIFE x2",
             "value": round(r["frames"] / r["dt"], 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
+            "warmup": args.warmup, "settle_steps": r["settle_steps"], "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
             "host_ms_per_step": None if r["host_dt"] is None else round(r["host_dt"] / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "net_size": list(r["dst_size"]), "frames_per_step": len(TS),
                        "weights": "seeded random IFNet 4.26-heavy", "parallelism": f"frame-sharded dp{world}"},
             "max_abs_vs_oracle": parity, "roofline": r["roofline"], "cpu_baseline": cpu,
         }
+        line["dist"] = dist_info
         if pcie is not None:
             line["pcie_inclusive"] = pcie
         for k in ("replica_loop", "config5_sharded", "writer_frames"):

@@ -134,19 +134,17 @@ def test_bench_sharded_legs_run_at_world_1():
 
 
 def test_bench_two_rank_rehearsal_over_gloo():
-    """`bench.py --gpus 2` under torch.distributed.run with two ranks sharing the one GPU and the collectives carried by
-    gloo (DRBA_BENCH_BACKEND=gloo, a rehearsal switch): the replica loop, the untimed sharded warm-up, the sharded headline
+    """`python bench.py --gpus 2` typed WITHOUT a launcher (the shape of the driver's N = 1 command): bench.py starts its
+    own ranks under torch.distributed.run.  Two ranks share the one GPU and the collectives are carried by gloo
+    (DRBA_BENCH_BACKEND=gloo, a rehearsal switch): the replica loop, the untimed sharded warm-up, the sharded headline
     clip with its streamed gather to rank 0 and the strong-scaling config-5 clip with its planted cut all execute with two
-    processes -- matching barriers, gather rounds and reductions -- and the writer receives every frame of both clips."""
+    processes -- matching barriers, gather rounds and reductions -- the writer receives every frame of both clips, and the
+    line says what torch.distributed saw (backend, world size, one entry per rank)."""
     import json
-    import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
     env = dict(os.environ, DRBA_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
-                        "--warmup", "2", "--config", "480p"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--config",
+                        "480p"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
@@ -155,3 +153,7 @@ def test_bench_two_rank_rehearsal_over_gloo():
     c5 = d["config5_sharded"]
     assert c5["clip_source_frames"] == 34 and c5["writer_frames"] == 86 and c5["frames_generated"] > 0 and c5["scaling"] == "strong"
     assert d["replica_loop"]["value"] > 0
+    j = d["dist"]
+    assert j["world_size"] == 2 and j["backend"].startswith("gloo") and [x["rank"] for x in j["devices"]] == [0, 1]
+    assert len({x["pid"] for x in j["devices"]}) == 2 and all(x["rank_seconds"] > 0 for x in j["devices"])
+    assert d["settle_steps"] > 0

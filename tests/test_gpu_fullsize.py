@@ -75,6 +75,9 @@ def _rife_fullsize(hip_backend, oracle_backend, src, net, scale, ts_seq):
 
 
 def _assert_rows(rows):
+    import inspect
+    from tests import report
+    report.record(inspect.stack()[1].function, rows)
     for r in rows:
         print(f"{r[0]:<40} err={r[1]:.3e} tol={r[2]:.1e} {r[3]}")
     bad = [r for r in rows if not r[1] <= r[2]]
@@ -196,3 +199,54 @@ def test_split_conv_configs_on_many_tile_shapes(hip_backend):
                          5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
     assert len(rows) >= 12
     _assert_rows(rows)
+
+
+def test_config3_one_clip_1080p_fps60_scdet_and_its_sharding(hip_backend):
+    """BASELINE.json configs[2] as ONE clip at the benchmarked size: 10 source frames 1080x1920 (net 1088x1920), 24 -> 60
+    fps (fractional timesteps + DRM), scene detection on with a planted cut -- what bench.py's `config3_*` leg times --
+    through the real driver loop on the HIP path (to_inp / to_out / check_scene on the device, lookahead and prefetch
+    active) against the same loop on the CPU oracle: same number of frames, same cut decisions (a different decision
+    would put a copy where a synthesised frame belongs: far more than 1 LSB), every byte within 1 LSB.
+    Then configs[4]'s logic at a benchmarked frame size: the clip frame-sharded over two ranks (run one after the other on
+    the one GPU, each rebuilding its halo state) must reproduce the sequential HIP run, at scale 1.0 and at scale 0.5."""
+    import oracle
+    from drba_amd import infer as drv
+    from drba_amd import parallel
+    from tests.clip_common import ListIO, cpu_hooks
+    from tests.test_gpu_parallel import _hooks
+    dev = hip_backend.dev
+    sd = synth.ifnet_state_dict(seed=0)
+    frames = synth.make_clip(10, 1080, 1920, seed=1234, cut_at=5)
+    to_inp, to_out = _hooks(dev)
+    hip = hip_backend.make_rife(sd, 1.0)
+    io = ListIO(frames, 24.0)
+    n = drv.interpolate_stream(hip, io, 60.0, enable_scdet=True, to_inp=to_inp, to_out=to_out)
+    torch.cuda.synchronize()
+    cio = ListIO(frames, 24.0)
+    c_inp, c_out, c_check = cpu_hooks()
+    drv.interpolate_stream(oracle.rife.RifeOracle(sd, 1.0), cio, 60.0, enable_scdet=True, to_inp=c_inp, to_out=c_out,
+                           check_scene=c_check)
+    assert n == len(io.written) == len(cio.written)
+    worst, differing, total = 0, 0, 0
+    for a, b in zip(io.written, cio.written):
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        worst, differing, total = max(worst, int(d.max())), differing + int((d > 0).sum()), total + d.size
+    rows = [("config 3 clip: HIP driver vs oracle driver, uint8 LSB", float(worst), 1.0,
+             f"{len(io.written)} frames, {differing}/{total} bytes differ")]
+    # ---- the same clip sharded over 2 ranks (sequentially on this GPU) vs the sequential HIP run
+    for scale in (1.0, 0.5):
+        m = hip if scale == 1.0 else hip_backend.make_rife(sd, 0.5)
+        seq = io.written
+        if scale != 1.0:
+            sio = ListIO(frames, 24.0)
+            drv.interpolate_stream(m, sio, 60.0, enable_scdet=True, to_inp=to_inp, to_out=to_out)
+            seq = sio.written
+        parts = []
+        for rank in range(2):
+            parts += parallel.interpolate_shard(m, frames, 24.0, 60.0, rank, 2, enable_scdet=True, to_inp=to_inp, to_out=to_out)
+        torch.cuda.synchronize()
+        assert len(parts) == len(seq)
+        w = max(int(np.abs(a.astype(np.int16) - b.astype(np.int16)).max()) for a, b in zip(parts, seq))
+        rows.append((f"config 3 clip sharded over 2 ranks vs sequential HIP run, scale {scale}, uint8 LSB", float(w), 1.0, ""))
+    _assert_rows(rows)
+    assert differing / total < 2e-3

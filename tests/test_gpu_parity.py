@@ -9,13 +9,20 @@ import numpy as np
 import pytest
 import torch
 
-from tests import cases, gpu_checks
+from tests import cases, gpu_checks, report
 
 pytestmark = pytest.mark.gpu
 
 
-def _assert_rows(rows):
+def _assert_rows(rows, fixture_too=False):
+    """Every row within its tolerance against the oracle; fixture_too: the same bar against the reference's own stored
+    outputs (`vs_fixture=` in the row's details)."""
+    import inspect
+    report.record(inspect.stack()[1].function, rows)
     bad = [(n, e, t, x) for n, e, t, x in rows if not e <= t]
+    if fixture_too:
+        bad += [(n, float(x.split("vs_fixture=")[1].split()[0]), t, "vs the reference fixture") for n, e, t, x in rows
+                if "vs_fixture=" in x and not float(x.split("vs_fixture=")[1].split()[0]) <= t]
     assert not bad, "\n".join(f"{n}: err={e:.3e} tol={t:.1e} {x}" for n, e, t, x in bad)
 
 
@@ -30,12 +37,12 @@ def test_native_library_is_what_runs():
 
 def test_ops_parity(hip_backend, oracle_backend, golden_dir):
     _assert_rows(gpu_checks.check_cases(cases.ops_cases(), hip_backend, oracle_backend, 2e-5,
-                                        np.load(os.path.join(golden_dir, "ops.npz"))))
+                                        np.load(os.path.join(golden_dir, "ops.npz"))), fixture_too=True)
 
 
 def test_drm_parity(hip_backend, oracle_backend, golden_dir):
     _assert_rows(gpu_checks.check_cases(cases.drm_cases(), hip_backend, oracle_backend, 2e-5,
-                                        np.load(os.path.join(golden_dir, "drm.npz"))))
+                                        np.load(os.path.join(golden_dir, "drm.npz"))), fixture_too=True)
 
 
 def test_conv_layers_parity(hip_backend):
@@ -54,7 +61,8 @@ def test_scene_detection_parity(hip_backend, golden_dir):
 def test_rife_end_to_end_parity(hip_backend, oracle_backend, golden_dir, scale, size):
     rows = gpu_checks.check_rife(hip_backend, oracle_backend, np.load(os.path.join(golden_dir, "rife.npz")), scale, size)
     frames = [r for r in rows if r[0].startswith(("ts_", "drba_cold", "drba_warm", "drba_nonlinear")) and "reuse" not in r[0]]
-    _assert_rows(frames)  # synthesised frames: 1e-3 max-abs
+    _assert_rows(frames, fixture_too=True)  # synthesised frames: 1e-3 max-abs vs the oracle AND vs the reference's stored frames
+    report.record(f"test_rife_end_to_end_parity flows/features scale={scale} size={size}", [r for r in rows if r not in frames])
     # flows / features: same bar except isolated hole-fill flips, which must stay rare
     for name, err, tol, extra in rows:
         if (name, err, tol, extra) in frames:
