@@ -52,6 +52,7 @@ SIGNATURES = {
     "drba_conv3x3_pick_cfg": (_i, [_i, _i, _i, _i, _i]),
     "drba_conv3x3_num_cfgs": (_i, []),
     "drba_conv3x3_cfg_stride": (_i, [_i]),
+    "drba_conv3x3_cfg_family": (_i, [_i]),
     "drba_deconv4x4_num_cfgs": (_i, []),
     "drba_conv3x3_packed_floats": (_z, [_i, _i, _i]),
     "drba_conv3x3_pack": (_i, [_p, _p, _i, _i, _i]),

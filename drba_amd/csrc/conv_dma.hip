@@ -24,7 +24,7 @@
 //   4 i + kq (i = 0..7) of the chunk -- with the channel stride of the window 400 dwords == 16 (mod 32) the 32 lanes a
 //   ds_read_b32 services together (kq = 0, 1) hit 32 distinct banks.  The weights are packed with the same mapping.
 // LDS (bytes): A[2] 2 x 51200 (window of a chunk, double buffered) | W[3] 3 x 9 KB x NT (ring of kernel-row fragment
-//   blocks [dx][nt][plane h/m/l][64 lanes][16 B]) | bias/beta[2] 2 x 256 | dump 1 KB (target of the padding DMAs that
+//   blocks [dx][nt][plane h/m/l][64 lanes][16 B]) | bias/beta[2] 2 x 512 | dump 1 KB (target of the padding DMAs that
 //   keep every wave's instruction count equal, so that the waits are compile-time immediates).
 // DMA schedule (chunk c of the workgroup's flat chunk sequence, steps dy = 0, 1, 2; "allow n" = s_waitcnt vmcnt(n)):
 //   top of (c,0): allow |g2| (+ the stores of an epilogue in between), barrier, issue g0 = W(c,2), A(c+1) units 0..31
@@ -58,7 +58,7 @@ constexpr int A_INSTR = A_BYTES / 1024;  // 50 wave-level DMA instructions of 64
 constexpr int A_P0 = 32, A_P1 = A_INSTR - A_P0;  // pieces: 4 + 3 instructions per wave (8 waves)
 constexpr int A_S0 = 4, A_S1 = 3;      // slots per wave
 static_assert(CS % 32 == 16 && A_BYTES % 1024 == 0 && A_P1 <= 8 * A_S1, "window layout");
-constexpr unsigned kOOB = 0x7FFFFFF0u;  // beyond any num_records: the load returns 0 (zero padding), never faults
+[[maybe_unused]] constexpr unsigned kOOB = 0x7FFFFFF0u;  // beyond any num_records: the load returns 0 (zero padding), never faults
 
 template <int NT_>
 struct DmaCfg {
@@ -66,7 +66,7 @@ struct DmaCfg {
   static constexpr int W_STEP = 3 * NT * 3 * 1024;     // bytes of one kernel row's fragments: [dx][nt][plane][64][16]
   static constexpr int W_INSTR = W_STEP / 1024;        // 9 NT
   static constexpr int W_S = (W_INSTR + 7) / 8;        // slots per wave
-  static constexpr int OFF_A = 0, OFF_W = 2 * A_BYTES, OFF_BB = OFF_W + 3 * W_STEP, OFF_DUMP = OFF_BB + 512;
+  static constexpr int OFF_A = 0, OFF_W = 2 * A_BYTES, OFF_BB = OFF_W + 3 * W_STEP, OFF_DUMP = OFF_BB + 1024;
   static constexpr int LDS_BYTES = OFF_DUMP + 1024;
   static constexpr int G0 = W_S + A_S0, G1 = W_S + A_S1, G2 = W_S + 2;  // DMA instructions per wave in the three groups
   static constexpr int STORES = 2 * NT;                // epilogue store instructions per wave and item
@@ -177,14 +177,15 @@ conv_dma_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, con
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr)(lds + dst), 16, voff, soff, 0, 0);
     }
   };
-  // bias / beta of the item's NTC output channels -> bb[parity]: [bias 0..NTC-1][beta 0..NTC-1] (every wave writes the same bytes)
+  // bias / beta of the item's NTC output channels -> bb[parity]: [bias: 64 lanes x 4 B][beta: 64 x 4 B] (a 4-byte DMA writes all
+  // 64 lanes, zeros for the lanes past NTC; every wave writes the same bytes)
   auto issue_BB = [&](const Item &c, int parity) {
     const int co = c.cz * Cfg::NTC + lane;
     const unsigned voff = (lane < Cfg::NTC && co < Cout) ? (unsigned)co * 4u : kOOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(bias_rsrc, (lds_ptr)(lds + Cfg::OFF_BB + parity * 256), 4, voff, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(beta_rsrc, (lds_ptr)(lds + Cfg::OFF_BB + parity * 256 + 128), 4, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(bias_rsrc, (lds_ptr)(lds + Cfg::OFF_BB + parity * 512), 4, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(beta_rsrc, (lds_ptr)(lds + Cfg::OFF_BB + parity * 512 + 256), 4, voff, 0, 0, 0);
   };
-  static_assert(Cfg::NTC <= 32, "bias/beta slots hold 32 channels");
+  static_assert(Cfg::NTC <= 64, "bias/beta slots hold 64 channels");
 
   int work = blockIdx.x;
   if (work >= total) return;
@@ -318,13 +319,13 @@ conv_dma_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, con
           __builtin_amdgcn_make_buffer_rsrc((void *)((res ? res : out) + img), 0, res ? obytes : 0u, 0x00020000);
       const __amdgpu_buffer_rsrc_t r2rsrc =
           __builtin_amdgcn_make_buffer_rsrc((void *)((res2 ? res2 : out) + img), 0, res2 ? obytes : 0u, 0x00020000);
-      const float *bb = ldsf + (Cfg::OFF_BB + par * 256) / 4;
+      const float *bb = ldsf + (Cfg::OFF_BB + par * 512) / 4;
       const int y = cur.y0 + wave, xb = cur.x0 + blk * 16 + q4 * 4;
       auto epilogue = [&](auto post) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int chA = nt * 16 + c8, coA = cur.cz * Cfg::NTC + chA;
-          const float bsA = bb[chA], bsB = bb[chA + 8], btA = bb[32 + chA], btB = bb[32 + chA + 8];
+          const float bsA = bb[chA], bsB = bb[chA + 8], btA = bb[64 + chA], btB = bb[64 + chA + 8];
           const bool in_img = y < H && xb < W;
           const unsigned base = (unsigned)(((coA * H + y) * W + xb) * 4);
           const unsigned oa = (in_img && coA < Cout) ? base : 0xffffffffu;

@@ -14,6 +14,16 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
                       int act, float post_slope, int pre_act, float pre_slope, void *stream);
 
 
+// the same arithmetic with every operand streamed by LDS-DMA and the activations split on the way into the MFMAs
+// (conv_dma.hip); cfg ids follow the conv_split family
+int conv_dma_num_cfgs();
+bool conv_dma_supports(int Cin, int Cout, int id);
+size_t conv_dma_packed_floats(int Cin, int Cout, int id);
+int conv_dma_pack(const float *w, float *packed, int Cin, int Cout, int id);
+int conv_dma_launch(int id, const float *in, const float *packed_w, const float *bias, const float *beta,
+                    const float *residual, const float *residual2, float *out, int N, int Cin, int H, int W, int Cout,
+                    int act, float post_slope, int pre_act, float pre_slope, void *stream);
+
 // transposed convolution 4x4 s2 p1 (cfg ids after conv.hip's fp32 deconv table)
 int deconv_split_num_cfgs();
 bool deconv_split_supports(int Cin, int Cout, int id);

@@ -126,6 +126,10 @@ int drba_ssim3d_32(const float *x1, const float *x2, float *out, void *stream);
 int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride); /* cost-model default */
 int drba_conv3x3_num_cfgs(void);         /* configs are 0..num-1; a host may time them and keep the fastest */
 int drba_conv3x3_cfg_stride(int cfg);    /* the stride (1 or 2) a config was built for */
+/* kernel family of a config: 0 = fp32 MFMA (conv.hip), 1 = split-bf16 with register staging (conv_split.hip: stride 1,
+ * Cin % 32 == 0), 2 = split-bf16 with every operand streamed by LDS-DMA (conv_dma.hip: additionally W % 4 == 0; the
+ * launch returns DRBA_EUNSUPPORTED otherwise) */
+int drba_conv3x3_cfg_family(int cfg);
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg);
 int drba_conv3x3_pack(const float *w /*[Cout,Cin,3,3] host or device-visible*/, float *packed,
                       int Cin, int Cout, int cfg);  /* HOST function: both pointers are host memory */
