@@ -110,10 +110,13 @@ def check_conv_layers(dev):
     lib = ops._lib.load()
     n_fp32 = 14
     for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
-        # (the LDS-DMA family moves its windows in 16-byte units: widths that are multiples of 4, still ragged in tiles)
+        # (the LDS-DMA family: 32 input channels, at most 32 output channels, widths that are multiples of 4 -- its windows
+        # move in 16-byte units -- still ragged in tiles)
         dma = lib.drba_conv3x3_cfg_family(cfg) == 2
-        for (nb, cin, cout, h, w, kind) in ((1, 32, 40, 11, 44 if dma else 45, "conv"), (2, 96, 32, 9, 72 if dma else 70, "res"),
-                                            (1, 64, 16, 5, 132 if dma else 130, "pre"), (2, 64, 64, 19, 36, "res")):
+        shapes = (((1, 32, 24, 11, 44, "conv"), (2, 32, 32, 9, 72, "res"), (1, 32, 32, 5, 132, "pre"), (2, 32, 32, 19, 36, "res"),
+                   (1, 32, 32, 8, 32, "conv")) if dma else
+                  ((1, 32, 40, 11, 45, "conv"), (2, 96, 32, 9, 70, "res"), (1, 64, 16, 5, 130, "pre"), (2, 64, 64, 19, 36, "res")))
+        for (nb, cin, cout, h, w, kind) in shapes:
             try:
                 x = torch.randn(nb, cin, h, w, generator=g) * 3.0
                 wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5

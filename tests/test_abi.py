@@ -63,7 +63,7 @@ def test_split_conv_weight_packing_reconstructs_fp32():
     for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
         assert lib.drba_conv3x3_cfg_stride(cfg) == 1
         assert lib.drba_conv3x3_packed_floats(20, 32, cfg) == 0
-        cin, cout = 64, 40
+        cin, cout = (32, 24) if lib.drba_conv3x3_cfg_family(cfg) == 2 else (64, 40)  # (the LDS-DMA family: 32 -> <= 32 channels)
         n = lib.drba_conv3x3_packed_floats(cin, cout, cfg)
         assert n > 0
         w = torch.randn(cout, cin, 3, 3, generator=g) * torch.logspace(-3, 3, cout).view(-1, 1, 1, 1)

@@ -19,9 +19,9 @@ dma = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_fam
 print("dma cfgs", dma, flush=True)
 g = torch.Generator().manual_seed(11)
 bad = 0
-cases = [(1, 32, 32, 8, 32, "res"), (1, 32, 32, 8, 32, "conv"), (2, 32, 32, 21, 100, "res"), (1, 64, 64, 19, 36, "res"),
-         (2, 96, 96, 9, 72, "res"), (1, 32, 40, 11, 44, "conv"), (1, 64, 16, 5, 132, "pre"), (1, 128, 128, 34, 60, "res"),
-         (1, 64, 48, 17, 64, "res2"), (2, 32, 32, 272, 480, "res"), (2, 64, 64, 136, 240, "res"), (1, 192, 192, 17, 32, "res")]
+cases = [(1, 32, 32, 8, 32, "res"), (1, 32, 32, 8, 32, "conv"), (2, 32, 32, 21, 100, "res"), (1, 32, 24, 11, 44, "conv"),
+         (1, 32, 16, 5, 132, "pre"), (1, 32, 32, 17, 64, "res2"), (2, 32, 32, 272, 480, "res"), (1, 32, 32, 1152, 1920, "res"),
+         (3, 32, 32, 30, 36, "res"), (1, 32, 32, 3, 4, "res")]
 for cfg in dma:
     for (nb, cin, cout, h, w, kind) in cases:
         x = torch.randn(nb, cin, h, w, generator=g) * 3.0
