@@ -22,7 +22,7 @@
 //     and the VALU work rides in the gaps (left to hipcc, each block's split sits in front of its own MFMAs).
 //   K order inside an MFMA: lane (m = lane % 16, kq = lane / 16) supplies k = 8 kq .. 8 kq + 7, mapped to channels
 //   4 i + kq (i = 0..7); the weights are packed with the same mapping.
-// LDS (bytes): A[2] 2 x 51200 | W 55296 = [dy][dx][nt][plane h/m/l][64 lanes][16 B].
+// LDS (bytes): A[2] 2 x 51200 | W 55296 = [dy][dx][nt][plane h/m/l][64 lanes][16 B] | 2 tile numbers.
 // ResConv layers (residual == input): the epilogue reads the residual from the window in LDS (exact fp32).
 #include "common.hpp"
 #include "conv_split.hpp"
@@ -30,6 +30,7 @@
 #include <string.h>
 
 #include <type_traits>
+#include <unordered_map>
 #include <utility>
 
 using namespace drba;
@@ -51,7 +52,8 @@ constexpr int A_BYTES = CK * CS * 4;     // 51200
 constexpr int W_BYTES = 9 * NT * 3 * 1024;  // 55296
 [[maybe_unused]] constexpr int W_INSTR = W_BYTES / 1024;
 constexpr int OFF_W = 2 * A_BYTES;
-constexpr int LDS_BYTES = OFF_W + W_BYTES;
+constexpr int OFF_IDX = OFF_W + W_BYTES;      // 2 x {x0, y0, image, tile number}: what the loader publishes per item
+constexpr int LDS_BYTES = OFF_IDX + 32;
 constexpr int NTHREADS = 9 * 64;         // 8 MFMA waves + the loader
 static_assert(CS % 32 == 16 && A_BYTES % 1024 == 0 && LDS_BYTES <= 160 * 1024, "window layout");
 [[maybe_unused]] constexpr unsigned kOOB = 0x7FFFFFF0u;  // beyond any num_records: the load returns 0 (zero padding), never faults
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(NTHREADS, 1)
 conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
           const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
           float *__restrict__ out, int H, int W, int Cout, int act, float post_slope, float pre_slope, int nbx, int nby,
-          int total) {
+          int total, int *__restrict__ counters, int *__restrict__ counters_next) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // the ONLY LDS object of the kernel
 
@@ -96,16 +98,27 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
   const int HW = H * W;
   const unsigned plane_bytes = (unsigned)HW * 4u;
 
-  auto decode = [&](int work) -> Item {
-    int t = xcd_band(work, total);
+  // Work distribution.  Tiles are numbered in (image, tile row, tile column) order and cut into 8 contiguous bands, one
+  // per XCD (workgroup b runs on XCD b % 8 -- observed dispatch order, used for speed only -- so that the halo rows
+  // neighbouring tiles share are fetched into one private L2).  A workgroup's FIRST tile is static (its rank inside its
+  // band); every further one is taken from its band's counter, then from the other bands' (atomicAdd by the loader, one
+  // tile ahead).  A static partition (tile = b + i * grid) assumes that all 256 workgroups start together: beside two
+  // other streams' kernels they do not -- a workgroup whose CU is still busy starts late and, with a fixed share, ends
+  // late, and the launch lasts twice its stand-alone time; taking tiles on demand, late workgroups simply do fewer.
+  // counters[0..7]: tiles handed out per band beyond the static ones.  Launches on a stream alternate between two sets
+  // of counters and each zeroes the set of the next one (counters_next), so nobody has to find out who finished last.
+  const int band_q = total >> 3, band_r = total & 7;
+  auto band_start = [&](int x) { return x < band_r ? x * (band_q + 1) : band_r * (band_q + 1) + (x - band_r) * band_q; };
+  auto band_len = [&](int x) { return band_q + (x < band_r ? 1 : 0); };
+  const int my_xcd = (int)(blockIdx.x & 7), n_static = (int)(gridDim.x >> 3);  // grid is a multiple of 8
+  auto decode = [&](int t) -> Item {
     Item c;
     const int bx = t % nbx;
     t /= nbx;
     c.x0 = bx * TW, c.y0 = (t % nby) * TH, c.n = t / nby;
     return c;
   };
-  int work = blockIdx.x;
-  if (work >= total) return;
+  int *lds_idx = reinterpret_cast<int *>(lds + OFF_IDX);  // [2][4]: the item behind barrier i in slot i & 1 (tile number -1: none)
 
   if (wave == 8) {
     // ================================================================ the loader
@@ -114,15 +127,14 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
     // group u % 10); rows / column groups outside the image read as zero through the buffer range check (the padding).
     // A lane's source offset relative to the window's origin is the same for every item: computed once (50 registers --
     // formed per item, the divisions made the loader the slowest wave of the workgroup: 20k clocks per tile)
-    unsigned a_rel[A_INSTR];
-    int a_rc[A_INSTR];  // row | (first column of the group << 8)
+    unsigned a_rel[A_INSTR];  // byte offset (a multiple of 16) | window row in the low 4 bits
+    const int lane10 = lane % (WC / 4);
 #pragma unroll
     for (int k = 0; k < A_INSTR; ++k) {
       const int u = k * 64 + lane;
       const int ch = u / (WR * (WC / 4)), e = u - ch * (WR * (WC / 4));
       const int r = e / (WC / 4), j = e - r * (WC / 4);
-      a_rel[k] = (unsigned)ch * plane_bytes + (unsigned)(r * W + 4 * j) * 4u;
-      a_rc[k] = r | ((4 * j) << 8);
+      a_rel[k] = ((unsigned)ch * plane_bytes + (unsigned)(r * W + 4 * j) * 4u) | (unsigned)r;
     }
     auto issue_A = [&](const Item &c, int ab) {
       const int ry = c.y0 - 1, cx = c.x0 - 4;
@@ -134,35 +146,102 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(img + ry * W + cx), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int k = 0; k < A_INSTR; ++k)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(lds + ab * A_BYTES + k * 1024), 16, a_rel[k], 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(lds + ab * A_BYTES + k * 1024), 16, a_rel[k] & ~15u, 0, 0, 0);
       } else {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, CK * plane_bytes, 0x00020000);
         const unsigned tb = (unsigned)((ry * W + cx) * 4);  // wraps for the first row / column: valid lanes add up >= 0
 #pragma unroll
         for (int k = 0; k < A_INSTR; ++k) {
-          const bool ok = (unsigned)(ry + (a_rc[k] & 0xff)) < (unsigned)H && (unsigned)(cx + (a_rc[k] >> 8)) < (unsigned)W;
-          const unsigned voff = ok ? a_rel[k] + tb : kOOB;
+          int j = lane10 + (k * 64) % (WC / 4);  // column group of unit 64 k + lane
+          j = j >= WC / 4 ? j - WC / 4 : j;
+          const bool ok = (unsigned)(ry + (int)(a_rel[k] & 15u)) < (unsigned)H && (unsigned)(cx + 4 * j) < (unsigned)W;
+          const unsigned voff = ok ? (a_rel[k] & ~15u) + tb : kOOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(lds + ab * A_BYTES + k * 1024), 16, voff, 0, 0, 0);
         }
       }
     };
-    issue_A(decode(work), 0);
+    // Next tile for this workgroup, -1 when there is none: one atomic on the own band's counter while it lasts, then ONE
+    // load of all eight counters and one attempt on the band with the most tiles left (its own workgroups keep draining
+    // it whether or not that succeeds; a chain of failing atomics, each a round trip to memory, cost 10 us at the end of
+    // every launch).  The own band's atomic is ISSUED before the window's 50 DMA instructions and its result read after
+    // them: returns come back in issue order, so read after them it would wait for the whole window.
+    auto band_tile = [&](int b, int k) -> int {
+      const int len = band_len(b), ns = min(n_static, len);
+      return ns + k < len ? band_start(b) + ns + k : -1;
+    };
+    auto ask = [&](int b) -> int {  // lane 0's return value is the ticket
+      int k = 0;
+      if (lane == 0) k = __hip_atomic_fetch_add(counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return k;
+    };
+    bool own_left = true;
+#ifdef DRBA_EXP_STATIC  // experiment: the static partition (tile = b + i * grid in band order), no counters
+    int static_i = 0;
+#endif
+    auto finish_grab = [&](int ticket) -> int {
+#ifdef DRBA_EXP_STATIC
+      const int w = (int)blockIdx.x + (++static_i) * (int)gridDim.x;
+      return w < total ? xcd_band(w, total) : -1;
+#endif
+      if (own_left) {
+        const int t = band_tile(my_xcd, __builtin_amdgcn_readfirstlane(ticket));
+        if (t >= 0) return t;
+        own_left = false;
+      }
+      int left = 0;
+      if (lane < 8) {
+        const int len = band_len(lane), ns = min(n_static, len);
+        left = len - ns - __hip_atomic_load(counters + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      int best = -1, most = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int l = __builtin_amdgcn_readlane(left, b);
+        if (l > most) most = l, best = b;
+      }
+      return best < 0 ? -1 : band_tile(best, __builtin_amdgcn_readfirstlane(ask(best)));
+    };
+    auto publish = [&](int tile, int slot) {  // the decoded tile (the MFMA waves do not repeat the divisions behind the barrier)
+      const Item c = decode(tile < 0 ? 0 : tile);
+      if (lane == 0) *reinterpret_cast<int4 *>(lds_idx + 4 * slot) = make_int4(c.x0, c.y0, c.n, tile);
+    };
+    if (blockIdx.x == 0 && lane < 8) counters_next[lane] = 0;  // the set the NEXT launch on this stream counts in
+    int cur = (int)(blockIdx.x >> 3) < band_len(my_xcd) ? band_start(my_xcd) + (int)(blockIdx.x >> 3) : -1;
     int ab = 0;
+    publish(cur, 0);
+    int nxt = -1;  // taken one tile ahead: the counter's round trip hides under the window's
+    if (cur >= 0) {  // (the first window is fetched by the MFMA waves, see there)
+#ifdef DRBA_EXP_STATIC
+      const int ticket = 0;
+#else
+      const int ticket = own_left ? ask(my_xcd) : 0;
+#endif
+      nxt = finish_grab(ticket);
+    }
 #ifdef DRBA_EXP_CLOCKS
     long long lc[4] = {0, 0, 0, 0};
 #endif
     while (true) {
-      // barrier i: the window of item i (and, the first time, the weights) has landed; every MFMA wave is done with
-      // item i - 1, whose buffer the window of item i + 1 may now overwrite
+      // barrier i: the window of item i (and, the first time, the weights) has landed and its tile number is published;
+      // every MFMA wave is done with item i - 1, whose buffer the window of item i + 1 may now overwrite
       DRBA_CLK(l0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       DRBA_CLK(l1);
       __builtin_amdgcn_s_barrier();
       DRBA_CLK(l2);
-      work += (int)gridDim.x;
-      if (work >= total) break;
+      if (cur < 0) break;
+      cur = nxt;
       ab ^= 1;
-      issue_A(decode(work), ab);
+      publish(cur, ab);
+      if (cur >= 0) {
+#ifdef DRBA_EXP_STATIC
+        const int ticket = 0;
+#else
+        const int ticket = own_left ? ask(my_xcd) : 0;
+#endif
+        issue_A(decode(cur), ab);
+        nxt = finish_grab(ticket);
+      }
       DRBA_CLK(l3);
 #ifdef DRBA_EXP_CLOCKS
       lc[0] += l1 - l0, lc[1] += l2 - l1, lc[2] += l3 - l2, lc[3] += 1;
@@ -187,6 +266,29 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr)(lds + OFF_W + k * 1024), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
     }
   }
+  // ... and the workgroup's FIRST window (its tile is static), 6-7 of the 50 instructions per wave: the MFMA waves have
+  // nothing else to do yet, and the loader alone needs 3k clocks to set itself up and 3k more to issue a window
+  {
+    const int first = (int)(blockIdx.x >> 3) < band_len(my_xcd) ? band_start(my_xcd) + (int)(blockIdx.x >> 3) : -1;
+    if (first >= 0) {
+      const Item c = decode(first);
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)c.n * CK * HW), 0, CK * plane_bytes, 0x00020000);
+      const int ry = c.y0 - 1, cx = c.x0 - 4;
+#pragma unroll
+      for (int i = 0; i < (A_INSTR + 7) / 8; ++i) {
+        const int k = i * 8 + wave;
+        if (k < A_INSTR) {
+          const int u = k * 64 + lane;
+          const int ch = u / (WR * (WC / 4)), e = u - ch * (WR * (WC / 4));
+          const int r = e / (WC / 4), j = e - r * (WC / 4);
+          const bool ok = (unsigned)(ry + r) < (unsigned)H && (unsigned)(cx + 4 * j) < (unsigned)W;
+          const unsigned voff = ok ? (unsigned)ch * plane_bytes + (unsigned)((ry + r) * W + cx + 4 * j) * 4u : kOOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(lds + k * 1024), 16, voff, 0, 0, 0);
+        }
+      }
+    }
+  }
   // The two MFMA waves of a SIMD (w, w + 4) compete for its matrix and VALU pipes; arbitration is by priority, then age.
   // Left at equal priority the younger wave gets the leftovers and finishes its blocks 40 % later (10.0k against 7.0k
   // clocks per tile, and the tile takes as long as the slower one; a constant higher priority for the younger half just
@@ -200,7 +302,8 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
   const int a_lane = kq * CS + (2 * rp) * WC + 16 * mw + m + 3;
   const int w_lane = OFF_W / 16 + lane;
 #ifdef DRBA_EXP_CLOCKS
-  long long clk_acc[5] = {0, 0, 0, 0, 0};
+  long long clk_acc[5] = {0, 0, 0, 0, 0}, first_barrier = 0;
+  const long long k_start = (long long)__builtin_readcyclecounter();
 #endif
 
   // per-lane epilogue constants: cout nt*16 + m
@@ -294,9 +397,13 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
   int ab = 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the weights (its only loads)
   while (true) {
-    const Item cur = decode(work);
     DRBA_CLK(t0);
     __builtin_amdgcn_s_barrier();  // barrier i (see the loader)
+    const int4 pub = *reinterpret_cast<const int4 *>(lds_idx + 4 * ab);
+    if (__builtin_amdgcn_readfirstlane(pub.w) < 0) break;
+    Item cur;
+    cur.x0 = __builtin_amdgcn_readfirstlane(pub.x), cur.y0 = __builtin_amdgcn_readfirstlane(pub.y);
+    cur.n = __builtin_amdgcn_readfirstlane(pub.z);
     DRBA_CLK(t1);
 #pragma unroll
     for (int o = 0; o < 2; ++o)
@@ -398,19 +505,22 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
       }
     }
     DRBA_CLK(t4);
+#ifdef DRBA_EXP_CLOCKS
+    if (clk_acc[4] == 0) first_barrier = t1 - t0;
+    else
+#endif
     DRBA_CLK_ADD(0, t0, t1);
     DRBA_CLK_ADD(1, t1, t2);
     DRBA_CLK_ADD(2, t2, t3);
     DRBA_CLK_ADD(3, t3, t4);
     DRBA_CLK_ADD(4, 0, 1);
-    work += (int)gridDim.x;
-    if (work >= total) break;
     ab ^= 1;
   }
 #ifdef DRBA_EXP_CLOCKS
-  if (blockIdx.x == 131 && lane == 0)
-    printf("wg %d wave %d: items %lld  barrier %lld  head %lld  blocks %lld  epilogue %lld (clocks per item)\n", (int)blockIdx.x,
-           wave, clk_acc[4], clk_acc[0] / clk_acc[4], clk_acc[1] / clk_acc[4], clk_acc[2] / clk_acc[4], clk_acc[3] / clk_acc[4]);
+  if ((blockIdx.x == 131 || blockIdx.x == 7) && lane == 0 && clk_acc[4] && (wave == 0 || wave == 5))
+    printf("wg %d wave %d: items %lld  barrier %lld  head %lld  blocks %lld  epilogue %lld (clocks per item)  first barrier %lld  total %lld\n",
+           (int)blockIdx.x, wave, clk_acc[4], clk_acc[0] / clk_acc[4], clk_acc[1] / clk_acc[4], clk_acc[2] / clk_acc[4],
+           clk_acc[3] / clk_acc[4], first_barrier, (long long)__builtin_readcyclecounter() - k_start);
 #endif
 #endif
 }
@@ -425,6 +535,30 @@ hipError_t lds_limit() {
   return e;
 }
 
+// The work counters of a launch: 8 ints, one per XCD band, zero when the launch starts.  Two sets per stream, used in
+// turn -- launches on one stream run one after the other, and each zeroes the set of its successor.  Allocated on a
+// stream's first launch (the library is driven from one host thread; the autotuner's first call of a layer is where
+// this happens).  mine: the set this launch counts in; next: the set it clears.
+bool counters_for(hipStream_t s, int *&mine, int *&next) {
+  struct Slot {
+    int *base;
+    unsigned parity;
+  };
+  static std::unordered_map<hipStream_t, Slot> tab;
+  auto it = tab.find(s);
+  if (it == tab.end()) {
+    int *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), 64) != hipSuccess) return false;
+    if (hipMemset(p, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+    it = tab.emplace(s, Slot{p, 0u}).first;
+  }
+  Slot &sl = it->second;
+  mine = sl.base + 8 * (sl.parity & 1u);
+  next = sl.base + 8 * ((sl.parity & 1u) ^ 1u);
+  sl.parity ^= 1u;
+  return true;
+}
+
 int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, const float *res2,
            float *out, int N, int H, int W, int Cout, int act, float post_slope, int pre_act, float pre_slope, hipStream_t s) {
   const int nbx = (W + TW - 1) / TW, nby = (H + TH - 1) / TH;
@@ -434,10 +568,12 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   if (grid > total) grid = (total + 7) / 8 * 8;
   dim3 g((unsigned)grid);
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(wpk);
+  int *counters = nullptr, *counters_next = nullptr;
+  if (!counters_for(s, counters, counters_next)) return DRBA_ELAUNCH;
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     DRBA_LAUNCH(kernel, g, dim3(NTHREADS), LDS_BYTES, s, in, wf, bias, beta, res, res2, out, H, W, Cout, act, post_slope,
-                pre_slope, nbx, nby, (int)total);
+                pre_slope, nbx, nby, (int)total, counters, counters_next);
     return DRBA_OK;
   };
   const bool rl = res && res == in && !res2 && !pre_act && Cout == CK;
