@@ -24,6 +24,16 @@ int conv_dma_launch(int id, const float *in, const float *packed_w, const float 
                     const float *residual, const float *residual2, float *out, int N, int Cin, int H, int W, int Cout,
                     int act, float post_slope, int pre_act, float pre_slope, void *stream);
 
+// the same per-wave program with the K dimension split across the waves of a workgroup, for multi-chunk layers on small
+// maps (conv_ks.hip); cfg ids follow the conv_dma family
+int conv_ks_num_cfgs();
+bool conv_ks_supports(int Cin, int Cout, int id);
+size_t conv_ks_packed_floats(int Cin, int Cout, int id);
+int conv_ks_pack(const float *w, float *packed, int Cin, int Cout, int id);
+int conv_ks_launch(int id, const float *in, const float *packed_w, const float *bias, const float *beta, const float *residual,
+                   const float *residual2, float *out, int N, int Cin, int H, int W, int Cout, int act, float post_slope,
+                   int pre_act, float pre_slope, void *stream);
+
 // transposed convolution 4x4 s2 p1 (cfg ids after conv.hip's fp32 deconv table)
 int deconv_split_num_cfgs();
 bool deconv_split_supports(int Cin, int Cout, int id);

@@ -128,7 +128,8 @@ int drba_conv3x3_num_cfgs(void);         /* configs are 0..num-1; a host may tim
 int drba_conv3x3_cfg_stride(int cfg);    /* the stride (1 or 2) a config was built for */
 /* kernel family of a config: 0 = fp32 MFMA (conv.hip), 1 = split-bf16 with register staging (conv_split.hip: stride 1,
  * Cin % 32 == 0), 2 = split-bf16 with every operand streamed by LDS-DMA (conv_dma.hip: additionally W % 4 == 0; the
- * launch returns DRBA_EUNSUPPORTED otherwise) */
+ * launch returns DRBA_EUNSUPPORTED otherwise: Cin == 32, Cout <= 32), 3 = split-bf16 with K split across the waves of a
+ * workgroup (conv_ks.hip: Cin = 64 / 96 / 128 / 192, small maps) */
 int drba_conv3x3_cfg_family(int cfg);
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg);
 int drba_conv3x3_pack(const float *w /*[Cout,Cin,3,3] host or device-visible*/, float *packed,

@@ -112,9 +112,13 @@ def check_conv_layers(dev):
     for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
         # (the LDS-DMA family: 32 input channels, at most 32 output channels, widths that are multiples of 4 -- its windows
         # move in 16-byte units -- still ragged in tiles)
-        dma = lib.drba_conv3x3_cfg_family(cfg) == 2
+        # the K-split family: 2 / 3 / 4 / 6 chunks of 32 input channels, any width (dword windows when it is not a multiple of 4)
+        fam = lib.drba_conv3x3_cfg_family(cfg)
+        dma = fam == 2
         shapes = (((1, 32, 24, 11, 44, "conv"), (2, 32, 32, 9, 72, "res"), (1, 32, 32, 5, 132, "pre"), (2, 32, 32, 19, 36, "res"),
                    (1, 32, 32, 8, 32, "conv")) if dma else
+                  ((1, 64, 40, 11, 45, "conv"), (2, 96, 32, 9, 70, "res"), (1, 64, 16, 5, 130, "pre"), (2, 64, 64, 19, 36, "res"),
+                   (2, 192, 192, 17, 30, "res"), (1, 128, 128, 7, 33, "res")) if fam == 3 else
                   ((1, 32, 40, 11, 45, "conv"), (2, 96, 32, 9, 70, "res"), (1, 64, 16, 5, 130, "pre"), (2, 64, 64, 19, 36, "res")))
         for (nb, cin, cout, h, w, kind) in shapes:
             try:
