@@ -109,6 +109,9 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip extra_configs / pcie_inclusive (configs 3-5 at N = 1)")
     p.add_argument("--no-lookahead", action="store_true", help="do not overlap the next step's coarse flow (A/B runs)")
+    p.add_argument("--conv-families", default=None,
+                   help="A/B runs: comma-separated kernel families the conv autotuner may pick from (0 fp32 MFMA, 1 split-bf16, "
+                        "2 LDS-DMA 32-channel, 3 K-split); default all")
     p.add_argument("--selftest-sharded", action="store_true",
                    help="N = 1 only: run the N > 1 legs' code (sharded warm-up + sharded run of the headline clip and of the "
                         "config-5 clip) on one GPU without a process group and print their rates; not the metric")
@@ -712,6 +715,9 @@ def describe_job(rank, world, r):
 
 def main():
     args = parse()
+    if args.conv_families is not None:
+        from drba_amd import ops as _ops
+        _ops.CONV_FAMILIES = {int(x) for x in args.conv_families.split(",")}
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -318,6 +318,9 @@ def ssim_thumb32(x1, x2):
 # first call for a new layer shape times every configuration built for that stride once on the device
 # and keeps the fastest ("measure, don't guess").  Results are shared by all layers of the same shape.
 AUTOTUNE = True
+# kernel families the autotuner may choose from (drba_conv3x3_cfg_family: 0 fp32 MFMA, 1 split-bf16 register staging, 2 LDS-DMA
+# 32-channel, 3 K-split); A/B runs narrow it (bench.py --conv-families)
+CONV_FAMILIES = {0, 1, 2, 3}
 _tuned = {}
 
 
@@ -390,6 +393,7 @@ class Conv3x3:
             cfg = self.force_cfg
         elif AUTOTUNE and x.is_cuda:
             cands = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_stride(c) == self.stride
+                     and lib.drba_conv3x3_cfg_family(c) in CONV_FAMILIES
                      and lib.drba_conv3x3_packed_floats(self.cin, self.cout, c) > 0]  # 0: the config cannot run this layer
             cfg = _tune(("conv3x3", n, cin, self.cout, h, w, self.stride), cands, lambda c: lib.drba_conv3x3(
                 _p(x), _p(self._pack(c)), _p(self.bias), _p(self.beta), _p(res), _p(res2), _p(out), n, cin, h, w,
