@@ -879,8 +879,8 @@ class LinearSplit:
         lead, x2 = x.shape[:-1], self._rows(x)
         m = x2.shape[0]
         out = torch.empty((m, self.n), dtype=torch.float32, device=x2.device)
-        _lib.check(_lib.load().drba_linear_split(_p(x2), _p(self.packed), _p(self.bias), _p(out), m, self.k, self.n,
-                                                 x2.stride(0), self.gelu, _stream()), "drba_linear_split")
+        _lib.check(_timed("linear_split", (m, self.k, self.n, self.gelu), 2.0 * m * self.k * self.n, "flop", lambda: _lib.load().drba_linear_split(
+            _p(x2), _p(self.packed), _p(self.bias), _p(out), m, self.k, self.n, x2.stride(0), self.gelu, _stream())), "drba_linear_split")
         return out.view(*lead, self.n)
 
     def cat(self, x1, x2):
@@ -896,8 +896,9 @@ class LinearSplit:
         self.k = keep
         m = a.shape[0]
         out = torch.empty((m, self.n), dtype=torch.float32, device=a.device)
-        _lib.check(_lib.load().drba_linear_split_cat(_p(a), _p(b), _p(self.packed), _p(self.bias), _p(out), m, k1, k2, self.n,
-                                                     a.stride(0), b.stride(0), self.gelu, _stream()), "drba_linear_split_cat")
+        _lib.check(_timed("linear_split_cat", (m, k1, k2, self.n, self.gelu), 2.0 * m * (k1 + k2) * self.n, "flop",
+                          lambda: _lib.load().drba_linear_split_cat(_p(a), _p(b), _p(self.packed), _p(self.bias), _p(out), m, k1, k2, self.n,
+                                                                    a.stride(0), b.stride(0), self.gelu, _stream())), "drba_linear_split_cat")
         return out.view(*lead, self.n)
 
     def layernorm(self, x, ln_w, ln_b, residual=None, eps=1e-5):
@@ -907,8 +908,10 @@ class LinearSplit:
         m = x2.shape[0]
         res = None if residual is None else _f32(residual)
         out = torch.empty((m, 128), dtype=torch.float32, device=x2.device)
-        _lib.check(_lib.load().drba_linear_split_layernorm(_p(x2), _p(self.packed), _p(self.bias), _p(_f32(ln_w)), _p(_f32(ln_b)),
-                                                           _p(res), _p(out), m, self.k, x2.stride(0), float(eps), _stream()),
+        lw, lb = _f32(ln_w), _f32(ln_b)
+        _lib.check(_timed("linear_split_layernorm", (m, self.k, 128), 2.0 * m * self.k * 128, "flop",
+                          lambda: _lib.load().drba_linear_split_layernorm(_p(x2), _p(self.packed), _p(self.bias), _p(lw), _p(lb),
+                                                                          _p(res), _p(out), m, self.k, x2.stride(0), float(eps), _stream())),
                    "drba_linear_split_layernorm")
         return out.view(*lead, 128)
 
@@ -931,8 +934,11 @@ def window_attention(q, k, v, h, w, splits, shift, scale):
     lib = _lib.load()
     nws = lib.drba_window_attention_ws_floats(b, h, w, int(splits))
     ws = _workspace(q.device, nws) if nws else None
-    _lib.check(lib.drba_window_attention(_p(q), _p(k), _p(v), _p(out), b, h, w, c, int(splits), int(bool(shift)),
-                                         float(scale), ldq, ldk, ldv, _p(ws), _stream()), "drba_window_attention")
+    # QK^T and PV: 2 x 2 L^2 C FLOP per window of L = (h / splits)(w / splits) tokens, b * splits^2 windows
+    L = (h // int(splits)) * (w // int(splits))
+    _lib.check(_timed("window_attention", (b, h, w, c, int(splits), int(bool(shift))), 4.0 * b * int(splits) ** 2 * L * L * c, "flop",
+                      lambda: lib.drba_window_attention(_p(q), _p(k), _p(v), _p(out), b, h, w, c, int(splits), int(bool(shift)),
+                                                        float(scale), ldq, ldk, ldv, _p(ws), _stream())), "drba_window_attention")
     return out
 
 

@@ -30,6 +30,12 @@ python tools/pmc_targets.py > /dev/null 2>&1   # autotune / warm outside the cou
 (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $REPO/tools/pmc_targets.py > /dev/null 2> $OUT/pmc_fetch.err; echo "pmc fetch exit $?")
 (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $REPO/tools/pmc_targets.py > /dev/null 2> $OUT/pmc_write.err; echo "pmc write exit $?")
 cp gpurun_out/pmc_manifest.json $OUT/ 2>/dev/null
+# matrix-core utilisation of the same targets: its own pass (SQ counters only, no trace domains beside the kernel trace)
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o m -- python $REPO/tools/pmc_targets.py > /dev/null 2> $OUT/pmc_mfma.err; echo "pmc mfma exit $?")
+cp gpurun_out/pmc_manifest.json $OUT/pmc_manifest_mfma.json 2>/dev/null
+M=$(ls $OUT/pmc_mfma/*counter_collection.csv 2>/dev/null | head -1)
+[ -n "$M" ] && (cd tools && python pmc_mfma.py $M $OUT/pmc_manifest_mfma.json $OUT/mfma_util.md > /dev/null)
+rm -rf $OUT/pmc_mfma/*kernel_trace.csv
 F=$(ls $OUT/pmc_fetch/*counter_collection.csv 2>/dev/null | head -1); Wc=$(ls $OUT/pmc_write/*counter_collection.csv 2>/dev/null | head -1)
 if [ -n "$F" ] && [ -n "$Wc" ]; then
   python tools/pmc_traffic.py $F $Wc $OUT/pmc_manifest.json $OUT/pmc_traffic.md && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json

@@ -61,7 +61,7 @@ for s in (1.0, 2.0):
 tprev = torch.randn(2, 13, H // 8, W // 8, generator=g).to(dev)
 xin4 = torch.empty(2, 52, H // 4, W // 4, device=dev)
 target("stage input s=4, both frames of a step", lambda: ops.stage_inputs(items, flows2, tprev, 8.0, 4.0, xin4))
-for (c, h, w, n) in ((64, 136, 240, 2), (32, 272, 480, 2), (96, 68, 120, 2), (128, 34, 60, 2)):
+for (c, h, w, n) in ((64, 136, 240, 2), (32, 272, 480, 2), (96, 68, 120, 2), (128, 34, 60, 2), (192, 17, 30, 2), (32, 544, 960, 2)):
     x = torch.randn(n, c, h, w, generator=g).to(dev)
     layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, True, torch.ones(1, c, 1, 1), device=dev)
     out = torch.empty_like(x)
@@ -72,6 +72,20 @@ target("block4 conv0.0 52->16 s2 1088x1920 N2", lambda: conv00(x52))
 x32 = torch.randn(2, 32, 272, 480, generator=g).to(dev)
 last = ops.Deconv4x4(torch.randn(32, 52, 4, 4, generator=g) * 0.05, torch.zeros(52), pixel_shuffle=True, device=dev)
 target("block4 lastconv 32->52 deconv + PixelShuffle 272x480 N2", lambda: last(x32))
+# GMFSS_UNION's matrix-core kernels at 1080p (1152x1920 -> 576x960 working resolution, GMFlow at 1/8: 72x120 = 8640 tokens,
+# fine scale 144x240 = 34560 tokens x 2 directions): fused window attention, the MLP's 256 -> 1024 linear, GridNet's
+# full-resolution 32-channel layer
+if os.environ.get("DRBA_PMC_GMFSS", "1") == "1":
+    qkv = torch.randn(2, 144 * 240, 384, generator=g).to(dev)
+    target("GMFlow window attention, fine scale (2 x 34560 tokens, 8x8 windows, C = 128)",
+           lambda: ops.window_attention(qkv[..., 0:128], qkv[..., 128:256], qkv[..., 256:384], 144, 240, 8, True, 128 ** -0.5), pick=0)
+    lin = ops.LinearSplit(torch.randn(1024, 256, generator=g) * 0.05, torch.zeros(1024), gelu=True, device=dev)
+    xt = torch.randn(2 * 144 * 240, 256, generator=g).to(dev)
+    target("transformer MLP 256 -> 1024 + GELU, 69120 tokens", lambda: lin(xt))
+    xg = torch.randn(1, 32, 1152, 1920, generator=g).to(dev)
+    grid = ops.Conv3x3(torch.randn(32, 32, 3, 3, generator=g) * 0.05, torch.zeros(32), 1, "prelu", None, device=dev, pre_slope=0.25, post_slope=0.25)
+    og = torch.empty_like(xg)
+    target("GridNet 32 -> 32 at 1152x1920 (PReLU pre-activation)", lambda: grid(xg, out=og))
 torch.cuda.synchronize()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(manifest, open(os.path.join(ROOT, "gpurun_out", "pmc_manifest.json"), "w"), indent=1)
