@@ -218,8 +218,22 @@ def _peak(name, unit):
     return FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma", "dense fp32 MFMA"
 
 
-def roofline_from_trace(recs, n_steps, traffic=None):
-    """recs: ops.trace_end() records of `n_steps` instrumented steps.  Ranks kernel symbols by total time."""
+def _symbol_totals(recs, n_steps):
+    """{symbol: (ms per step, launches per step, mean us)} of a block of traced steps."""
+    acc = {}
+    for r in recs or []:
+        a = acc.setdefault(r["name"], [0.0, 0])
+        a[0] += r["ms"]
+        a[1] += 1
+    return {k: (v[0] / n_steps, v[1] / n_steps, v[0] / v[1] * 1e3) for k, v in acc.items()}
+
+
+def roofline_from_trace(recs, n_steps, traffic=None, serial=None):
+    """recs: ops.trace_end() records of `n_steps` instrumented steps of the loop as it is timed (three streams).
+    serial: _symbol_totals of the same steps run on ONE stream (no lookahead, no prefetch): a kernel's duration there is its
+    own execution -- in the three-stream loop a launch of a small side-stream kernel also spans the time its workgroups wait
+    for a CU that the main stream's kernels hold (a 17 us layer reads 59 us), so the symbols are RANKED by their
+    single-stream time per step when that is available, and both durations are reported."""
     if not recs or n_steps <= 0:
         return None
     agg = {}
@@ -236,7 +250,10 @@ def roofline_from_trace(recs, n_steps, traffic=None):
             g[1] += 1
             g[2] += r["work"]
     total_ms = sum(a["ms"] for a in agg.values())
-    ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+    if serial:
+        ranked = sorted(agg.items(), key=lambda kv: -(serial.get(kv[0], (0.0, 0, 0))[0]))
+    else:
+        ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
 
     def entry(name, a, with_geo):
         e = {"kernel": name, "launches_per_step": round(a["n"] / n_steps, 2), "avg_us": round(a["ms"] / a["n"] * 1e3, 2),
@@ -251,6 +268,10 @@ def roofline_from_trace(recs, n_steps, traffic=None):
             e.update({"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                       "algorithmic_per_launch": a["work"] / a["n"], "peak_basis": basis,
                       "traffic": (round(sum(tr[lab] * g[1] for lab, g in a["geo"].items()) / a["n"]) if known and tr else None)})
+            if serial and name in serial:
+                sm, sn, su = serial[name]
+                e["serial_avg_us"], e["serial_ms_per_step"] = round(su, 2), round(sm, 4)
+                e["frac_serial"] = round(a["work"] / a["n"] / (su * 1e-6) / (1e9 if a["unit"] == "byte" else 1e12) / peak, 4)
             if with_geo:
                 e["by_geometry"] = [
                     {"launch": lab, "launches_per_step": round(g[1] / n_steps, 2), "avg_us": round(g[0] / g[1] * 1e3, 2),
@@ -282,6 +303,9 @@ def roofline_from_trace(recs, n_steps, traffic=None):
             roof["avg_concurrency"] = round(total_ms / span, 2)
     roof["kernels_per_step"] = round(len(recs) / n_steps, 1)
     roof["instrumented_steps"] = n_steps
+    roof["ranked_by"] = "single-stream kernel time per step" if serial else "in-step kernel time per step"
+    if serial:
+        roof["serial_step_kernels_ms"] = round(sum(v[0] for v in serial.values()), 3)
     return roof
 
 
@@ -368,7 +392,7 @@ def _quiet_gc():
     gc.freeze()
 
 
-def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False):
+def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False, settle=True):
     """The N = 1 loop of the module docstring over `frames` (sequence of uint8 HWC frames: device tensors, or -- with
     pcie=True -- pinned host tensors with the outputs copied back to pinned host buffers).
     -> (seconds for args.steps steps, host-side enqueue seconds, trace records, instrumented steps)."""
@@ -403,25 +427,32 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
     prefetch_pair = getattr(model, "prefetch_pair", None) if lookahead else None
 
     def step():
-        # the driver reads ahead (as drba_amd.infer.interpolate_stream does): the next step's coarse flow and
-        # low-resolution stages overlap this step's interpolation on a side stream, and the frame after that has its
-        # context encoder started on a third one; every frame is still converted / encoded exactly once, one per step
+        # the driver reads ahead (as drba_amd.infer.interpolate_stream does): the next steps' frames are converted -- and
+        # their context encoders and coarse flows started on a third stream -- three frames ahead, the model is told the
+        # frames and timesteps of the next iterations (it computes two consecutive steps in one stacked pass and stages the
+        # low-resolution part of the pair after them on a side stream); every frame is still converted / encoded exactly
+        # once, one per step, and K timed steps contain K steps of work
         I2 = state.pop("next", None)
         if I2 is None:
             I2 = to_inp(state["k"])
-        nxt = state.pop("next2", None)
-        if nxt is None and lookahead:
-            nxt = to_inp(state["k"] + 1)
-        if prefetch is not None:
-            state["next2"] = to_inp(state["k"] + 2)
-            prefetch(state["next2"])
-            if prefetch_pair is not None and nxt is not None:
-                prefetch_pair(nxt, state["next2"])  # the pair the next step's lookahead starts from
-        out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True,
-                                                      lookahead=None if nxt is None else (nxt, TS))
+        ahead = state.setdefault("ahead", [])  # frames k+1, k+2, k+3 (network inputs)
+        if lookahead:
+            while len(ahead) < (3 if prefetch is not None else 1):
+                x = to_inp(state["k"] + 1 + len(ahead))
+                if prefetch is not None:
+                    prefetch(x)
+                    if prefetch_pair is not None:
+                        prefetch_pair(ahead[-1] if ahead else I2, x)
+                ahead.append(x)
+        look = None
+        if ahead:
+            look = (ahead[0], TS)
+            if len(ahead) >= 3:
+                look = look + (ahead[1], TS, ahead[2], TS)
+        out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True, lookahead=look)
         res = [to_out(x) for x in out]
         state["I0"], state["I1"] = state["I1"], I2
-        state["next"] = nxt
+        state["next"] = ahead.pop(0) if ahead else None
         state["k"] += 1
         return res
 
@@ -431,7 +462,7 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False)
     # whose first GPU process this is, three steps do not reach the steady state: the first ~30 steps enqueue at 3.5 ms
     # each instead of 1.0 ms (allocator growth, first touches) and a 20-step timed region started there reads 508 instead
     # of 670 frames/s (profiles/README.md).  So the untimed warm-up goes on for kSettleSeconds of steps.
-    t_settle, settled = time.perf_counter() + kSettleSeconds, 0
+    t_settle, settled = time.perf_counter() + (kSettleSeconds if settle else 0.0), 0
     while time.perf_counter() < t_settle:
         step()
         settled += 1
@@ -591,7 +622,18 @@ def gpu_leg(args, rank, world):
     dt, t_host, recs, traced, dst = step_loop(model, frames, n_total, args, world, trace=not args.no_roofline)
     r["dst_size"] = dst
     r["settle_steps"] = LAST_SETTLE["steps"]
-    r["roofline"] = roofline_from_trace(recs, traced, _traffic_table()) if recs else None
+    serial = None
+    if recs and world == 1 and not args.no_lookahead:
+        # the same steps on ONE stream (no lookahead / prefetch), every launch traced: each kernel's own duration, the
+        # ranking of the symbols and what rocprofv3's table of this command should agree with
+        a1 = argparse.Namespace(**{**vars(args), "steps": 0, "warmup": 2, "no_lookahead": True})
+        _, _, recs1, traced1, _ = step_loop(model, frames, 2, a1, world, trace=True, settle=False)
+        serial = _symbol_totals(recs1, traced1) if recs1 else None
+        if serial and os.environ.get("DRBA_BENCH_SERIAL_TABLE"):  # the whole single-stream table (diagnostic)
+            inst = _symbol_totals(recs, traced)
+            for k, (ms, n, us) in sorted(serial.items(), key=lambda kv: -kv[1][0]):
+                log(f"serial {ms:7.4f} ms/step {n:5.1f} x {us:7.1f} us | in-step {inst.get(k, (0, 0, 0))[2]:7.1f} us | {k[:110]}")
+    r["roofline"] = roofline_from_trace(recs, traced, _traffic_table(), serial) if recs else None
     if world == 1:
         r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps})
         if r["roofline"] and r["roofline"].get("bound") == "mfma":

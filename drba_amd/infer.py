@@ -115,14 +115,27 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
         last[0] = x
         return raw, x
 
-    # with prefetch_frame the loop reads TWO frames ahead (same frames, same order, same outputs): (i3, I3) is the
-    # lookahead frame of this iteration, (i4, I4) only has its encoder started
+    # A model that can look ahead gets the loop reading THREE frames ahead (same frames, same order, same outputs): (i3, I3)
+    # is the lookahead frame of this iteration; a model that can (RIFE: `prefetch_frame`) has the encoder and the coarse flow
+    # of every frame started the moment it is read, and is told the frames and timesteps of the next iterations so that it
+    # may compute two consecutive steps in one stacked pass (RIFE._drba_pair): the next iteration then only collects.
+    depth = 3 if prefetch is not None else (1 if can_look else 0)
     i2, I2 = read()
-    i3, I3 = read() if i2 is not None else (None, None)
+    ahead = []  # [(raw, tensor)] of the frames after I2, oldest first
+    while len(ahead) < depth and not eof[0] and i2 is not None:
+        r, x = read()
+        if r is None:
+            break
+        ahead.append((r, x))
+    cut_next = None  # scene cut between I2 and the frame after it, when it was already evaluated
     while i2 is not None:
-        i4, I4 = read() if (prefetch is not None and i3 is not None) else (None, None)
+        I3 = ahead[0][1] if ahead else None
         ts = _tools.calc_t(idx, times, mapper)
-        cut_right = bool(check_scene(I1, I2, scdet_threshold)) if enable_scdet else False
+        if cut_next is not None:
+            cut_right = cut_next
+        else:
+            cut_right = bool(check_scene(I1, I2, scdet_threshold)) if enable_scdet else False
+        cut_next = None
         if cut_left and cut_right:
             out, reuse = [I1 for _ in ts], None
         elif cut_left:
@@ -134,14 +147,24 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
             out = model.inference_ts(I0, I1, ts[ts <= 1])
             out.extend([I1 for _ in ts[ts > 1] - 1])
         elif can_look and I3 is not None:
-            out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True,
-                                                 lookahead=(I3, _tools.calc_t(idx + 1, times, mapper)))
+            look = (I3, _tools.calc_t(idx + 1, times, mapper))
+            if prefetch is not None:
+                # the next iteration is a DRBA step too (no cut on its right): the model may take both in one pass
+                cut_next = bool(check_scene(I2, I3, scdet_threshold)) if enable_scdet else False
+                if not cut_next:
+                    I4 = ahead[1][1] if len(ahead) > 1 else None
+                    I5 = ahead[2][1] if len(ahead) > 2 else None
+                    look = look + (I4, _tools.calc_t(idx + 2, times, mapper), I5, _tools.calc_t(idx + 3, times, mapper))
+            out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=look)
         else:
             out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)
         emit(out, src_size)
         I0, I1 = I1, I2
-        i2, I2 = i3, I3
-        i3, I3 = (i4, I4) if prefetch is not None else read()
+        i2, I2 = ahead.pop(0) if ahead else (read() if depth == 0 else (None, None))
+        if depth and not eof[0]:
+            r, x = read()
+            if r is not None:
+                ahead.append((r, x))
         cut_left = cut_right
         idx += 1
         if on_step:

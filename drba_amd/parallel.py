@@ -83,8 +83,14 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
             cache[k] = to_inp(frames[k], dst_size)
         return cache[k]
 
-    def cut(k):  # scene cut between frame k and k+1
-        return bool(check_scene(inp(k), inp(k + 1), scdet_threshold)) if enable_scdet else False
+    cuts = {}
+
+    def cut(k):  # scene cut between frame k and k+1 (each pair is tested once: the loop looks one step ahead)
+        if not enable_scdet:
+            return False
+        if k not in cuts:
+            cuts[k] = bool(check_scene(inp(k), inp(k + 1), scdet_threshold))
+        return cuts[k]
 
     out = []
 
@@ -114,6 +120,7 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
     can_look = bool(getattr(model, "supports_lookahead", False))
     prefetch = getattr(model, "prefetch_frame", None) if can_look else None
     prefetch_pair = getattr(model, "prefetch_pair", None) if can_look else None
+    prefetched = set()
     for k in range(a, b):
         I0, I1, I2 = inp(k), inp(k + 1), inp(k + 2)
         ts = _tools.calc_t(k, times, mapper)
@@ -127,14 +134,23 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
             reuse = None
             res = list(model.inference_ts(I0, I1, ts[ts <= 1])) + [I1 for _ in ts[ts > 1] - 1]
         elif can_look and k + 1 < b and k + 3 < n:
-            # one-frame lookahead inside the shard (drba_amd/models/lookahead.py): frame k+3 is I2 of iteration k+1; the
-            # frame after it has its encoder and the coarse flow of the pair (k+3, k+4) -- what iteration k+1's lookahead
-            # starts from -- put on the prefetch stream, as the sequential driver does by reading two frames ahead
-            if prefetch is not None and k + 2 < b and k + 4 < n:
-                prefetch(inp(k + 4))
-                if prefetch_pair is not None:
-                    prefetch_pair(inp(k + 3), inp(k + 4))
-            res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=(inp(k + 3), _tools.calc_t(k + 1, times, mapper)))
+            # lookahead inside the shard (drba_amd/models/lookahead.py): frame k+3 is I2 of iteration k+1.  A model that can
+            # (RIFE) has the encoder and the coarse flow of every frame up to three ahead started on the prefetch stream, as
+            # the sequential driver does, and is told the next iterations' frames and timesteps: it computes iterations k and
+            # k+1 in one stacked pass when there is no cut on k+1's right (RIFE._drba_pair)
+            look = (inp(k + 3), _tools.calc_t(k + 1, times, mapper))
+            if prefetch is not None:
+                for j in range(k + 3, min(k + 5, b + 1, n - 1) + 1):
+                    if j not in prefetched:
+                        prefetched.add(j)
+                        prefetch(inp(j))
+                        if prefetch_pair is not None:
+                            prefetch_pair(inp(j - 1), inp(j))
+                if not cut(k + 2):
+                    I4 = inp(k + 4) if (k + 2 < b and k + 4 < n) else None
+                    I5 = inp(k + 5) if (k + 3 < b and k + 5 < n) else None
+                    look = look + (I4, _tools.calc_t(k + 2, times, mapper), I5, _tools.calc_t(k + 3, times, mapper))
+            res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=look)
         else:
             res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)
         emit(res)

@@ -6,7 +6,9 @@
  * operator surface.  Each entry point below replaces one reference
  * operator (or a fused group of them) and cites it.  Conventions for every function:
  *   - all pointers are DEVICE pointers to contiguous fp32 NCHW data unless noted;
- *   - caller owns all memory; the library never allocates, frees or synchronises;
+ *   - caller owns all memory; the library never allocates, frees or synchronises -- one exception (ABI version 2):
+ *     drba_conv3x3 with a family-2 configuration keeps 64 bytes of work counters per stream, allocated (hipMalloc +
+ *     hipMemset + one device synchronisation) on that stream's first such launch and never freed;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*), re-entrant across streams;
  *   - returns 0 on success or a negative DRBA_E* code (see drba_error_string);
  *   - `ws` arguments are caller-provided scratch of at least the documented size.
@@ -27,9 +29,10 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  2 (round 2 of this tree): drba_timing_* and drba_softmax_expect2 removed; drba_flow_reverse and
- * drba_drm_rife_linear take a workspace that must be ZERO on entry (they leave it zero on return: self-cleaning
- * accumulator) instead of clearing it themselves; batched stage entry points added.  1: the first release. */
+/* ABI version.  2: drba_timing_* and drba_softmax_expect2 removed; drba_flow_reverse and drba_drm_rife_linear take a
+ * workspace that must be ZERO on entry (they leave it zero on return: self-cleaning accumulator) instead of clearing it
+ * themselves; batched stage entry points added; drba_conv3x3_cfg_family added and configuration ids 19 (LDS-DMA, 32
+ * channels) / 20 (K split across waves) behind drba_conv3x3; the allocation exception above.  1: the first release. */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 

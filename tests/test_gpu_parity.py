@@ -293,3 +293,50 @@ def test_rife_many_timesteps_and_model_scale_above_one(hip_backend, oracle_backe
     plain = hip.inference_ts(g[0], g[1], list(np.linspace(0, 1, n_ts + 2)))
     pref = ora.inference_ts(fr[0], fr[1], list(np.linspace(0, 1, n_ts + 2)))
     assert max(float((a.cpu() - b).abs().max()) for a, b in zip(plain, pref)) <= 1e-3
+
+
+@pytest.mark.parametrize("ts_name", ("t2", "fps60"))
+def test_step_pairs_match_single_steps(hip_backend, ts_name):
+    """With the driver announcing three frames ahead, RIFE computes two consecutive DRBA steps in one stacked IFNet pass
+    (4 samples per launch), stages the low-resolution part of the NEXT pair on the side stream, and the second call of a
+    pair only collects its result.  Frames and the carried reuse state must equal the step-by-step computation (same
+    kernels on other batch sizes: the autotuner may pick another tiling for N = 4, hence 1e-5 instead of bit equality)."""
+    from drba_amd.utils import synth
+    sd = synth.ifnet_state_dict(seed=0)
+    H, W = 128, 192
+    base = cases.rife_frames(H, W)
+    g = torch.Generator().manual_seed(3)
+    frames = [f.to(hip_backend.dev) for f in base] + [torch.rand(1, 3, H, W, generator=g).to(hip_backend.dev) for _ in range(5)]
+    ts_seq = [np.array([0.75, 1.25])] * 16 if ts_name == "t2" else [np.array([0.6, 1.0, 1.4]), np.array([0.8, 1.2])] * 8
+
+    def run(pairs):
+        m = hip_backend.make_rife(sd, 1.0)
+        m.PAIR_STEPS = pairs
+        fr = [f.clone() for f in frames]  # fresh tensor objects: the caches are keyed by frame identity
+        for x in fr[2:5]:
+            m.prefetch_frame(x)
+        m.prefetch_pair(fr[2], fr[3])
+        m.prefetch_pair(fr[3], fr[4])
+        outs, reuse, collected = [], None, 0
+        for k in range(len(fr) - 2):
+            if k + 5 < len(fr):
+                m.prefetch_frame(fr[k + 5])
+                m.prefetch_pair(fr[k + 4], fr[k + 5])
+            look = None
+            if k + 3 < len(fr):
+                look = (fr[k + 3], ts_seq[k + 1])
+                if k + 4 < len(fr):
+                    look = look + (fr[k + 4], ts_seq[k + 2], fr[k + 5] if k + 5 < len(fr) else None, ts_seq[k + 3])
+            was_cached = m._pair_out is not None
+            o, reuse = m.inference_ts_drba(fr[k], fr[k + 1], fr[k + 2], ts_seq[k], reuse, True, lookahead=look)
+            collected += int(was_cached and m._pair_out is None)
+            outs += o
+        torch.cuda.synchronize()
+        return outs, reuse, collected
+
+    a, ra, n_pairs = run(True)
+    b, rb, none = run(False)
+    assert n_pairs >= 2 and none == 0, (n_pairs, none)  # pairs were formed (the first call is cold: reuse is None)
+    assert len(a) == len(b)
+    for x, y in zip(a + list(ra), b + list(rb)):
+        assert float((x - y).abs().max()) <= 1e-5
