@@ -109,6 +109,7 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip extra_configs / pcie_inclusive (configs 3-5 at N = 1)")
     p.add_argument("--no-lookahead", action="store_true", help="do not overlap the next step's coarse flow (A/B runs)")
+    p.add_argument("--group", type=int, default=None, help="A/B runs: RIFE.GROUP, consecutive steps per stacked IFNet pass (1: off)")
     p.add_argument("--conv-families", default=None,
                    help="A/B runs: comma-separated kernel families the conv autotuner may pick from (0 fp32 MFMA, 1 split-bf16, "
                         "2 LDS-DMA 32-channel, 3 K-split); default all")
@@ -429,15 +430,15 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
     def step():
         # the driver reads ahead (as drba_amd.infer.interpolate_stream does): the next steps' frames are converted -- and
         # their context encoders and coarse flows started on a third stream -- three frames ahead, the model is told the
-        # frames and timesteps of the next iterations (it computes two consecutive steps in one stacked pass and stages the
-        # low-resolution part of the pair after them on a side stream); every frame is still converted / encoded exactly
-        # once, one per step, and K timed steps contain K steps of work
+        # frames and timesteps of the next iterations (it computes RIFE.GROUP consecutive steps in one stacked pass and stages the
+        # low-resolution part of the group after them on a side stream); every frame is still converted / encoded exactly
+        # once, one per step, and K timed steps contain K steps of work (K a multiple of the group size: 20 = 5 x 4)
         I2 = state.pop("next", None)
         if I2 is None:
             I2 = to_inp(state["k"])
         ahead = state.setdefault("ahead", [])  # frames k+1, k+2, k+3 (network inputs)
         if lookahead:
-            while len(ahead) < (3 if prefetch is not None else 1):
+            while len(ahead) < (max(3, 2 * int(getattr(model, "GROUP", 1)) - 1) if prefetch is not None else 1):
                 x = to_inp(state["k"] + 1 + len(ahead))
                 if prefetch is not None:
                     prefetch(x)
@@ -447,8 +448,8 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
         look = None
         if ahead:
             look = (ahead[0], TS)
-            if len(ahead) >= 3:
-                look = look + (ahead[1], TS, ahead[2], TS)
+            if len(ahead) >= 3:  # (frame, ts) of the following steps: all of them DRBA steps (no scene detection in this loop)
+                look = tuple(v for x in ahead for v in (x, TS))
         out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True, lookahead=look)
         res = [to_out(x) for x in out]
         state["I0"], state["I1"] = state["I1"], I2
@@ -774,6 +775,9 @@ def describe_job(rank, world, r):
 
 def main():
     args = parse()
+    if args.group is not None:
+        from drba_amd.models.rife import RIFE as _R
+        _R.GROUP = int(args.group)
     if args.conv_families is not None:
         from drba_amd import ops as _ops
         _ops.CONV_FAMILIES = {int(x) for x in args.conv_families.split(",")}

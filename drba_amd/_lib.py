@@ -108,7 +108,7 @@ class StageItem(C.Structure):
                 ("tmp_prev", C.c_void_p), ("flow_out", C.c_void_p), ("out", C.c_void_p)]
 
 
-MAX_STAGE_ITEMS = 4  # DRBA_MAX_STAGE_ITEMS
+MAX_STAGE_ITEMS = 8  # DRBA_MAX_STAGE_ITEMS
 
 _lib = None
 

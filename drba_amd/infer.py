@@ -60,6 +60,8 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
     """
     to_inp = to_inp or _tools.to_inp
     to_out = to_out or _tools.to_out
+    # the library's own scene test can be asked for ahead of its use (tools.SceneChecks); an injected one is called in place
+    ahead_checks = _tools.SceneChecks(scdet_threshold) if (check_scene is None and enable_scdet) else None
     check_scene = check_scene or _tools.check_scene
     src_fps = video_io.src_fps
     if dst_fps <= src_fps:
@@ -108,6 +110,8 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
             eof[0] = True
             return None, None
         x = to_inp(raw, dst_size)
+        if ahead_checks is not None and x.is_cuda:
+            ahead_checks.submit((id(last[0]), id(x)), last[0], x)  # the cut test of this pair: needed up to three iterations later
         if prefetch is not None:
             prefetch(x)
             if prefetch_pair is not None:
@@ -115,11 +119,17 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
         last[0] = x
         return raw, x
 
+    def is_cut(a, b):
+        if ahead_checks is not None and a.is_cuda:
+            return ahead_checks.cut((id(a), id(b)), a, b)
+        return bool(check_scene(a, b, scdet_threshold))
+
     # A model that can look ahead gets the loop reading THREE frames ahead (same frames, same order, same outputs): (i3, I3)
     # is the lookahead frame of this iteration; a model that can (RIFE: `prefetch_frame`) has the encoder and the coarse flow
     # of every frame started the moment it is read, and is told the frames and timesteps of the next iterations so that it
-    # may compute two consecutive steps in one stacked pass (RIFE._drba_pair): the next iteration then only collects.
-    depth = 3 if prefetch is not None else (1 if can_look else 0)
+    # may compute several consecutive steps in one stacked pass (RIFE._drba_group): the next iterations then only collect.
+    group = int(getattr(model, "GROUP", 1)) if prefetch is not None else 1
+    depth = max(3, 2 * group - 1) if prefetch is not None else (1 if can_look else 0)
     i2, I2 = read()
     ahead = []  # [(raw, tensor)] of the frames after I2, oldest first
     while len(ahead) < depth and not eof[0] and i2 is not None:
@@ -134,7 +144,7 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
         if cut_next is not None:
             cut_right = cut_next
         else:
-            cut_right = bool(check_scene(I1, I2, scdet_threshold)) if enable_scdet else False
+            cut_right = is_cut(I1, I2) if enable_scdet else False
         cut_next = None
         if cut_left and cut_right:
             out, reuse = [I1 for _ in ts], None
@@ -149,12 +159,19 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
         elif can_look and I3 is not None:
             look = (I3, _tools.calc_t(idx + 1, times, mapper))
             if prefetch is not None:
-                # the next iteration is a DRBA step too (no cut on its right): the model may take both in one pass
-                cut_next = bool(check_scene(I2, I3, scdet_threshold)) if enable_scdet else False
-                if not cut_next:
-                    I4 = ahead[1][1] if len(ahead) > 1 else None
-                    I5 = ahead[2][1] if len(ahead) > 2 else None
-                    look = look + (I4, _tools.calc_t(idx + 2, times, mapper), I5, _tools.calc_t(idx + 3, times, mapper))
+                # the following iterations, as far as they are DRBA steps too (no cut up to the last frame named): the model may
+                # take them in one stacked pass with this one and stage the group after them
+                entries, prev = [], I2
+                for j, (_, x) in enumerate(ahead):
+                    c = is_cut(prev, x) if enable_scdet else False
+                    if j == 0:
+                        cut_next = c
+                    if c:
+                        break
+                    entries += [x, _tools.calc_t(idx + 1 + j, times, mapper)]
+                    prev = x
+                if len(entries) >= 4:
+                    look = tuple(entries)
             out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=look)
         else:
             out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)

@@ -201,77 +201,103 @@ class RIFE:
         got = self._look.take(a, b) if self._look is not None else None
         return got if got is not None else (self._pair_flow(a, b, fa), None)
 
-    PAIR_STEPS = True  # two consecutive steps per IFNet pass when the driver announces enough frames (class attribute: A/B runs)
-    _pair_out = None   # the second step of a pair, computed by the previous call: (I0, I1, I2, ts, reuse_in, outputs, reuse_out)
-    _look2 = None      # side-stream staging of the NEXT pair of steps
+    GROUP = 4          # consecutive steps per stacked IFNet pass when the driver announces enough frames (class attribute: A/B runs; 1: off)
+    _group_out = ()    # the later steps of a group, computed by an earlier call: [(I0, I1, I2, ts, reuse_in, outputs, reuse_out)]
+    _look2 = None      # side-stream staging of the NEXT group of steps
 
-    def _stage_pair(self, A, B, C, D, E, ts_c, ts_d, reuse_c):
-        """Side stream: the pair of steps after the one being computed -- (B, C, D) with ts_c and (C, D, E) with ts_d; reuse_c is
-        what the step (A, B, C) hands on.  Coarse flows of (C, D) and (D, E) (from prefetch_pair where the driver started
-        them), the four DRM maps and the first SIDE_STAGES IFNet stages of all their frames stacked."""
+    def _group_items(self, F, ts_list, reuse0, P):
+        """Work items of the steps (F[j], F[j+1], F[j+2]; ts_list[j]), j = 0 .. len(ts_list) - 1: P[j] = calc_flow(F[j+1], F[j+2]),
+        reuse0 what the step before the first one handed on.  -> (per-step outputs with placeholders, per-step item counts,
+        all items, per-step reuse: reuses[j] enters step j, reuses[j + 1] leaves it)."""
+        outs, counts, items, reuses = [], [], [], [reuse0]
+        for j, ts in enumerate(ts_list):
+            r, p = reuses[j], P[j]
+            o, it = self._items(F[j], F[j + 1], F[j + 2], ts, True, r[0], p[0], r[3], r[2], p[3])
+            outs.append(o)
+            counts.append(len(it))
+            items += it
+            reuses.append((p[1], p[0], p[3], p[2]))  # (flow21, flow12, f2, f1), reference rife.py:109
+        return outs, counts, items, reuses
+
+    def _stage_group(self, F, ts_list, reuse0):
+        """Side stream: the group of steps after the one being computed -- steps (F[j], F[j+1], F[j+2]; ts_list[j]).  Coarse
+        flows of the new frame pairs (from prefetch_pair where the driver started them), the DRM maps and the first
+        SIDE_STAGES IFNet stages of all their frames stacked."""
         if self._look2 is None:
             self._look2 = Lookahead()
+        n = len(ts_list)
 
         def work():
-            p_cd = self._pair_flow(C, D, reuse_c[2])       # (flow C->D, flow D->C, fC, fD)
-            p_de = self._pair_flow(D, E, p_cd[3])
-            out_a, items_a = self._items(B, C, D, ts_c, True, reuse_c[0], p_cd[0], reuse_c[3], reuse_c[2], p_cd[3])
-            out_b, items_b = self._items(C, D, E, ts_d, True, p_cd[1], p_de[0], p_cd[2], p_cd[3], p_de[3])
-            items = items_a + items_b
+            P, fa = [], reuse0[2]
+            for j in range(n):
+                P.append(self._pair_flow(F[j + 1], F[j + 2], fa))
+                fa = P[-1][3]
+            outs, counts, items, reuses = self._group_items(F, ts_list, reuse0, P)
             state = self.ifnet.forward_pairs(items, self.scale_list, 0, self.SIDE_STAGES) if items else None
-            return {"B": B, "C": C, "ts": (ts_c, ts_d), "flow10": reuse_c[0], "p_cd": p_cd, "p_de": p_de, "out": (out_a, out_b),
-                    "n_a": len(items_a), "items": items, "state": state}
-        self._look2.start(D, E, work, inputs=tuple(t for t in (B, C) + tuple(reuse_c) if t is not None))
+            return {"F": tuple(F), "ts": ts_list, "flow10": reuse0[0], "P": P, "outs": outs, "counts": counts, "items": items,
+                    "reuses": reuses, "state": state}
+        self._look2.start(F[n], F[n + 1], work, inputs=tuple(t for t in tuple(F[:n]) + tuple(reuse0) if t is not None))
 
-    def _drba_pair(self, I0, I1, I2, ts, reuse, I3, ts1, more):
-        """Steps (I0, I1, I2; ts) and (I1, I2, I3; ts1) in ONE stacked IFNet pass: the frames of two steps are 4 instead of 2
-        samples per launch -- 11 % less kernel time per frame at 1080p (the low-resolution stages are latency-bound: 18 %)
-        and half the launches.  Returns the first step's result and keeps the second for the next call.  `more` = (I4, ts2, I5,
-        ts3) or None: the frames of the pair after this one, whose low-resolution stages start on the side stream now."""
-        flow10, flow01, f1, f0 = reuse
-        staged = self._look2.take(I2, I3) if self._look2 is not None else None
-        if not (staged is not None and staged["B"] is I0 and staged["C"] is I1 and staged["flow10"] is flow10
-                and np.array_equal(staged["ts"][0], ts) and np.array_equal(staged["ts"][1], ts1)):
+    def _drba_group(self, F, ts_list, reuse, more):
+        """Steps (F[j], F[j+1], F[j+2]; ts_list[j]), j = 0 .. g - 1, in ONE stacked IFNet pass: the frames of g steps are 2 g instead
+        of 2 samples per launch -- at 1080p 11 % less kernel time per frame for g = 2 and 17 % for g = 4 (the low-resolution
+        stages are latency-bound: 18 % / 31 %), and 1 / g of the launches.  Returns the first step's result and keeps the others
+        for the next calls.  `more` = ([frames], [ts]) of the group after this one (its frames continue F), whose
+        low-resolution stages start on the side stream now, or None."""
+        g = len(ts_list)
+        staged = self._look2.take(F[g], F[g + 1]) if self._look2 is not None else None
+        if not (staged is not None and len(staged["ts"]) == g and all(a is b for a, b in zip(staged["F"], F))
+                and staged["flow10"] is reuse[0] and all(np.array_equal(a, b) for a, b in zip(staged["ts"], ts_list))):
             staged = None
         if staged is not None:
-            p12, p23 = staged["p_cd"], staged["p_de"]
+            P, outs, counts, items, reuses = (staged[k] for k in ("P", "outs", "counts", "items", "reuses"))
         else:
-            p12 = self._flow_pair(I1, I2, reuse[2])[0]
-            p23 = self._pair_flow(I2, I3, p12[3])
-        flow12, flow21, f1, f2 = p12
-        flow23, flow32, _, f3 = p23
-        reuse_a, reuse_b = (flow21, flow12, f2, f1), (flow32, flow23, f3, f2)
+            P = [self._flow_pair(F[1], F[2], reuse[2])[0]]
+            for j in range(1, g):
+                P.append(self._pair_flow(F[j + 1], F[j + 2], P[-1][3]))
+            outs, counts, items, reuses = self._group_items(F, ts_list, reuse, P)
         if more is not None:
-            self._stage_pair(I1, I2, I3, more[0], more[2], np.array(more[1], dtype=np.float64), np.array(more[3], dtype=np.float64), reuse_b)
+            self._stage_group(list(F[g:]) + list(more[0]), list(more[1]), reuses[g])
         if staged is not None:
-            (out_a, out_b), n_a, items = staged["out"], staged["n_a"], staged["items"]
             frames = self.ifnet.forward_pairs(items, self.scale_list, self.SIDE_STAGES, 5, staged["state"]) if items else []
         else:
-            out_a, items_a = self._items(I0, I1, I2, ts, True, flow10, flow12, f0, f1, f2)
-            out_b, items_b = self._items(I1, I2, I3, ts1, True, flow21, flow23, f1, f2, f3)
-            n_a, items = len(items_a), items_a + items_b
             frames = self.ifnet.forward_pairs(items, self.scale_list) if items else []
-        out_a = [frames[o] if isinstance(o, int) else o for o in out_a]
-        out_b = [frames[n_a + o] if isinstance(o, int) else o for o in out_b]
-        self._pair_out = (I1, I2, I3, ts1, reuse_a, out_b, reuse_b)
-        return out_a, reuse_a
+        res, base = [], 0
+        for j in range(g):
+            res.append([frames[base + o] if isinstance(o, int) else o for o in outs[j]])
+            base += counts[j]
+        self._group_out = [(F[j], F[j + 1], F[j + 2], ts_list[j], reuses[j], res[j], reuses[j + 1]) for j in range(1, g)]
+        return res[0], reuses[1]
 
     def inference_ts_drba(self, I0, I1, I2, ts, reuse=None, linear=False, lookahead=None):
         """reference rife.py:77-109.  `lookahead` (not in the reference): the frame that will be I2 of the next call,
         or (that frame, the next call's ts).  calc_flow(I2, next) -- and, when the timesteps are known, the DRM maps
         and the first SIDE_STAGES low-resolution IFNet stages of the next step -- run on a side stream under this
         call's full-resolution stages; the next call resumes from there if its arguments match.
-        (next, ts1, next2, ts2[, next3, ts3]) -- the driver reading further ahead -- lets this call compute the NEXT step
-        together with this one (_drba_pair): the next call then only collects its result."""
-        po, self._pair_out = self._pair_out, None
-        if (po is not None and reuse and po[0] is I0 and po[1] is I1 and po[2] is I2 and po[4][0] is reuse[0]
-                and np.array_equal(po[3], np.asarray(ts, dtype=np.float64))):
-            return po[5], po[6]  # the second step of the pair the previous call computed
-        if (self.PAIR_STEPS and linear and reuse and isinstance(lookahead, (tuple, list)) and len(lookahead) >= 4
-                and lookahead[0] is not None and I0.is_cuda):  # (4 or more entries = the driver vouches for the next step: no cut)
-            more = tuple(lookahead[2:6]) if len(lookahead) >= 6 and lookahead[2] is not None and lookahead[4] is not None else None
-            return self._drba_pair(I0, I1, I2, np.asarray(ts, dtype=np.float64), reuse, lookahead[0],
-                                   np.asarray(lookahead[1], dtype=np.float64), more)
+        (next, ts1, next2, ts2, ...) -- the driver reading further ahead and vouching that the calls it announces are plain DRBA
+        steps -- lets this call compute the next GROUP - 1 steps together with this one (_drba_group): the following calls
+        then only collect their results."""
+        if self._group_out:
+            po, self._group_out = self._group_out[0], self._group_out[1:]
+            if (reuse and po[0] is I0 and po[1] is I1 and po[2] is I2 and po[4][0] is reuse[0]
+                    and np.array_equal(po[3], np.asarray(ts, dtype=np.float64))):
+                return po[5], po[6]  # a later step of the group an earlier call computed
+            self._group_out = ()     # another call pattern than announced: what was computed ahead is dropped
+        if self.GROUP > 1 and linear and reuse and isinstance(lookahead, (tuple, list)) and len(lookahead) >= 4 and I0.is_cuda:
+            # (frame, ts) of the following calls; two or more entries = the driver vouches that all of them are plain DRBA steps
+            # (no scene cut up to the last frame it names); one entry alone is the one-step lookahead below
+            ahead = []
+            for j in range(0, len(lookahead) - 1, 2):
+                if lookahead[j] is None or lookahead[j + 1] is None:
+                    break
+                ahead.append((lookahead[j], np.asarray(lookahead[j + 1], dtype=np.float64)))
+            g = min(self.GROUP, len(ahead) + 1)  # a group of g steps needs the entries of the g - 1 calls after this one
+            if g >= 2 and len(ahead) >= 2:
+                F = [I0, I1, I2] + [a[0] for a in ahead[:g - 1]]
+                ts_list = [np.asarray(ts, dtype=np.float64)] + [a[1] for a in ahead[:g - 1]]
+                rest = ahead[g - 1:]
+                more = ([a[0] for a in rest[:g]], [a[1] for a in rest[:g]]) if len(rest) >= g else None
+                return self._drba_group(F, ts_list, reuse, more)
         flow10, flow01, f1, f0 = self.calc_flow(I1, I0) if not reuse else reuse
         (flow12, flow21, f1, f2), staged = self._flow_pair(I1, I2, None if reuse is None else reuse[2])
         nxt, ts_nxt = split_lookahead(lookahead)

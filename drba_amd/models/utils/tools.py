@@ -88,6 +88,37 @@ def check_scene(x1, x2, scdet_threshold=0.3):
     return _ops.ssim_thumb32(x1, x2) < scdet_threshold
 
 
+class SceneChecks:
+    """check_scene for frame pairs announced ahead of their use (not in the reference, same decisions): submit(key, x1, x2)
+    enqueues the test when the driver has both frames, cut(key, x1, x2) returns the bool -- waiting only for that test's own
+    event -- and remembers it (the drivers ask for the same pair in several iterations).  `key` identifies the pair for
+    the caller (frame indices, or object ids -- the entry keeps the frames, so an id cannot be recycled while it is here);
+    the last 32 pairs are kept."""
+
+    def __init__(self, scdet_threshold=0.3):
+        self.thr, self.pending, self.done = scdet_threshold, {}, {}
+
+    def submit(self, key, x1, x2):
+        if key not in self.pending and key not in self.done:
+            self.pending[key] = (_ops.ssim_thumb32_async(x1, x2), x1, x2)
+
+    def cut(self, key, x1, x2):
+        d = self.done.get(key)
+        if d is not None and d[1] is x1 and d[2] is x2:
+            return d[0]
+        self.done.pop(key, None)
+        p = self.pending.pop(key, None)
+        if p is None or p[1] is not x1 or p[2] is not x2:
+            p = (_ops.ssim_thumb32_async(x1, x2), x1, x2)
+        (host, ev), _, _ = p
+        ev.synchronize()
+        res = float(host.item()) < self.thr
+        self.done[key] = (res, x1, x2)
+        while len(self.done) > 32:
+            self.done.pop(next(iter(self.done)))
+        return res
+
+
 # ----------------------------------------------------------------------------- timestep mapping
 class TMapper:
     """Maps a source-frame interval to the output timestamps that fall inside it (tools.py:120-134)."""

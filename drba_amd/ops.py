@@ -313,6 +313,21 @@ def ssim_thumb32(x1, x2):
     return float(out.item())
 
 
+def ssim_thumb32_async(x1, x2):
+    """The same metric without waiting for it: -> (pinned host tensor [1], event).  The driver asks for the test of a frame
+    pair when the second frame is READ -- three iterations before it branches on it -- and reads the value after
+    event.synchronize(): by then the two small kernels have long run, and the host no longer drains the whole queue of
+    synthesis kernels once per source frame to learn one float."""
+    a, b = resize_bilinear(x1, (32, 32)), resize_bilinear(x2, (32, 32))
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().drba_ssim3d_32(_p(a), _p(b), _p(out), _stream()), "drba_ssim3d_32")
+    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+    host.copy_(out, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(a.device))
+    return host, ev
+
+
 # ----------------------------------------------------------------------------- convolutions
 # Kernel-configuration choice.  The library's cost model gives a default; with AUTOTUNE on (default) the
 # first call for a new layer shape times every configuration built for that stride once on the device

@@ -67,6 +67,8 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
     function returns []."""
     to_inp = to_inp or _tools.to_inp
     to_out = to_out or _tools.to_out
+    # the library's own scene test can be asked for ahead of its use (tools.SceneChecks); an injected one is called in place
+    ahead_checks = _tools.SceneChecks(scdet_threshold) if (check_scene is None and enable_scdet) else None
     check_scene = check_scene or _tools.check_scene
     if dst_fps <= src_fps:
         raise ValueError(f"dst fps should be greater than src fps, but got dst_fps={dst_fps} and src_fps={src_fps}")
@@ -89,7 +91,10 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
         if not enable_scdet:
             return False
         if k not in cuts:
-            cuts[k] = bool(check_scene(inp(k), inp(k + 1), scdet_threshold))
+            if ahead_checks is not None and inp(k).is_cuda:
+                cuts[k] = ahead_checks.cut(k, inp(k), inp(k + 1))
+            else:
+                cuts[k] = bool(check_scene(inp(k), inp(k + 1), scdet_threshold))
         return cuts[k]
 
     out = []
@@ -121,6 +126,7 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
     prefetch = getattr(model, "prefetch_frame", None) if can_look else None
     prefetch_pair = getattr(model, "prefetch_pair", None) if can_look else None
     prefetched = set()
+    depth = max(3, 2 * int(getattr(model, "GROUP", 1)) - 1) if prefetch is not None else 1
     for k in range(a, b):
         I0, I1, I2 = inp(k), inp(k + 1), inp(k + 2)
         ts = _tools.calc_t(k, times, mapper)
@@ -140,16 +146,23 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
             # k+1 in one stacked pass when there is no cut on k+1's right (RIFE._drba_pair)
             look = (inp(k + 3), _tools.calc_t(k + 1, times, mapper))
             if prefetch is not None:
-                for j in range(k + 3, min(k + 5, b + 1, n - 1) + 1):
+                far = min(k + 2 + depth, b + 1, n - 1)  # last frame this shard may name: iteration b - 1 reads frame b + 1
+                for j in range(k + 3, far + 1):
                     if j not in prefetched:
                         prefetched.add(j)
+                        if ahead_checks is not None and j - 1 not in cuts:
+                            ahead_checks.submit(j - 1, inp(j - 1), inp(j))  # the cut test the iterations before j - 1 will ask for
                         prefetch(inp(j))
                         if prefetch_pair is not None:
                             prefetch_pair(inp(j - 1), inp(j))
-                if not cut(k + 2):
-                    I4 = inp(k + 4) if (k + 2 < b and k + 4 < n) else None
-                    I5 = inp(k + 5) if (k + 3 < b and k + 5 < n) else None
-                    look = look + (I4, _tools.calc_t(k + 2, times, mapper), I5, _tools.calc_t(k + 3, times, mapper))
+                # the following iterations of this shard, as far as they are DRBA steps too (no cut up to the last frame named)
+                entries = []
+                for j in range(k + 3, far + 1):  # entry: iteration j - 2, whose I2 is frame j
+                    if cut(j - 1):
+                        break
+                    entries += [inp(j), _tools.calc_t(j - 2, times, mapper)]
+                if len(entries) >= 4:
+                    look = tuple(entries)
             res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True, lookahead=look)
         else:
             res, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, linear=True)

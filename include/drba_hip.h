@@ -195,7 +195,7 @@ int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0
  * names its own frames / features / timestep / flow / previous head output / outputs (the fields have the meaning of the
  * arguments above; flow_out != NULL requests the fold); the items agree on which optional pointers are given.
  * n_items <= DRBA_MAX_STAGE_ITEMS. */
-#define DRBA_MAX_STAGE_ITEMS 4
+#define DRBA_MAX_STAGE_ITEMS 8
 typedef struct drba_stage_item {
   const float *img0, *img1, *f0, *f1, *f0_pair, *f1_pair, *timestep_map;
   float timestep_scalar;

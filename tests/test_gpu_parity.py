@@ -295,48 +295,53 @@ def test_rife_many_timesteps_and_model_scale_above_one(hip_backend, oracle_backe
     assert max(float((a.cpu() - b).abs().max()) for a, b in zip(plain, pref)) <= 1e-3
 
 
-@pytest.mark.parametrize("ts_name", ("t2", "fps60"))
-def test_step_pairs_match_single_steps(hip_backend, ts_name):
-    """With the driver announcing three frames ahead, RIFE computes two consecutive DRBA steps in one stacked IFNet pass
-    (4 samples per launch), stages the low-resolution part of the NEXT pair on the side stream, and the second call of a
-    pair only collects its result.  Frames and the carried reuse state must equal the step-by-step computation (same
-    kernels on other batch sizes: the autotuner may pick another tiling for N = 4, hence 1e-5 instead of bit equality)."""
+@pytest.mark.parametrize("ts_name,group", (("t2", 2), ("t2", 4), ("fps60", 4), ("fps60", 3)))
+def test_step_groups_match_single_steps(hip_backend, ts_name, group):
+    """With the driver announcing frames ahead, RIFE computes GROUP consecutive DRBA steps in one stacked IFNet pass (2 GROUP
+    samples per launch), stages the low-resolution part of the NEXT group on the side stream, and the later calls of a
+    group only collect their results.  Frames and the carried reuse state must equal the step-by-step computation (same
+    kernels on other batch sizes: the autotuner may pick another tiling for N = 8, hence 1e-5 instead of bit equality).
+    The clip ends inside a group and the driver's entries run out before it: partial groups, unstaged groups."""
     from drba_amd.utils import synth
     sd = synth.ifnet_state_dict(seed=0)
     H, W = 128, 192
     base = cases.rife_frames(H, W)
     g = torch.Generator().manual_seed(3)
-    frames = [f.to(hip_backend.dev) for f in base] + [torch.rand(1, 3, H, W, generator=g).to(hip_backend.dev) for _ in range(5)]
-    ts_seq = [np.array([0.75, 1.25])] * 16 if ts_name == "t2" else [np.array([0.6, 1.0, 1.4]), np.array([0.8, 1.2])] * 8
+    frames = [f.to(hip_backend.dev) for f in base] + [torch.rand(1, 3, H, W, generator=g).to(hip_backend.dev) for _ in range(11)]
+    ts_seq = [np.array([0.75, 1.25])] * 32 if ts_name == "t2" else [np.array([0.6, 1.0, 1.4]), np.array([0.8, 1.2])] * 16
 
-    def run(pairs):
+    def run(grp):
         m = hip_backend.make_rife(sd, 1.0)
-        m.PAIR_STEPS = pairs
+        m.GROUP = grp
+        depth = max(3, 2 * grp - 1)
         fr = [f.clone() for f in frames]  # fresh tensor objects: the caches are keyed by frame identity
-        for x in fr[2:5]:
-            m.prefetch_frame(x)
-        m.prefetch_pair(fr[2], fr[3])
-        m.prefetch_pair(fr[3], fr[4])
+        nf = len(fr)
+        for j in range(2, min(2 + depth + 1, nf)):
+            m.prefetch_frame(fr[j])
+            if j > 2:
+                m.prefetch_pair(fr[j - 1], fr[j])
         outs, reuse, collected = [], None, 0
-        for k in range(len(fr) - 2):
-            if k + 5 < len(fr):
-                m.prefetch_frame(fr[k + 5])
-                m.prefetch_pair(fr[k + 4], fr[k + 5])
+        for k in range(nf - 2):
+            j = k + 3 + depth
+            if j < nf:
+                m.prefetch_frame(fr[j])
+                m.prefetch_pair(fr[j - 1], fr[j])
+            ahead = list(range(k + 3, min(k + 3 + depth, nf)))
             look = None
-            if k + 3 < len(fr):
-                look = (fr[k + 3], ts_seq[k + 1])
-                if k + 4 < len(fr):
-                    look = look + (fr[k + 4], ts_seq[k + 2], fr[k + 5] if k + 5 < len(fr) else None, ts_seq[k + 3])
-            was_cached = m._pair_out is not None
+            if ahead:
+                look = (fr[ahead[0]], ts_seq[k + 1])
+                if len(ahead) >= 2:
+                    look = tuple(v for i, a in enumerate(ahead) for v in (fr[a], ts_seq[k + 1 + i]))
+            was_cached = len(m._group_out) > 0
             o, reuse = m.inference_ts_drba(fr[k], fr[k + 1], fr[k + 2], ts_seq[k], reuse, True, lookahead=look)
-            collected += int(was_cached and m._pair_out is None)
+            collected += int(was_cached)
             outs += o
         torch.cuda.synchronize()
         return outs, reuse, collected
 
-    a, ra, n_pairs = run(True)
-    b, rb, none = run(False)
-    assert n_pairs >= 2 and none == 0, (n_pairs, none)  # pairs were formed (the first call is cold: reuse is None)
+    a, ra, n_collected = run(group)
+    b, rb, none = run(1)
+    assert n_collected >= group and none == 0, (n_collected, none)  # groups were formed (the first call is cold: reuse is None)
     assert len(a) == len(b)
     for x, y in zip(a + list(ra), b + list(rb)):
         assert float((x - y).abs().max()) <= 1e-5
