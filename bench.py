@@ -469,6 +469,9 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
         settled += 1
         if settled % 8 == 0:
             torch.cuda.synchronize()
+    while getattr(model, "_group_out", ()):  # the timed region starts on a call that computes a group of steps, so that K calls
+        step()                                # hold ceil(K / GROUP) group computations whatever the phase of the settling loop was
+        settled += 1
     torch.cuda.synchronize()
     LAST_SETTLE["steps"] = settled
     _quiet_gc()
@@ -777,7 +780,8 @@ def main():
     args = parse()
     if args.group is not None:
         from drba_amd.models.rife import RIFE as _R
-        _R.GROUP = int(args.group)
+        _R.GROUP = abs(int(args.group))
+        _R.BATCH_COARSE = int(args.group) > 0  # (negative: groups without the batched coarse flows)
     if args.conv_families is not None:
         from drba_amd import ops as _ops
         _ops.CONV_FAMILIES = {int(x) for x in args.conv_families.split(",")}

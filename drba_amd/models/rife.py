@@ -82,6 +82,48 @@ class RIFE:
             _ops.pair_interleaved(f1)
         return flow01, flow10, f0, f1
 
+    def calc_flow_batch(self, pairs):
+        """calc_flow for several frame pairs [(a, b, fa, fb)] at once: block 0 runs ONCE over the stacked pairs (its 11 launches
+        are latency-bound on a 1/16-resolution map: four pairs cost little more than one), the flow reversal once over all
+        directions.  -> [(flow01, flow10, fa, fb)], the values calc_flow returns pair by pair."""
+        B = len(pairs)
+        _, _, H, W = pairs[0][0].shape
+        s = self.scale_list[0]
+        h, w = int(np.floor(H * (1.0 / s))), int(np.floor(W * (1.0 / s)))
+        xin = torch.empty((B, 39, h, w), dtype=torch.float32, device=pairs[0][0].device)
+        _ops.stage_inputs([(a, b, 0.5, fa, fb) for a, b, fa, fb in pairs], None, None, 1.0, s, xin, lds=False)
+        flow = _ops.flow_updates(self.ifnet.block[0].core(xin), [None] * B, H, W, s, whole=True)  # [B,4,H,W]
+        rev = _ops.flow_reverse(flow.reshape(2 * B, 2, H, W))
+        out = []
+        for k, (a, b, fa, fb) in enumerate(pairs):
+            if _ops.PAIR_FEATURES:
+                _ops.pair_interleaved(fa)
+                _ops.pair_interleaved(fb)
+            out.append((rev[2 * k:2 * k + 1], rev[2 * k + 1:2 * k + 2], fa, fb))
+        return out
+
+    def _group_flows(self, F, n, fa):
+        """calc_flow(F[j+1], F[j+2]) for j = 0 .. n-1 (fa: features of F[1] if known): taken from prefetch_pair where the driver
+        started it, the rest in one batched pass."""
+        P, todo = [None] * n, []
+        for j in range(n):
+            a, b = F[j + 1], F[j + 2]
+            c = getattr(b, "_drba_pairflow", None)
+            if c is not None and c[0]() is a and c[3] == id(self):
+                P[j] = self._pair_flow(a, b, None)
+            else:
+                todo.append(j)
+        if todo:
+            feats = {}
+            for j in todo:
+                for x in (F[j + 1], F[j + 2]):
+                    if id(x) not in feats:
+                        feats[id(x)] = fa if (x is F[1] and fa is not None) else self._encoded(x)
+            res = self.calc_flow_batch([(F[j + 1], F[j + 2], feats[id(F[j + 1])], feats[id(F[j + 2])]) for j in todo])
+            for j, r in zip(todo, res):
+                P[j] = r
+        return P
+
     def prefetch_frame(self, I):
         """Optional (not in the reference): start the context encoder of a frame the driver has just read -- it depends on
         nothing but the frame -- on its own HIP stream.  The lookahead's serial chain (encoder -> block0 -> flow reversal ->
@@ -111,6 +153,10 @@ class RIFE:
         the prefetch stream, behind the two frames' encoders.  With the driver reading two frames ahead this is the pair
         the NEXT call's lookahead starts from, so the lookahead stream's chain begins at the DRM maps."""
         if not a.is_cuda or getattr(b, "_drba_pairflow", None) is not None:
+            return
+        if self.GROUP > 1 and self.BATCH_COARSE:  # the coarse flows of a group's new pairs are made in ONE batched pass where the group is staged
+            self.prefetch_frame(a)
+            self.prefetch_frame(b)
             return
         self.prefetch_frame(a)
         self.prefetch_frame(b)
@@ -201,6 +247,7 @@ class RIFE:
         got = self._look.take(a, b) if self._look is not None else None
         return got if got is not None else (self._pair_flow(a, b, fa), None)
 
+    BATCH_COARSE = True  # with GROUP > 1: calc_flow of a group's new frame pairs in one batched pass (A/B runs)
     GROUP = 4          # consecutive steps per stacked IFNet pass when the driver announces enough frames (class attribute: A/B runs; 1: off)
     _group_out = ()    # the later steps of a group, computed by an earlier call: [(I0, I1, I2, ts, reuse_in, outputs, reuse_out)]
     _look2 = None      # side-stream staging of the NEXT group of steps
@@ -228,10 +275,7 @@ class RIFE:
         n = len(ts_list)
 
         def work():
-            P, fa = [], reuse0[2]
-            for j in range(n):
-                P.append(self._pair_flow(F[j + 1], F[j + 2], fa))
-                fa = P[-1][3]
+            P = self._group_flows(F, n, reuse0[2])
             outs, counts, items, reuses = self._group_items(F, ts_list, reuse0, P)
             state = self.ifnet.forward_pairs(items, self.scale_list, 0, self.SIDE_STAGES) if items else None
             return {"F": tuple(F), "ts": ts_list, "flow10": reuse0[0], "P": P, "outs": outs, "counts": counts, "items": items,
@@ -252,9 +296,8 @@ class RIFE:
         if staged is not None:
             P, outs, counts, items, reuses = (staged[k] for k in ("P", "outs", "counts", "items", "reuses"))
         else:
-            P = [self._flow_pair(F[1], F[2], reuse[2])[0]]
-            for j in range(1, g):
-                P.append(self._pair_flow(F[j + 1], F[j + 2], P[-1][3]))
+            got = self._look.take(F[1], F[2]) if self._look is not None else None  # a one-step lookahead of the call before
+            P = [got[0]] + self._group_flows(F[1:], g - 1, got[0][3]) if got is not None else self._group_flows(F, g, reuse[2])
             outs, counts, items, reuses = self._group_items(F, ts_list, reuse, P)
         if more is not None:
             self._stage_group(list(F[g:]) + list(more[0]), list(more[1]), reuses[g])

@@ -699,8 +699,9 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
     return [flow_out[k:k + 1] for k in range(B)] if fold else None
 
 
-def flow_updates(tmp, flows, H, W, scale):
-    """flow_k + up(tmp[k][:4]) * scale for every item of a stage in one launch -> list of [1,4,H,W] (slices of one tensor)."""
+def flow_updates(tmp, flows, H, W, scale, whole=False):
+    """flow_k + up(tmp[k][:4]) * scale for every item of a stage in one launch -> list of [1,4,H,W] (slices of one tensor;
+    whole=True: that [B,4,H,W] tensor itself)."""
     tmp = _f32(tmp)
     B, c, h, w = tmp.shape
     out = torch.empty((B, 4, H, W), dtype=torch.float32, device=tmp.device)
@@ -713,7 +714,7 @@ def flow_updates(tmp, flows, H, W, scale):
                       lambda: _lib.load().drba_ifblock_update_batch(C.cast(a_tmp, C.c_void_p), C.cast(a_in, C.c_void_p),
                                                                     C.cast(a_out, C.c_void_p), B, h, w, H, W, float(scale),
                                                                     _stream())), "drba_ifblock_update_batch")
-    return [out[k:k + 1] for k in range(B)]
+    return out if whole else [out[k:k + 1] for k in range(B)]
 
 
 def warp_blend_fold(img0, img1, flow_prev, tmp_last, scale):

@@ -154,6 +154,7 @@ def test_prefetched_encoder_matches_inline(hip_backend):
 
     def run(prefetch):
         m = hip_backend.make_rife(sd, 1.0)
+        m.GROUP = 1  # the one-step machinery (with groups of steps the coarse flows are made where a group is staged)
         frames = [f.clone() for f in fr]  # fresh tensor objects: the prefetch is keyed by frame identity
         outs, reuse = [], None
         if prefetch:
@@ -185,6 +186,7 @@ def test_prefetch_does_not_retain_frames(hip_backend):
     import gc
     from drba_amd.utils import synth
     m = hip_backend.make_rife(synth.ifnet_state_dict(seed=0), 1.0)
+    m.GROUP = 1
     dev = hip_backend.dev
     g = torch.Generator().manual_seed(5)
     base = [torch.rand(1, 3, 128, 192, generator=g).to(dev) for _ in range(4)]
