@@ -220,13 +220,18 @@ def _peak(name, unit):
 
 
 def _symbol_totals(recs, n_steps):
-    """{symbol: (ms per step, launches per step, mean us)} of a block of traced steps."""
+    """{symbol: (ms per step, launches per step, mean us, algorithmic work per ms or None)} of a block of traced steps.
+    The work rate is the block's OWN: a single-stream block launches 2 samples per kernel, the timed loop 8."""
     acc = {}
     for r in recs or []:
-        a = acc.setdefault(r["name"], [0.0, 0])
+        a = acc.setdefault(r["name"], [0.0, 0, 0.0, 0])
         a[0] += r["ms"]
         a[1] += 1
-    return {k: (v[0] / n_steps, v[1] / n_steps, v[0] / v[1] * 1e3) for k, v in acc.items()}
+        if r["work"] is not None:
+            a[2] += r["work"]
+            a[3] += 1
+    return {k: (v[0] / n_steps, v[1] / n_steps, v[0] / v[1] * 1e3, (v[2] / v[0] if v[3] == v[1] and v[0] > 0 else None))
+            for k, v in acc.items()}
 
 
 def roofline_from_trace(recs, n_steps, traffic=None, serial=None):
@@ -252,7 +257,7 @@ def roofline_from_trace(recs, n_steps, traffic=None, serial=None):
             g[2] += r["work"]
     total_ms = sum(a["ms"] for a in agg.values())
     if serial:
-        ranked = sorted(agg.items(), key=lambda kv: -(serial.get(kv[0], (0.0, 0, 0))[0]))
+        ranked = sorted(agg.items(), key=lambda kv: -(serial.get(kv[0], (0.0,))[0]))
     else:
         ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
 
@@ -270,9 +275,11 @@ def roofline_from_trace(recs, n_steps, traffic=None, serial=None):
                       "algorithmic_per_launch": a["work"] / a["n"], "peak_basis": basis,
                       "traffic": (round(sum(tr[lab] * g[1] for lab, g in a["geo"].items()) / a["n"]) if known and tr else None)})
             if serial and name in serial:
-                sm, sn, su = serial[name]
+                sm, sn, su, swork = serial[name]
                 e["serial_avg_us"], e["serial_ms_per_step"] = round(su, 2), round(sm, 4)
-                e["frac_serial"] = round(a["work"] / a["n"] / (su * 1e-6) / (1e9 if a["unit"] == "byte" else 1e12) / peak, 4)
+                e["serial_launches_per_step"] = round(sn, 2)
+                if swork is not None:  # the single-stream launches' own work over their own time
+                    e["frac_serial"] = round(swork * 1e3 / (1e9 if a["unit"] == "byte" else 1e12) / peak, 4)
             if with_geo:
                 e["by_geometry"] = [
                     {"launch": lab, "launches_per_step": round(g[1] / n_steps, 2), "avg_us": round(g[0] / g[1] * 1e3, 2),
@@ -635,7 +642,7 @@ def gpu_leg(args, rank, world):
         serial = _symbol_totals(recs1, traced1) if recs1 else None
         if serial and os.environ.get("DRBA_BENCH_SERIAL_TABLE"):  # the whole single-stream table (diagnostic)
             inst = _symbol_totals(recs, traced)
-            for k, (ms, n, us) in sorted(serial.items(), key=lambda kv: -kv[1][0]):
+            for k, (ms, n, us, _) in sorted(serial.items(), key=lambda kv: -kv[1][0]):
                 log(f"serial {ms:7.4f} ms/step {n:5.1f} x {us:7.1f} us | in-step {inst.get(k, (0, 0, 0))[2]:7.1f} us | {k[:110]}")
     r["roofline"] = roofline_from_trace(recs, traced, _traffic_table(), serial) if recs else None
     if world == 1:

@@ -51,27 +51,32 @@ ops.pair_interleaved(f0), ops.pair_interleaved(f1)  # made once, as in the pipel
 img2 = torch.rand(1, 3, H, W, generator=g).to(dev)
 f2 = torch.randn(1, 16, H, W, generator=g).to(dev)
 ops.pair_interleaved(f2)
-items = [(img1, img0, tmap, f1, f0), (img1, img2, tmap, f1, f2)]
+items2 = [(img1, img0, tmap, f1, f0), (img1, img2, tmap, f1, f2)]
 flows2 = [flow, (flow * 0.9).contiguous()]
-for s in (1.0, 2.0):
-    tprev = torch.randn(2, 13, int(H / (2 * s)), int(W / (2 * s)), generator=g).to(dev)
-    xin = torch.empty(2, 52, int(H / s), int(W / s), device=dev)
-    target(f"stage input s={s:.0f} with the folded flow update, both frames of a step",
-           lambda: ops.stage_inputs(items, flows2, tprev, 2 * s, s, xin, fold=True))
-tprev = torch.randn(2, 13, H // 8, W // 8, generator=g).to(dev)
-xin4 = torch.empty(2, 52, H // 4, W // 4, device=dev)
-target("stage input s=4, both frames of a step", lambda: ops.stage_inputs(items, flows2, tprev, 8.0, 4.0, xin4))
-for (c, h, w, n) in ((64, 136, 240, 2), (32, 272, 480, 2), (96, 68, 120, 2), (128, 34, 60, 2), (192, 17, 30, 2), (32, 544, 960, 2)):
-    x = torch.randn(n, c, h, w, generator=g).to(dev)
-    layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, True, torch.ones(1, c, 1, 1), device=dev)
-    out = torch.empty_like(x)
-    target(f"ResConv {c}->{c}ch {h}x{w} N{n}", lambda: layer(x, residual=x, out=out))
-x52 = torch.randn(2, 52, H, W, generator=g).to(dev)
-conv00 = ops.Conv3x3(torch.randn(16, 52, 3, 3, generator=g) * 0.05, torch.zeros(16), 2, True, None, device=dev)
-target("block4 conv0.0 52->16 s2 1088x1920 N2", lambda: conv00(x52))
-x32 = torch.randn(2, 32, 272, 480, generator=g).to(dev)
-last = ops.Deconv4x4(torch.randn(32, 52, 4, 4, generator=g) * 0.05, torch.zeros(52), pixel_shuffle=True, device=dev)
-target("block4 lastconv 32->52 deconv + PixelShuffle 272x480 N2", lambda: last(x32))
+# N = 2: the samples of one `-t 2` step (what a step-by-step driver launches); N = 8: a group of 4 steps (RIFE.GROUP, what
+# bench.py's loop launches) -- the launch label ends in N, so both geometries get their own row
+for n in (2, 8):
+    items, flows = items2 * (n // 2), flows2 * (n // 2)
+    for s in (1.0, 2.0):
+        tprev = torch.randn(n, 13, int(H / (2 * s)), int(W / (2 * s)), generator=g).to(dev)
+        xin = torch.empty(n, 52, int(H / s), int(W / s), device=dev)
+        target(f"stage input s={s:.0f} with the folded flow update, {n} samples",
+               lambda: ops.stage_inputs(items, flows, tprev, 2 * s, s, xin, fold=True))
+    tprev = torch.randn(n, 13, H // 8, W // 8, generator=g).to(dev)
+    xin4 = torch.empty(n, 52, H // 4, W // 4, device=dev)
+    target(f"stage input s=4, {n} samples", lambda: ops.stage_inputs(items, flows, tprev, 8.0, 4.0, xin4))
+    for (c, h, w) in ((64, 136, 240), (32, 272, 480), (96, 68, 120), (128, 34, 60), (192, 17, 30)) + (((32, 544, 960),) if n == 2 else ()):
+        x = torch.randn(n, c, h, w, generator=g).to(dev)
+        layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, True, torch.ones(1, c, 1, 1), device=dev)
+        out = torch.empty_like(x)
+        target(f"ResConv {c}->{c}ch {h}x{w} N{n}", lambda: layer(x, residual=x, out=out))
+    x52 = torch.randn(n, 52, H, W, generator=g).to(dev)
+    conv00 = ops.Conv3x3(torch.randn(16, 52, 3, 3, generator=g) * 0.05, torch.zeros(16), 2, True, None, device=dev)
+    target(f"block4 conv0.0 52->16 s2 1088x1920 N{n}", lambda: conv00(x52))
+    x32 = torch.randn(n, 32, 272, 480, generator=g).to(dev)
+    last = ops.Deconv4x4(torch.randn(32, 52, 4, 4, generator=g) * 0.05, torch.zeros(52), pixel_shuffle=True, device=dev)
+    target(f"block4 lastconv 32->52 deconv + PixelShuffle 272x480 N{n}", lambda: last(x32))
+    del x52, xin, x32
 # GMFSS_UNION's matrix-core kernels at 1080p (1152x1920 -> 576x960 working resolution, GMFlow at 1/8: 72x120 = 8640 tokens,
 # fine scale 144x240 = 34560 tokens x 2 directions): fused window attention, the MLP's 256 -> 1024 linear, GridNet's
 # full-resolution 32-channel layer
