@@ -113,6 +113,8 @@ def parse():
     p.add_argument("--conv-families", default=None,
                    help="A/B runs: comma-separated kernel families the conv autotuner may pick from (0 fp32 MFMA, 1 split-bf16, "
                         "2 LDS-DMA 32-channel, 3 K-split); default all")
+    p.add_argument("--no-stage-conv", action="store_true",
+                   help="A/B runs: the scale-1 stage input and conv0[0] as two kernels (ops.STAGE_CONV_FUSED = False)")
     p.add_argument("--selftest-sharded", action="store_true",
                    help="N = 1 only: run the N > 1 legs' code (sharded warm-up + sharded run of the headline clip and of the "
                         "config-5 clip) on one GPU without a process group and print their rates; not the metric")
@@ -789,6 +791,9 @@ def main():
         from drba_amd.models.rife import RIFE as _R
         _R.GROUP = abs(int(args.group))
         _R.BATCH_COARSE = int(args.group) > 0  # (negative: groups without the batched coarse flows)
+    if args.no_stage_conv:
+        from drba_amd import ops as _ops0
+        _ops0.STAGE_CONV_FUSED = False
     if args.conv_families is not None:
         from drba_amd import ops as _ops
         _ops.CONV_FAMILIES = {int(x) for x in args.conv_families.split(",")}

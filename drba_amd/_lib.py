@@ -66,6 +66,10 @@ SIGNATURES = {
     "drba_ifblock_input_lds": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _f, _p, _p, _i, _i, _i, _i, _f, _p]),
     "drba_ifblock_input_batch": (_i, [_p, _i, _i, _i, _f, _i, _i, _i, _i, _f, _p]),
     "drba_ifblock_input_lds_batch": (_i, [_p, _i, _i, _i, _f, _i, _i, _i, _i, _f, _p]),
+    "drba_stage_conv0_packed_floats": (_z, []),
+    "drba_stage_conv0_pack": (_i, [_p, _p]),
+    "drba_stage_conv0_supported": (_i, [_i, _i, _f, _f, _i]),
+    "drba_stage_conv0_batch": (_i, [_p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
     "drba_ifblock_update_batch": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "drba_warp_blend_fold": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
     "drba_pair_interleave": (_i, [_p, _p, _i, _i, _i, _p]),

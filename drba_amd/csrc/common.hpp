@@ -205,4 +205,13 @@ __device__ __forceinline__ Lerp lerp_src(int dst, float scale, int size) {
   return l;
 }
 
+// One bilinear upsample value from its four taps, each 1-D interpolation as fma(w0, a, w1 * b) -- the form ATen's
+// upsample kernels evaluate (established bit for bit on to_inp, ifnet_glue.hip).  Spelled out so that every kernel that
+// upsamples the previous head output (ifblock_input_lds, stage_conv0) produces the same bits.
+__device__ __forceinline__ float lerp2_fma(float wy0, float wy1, float wx0, float wx1, float p00, float p01, float p10, float p11) {
+  const float top = __fmaf_rn(wx0, p00, __fmul_rn(wx1, p01));
+  const float bot = __fmaf_rn(wx0, p10, __fmul_rn(wx1, p11));
+  return __fmaf_rn(wy0, top, __fmul_rn(wy1, bot));
+}
+
 }  // namespace drba

@@ -486,16 +486,15 @@ ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, 
   const Lerp a = lerp_src(Y, inv_prev_scale, hp), b = lerp_src(X, inv_prev_scale, wp);
   const int r0 = a.i0 - ry0, r1 = a.i1 - ry0, c0 = b.i0 - rx0, c1 = b.i1 - rx0;
   auto prev_up = [&](int c) -> float {
-    const float top = b.w0 * prev[c][r0][c0] + b.w1 * prev[c][r0][c1];
-    const float bot = b.w0 * prev[c][r1][c0] + b.w1 * prev[c][r1][c1];
-    return a.w0 * top + a.w1 * bot;
+    return lerp2_fma(a.w0, a.w1, b.w0, b.w1, prev[c][r0][c0], prev[c][r0][c1], prev[c][r1][c0], prev[c][r1][c1]);
   };
   float fls[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (FOLD) {
-      const float fd = prev_up(c) * prev_scale;  // ifblock_update: flow_in + up(tmp) * scale
-      fls[c] = flow ? flow[(size_t)c * P + q] + fd : fd;
+      // ifblock_update: flow_in + up(tmp) * scale -- product and sum rounded separately, as torch evaluates them
+      const float fd = __fmul_rn(prev_up(c), prev_scale);
+      fls[c] = flow ? __fadd_rn(flow[(size_t)c * P + q], fd) : fd;
       // scale <= 2: the sample points are the full-resolution pixels, each exactly once
       if (VS) {
         if (SINGLE) park(c, fls[c]);

@@ -56,6 +56,8 @@ class IFBlock:
         self.lastconv = _ops.Deconv4x4(g("lastconv.0.weight"), g("lastconv.0.bias"), pixel_shuffle=True, device=device)
         self.chain = _ops.ConvChain([(self.conv0_0, False), (self.conv0_1, False)] + [(rc, True) for rc in self.convblock]
                                     + [(self.lastconv, False)])
+        # the core after conv0[0], for the stage whose input gather and first convolution are one kernel (ops.stage_conv0)
+        self.chain_tail = _ops.ConvChain([(self.conv0_1, False)] + [(rc, True) for rc in self.convblock] + [(self.lastconv, False)])
 
     def core(self, x):
         """conv0 -> 8 x ResConv (lrelu(conv(x) * beta + x)) -> deconv + PixelShuffle: [N, 13, 4h, 4w]; one library call."""
@@ -155,20 +157,27 @@ class IFNet:
         for i in range(first, last):
             s = scale_list[i]
             h, w = int(np.floor(H * (1.0 / s))), int(np.floor(W * (1.0 / s)))
-            xin = torch.empty((B, 52 if i else 39, h, w), dtype=torch.float32, device=dev)
             lds = i > 0 and self._lds_ok(s, s_prev)
             fold = pending and lds and s <= 2
             # every item's glue kernel of a stage is ONE launch (blockIdx.y = item): these launches are latency-bound on the
             # small maps, and each one costs the gap a dependent dispatch waits for its predecessor
             if pending and not fold:
                 flows = _ops.flow_updates(tmp, flows, H, W, s_prev)
-            if fold:
-                flows = _ops.stage_inputs(items, flows, tmp, s_prev, s, xin, fold=True)
-            elif lds:
-                _ops.stage_inputs(items, flows, tmp, s_prev, s, xin)
+            if lds and s == 1 and _ops.stage_conv0_ok(self.block[i].conv0_0, H, W, s, s_prev):
+                # scale 1: the 52-channel stage input (435 MB per 1080p sample) is consumed by conv0[0] inside the kernel
+                # that gathers it and never written
+                y0, fl = _ops.stage_conv0(items, flows, tmp, s_prev, self.block[i].conv0_0, fold=fold)
+                flows = fl if fold else flows
+                tmp = self.block[i].chain_tail(y0)
             else:
-                _ops.stage_inputs(items, flows, tmp, s_prev, s, xin, lds=False)
-            tmp = self.block[i].core(xin)  # [B,13,H/s,W/s]: flow delta (4), mask (1), feat (8)
+                xin = torch.empty((B, 52 if i else 39, h, w), dtype=torch.float32, device=dev)
+                if fold:
+                    flows = _ops.stage_inputs(items, flows, tmp, s_prev, s, xin, fold=True)
+                elif lds:
+                    _ops.stage_inputs(items, flows, tmp, s_prev, s, xin)
+                else:
+                    _ops.stage_inputs(items, flows, tmp, s_prev, s, xin, lds=False)
+                tmp = self.block[i].core(xin)  # [B,13,H/s,W/s]: flow delta (4), mask (1), feat (8)
             s_prev = s
             # leave the update to the consumer if that one can fold it
             # (the final warp_blend_fold takes scale >= 1 only: with a model scale > 1 the last stage runs at s < 1 and

@@ -699,6 +699,60 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
     return [flow_out[k:k + 1] for k in range(B)] if fold else None
 
 
+STAGE_CONV_FUSED = True  # the scale-1 stage input and the IFBlock's first convolution in one kernel (bench.py --no-stage-conv: A/B)
+
+
+def stage_conv0_ok(conv, H, W, scale, prev_scale):
+    """Can drba_stage_conv0_batch replace stage_inputs(scale) + conv (the IFBlock's first convolution)?"""
+    return bool(STAGE_CONV_FUSED and PAIR_FEATURES and conv.cin == 52 and conv.stride == 2 and conv.act == 1 and conv.beta is None
+                and conv.pre_slope is None and conv.post_slope == 0.0
+                and _lib.load().drba_stage_conv0_supported(H, W, float(scale), float(prev_scale), conv.cout))
+
+
+def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False):
+    """The scale-1 stage input of every item fused with `conv` (52 -> 16, stride 2, LeakyReLU): stage_inputs(..., scale=1)
+    followed by conv(xin) without the 52-channel tensor (drba_stage_conv0_batch).  Returns (y0 [B,16,Ho,Wo], folded flows
+    or None)."""
+    B = len(items)
+    if B > _lib.MAX_STAGE_ITEMS:
+        raise _lib.DrbaHipError(f"stage_conv0: at most {_lib.MAX_STAGE_ITEMS} items per launch")
+    img0 = _f32(items[0][0])
+    _, _, H, W = img0.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dev = img0.device
+    if getattr(conv, "_stage_pack", None) is None:
+        lib = _lib.load()
+        buf = torch.empty(lib.drba_stage_conv0_packed_floats(), dtype=torch.float32)
+        _lib.check(lib.drba_stage_conv0_pack(C.c_void_p(conv.w_host.data_ptr()), C.c_void_p(buf.data_ptr())), "drba_stage_conv0_pack")
+        conv._stage_pack = buf.to(dev)
+    tmp_prev = _f32(tmp_prev)
+    hp, wp = tmp_prev.shape[2], tmp_prev.shape[3]
+    out = torch.empty((B, conv.cout, Ho, Wo), dtype=torch.float32, device=dev)
+    flow_out = torch.empty((B, 4, H, W), dtype=torch.float32, device=dev) if fold else None
+    arr = (_lib.StageItem * B)()
+    keep = []
+    for k, (i0, i1, t, f0, f1) in enumerate(items):
+        i0, i1, f0, f1 = _f32(i0), _f32(i1), _f32(f0), _f32(f1)
+        tmap, tsc = (None, float(t)) if not torch.is_tensor(t) else (_f32(t), 0.0)
+        fl = None if (flows is None or flows[k] is None) else _f32(flows[k])
+        f0p, f1p = pair_interleaved(f0), pair_interleaved(f1)
+        keep += [i0, i1, f0, f1, tmap, fl, f0p, f1p]
+        a = arr[k]
+        a.img0, a.img1, a.f0, a.f1, a.f0_pair, a.f1_pair = _ptr(i0), _ptr(i1), _ptr(f0), _ptr(f1), _ptr(f0p), _ptr(f1p)
+        a.timestep_map, a.timestep_scalar, a.flow = _ptr(tmap), tsc, _ptr(fl)
+        a.tmp_prev, a.flow_out, a.out = tmp_prev[k].data_ptr(), (None if flow_out is None else flow_out[k].data_ptr()), out[k].data_ptr()
+    # algorithmic bytes: 43 source channels read once per full-resolution point, the 16-channel quarter-size output (and the
+    # folded flow) written; 2 * 16 * 52 * 9 FLOP per output pixel ride along (50 us per 1080p sample at the fp32 MFMA peak,
+    # 53 us of HBM time: the byte roofline is the binding one)
+    nbytes = B * 4.0 * (43.0 * H * W + conv.cout * Ho * Wo + (4.0 * H * W if fold else 0.0))
+    bias = None if conv.bias is None else conv.bias.data_ptr()
+    _lib.check(_timed("stage_conv0" + ("+fold" if fold else ""), (52, conv.cout, H, W, B), nbytes, "byte",
+                      lambda: _lib.load().drba_stage_conv0_batch(C.cast(arr, C.c_void_p), B, hp, wp, float(prev_scale), H, W,
+                                                                 conv._stage_pack.data_ptr(), bias, _stream())),
+               "drba_stage_conv0_batch")
+    return out, ([flow_out[k:k + 1] for k in range(B)] if fold else None)
+
+
 def flow_updates(tmp, flows, H, W, scale, whole=False):
     """flow_k + up(tmp[k][:4]) * scale for every item of a stage in one launch -> list of [1,4,H,W] (slices of one tensor;
     whole=True: that [B,4,H,W] tensor itself)."""

@@ -206,6 +206,17 @@ int drba_ifblock_input_batch(const drba_stage_item_t *items, int n_items, int hp
                              int h, int w, float scale, void *stream);
 int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
                                  int h, int w, float scale, void *stream);
+/* The scale-1 stage input fused with the IFBlock's first convolution (IFNet_HDv3.py:85-88 followed by conv0[0] of :64-66,
+ * 52 -> 16 channels, stride 2, pad 1, LeakyReLU(0.2)): drba_ifblock_input_lds_batch(scale = 1) + drba_conv3x3(stride 2)
+ * in one kernel, the 52-channel stage input never reaches HBM (stage_conv.hip).  items[k].out is the CONVOLUTION's output
+ * [16, (H-1)/2+1, (W-1)/2+1]; f0_pair / f1_pair and tmp_prev are required; flow_out non-NULL folds the previous stage's
+ * flow update in exactly as drba_ifblock_input_lds_batch does.  prev_scale must be 2.  `packed_w`: device copy of
+ * drba_stage_conv0_pack's output (HOST function: w [16,52,3,3] and packed are host memory). */
+size_t drba_stage_conv0_packed_floats(void);
+int drba_stage_conv0_pack(const float *w, float *packed);
+int drba_stage_conv0_supported(int H, int W, float scale, float prev_scale, int Cout);
+int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
+                           const float *packed_w, const float *bias, void *stream);
 /* drba_ifblock_update for several items (arrays of n_items device pointers; flow_in may be NULL or hold NULLs). */
 int drba_ifblock_update_batch(const float *const *tmp, const float *const *flow_in, float *const *flow_out, int n_items,
                               int h, int w, int H, int W, float scale, void *stream);

@@ -252,6 +252,17 @@ def _glue_stage_rows(dev, g, D, H, W, scales):
                 tag = "no prior flow" if fprev is None else "prior flow"
                 rows.append((f"ifblock_input_lds + folded update s={s} ({tag}): flow_out", _diff(fo, fl2), 1e-5 * sp, ""))
                 rows.append((f"ifblock_input_lds + folded update s={s} ({tag}): stage input", _diff(got2, ref2), 1e-4, ""))
+                if s == 1.0:  # ... and fused with the IFBlock's first convolution (stage_conv.hip): conv0[0] of the reference on ref2
+                    wt, bs = torch.randn(16, 52, 3, 3, generator=g) / (52 * 9) ** 0.5, torch.randn(16, generator=g) * 0.1
+                    conv = ops.Conv3x3(wt, bs, 2, True, None, device=dev)
+                    refy = F.leaky_relu(F.conv2d(ref2.double(), wt.double(), bs.double(), stride=2, padding=1), 0.2).float()
+                    item = [(D(img0), D(img1), D(tmap), D(f0), D(f1))]
+                    assert ops.stage_conv0_ok(conv, H, W, s, sp)
+                    y, fo2 = ops.stage_conv0(item, [None if fprev is None else D(fprev)], D(tprev), sp, conv, fold=True)
+                    rows.append((f"stage_conv0 (stage input + conv0[0] fused) + folded update ({tag}): conv output", _diff(y, refy), 1e-4, ""))
+                    rows.append((f"stage_conv0 + folded update ({tag}): flow_out", _diff(fo2[0], fl2), 1e-5 * sp, ""))
+                    y, _ = ops.stage_conv0(item, [D(fl2.contiguous())], D(tprev), sp, conv, fold=False)
+                    rows.append((f"stage_conv0, finished flow given ({tag}): conv output", _diff(y, refy), 1e-4, ""))
         # update
         h, w = int(H / s), int(W / s)
         tmp = torch.randn(1, 13, h, w, generator=g)
@@ -272,7 +283,8 @@ def check_glue(dev):
     D = lambda t: t.to(dev)  # noqa: E731
     # 64x128: whole tiles at every scale down to 1/8 -> the vector-store form of ifblock_input_lds; 72x136: ragged tiles ->
     # the element-wise stores
-    for (H, W), scales in (((64, 128), (16.0, 8.0, 4.0, 2.0, 1.0, 32.0)), ((72, 136), (4.0, 2.0, 1.0))):
+    # 70x90 / 38x66: output tiles of the fused stage_conv0 cut by the border, output widths that are not multiples of 4
+    for (H, W), scales in (((64, 128), (16.0, 8.0, 4.0, 2.0, 1.0, 32.0)), ((72, 136), (4.0, 2.0, 1.0)), ((70, 90), (1.0,)), ((38, 66), (1.0,))):
         rows += _glue_stage_rows(dev, g, D, H, W, scales)
     H, W = 64, 128
     img0, img1 = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 3, H, W, generator=g)

@@ -52,6 +52,30 @@ def test_conv_weight_packing_layout(cin, cout, stride):
     assert np.array_equal(nz, np.sort(w.numpy().reshape(-1)))  # every weight exactly once
 
 
+def test_stage_conv0_weight_packing_and_argument_checks():
+    """stage_conv.hip: [group][tap][lane] fragments, lane = (cout = l & 15, slot = l >> 4), the 52 stage-input channels in
+    the order the gather emits them (IFNet_HDv3.py:85-88 concatenation order as the channel index)."""
+    lib = _lib.load()
+    n = lib.drba_stage_conv0_packed_floats()
+    assert n == 13 * 9 * 64
+    w = torch.arange(16 * 52 * 9, dtype=torch.float32).reshape(16, 52, 3, 3) + 1
+    buf = torch.full((n,), -1.0)
+    assert lib.drba_stage_conv0_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr())) == 0
+    p = buf.numpy().reshape(13, 9, 4, 16)  # [group][tap][slot][cout]
+    assert np.array_equal(np.sort(p.reshape(-1)), np.sort(w.numpy().reshape(-1)))  # every weight exactly once
+    groups = [(0, 1, 2, 38), (3, 4, 5, 39)] + [(6 + 2 * k, 7 + 2 * k, 22 + 2 * k, 23 + 2 * k) for k in range(8)] + \
+             [(40, 41, 42, 43), (44, 45, 46, 47), (48, 49, 50, 51)]
+    wn = w.numpy().reshape(16, 52, 9)
+    for g, chans in enumerate(groups):
+        for j, ci in enumerate(chans):
+            assert np.array_equal(p[g, :, j, :], wn[:, ci, :].T)
+    assert lib.drba_stage_conv0_pack(None, None) == -1
+    assert lib.drba_stage_conv0_supported(1088, 1920, 1.0, 2.0, 16) == 1
+    assert lib.drba_stage_conv0_supported(1088, 1920, 2.0, 4.0, 16) == 0   # scale 1 only
+    assert lib.drba_stage_conv0_supported(1088, 1920, 1.0, 2.0, 32) == 0   # block 4's 16 output channels only
+    assert lib.drba_stage_conv0_batch(None, 1, 4, 4, 2.0, 8, 8, None, None, None) == -1
+
+
 def test_split_conv_weight_packing_reconstructs_fp32():
     """conv_split.hip packs every weight as three bf16 terms h + m + l (cfg ids after the fp32 table): their sum must be
     the fp32 weight up to its last mantissa bit, every weight exactly once, and a layer the family cannot run

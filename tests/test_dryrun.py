@@ -21,7 +21,7 @@ class _StubLib:
 
     def __getattr__(self, name):
         real = getattr(self._real, name)
-        if name.endswith(("_pick_cfg", "_packed_floats", "_pack", "_ws_floats", "drba_abi_version", "drba_error_string")):
+        if name.endswith(("_pick_cfg", "_packed_floats", "_pack", "_ws_floats", "_supported", "drba_abi_version", "drba_error_string")):
             return real  # pure host functions: run for real
         argtypes = real.argtypes
 
