@@ -69,7 +69,9 @@ SIGNATURES = {
     "drba_stage_conv0_packed_floats": (_z, []),
     "drba_stage_conv0_pack": (_i, [_p, _p]),
     "drba_stage_conv0_supported": (_i, [_i, _i, _f, _f, _i]),
-    "drba_stage_conv0_batch": (_i, [_p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
+    "drba_stage_conv0_batch": (_i, [_p, _i, _p, _i, _i, _f, _i, _i, _p, _p, _p]),
+    "drba_ifblock_input_lazy_batch": (_i, [_p, _i, _p, _i, _i, _f, _i, _i, _i, _i, _f, _p]),
+    "drba_warp_blend_lazy_batch": (_i, [_p, _i, _p, _i, _i, _f, _i, _i, _p]),
     "drba_ifblock_update_batch": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "drba_warp_blend_fold": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
     "drba_pair_interleave": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -109,7 +111,15 @@ class StageItem(C.Structure):
     """include/drba_hip.h: drba_stage_item_t"""
     _fields_ = [("img0", C.c_void_p), ("img1", C.c_void_p), ("f0", C.c_void_p), ("f1", C.c_void_p), ("f0_pair", C.c_void_p),
                 ("f1_pair", C.c_void_p), ("timestep_map", C.c_void_p), ("timestep_scalar", C.c_float), ("flow", C.c_void_p),
-                ("tmp_prev", C.c_void_p), ("flow_out", C.c_void_p), ("out", C.c_void_p)]
+                ("tmp_prev", C.c_void_p), ("flow_out", C.c_void_p), ("out", C.c_void_p), ("term", C.c_void_p * 4)]
+
+
+MAX_FLOW_TERMS = 4  # DRBA_MAX_FLOW_TERMS
+
+
+class FlowTerms(C.Structure):
+    """include/drba_hip.h: drba_flow_terms_t"""
+    _fields_ = [("n", C.c_int), ("h", C.c_int * 4), ("w", C.c_int * 4), ("scale", C.c_float * 4)]
 
 
 MAX_STAGE_ITEMS = 8  # DRBA_MAX_STAGE_ITEMS

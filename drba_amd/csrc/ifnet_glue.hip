@@ -5,6 +5,7 @@
 //   warp_blend    : final two warps + sigmoid blend
 // plus bilinear resize and the uint8<->fp32 frame conversions used by to_inp/to_out.
 #include "common.hpp"
+#include "flow_terms.hpp"
 
 #include <string.h>
 
@@ -404,13 +405,19 @@ constexpr int kPrevRW = 20, kPrevRH = 6;  // LDS footprint capacity (columns pad
 // as 16 bytes per lane: scale 1: 4 channels x (32 x 2 pixels) per store, 14 stores; scale >= 2: all 52 channels x 16
 // pixels in 4 stores; the folded flow update (a 32 x 2 full-resolution block per wave either way) in one.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-template <bool SINGLE, bool FOLD, bool VS>
+// FMODE: 0 = the finished flow is read; 1 = FOLD (above: flow_prev + the previous stage's update, written to flow_out);
+// 2 = LAZY: the flow is the sum of the terms (flow_terms.hpp) + the previous stage's update, nothing is written -- any scale.
+constexpr int kTermR = 5, kTermC = 12;  // term footprint capacity under a tile (32 x 8 px at scale <= 2, 16s x 4s beyond; terms at >= 4 x scale)
+template <bool SINGLE, int FMODE, bool VS>
 __global__ void __launch_bounds__(256)
-ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, float prev_scale, int H, int W, int h, int w,
-                  float scale) {
+ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, float inv_prev_scale, float prev_scale, int H, int W,
+                  int h, int w, float scale) {
+  constexpr bool FOLD = FMODE != 0, WRITES = FMODE == 1, LAZY = FMODE == 2;
   DRBA_UNPACK_STAGE_ITEM(items);
   float *__restrict__ flow_out = item_.flow_out;
   __shared__ float prev[13][kPrevRH][kPrevRW];
+  __shared__ float tl[LAZY ? kMaxTerms * 4 * kTermR * kTermC : 1];
+  int trx0[kMaxTerms], try0[kMaxTerms];
   constexpr int STG = VS ? (SINGLE ? 4 * 64 : 52 * 16 + 4 * 64) : 1;  // floats per wave
   __shared__ __attribute__((aligned(16))) float stg_all[4 * STG];
   constexpr int LPO = SINGLE ? 1 : 4;
@@ -431,6 +438,7 @@ ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, 
     const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
     prev[C0 + c][r][col] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
   }
+  if (LAZY) terms_stage<kTermR, kTermC, 256>(tl, T, item_.term, Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -489,9 +497,13 @@ ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, 
     return lerp2_fma(a.w0, a.w1, b.w0, b.w1, prev[c][r0][c0], prev[c][r0][c1], prev[c][r1][c0], prev[c][r1][c1]);
   };
   float fls[4];
+  const bool have_terms = LAZY && terms_flow<kTermR, kTermC>(tl, T, trx0, try0, X, Y, fls);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    if (FOLD) {
+    if (LAZY) {
+      const float fd = __fmul_rn(prev_up(c), prev_scale);
+      fls[c] = have_terms ? __fadd_rn(fls[c], fd) : fd;
+    } else if (FOLD) {
       // ifblock_update: flow_in + up(tmp) * scale -- product and sum rounded separately, as torch evaluates them
       const float fd = __fmul_rn(prev_up(c), prev_scale);
       fls[c] = flow ? __fadd_rn(flow[(size_t)c * P + q], fd) : fd;
@@ -506,7 +518,7 @@ ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, 
       fls[c] = flow[(size_t)c * P + q];
     }
   }
-  if (VS && FOLD) {
+  if (VS && WRITES) {
     if (SINGLE) flush32x2(ws, flow_out, P, W, ox_a, oy_a + 2 * wave, g4);
     else flush32x2(ws + 52 * 16, flow_out, P, W, 2 * ox_a, 2 * (oy_a + wave), g4);  // scale 2: rows 2y, 2y+1, columns 2x..
   }
@@ -621,11 +633,22 @@ ifblock_input_lds(const StageItems items, int hp, int wp, float inv_prev_scale, 
 
 // warp_blend with the LAST stage's flow update folded in: flow = flow_prev + up(tmp[0:4]) * scale is formed per pixel
 // (never stored: nothing reads the final flow), the mask is tmp's channel 4; tmp's footprint is staged through LDS.
+// LAZY: the flow before the last stage is the sum of the terms (flow_terms.hpp); the items of a stage in one launch.
+constexpr int kWbTermR = 6, kWbTermC = 18;  // term footprint capacity under a 32 x 8 tile (terms at >= 2 x the last scale >= 2)
+struct BlendItems {
+  const float *img0[kMaxItems], *img1[kMaxItems], *flow[kMaxItems], *tmp[kMaxItems];
+  float *out[kMaxItems];
+  const float *term[kMaxItems][kMaxTerms];
+};
+template <bool LAZY>
 __global__ void __launch_bounds__(256)
-warp_blend_fold_kernel(const float *__restrict__ img0, const float *__restrict__ img1, const float *__restrict__ flow,
-                       const float *__restrict__ tmp, int h, int w, float inv_scale, float scale, float *__restrict__ out,
-                       int H, int W) {
+warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int w, float inv_scale, float scale, int H, int W) {
+  const float *__restrict__ img0 = items.img0[blockIdx.y], *__restrict__ img1 = items.img1[blockIdx.y];
+  const float *__restrict__ flow = items.flow[blockIdx.y], *__restrict__ tmp = items.tmp[blockIdx.y];
+  float *__restrict__ out = items.out[blockIdx.y];
   __shared__ float prev[5][10][36];
+  __shared__ float tl[LAZY ? kMaxTerms * 4 * kWbTermR * kWbTermC : 1];
+  int trx0[kMaxTerms], try0[kMaxTerms];
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
   const int tiles_x = (W + kTileW - 1) / kTileW;
   int tx, ty;
@@ -637,6 +660,7 @@ warp_blend_fold_kernel(const float *__restrict__ img0, const float *__restrict__
     const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
     prev[c][r][col] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
   }
+  if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[blockIdx.y], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
   const int x = Xa + (threadIdx.x & (kTileW - 1)), y = Ya + (threadIdx.x >> 5);
   if (x >= W || y >= H) return;
@@ -644,15 +668,15 @@ warp_blend_fold_kernel(const float *__restrict__ img0, const float *__restrict__
   const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
   const int r0 = ly.i0 - ry0, r1 = ly.i1 - ry0, c0 = lx.i0 - rx0, c1 = lx.i1 - rx0;
   auto up = [&](int c) -> float {
-    const float top = lx.w0 * prev[c][r0][c0] + lx.w1 * prev[c][r0][c1];
-    const float bot = lx.w0 * prev[c][r1][c0] + lx.w1 * prev[c][r1][c1];
-    return ly.w0 * top + ly.w1 * bot;
+    return lerp2_fma(ly.w0, ly.w1, lx.w0, lx.w1, prev[c][r0][c0], prev[c][r0][c1], prev[c][r1][c0], prev[c][r1][c1]);
   };
   float fl[4];
+  const bool have_terms = LAZY && terms_flow<kWbTermR, kWbTermC>(tl, T, trx0, try0, x, y, fl);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float fd = up(c) * scale;
-    fl[c] = flow ? flow[(size_t)c * P + p] + fd : fd;
+    const float fd = __fmul_rn(up(c), scale);  // ifblock_update's arithmetic: product and sum rounded separately
+    if (LAZY) fl[c] = have_terms ? __fadd_rn(fl[c], fd) : fd;
+    else fl[c] = flow ? __fadd_rn(flow[(size_t)c * P + p], fd) : fd;
   }
   const Taps t0 = taps_border(warp_coord(x, W, fl[0]), warp_coord(y, H, fl[1]), W, H);
   const Taps t1 = taps_border(warp_coord(x, W, fl[2]), warp_coord(y, H, fl[3]), W, H);
@@ -847,16 +871,33 @@ int drba_ifblock_input(const float *img0, const float *img1, const float *f0, co
   return drba_ifblock_input_batch(&it, 1, hp, wp, prev_scale, H, W, h, w, scale, stream);
 }
 
-int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
-                                 int h, int w, float scale, void *stream) {
-  const int rc = stage_items_ok(items, n_items, true);
-  if (rc != DRBA_OK) return rc;
+// mode 0 / 1 (flow given / folded update written, chosen by items[0].flow_out) or 2 (lazy: the flow is `terms` + the fold)
+static int ifblock_input_lds_launch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int hp, int wp,
+                                    float prev_scale, int H, int W, int h, int w, float scale, void *stream) {
+  const bool lazy = terms != nullptr;
+  if (!items || n_items <= 0 || n_items > kMaxItems) return DRBA_EINVAL;
+  if (lazy) {
+    for (int k = 0; k < n_items; ++k) {
+      const drba_stage_item_t &I = items[k];
+      if (!I.img0 || !I.img1 || !I.f0 || !I.f1 || !I.out || !I.tmp_prev || I.flow || I.flow_out) return DRBA_EINVAL;
+      if ((I.f0_pair == nullptr) != (I.f1_pair == nullptr) || (I.f0_pair == nullptr) != (items[0].f0_pair == nullptr)) return DRBA_EINVAL;
+      for (int i = 0; i < terms->n && i < kMaxTerms; ++i)
+        if (!I.term[i]) return DRBA_EINVAL;
+    }
+  } else {
+    const int rc = stage_items_ok(items, n_items, true);
+    if (rc != DRBA_OK) return rc;
+  }
   if (H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
   if (hp <= 0 || wp <= 0 || !(prev_scale > 0.f)) return DRBA_EINVAL;
-  const bool fold = items[0].flow_out != nullptr;
-  if (fold && scale > 2.f) return DRBA_EUNSUPPORTED;   // the fold needs every full-resolution pixel sampled once
+  const bool fold = !lazy && items[0].flow_out != nullptr;
+  if (fold && scale > 2.f) return DRBA_EUNSUPPORTED;   // the fold WRITES the flow: every full-resolution pixel must be sampled once
   if (scale != 1.f && scale != 2.f && scale != 4.f && scale != 8.f && scale != 16.f && scale != 32.f) return DRBA_EUNSUPPORTED;
   if (prev_scale != 2.f * scale) return DRBA_EUNSUPPORTED;  // IFNet's pyramid; bounds the staged footprint to 18 x 6 pixels
+  FlowTermsArg T;
+  if (!flow_terms_arg(terms, T)) return DRBA_EINVAL;
+  for (int i = 0; i < T.n; ++i)
+    if (T.scale[i] < 2.f * prev_scale) return DRBA_EUNSUPPORTED;  // earlier stages of the pyramid only (bounds their footprints)
   StageItems its;
   memset(&its, 0, sizeof(its));
   for (int k = 0; k < n_items; ++k) its.it[k] = items[k];
@@ -871,24 +912,38 @@ int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, in
   for (int k = 0; k < n_items; ++k)
     vs = vs && ((uintptr_t)items[k].out & 15) == 0 &&
          (!fold || (((uintptr_t)items[k].flow_out & 15) == 0 && (single || (W == 2 * w && H == 2 * h))));
-#define DRBA_IFL(SG, FO, VS_) \
-  DRBA_LAUNCH((ifblock_input_lds<SG, FO, VS_>), dim3(tiles, n_items), dim3(kBlock), 0, s, its, hp, wp, ips, prev_scale, H, W, h, w, scale)
-#define DRBA_IFL2(SG, FO) \
+#define DRBA_IFL(SG, FM, VS_) \
+  DRBA_LAUNCH((ifblock_input_lds<SG, FM, VS_>), dim3(tiles, n_items), dim3(kBlock), 0, s, its, T, hp, wp, ips, prev_scale, H, W, h, w, scale)
+#define DRBA_IFL2(SG, FM) \
   do {                    \
-    if (vs) DRBA_IFL(SG, FO, true); \
-    else DRBA_IFL(SG, FO, false);   \
+    if (vs) DRBA_IFL(SG, FM, true); \
+    else DRBA_IFL(SG, FM, false);   \
   } while (0)
-  if (fold) {
-    if (single) DRBA_IFL2(true, true);
-    else DRBA_IFL2(false, true);
+  if (lazy) {
+    if (single) DRBA_IFL2(true, 2);
+    else DRBA_IFL2(false, 2);
+  } else if (fold) {
+    if (single) DRBA_IFL2(true, 1);
+    else DRBA_IFL2(false, 1);
   } else {
-    if (single) DRBA_IFL2(true, false);
-    else DRBA_IFL2(false, false);
+    if (single) DRBA_IFL2(true, 0);
+    else DRBA_IFL2(false, 0);
   }
 #undef DRBA_IFL2
 #undef DRBA_IFL
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
+}
+
+int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
+                                 int h, int w, float scale, void *stream) {
+  return ifblock_input_lds_launch(items, n_items, nullptr, hp, wp, prev_scale, H, W, h, w, scale, stream);
+}
+
+int drba_ifblock_input_lazy_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int hp, int wp,
+                                  float prev_scale, int H, int W, int h, int w, float scale, void *stream) {
+  if (!terms) return DRBA_EINVAL;
+  return ifblock_input_lds_launch(items, n_items, terms, hp, wp, prev_scale, H, W, h, w, scale, stream);
 }
 
 int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0, const float *f1, const float *f0_pair,
@@ -902,8 +957,37 @@ int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0
 int drba_warp_blend_fold(const float *img0, const float *img1, const float *flow, const float *tmp_last, int h, int w,
                          float scale, float *out, int H, int W, void *stream) {
   if (!img0 || !img1 || !tmp_last || !out || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale >= 1.f)) return DRBA_EINVAL;
-  DRBA_LAUNCH(warp_blend_fold_kernel, dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, img0, img1, flow, tmp_last, h,
-              w, (float)(1.0 / (double)scale), scale, out, H, W);
+  BlendItems its;
+  memset(&its, 0, sizeof(its));
+  its.img0[0] = img0, its.img1[0] = img1, its.flow[0] = flow, its.tmp[0] = tmp_last, its.out[0] = out;
+  FlowTermsArg T;
+  flow_terms_arg(nullptr, T);
+  DRBA_LAUNCH((warp_blend_fold_kernel<false>), dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, its, T, h, w,
+              (float)(1.0 / (double)scale), scale, H, W);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_warp_blend_lazy_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int h, int w, float scale,
+                               int H, int W, void *stream) {
+  if (!items || !terms || n_items <= 0 || n_items > kMaxItems || H <= 1 || W <= 1 || h <= 0 || w <= 0 || !(scale >= 1.f)) return DRBA_EINVAL;
+  FlowTermsArg T;
+  if (!flow_terms_arg(terms, T)) return DRBA_EINVAL;
+  for (int i = 0; i < T.n; ++i)
+    if (T.scale[i] < 2.f * scale || T.scale[i] < 2.f) return DRBA_EUNSUPPORTED;  // earlier stages of the pyramid (bounds their footprints)
+  BlendItems its;
+  memset(&its, 0, sizeof(its));
+  for (int k = 0; k < n_items; ++k) {
+    const drba_stage_item_t &I = items[k];
+    if (!I.img0 || !I.img1 || !I.tmp_prev || !I.out) return DRBA_EINVAL;
+    its.img0[k] = I.img0, its.img1[k] = I.img1, its.tmp[k] = I.tmp_prev, its.out[k] = I.out;
+    for (int i = 0; i < T.n; ++i) {
+      if (!I.term[i]) return DRBA_EINVAL;
+      its.term[k][i] = I.term[i];
+    }
+  }
+  DRBA_LAUNCH((warp_blend_fold_kernel<true>), dim3(tiles_for(W, H), n_items), dim3(kBlock), 0, (hipStream_t)stream, its, T, h, w,
+              (float)(1.0 / (double)scale), scale, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -20,6 +20,7 @@
 // that own a pixel, as in ifblock_input_lds<.., FOLD = true, ..>; per-point arithmetic is that kernel's, term by term.
 // Exact fp32 products (fp32 MFMA): the result differs from the unfused pair only by the accumulation order.
 #include "common.hpp"
+#include "flow_terms.hpp"
 
 #include <string.h>
 
@@ -50,7 +51,9 @@ struct Geo {
   static constexpr int PR = TOH + 3;             // tmp_prev footprint capacity, rows
   static constexpr int WL = WRES ? W_FLOATS : 2 * WG_FLOATS;
   static constexpr int WV = (WG_FLOATS + THREADS - 1) / THREADS;  // streamed weights: floats per lane and group
-  static constexpr int LDS_FLOATS = WL + 2 * 4 * CS + 13 * PR * PC;
+  static constexpr int TR = TOH / 2 + 4, TC = 12;  // term footprint capacity: (2 TOH + 1 rows, 33 columns) at >= 1/4 resolution
+  static constexpr int TERM_FLOATS = kMaxTerms * 4 * TR * TC;
+  static constexpr int LDS_FLOATS = WL + 2 * 4 * CS + 13 * PR * PC + TERM_FLOATS;
   static_assert(32 + WR <= 64, "upper row + left column on one wave");
 };
 
@@ -88,16 +91,20 @@ __device__ __forceinline__ void lds_barrier() {
 #ifndef DRBA_SC_DEPTH
 #define DRBA_SC_DEPTH 1
 #endif
-template <bool FOLD, class G_>
+// FMODE: 0 = the finished flow is read; 1 = FOLD (flow_prev + the previous stage's update, written to flow_out); 2 = LAZY
+// (the flow is the sum of the terms, flow_terms.hpp, + the previous stage's update; nothing but the convolution is written)
+template <int FMODE, class G_>
 __global__ void __launch_bounds__(G_::THREADS)
-stage_conv0(const StageItems items, const float *__restrict__ wpk, const float *__restrict__ bias, int hp, int wp, float inv_prev_scale,
-            float prev_scale, int H, int W, int Ho, int Wo, int tiles_x) {
+stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restrict__ wpk, const float *__restrict__ bias, int hp, int wp,
+            float inv_prev_scale, float prev_scale, int H, int W, int Ho, int Wo, int tiles_x) {
+  constexpr bool FOLD = FMODE != 0, WRITES = FMODE == 1, LAZY = FMODE == 2;
   constexpr int TOH = G_::TOH, WR = G_::WR, CS = G_::CS, THREADS = G_::THREADS, PR = G_::PR;
   constexpr bool WRES = G_::WRES;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *wl = lds;                         // WRES: [13][9][64]; else [2][9][64]
   float *win = lds + G_::WL;               // [2][4][CS]
   float *prev = win + 2 * 4 * CS;          // [13][PR][PC]
+  float *tl = prev + 13 * PR * PC;         // [kMaxTerms][4][TR * TC]
   // the item is picked by blockIdx.y out of the by-value argument: the compiler does not see that its fields are
   // wave-uniform (it would address every load per lane and wrap every buffer load in a waterfall loop) -- state it
   typedef __attribute__((address_space(1))) float *gptr;
@@ -111,6 +118,7 @@ stage_conv0(const StageItems items, const float *__restrict__ wpk, const float *
     cgptr img0, img1, f0_pair, f1_pair, timestep_map, flow, tmp_prev;
     gptr flow_out, out;
     float timestep_scalar;
+    const float *term[kMaxTerms];
   } item;
   {
     const drba_stage_item_t &src = items.it[blockIdx.y];
@@ -118,6 +126,8 @@ stage_conv0(const StageItems items, const float *__restrict__ wpk, const float *
     item.timestep_map = uniform(src.timestep_map), item.flow = uniform(src.flow), item.tmp_prev = uniform(src.tmp_prev);
     item.flow_out = uniform(src.flow_out), item.out = uniform(src.out);
     item.timestep_scalar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(src.timestep_scalar)));
+#pragma unroll
+    for (int i = 0; i < kMaxTerms; ++i) item.term[i] = (const float *)uniform(src.term[i]);
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t P = (size_t)H * W, p_prev = (size_t)hp * wp;
@@ -191,6 +201,8 @@ stage_conv0(const StageItems items, const float *__restrict__ wpk, const float *
 #pragma unroll
     for (int c = C0; c < 13; ++c) prev[(c * PR + pr_r) * PC + pr_c] = pv[c];
   }
+  int trx0[kMaxTerms], try0[kMaxTerms];
+  if (LAZY) terms_stage<G_::TR, G_::TC, THREADS>(tl, T, item.term, Xa, Ya, Xb, Yb, tid, trx0, try0);
   __syncthreads();
 
   // taps of the previous head output's upsample at (X, Y), relative to the staged footprint
@@ -201,9 +213,13 @@ stage_conv0(const StageItems items, const float *__restrict__ wpk, const float *
     return lerp2_fma(la.w0, la.w1, lb.w0, lb.w1, pp[pr0 + pc0], pp[pr0 + pc1], pp[pr1 + pc0], pp[pr1 + pc1]);
   };
   float fls[4];
+  const bool have_terms = LAZY && terms_flow<G_::TR, G_::TC>(tl, T, trx0, try0, X, Y, fls);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    if (FOLD) {
+    if (LAZY) {
+      const float fd = __fmul_rn(prev_up(c), prev_scale);
+      fls[c] = have_terms ? __fadd_rn(fls[c], fd) : fd;
+    } else if (FOLD) {
       // ifblock_update: flow_in + up(tmp) * scale, product and sum rounded separately as torch evaluates them (and as
       // ifblock_input_lds does: the two kernels hand identical flows to warp_blend_fold)
       const float fd = __fmul_rn(prev_up(c), prev_scale);
@@ -212,7 +228,7 @@ stage_conv0(const StageItems items, const float *__restrict__ wpk, const float *
       fls[c] = fr[c];
     }
   }
-  if (FOLD && owner) {
+  if (WRITES && owner) {
     const gptr fout = item.flow_out;
 #pragma unroll
     for (int c = 0; c < 4; ++c) fout[(size_t)c * P + q] = fls[c];
@@ -385,20 +401,31 @@ int drba_stage_conv0_supported(int H, int W, float scale, float prev_scale, int 
   return (H >= 2 && W >= 2 && scale == 1.f && prev_scale == 2.f && Cout == drba_stage_conv::COUT) ? 1 : 0;
 }
 
-int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
-                           const float *packed_w, const float *bias, void *stream) {
+int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int hp, int wp, float prev_scale,
+                           int H, int W, const float *packed_w, const float *bias, void *stream) {
   using namespace drba_stage_conv;
   if (!items || n_items <= 0 || n_items > DRBA_MAX_STAGE_ITEMS || !packed_w || H < 2 || W < 2 || hp <= 0 || wp <= 0) return DRBA_EINVAL;
   if (prev_scale != 2.f) return DRBA_EUNSUPPORTED;  // IFNet's pyramid: the stage before scale 1 ran at scale 2 (bounds the staged footprint)
   if ((uint64_t)H * W * 16 * 4 >= (1ull << 32)) return DRBA_EUNSUPPORTED;  // buffer-load offsets are 32-bit
   StageItems its;
   memset(&its, 0, sizeof(its));
-  const bool fold = items[0].flow_out != nullptr;
+  const bool lazy = terms != nullptr;
+  const bool fold = !lazy && items[0].flow_out != nullptr;
+  FlowTermsArg T;
+  if (!flow_terms_arg(terms, T)) return DRBA_EINVAL;
+  for (int i = 0; i < T.n; ++i)
+    if (T.scale[i] < 4.f) return DRBA_EUNSUPPORTED;  // earlier stages of the pyramid only (bounds their footprints)
   for (int k = 0; k < n_items; ++k) {
     const drba_stage_item_t &I = items[k];
     if (!I.img0 || !I.img1 || !I.f0_pair || !I.f1_pair || !I.tmp_prev || !I.out) return DRBA_EINVAL;
-    if ((I.flow_out != nullptr) != fold || (!fold && !I.flow)) return DRBA_EINVAL;
-    if ((I.flow == nullptr) != (items[0].flow == nullptr)) return DRBA_EINVAL;
+    if (lazy) {
+      if (I.flow || I.flow_out) return DRBA_EINVAL;
+      for (int i = 0; i < T.n; ++i)
+        if (!I.term[i]) return DRBA_EINVAL;
+    } else {
+      if ((I.flow_out != nullptr) != fold || (!fold && !I.flow)) return DRBA_EINVAL;
+      if ((I.flow == nullptr) != (items[0].flow == nullptr)) return DRBA_EINVAL;
+    }
     its.it[k] = I;
   }
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -406,9 +433,9 @@ int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, int hp, 
   hipStream_t s = (hipStream_t)stream;
   // workgroup shape (TUNING builds: DRBA_SC_TOH = 4 / 6 / 8 output rows, DRBA_SC_WRES = 1 keeps all weights in LDS)
   static const int toh = env_int("DRBA_SC_TOH", 8), wres = env_int("DRBA_SC_WRES", 1);
-#define DRBA_SC_GO(FO, T, R)                                                                                             \
+#define DRBA_SC_GO(FO, TT, R)                                                                                            \
   do {                                                                                                                     \
-    using G_ = Geo<T, R>;                                                                                                  \
+    using G_ = Geo<TT, R>;                                                                                                 \
     constexpr size_t lds_bytes = (size_t)G_::LDS_FLOATS * 4;                                                               \
     static bool attr_done = false;                                                                                         \
     if (!attr_done) {                                                                                                      \
@@ -417,14 +444,15 @@ int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, int hp, 
         return DRBA_ELAUNCH;                                                                                               \
       attr_done = true;                                                                                                    \
     }                                                                                                                      \
-    const int tiles_x = (Wo + TOW - 1) / TOW, tiles_y = (Ho + T - 1) / T;                                                  \
-    DRBA_LAUNCH((stage_conv0<FO, G_>), dim3(tiles_x * tiles_y, n_items), dim3(G_::THREADS), lds_bytes, s, its, packed_w, bias, hp, \
-                wp, ips, prev_scale, H, W, Ho, Wo, tiles_x);                                                               \
+    const int tiles_x = (Wo + TOW - 1) / TOW, tiles_y = (Ho + TT - 1) / TT;                                                \
+    DRBA_LAUNCH((stage_conv0<FO, G_>), dim3(tiles_x * tiles_y, n_items), dim3(G_::THREADS), lds_bytes, s, its, T, packed_w, bias, \
+                hp, wp, ips, prev_scale, H, W, Ho, Wo, tiles_x);                                                           \
   } while (0)
-#define DRBA_SC_GO2(T, R)        \
+#define DRBA_SC_GO2(T_, R)       \
   do {                           \
-    if (fold) DRBA_SC_GO(true, T, R); \
-    else DRBA_SC_GO(false, T, R);     \
+    if (lazy) DRBA_SC_GO(2, T_, R);   \
+    else if (fold) DRBA_SC_GO(1, T_, R); \
+    else DRBA_SC_GO(0, T_, R);        \
   } while (0)
   if (wres) {
     if (toh == 4) DRBA_SC_GO2(4, true);

@@ -58,6 +58,14 @@ class IFBlock:
                                     + [(self.lastconv, False)])
         # the core after conv0[0], for the stage whose input gather and first convolution are one kernel (ops.stage_conv0)
         self.chain_tail = _ops.ConvChain([(self.conv0_1, False)] + [(rc, True) for rc in self.convblock] + [(self.lastconv, False)])
+        # the LAST stage's head output is only read for flow (4 channels) and mask (1): `feat`, its other 8 channels, feeds the
+        # next stage and there is none (IFNet_HDv3.py:146-167) -- 20 of the transposed convolution's 52 pre-shuffle channels
+        # (PixelShuffle(2): output channel c = channels 4c .. 4c+3) are computed and written, [N, 5, H/s, W/s]
+        self.lastconv5 = _ops.Deconv4x4(g("lastconv.0.weight")[:, :20].contiguous(), g("lastconv.0.bias")[:20].contiguous(),
+                                        pixel_shuffle=True, device=device)
+        self.chain5 = _ops.ConvChain([(self.conv0_0, False), (self.conv0_1, False)] + [(rc, True) for rc in self.convblock]
+                                     + [(self.lastconv5, False)])
+        self.chain_tail5 = _ops.ConvChain([(self.conv0_1, False)] + [(rc, True) for rc in self.convblock] + [(self.lastconv5, False)])
 
     def core(self, x):
         """conv0 -> 8 x ResConv (lrelu(conv(x) * beta + x)) -> deconv + PixelShuffle: [N, 13, 4h, 4w]; one library call."""
@@ -143,14 +151,24 @@ class IFNet:
             # the batched glue launches take at most M items (drba_hip.h DRBA_MAX_STAGE_ITEMS): a step with more frames to
             # synthesise (`-t 6`, 24 -> 144 fps, ...) runs as independent groups of M -- the samples do not interact
             parts = []
+            lazy = state is not None and state[3] == "lazy"
             for a in range(0, B, M):
-                st = None if state is None else (list(state[0][a:a + M]), None if state[1] is None else state[1][a:a + M],
-                                                 state[2], state[3])
+                if state is None:
+                    st = None
+                elif lazy:  # state[0]: the terms [(head output [B,13,h,w], scale), ...]
+                    st = ([(t[a:a + M], s) for t, s in state[0]], state[1][a:a + M], state[2], state[3])
+                else:
+                    st = (list(state[0][a:a + M]), None if state[1] is None else state[1][a:a + M], state[2], state[3])
                 parts.append(self.forward_pairs(items[a:a + M], scale_list, first, last, st))
             if last < 5:
+                if parts[0][3] == "lazy":
+                    terms = [(torch.cat([p[0][i][0] for p in parts], 0), parts[0][0][i][1]) for i in range(len(parts[0][0]))]
+                    return (terms, torch.cat([p[1] for p in parts], 0), parts[0][2], "lazy")
                 return ([f for p in parts for f in p[0]], torch.cat([p[1] for p in parts], 0), parts[0][2], parts[0][3])
             return [f for p in parts for f in p]
         _, _, H, W = items[0][0].shape
+        if state is not None and state[3] == "lazy" or state is None and self._lazy_ok(scale_list):
+            return self._forward_pairs_lazy(items, scale_list, first, last, state)
         flows, tmp, s_prev, pending = state if state is not None else ([None] * B, None, 1.0, False)
         flows = list(flows)
         dev = items[0][0].device
@@ -159,6 +177,7 @@ class IFNet:
             h, w = int(np.floor(H * (1.0 / s))), int(np.floor(W * (1.0 / s)))
             lds = i > 0 and self._lds_ok(s, s_prev)
             fold = pending and lds and s <= 2
+            final = i == 4  # the last stage: only flow and mask of its head output are read
             # every item's glue kernel of a stage is ONE launch (blockIdx.y = item): these launches are latency-bound on the
             # small maps, and each one costs the gap a dependent dispatch waits for its predecessor
             if pending and not fold:
@@ -168,7 +187,7 @@ class IFNet:
                 # that gathers it and never written
                 y0, fl = _ops.stage_conv0(items, flows, tmp, s_prev, self.block[i].conv0_0, fold=fold)
                 flows = fl if fold else flows
-                tmp = self.block[i].chain_tail(y0)
+                tmp = (self.block[i].chain_tail5 if final else self.block[i].chain_tail)(y0)
             else:
                 xin = torch.empty((B, 52 if i else 39, h, w), dtype=torch.float32, device=dev)
                 if fold:
@@ -177,7 +196,7 @@ class IFNet:
                     _ops.stage_inputs(items, flows, tmp, s_prev, s, xin)
                 else:
                     _ops.stage_inputs(items, flows, tmp, s_prev, s, xin, lds=False)
-                tmp = self.block[i].core(xin)  # [B,13,H/s,W/s]: flow delta (4), mask (1), feat (8)
+                tmp = (self.block[i].chain5 if final else self.block[i].chain)(xin)  # [B,13,H/s,W/s]: flow delta (4), mask (1), feat (8)
             s_prev = s
             # leave the update to the consumer if that one can fold it
             # (the final warp_blend_fold takes scale >= 1 only: with a model scale > 1 the last stage runs at s < 1 and
@@ -192,6 +211,45 @@ class IFNet:
         if pending:
             return [_ops.warp_blend_fold(it[0], it[1], flows[k], tmp[k:k + 1], s_prev) for k, it in enumerate(items)]
         return [_ops.warp_blend(it[0], it[1], flows[k], tmp[k:k + 1], s_prev) for k, it in enumerate(items)]
+
+    def _lazy_ok(self, scale_list):
+        """The running flow as terms (ops.LAZY_FLOW): every warped stage through the LDS gather (scales 32..1, each half the
+        previous one) and a last stage at scale >= 1; anything else (a model scale > 1, ...) keeps the materialised flow."""
+        sl = list(scale_list[:5])
+        return bool(_ops.LAZY_FLOW and _ops.LDS_STAGE_INPUT and _ops.PAIR_FEATURES and len(sl) == 5 and sl[4] >= 1
+                    and all(self._lds_ok(sl[i], sl[i - 1]) for i in range(1, 5)))
+
+    def _forward_pairs_lazy(self, items, scale_list, first, last, state):
+        """forward_pairs without a full-resolution flow tensor: IFNet_HDv3.py:146-160's flow = flow + up(tmp_i[:, :4]) * s_i is kept
+        as the list of head outputs (`terms`, 1/32 .. 1/2 resolution) and evaluated by the kernels that need it, at their
+        sample points -- no ifblock_update pass after a stage, no flow read or written by a gather, one warp_blend launch
+        for all items.  State between calls: (terms, newest head output, its scale, "lazy")."""
+        B = len(items)
+        _, _, H, W = items[0][0].shape
+        dev = items[0][0].device
+        terms, tmp, s_prev, _ = state if state is not None else ([], None, 1.0, "lazy")
+        terms = list(terms)
+        for i in range(first, last):
+            s = scale_list[i]
+            h, w = int(np.floor(H * (1.0 / s))), int(np.floor(W * (1.0 / s)))
+            if i == 0:
+                xin = torch.empty((B, 39, h, w), dtype=torch.float32, device=dev)
+                _ops.stage_inputs(items, None, None, s_prev, s, xin, lds=False)
+                tmp_new = self.block[i].core(xin)
+            else:
+                final = i == 4  # the last stage: only flow and mask of its head output are read (IFBlock.lastconv5)
+                if s == 1 and _ops.stage_conv0_ok(self.block[i].conv0_0, H, W, s, s_prev):
+                    y0, _ = _ops.stage_conv0(items, None, tmp, s_prev, self.block[i].conv0_0, terms=terms)
+                    tmp_new = (self.block[i].chain_tail5 if final else self.block[i].chain_tail)(y0)
+                else:
+                    xin = torch.empty((B, 52, h, w), dtype=torch.float32, device=dev)
+                    _ops.stage_inputs(items, None, tmp, s_prev, s, xin, terms=terms)
+                    tmp_new = (self.block[i].chain5 if final else self.block[i].chain)(xin)
+                terms.append((tmp, s_prev))
+            tmp, s_prev = tmp_new, s
+        if last < 5:
+            return terms, tmp, s_prev, "lazy"
+        return _ops.warp_blend_lazy(items, terms, tmp, s_prev)
 
     def __call__(self, x, timestep=0.5, scale_list=(8, 4, 2, 1), training=False, fastmode=True, ensemble=False,
                  f0=None, f1=None):

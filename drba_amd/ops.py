@@ -647,14 +647,41 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds=True):
+LAZY_FLOW = True  # IFNet's running flow as a list of terms (earlier head outputs) evaluated inside the consumers instead of a
+#                   full-resolution tensor updated after every stage (drba_hip.h drba_flow_terms_t; bench.py --no-lazy-flow: A/B)
+
+
+def _flow_terms(terms, B):
+    """terms: [(head output [B,13,h,w], stage scale), ...] oldest first -> (ctypes drba_flow_terms_t, the float32 tensors)."""
+    if len(terms) > _lib.MAX_FLOW_TERMS:
+        raise _lib.DrbaHipError(f"at most {_lib.MAX_FLOW_TERMS} flow terms")
+    ft = _lib.FlowTerms()
+    ft.n = len(terms)
+    ts = []
+    for i, (t, s) in enumerate(terms):
+        t = _f32(t)
+        if t.shape[0] != B or t.shape[1] != 13:
+            raise _lib.DrbaHipError(f"flow term {i}: expected [{B},13,h,w], got {tuple(t.shape)}")
+        ft.h[i], ft.w[i], ft.scale[i] = t.shape[2], t.shape[3], float(s)
+        ts.append(t)
+    return ft, ts
+
+
+def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds=True, terms=None):
     """The stage input of EVERY item of a stage in one launch (drba_ifblock_input[_lds]_batch).
     items: [(img0, img1, timestep, f0, f1), ...]; flows: per-item running flow (or None); tmp_prev: the previous stage's
     stacked head output [B,13,hp,wp] (or None at the first stage); out: the stacked [B,nch,h,w] stage input.
-    fold=True (lds only): returns the list of folded running flows (slices of one new [B,4,H,W] tensor)."""
+    fold=True (lds only): returns the list of folded running flows (slices of one new [B,4,H,W] tensor).
+    terms (lds only, instead of flows / fold): the running flow BEFORE tmp_prev's update as [(head output [B,13,h,w], scale), ...]
+    of the earlier stages, oldest first; the kernel forms flow = sum(terms) + up(tmp_prev[:, :4]) * prev_scale at its sample
+    points (drba_ifblock_input_lazy_batch) and nothing but `out` is written."""
     B = len(items)
     if B > _lib.MAX_STAGE_ITEMS:
         raise _lib.DrbaHipError(f"stage_inputs: at most {_lib.MAX_STAGE_ITEMS} items per launch")
+    lazy = terms is not None
+    if lazy and (flows is not None or fold or not lds):
+        raise _lib.DrbaHipError("stage_inputs: terms replace flows / fold (lds path only)")
+    ft, tts = _flow_terms(terms, B) if lazy else (None, [])
     img0 = _f32(items[0][0])
     _, _, H, W = img0.shape
     h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
@@ -662,6 +689,8 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
     nch = 52 if (has_flow or lds) else 39
     if tuple(out.shape) != (B, nch, h, w) or not out.is_contiguous():
         raise _lib.DrbaHipError(f"stage_inputs: out must be a contiguous [{B},{nch},{h},{w}] tensor")
+    if lazy and tmp_prev is None:
+        raise _lib.DrbaHipError("stage_inputs: terms need tmp_prev (the newest head output)")
     flow_out = torch.empty((B, 4, H, W), dtype=torch.float32, device=img0.device) if fold else None
     hp = wp = 0
     ps = 1.0
@@ -684,8 +713,16 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
         a.tmp_prev = None if tmp_prev is None else tmp_prev[k].data_ptr()
         a.flow_out = None if flow_out is None else flow_out[k].data_ptr()
         a.out = out[k].data_ptr()
+        for i, t in enumerate(tts):
+            a.term[i] = t[k].data_ptr()
     pts = H * W if scale <= 2 else 4 * h * w
     lib = _lib.load()
+    if lazy:
+        nbytes = B * 4.0 * (39 * pts + 52 * h * w)  # no flow read, none written: the terms are a few KB per tile
+        _lib.check(_timed("ifblock_input_lds+lazy", (52, H, W, h, w, B), nbytes, "byte",
+                          lambda: lib.drba_ifblock_input_lazy_batch(C.cast(arr, C.c_void_p), B, C.cast(C.pointer(ft), C.c_void_p), hp, wp, ps, H, W, h, w,
+                                                                    float(scale), _stream())), "drba_ifblock_input_lazy_batch")
+        return None
     if lds:
         nbytes = B * 4.0 * (43 * pts + 52 * h * w + (4 * pts if fold else 0))
         _lib.check(_timed("ifblock_input_lds" + ("+fold" if fold else ""), (52, H, W, h, w, B), nbytes, "byte",
@@ -709,11 +746,15 @@ def stage_conv0_ok(conv, H, W, scale, prev_scale):
                 and _lib.load().drba_stage_conv0_supported(H, W, float(scale), float(prev_scale), conv.cout))
 
 
-def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False):
+def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None):
     """The scale-1 stage input of every item fused with `conv` (52 -> 16, stride 2, LeakyReLU): stage_inputs(..., scale=1)
     followed by conv(xin) without the 52-channel tensor (drba_stage_conv0_batch).  Returns (y0 [B,16,Ho,Wo], folded flows
-    or None)."""
+    or None).  terms: as in stage_inputs (instead of flows / fold)."""
     B = len(items)
+    lazy = terms is not None
+    if lazy and (flows is not None or fold):
+        raise _lib.DrbaHipError("stage_conv0: terms replace flows / fold")
+    ft, tts = _flow_terms(terms, B) if lazy else (None, [])
     if B > _lib.MAX_STAGE_ITEMS:
         raise _lib.DrbaHipError(f"stage_conv0: at most {_lib.MAX_STAGE_ITEMS} items per launch")
     img0 = _f32(items[0][0])
@@ -741,14 +782,16 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False):
         a.img0, a.img1, a.f0, a.f1, a.f0_pair, a.f1_pair = _ptr(i0), _ptr(i1), _ptr(f0), _ptr(f1), _ptr(f0p), _ptr(f1p)
         a.timestep_map, a.timestep_scalar, a.flow = _ptr(tmap), tsc, _ptr(fl)
         a.tmp_prev, a.flow_out, a.out = tmp_prev[k].data_ptr(), (None if flow_out is None else flow_out[k].data_ptr()), out[k].data_ptr()
+        for i, t in enumerate(tts):
+            a.term[i] = t[k].data_ptr()
     # algorithmic bytes: 43 source channels read once per full-resolution point, the 16-channel quarter-size output (and the
     # folded flow) written; 2 * 16 * 52 * 9 FLOP per output pixel ride along (50 us per 1080p sample at the fp32 MFMA peak,
     # 53 us of HBM time: the byte roofline is the binding one)
-    nbytes = B * 4.0 * (43.0 * H * W + conv.cout * Ho * Wo + (4.0 * H * W if fold else 0.0))
+    nbytes = B * 4.0 * ((39.0 if lazy else 43.0) * H * W + conv.cout * Ho * Wo + (4.0 * H * W if fold else 0.0))
     bias = None if conv.bias is None else conv.bias.data_ptr()
-    _lib.check(_timed("stage_conv0" + ("+fold" if fold else ""), (52, conv.cout, H, W, B), nbytes, "byte",
-                      lambda: _lib.load().drba_stage_conv0_batch(C.cast(arr, C.c_void_p), B, hp, wp, float(prev_scale), H, W,
-                                                                 conv._stage_pack.data_ptr(), bias, _stream())),
+    _lib.check(_timed("stage_conv0" + ("+fold" if fold else "+lazy" if lazy else ""), (52, conv.cout, H, W, B), nbytes, "byte",
+                      lambda: _lib.load().drba_stage_conv0_batch(C.cast(arr, C.c_void_p), B, (C.cast(C.pointer(ft), C.c_void_p) if lazy else None), hp, wp,
+                                                                 float(prev_scale), H, W, conv._stage_pack.data_ptr(), bias, _stream())),
                "drba_stage_conv0_batch")
     return out, ([flow_out[k:k + 1] for k in range(B)] if fold else None)
 
@@ -782,6 +825,33 @@ def warp_blend_fold(img0, img1, flow_prev, tmp_last, scale):
     _lib.check(_timed("warp_blend_fold", (H, W), nbytes, "byte", lambda: _lib.load().drba_warp_blend_fold(
         _p(img0), _p(img1), _p(flow_prev), _p(tmp_last), h, w, float(scale), _p(out), H, W, _stream())), "drba_warp_blend_fold")
     return out
+
+
+def warp_blend_lazy(items, terms, tmp_last, scale):
+    """The final frames of every item of a stage in one launch, the flow before the last stage given as terms
+    (drba_warp_blend_lazy_batch): items = [(img0, img1, ...), ...], tmp_last [B,13,h,w] -> list of [1,3,H,W]."""
+    B = len(items)
+    if B > _lib.MAX_STAGE_ITEMS:
+        raise _lib.DrbaHipError(f"warp_blend_lazy: at most {_lib.MAX_STAGE_ITEMS} items per launch")
+    tmp_last = _f32(tmp_last)
+    ft, tts = _flow_terms(terms, B)
+    img0 = _f32(items[0][0])
+    _, _, H, W = img0.shape
+    h, w = tmp_last.shape[2], tmp_last.shape[3]
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=img0.device)
+    arr = (_lib.StageItem * B)()
+    keep = []
+    for k, it in enumerate(items):
+        i0, i1 = _f32(it[0]), _f32(it[1])
+        keep += [i0, i1]
+        a = arr[k]
+        a.img0, a.img1, a.tmp_prev, a.out = _ptr(i0), _ptr(i1), tmp_last[k].data_ptr(), out[k].data_ptr()
+        for i, t in enumerate(tts):
+            a.term[i] = t[k].data_ptr()
+    nbytes = B * 4.0 * ((6 + 3) * H * W + 5 * h * w)
+    _lib.check(_timed("warp_blend_lazy", (H, W, B), nbytes, "byte", lambda: _lib.load().drba_warp_blend_lazy_batch(
+        C.cast(arr, C.c_void_p), B, C.cast(C.pointer(ft), C.c_void_p), h, w, float(scale), H, W, _stream())), "drba_warp_blend_lazy_batch")
+    return [out[k:k + 1] for k in range(B)]
 
 
 def ifblock_update(tmp, flow_in, H, W, scale, want_mask_feat=False):

@@ -29,7 +29,9 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  2: drba_timing_* and drba_softmax_expect2 removed; drba_flow_reverse and drba_drm_rife_linear take a
+/* ABI version.  3: drba_stage_item_t grew by term[DRBA_MAX_FLOW_TERMS]; drba_flow_terms_t and the entry points that take the
+ * running flow as terms (drba_ifblock_input_lazy_batch, drba_warp_blend_lazy_batch); drba_stage_conv0_*.
+ * 2: drba_timing_* and drba_softmax_expect2 removed; drba_flow_reverse and drba_drm_rife_linear take a
  * workspace that must be ZERO on entry (they leave it zero on return: self-cleaning accumulator) instead of clearing it
  * themselves; batched stage entry points added; drba_conv3x3_cfg_family added and configuration ids 19 (LDS-DMA, 32
  * channels) / 20 (K split across waves) behind drba_conv3x3; the allocation exception above.  1: the first release. */
@@ -196,12 +198,24 @@ int drba_ifblock_input_lds(const float *img0, const float *img1, const float *f0
  * arguments above; flow_out != NULL requests the fold); the items agree on which optional pointers are given.
  * n_items <= DRBA_MAX_STAGE_ITEMS. */
 #define DRBA_MAX_STAGE_ITEMS 8
+#define DRBA_MAX_FLOW_TERMS 4
 typedef struct drba_stage_item {
   const float *img0, *img1, *f0, *f1, *f0_pair, *f1_pair, *timestep_map;
   float timestep_scalar;
   const float *flow, *tmp_prev;
   float *flow_out, *out;
+  const float *term[DRBA_MAX_FLOW_TERMS]; /* the "lazy" entry points: head outputs [13,h_i,w_i] of the stages BEFORE tmp_prev, oldest first */
 } drba_stage_item_t;
+/* The running flow as a list of terms instead of a full-resolution tensor (IFNet_HDv3.py:146-160: flow = flow + up(tmp_i[:, :4]) * s_i
+ * after every stage): term i is the head output of an earlier stage, [13, h[i], w[i]], upsampled x scale[i].  The entry points
+ * that take one evaluate flow = sum_i up(term_i[0:4]) * scale[i] + up(tmp_prev[0:4]) * prev_scale at their sample points
+ * (every product and sum rounded as the stored updates would be) -- no drba_ifblock_update pass, no flow tensor.
+ * item.flow and item.flow_out must be NULL there. */
+typedef struct drba_flow_terms {
+  int n;
+  int h[DRBA_MAX_FLOW_TERMS], w[DRBA_MAX_FLOW_TERMS];
+  float scale[DRBA_MAX_FLOW_TERMS];
+} drba_flow_terms_t;
 int drba_ifblock_input_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
                              int h, int w, float scale, void *stream);
 int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
@@ -210,13 +224,20 @@ int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, in
  * 52 -> 16 channels, stride 2, pad 1, LeakyReLU(0.2)): drba_ifblock_input_lds_batch(scale = 1) + drba_conv3x3(stride 2)
  * in one kernel, the 52-channel stage input never reaches HBM (stage_conv.hip).  items[k].out is the CONVOLUTION's output
  * [16, (H-1)/2+1, (W-1)/2+1]; f0_pair / f1_pair and tmp_prev are required; flow_out non-NULL folds the previous stage's
- * flow update in exactly as drba_ifblock_input_lds_batch does.  prev_scale must be 2.  `packed_w`: device copy of
+ * flow update in exactly as drba_ifblock_input_lds_batch does; with `terms` the flow is the lazy sum.  prev_scale must be 2.  `packed_w`: device copy of
  * drba_stage_conv0_pack's output (HOST function: w [16,52,3,3] and packed are host memory). */
+/* drba_ifblock_input_lds_batch with the flow given as terms (any scale of the pyramid; nothing but `out` is written). */
+int drba_ifblock_input_lazy_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int hp, int wp,
+                                  float prev_scale, int H, int W, int h, int w, float scale, void *stream);
+/* drba_warp_blend_fold for the items of a stage in one launch, the flow before the last stage given as terms: the items'
+ * img0, img1, tmp_prev (the LAST head output [13,h,w], stage scale `scale` >= 1), term[] and out ([3,H,W]) are read. */
+int drba_warp_blend_lazy_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int h, int w,
+                               float scale, int H, int W, void *stream);
 size_t drba_stage_conv0_packed_floats(void);
 int drba_stage_conv0_pack(const float *w, float *packed);
 int drba_stage_conv0_supported(int H, int W, float scale, float prev_scale, int Cout);
-int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, int hp, int wp, float prev_scale, int H, int W,
-                           const float *packed_w, const float *bias, void *stream);
+int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms /* NULL: flow / fold as above */,
+                           int hp, int wp, float prev_scale, int H, int W, const float *packed_w, const float *bias, void *stream);
 /* drba_ifblock_update for several items (arrays of n_items device pointers; flow_in may be NULL or hold NULLs). */
 int drba_ifblock_update_batch(const float *const *tmp, const float *const *flow_in, float *const *flow_out, int n_items,
                               int h, int w, int H, int W, float scale, void *stream);

@@ -263,6 +263,38 @@ def _glue_stage_rows(dev, g, D, H, W, scales):
                     rows.append((f"stage_conv0 + folded update ({tag}): flow_out", _diff(fo2[0], fl2), 1e-5 * sp, ""))
                     y, _ = ops.stage_conv0(item, [D(fl2.contiguous())], D(tprev), sp, conv, fold=False)
                     rows.append((f"stage_conv0, finished flow given ({tag}): conv output", _diff(y, refy), 1e-4, ""))
+        # the running flow as terms (flow_terms.hpp): flow = sum_i up(term_i[:4]) * s_i + up(tprev[:4]) * sp, formed inside the gather
+        # at every scale (0, 1 or 2 earlier head outputs: at 1/(4s) and 1/(8s) resolution where the frame is large enough)
+        terms = [(torch.randn(1, 13, int(H / st), int(W / st), generator=g), st) for st in (8.0 * s, 4.0 * s)
+                 if H / st >= 2 and W / st >= 2 and H % st == 0 and W % st == 0]
+        if H % sp == 0 and W % sp == 0:
+            fl3 = None
+            for tt, st in terms + [(tprev, sp)]:
+                d = F.interpolate(tt[:, :4], scale_factor=st, mode="bilinear", align_corners=False) * st
+                fl3 = d if fl3 is None else fl3 + d
+            w0, w1 = oracle.ops.backwarp(img0, fl3[:, :2]), oracle.ops.backwarp(img1, fl3[:, 2:4])
+            wf0, wf1 = oracle.ops.backwarp(f0, fl3[:, :2]), oracle.ops.backwarp(f1, fl3[:, 2:4])
+            x3 = F.interpolate(torch.cat((w0, w1, wf0, wf1, tmap, mask, feat), 1), scale_factor=1.0 / s, mode="bilinear", align_corners=False)
+            ref3 = torch.cat((x3, F.interpolate(fl3, scale_factor=1.0 / s, mode="bilinear", align_corners=False) * 1.0 / s), 1)
+            item = [(D(img0), D(img1), D(tmap), D(f0), D(f1))]
+            dterms = [(D(tt), st) for tt, st in terms]
+            xin = torch.empty(1, 52, int(H / s), int(W / s), device=dev)
+            ops.stage_inputs(item, None, D(tprev), sp, s, xin, terms=dterms)
+            mag = float(fl3.abs().max())
+            rows.append((f"ifblock_input_lds, flow as {len(terms)} terms + fold s={s}: stage input", _diff(xin, ref3), 1e-4 + 2e-6 * mag, ""))
+            if s == 1.0:
+                wt, bs = torch.randn(16, 52, 3, 3, generator=g) / (52 * 9) ** 0.5, torch.randn(16, generator=g) * 0.1
+                conv = ops.Conv3x3(wt, bs, 2, True, None, device=dev)
+                refy = F.leaky_relu(F.conv2d(ref3.double(), wt.double(), bs.double(), stride=2, padding=1), 0.2).float()
+                y, _ = ops.stage_conv0(item, None, D(tprev), sp, conv, terms=dterms)
+                rows.append((f"stage_conv0, flow as {len(terms)} terms + fold: conv output", _diff(y, refy), 1e-4 + 2e-6 * mag, ""))
+            if s >= 1:  # the final synthesis from the same terms, `tprev` as the LAST head output at scale sp
+                m3 = torch.sigmoid(upp[:, 4:5])
+                refb = oracle.ops.backwarp(img0, fl3[:, :2]) * m3 + oracle.ops.backwarp(img1, fl3[:, 2:4]) * (1 - m3)
+                wterms = [(D(tt), st) for tt, st in terms if st >= 2 * sp]
+                if len(wterms) == len(terms):
+                    got = ops.warp_blend_lazy([(D(img0), D(img1))], wterms, D(tprev), sp)[0]
+                    rows.append((f"warp_blend_lazy, {len(terms)} terms, last scale {sp}", _diff(got, refb), 2e-5 + 2e-6 * mag, ""))
         # update
         h, w = int(H / s), int(W / s)
         tmp = torch.randn(1, 13, h, w, generator=g)

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in include/drba_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in drba_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.drba_abi_version() == 2
+    assert lib.drba_abi_version() == 3
     assert lib.drba_error_string(-1) == b"invalid argument"
 
 
@@ -73,7 +73,7 @@ def test_stage_conv0_weight_packing_and_argument_checks():
     assert lib.drba_stage_conv0_supported(1088, 1920, 1.0, 2.0, 16) == 1
     assert lib.drba_stage_conv0_supported(1088, 1920, 2.0, 4.0, 16) == 0   # scale 1 only
     assert lib.drba_stage_conv0_supported(1088, 1920, 1.0, 2.0, 32) == 0   # block 4's 16 output channels only
-    assert lib.drba_stage_conv0_batch(None, 1, 4, 4, 2.0, 8, 8, None, None, None) == -1
+    assert lib.drba_stage_conv0_batch(None, 1, None, 4, 4, 2.0, 8, 8, None, None, None) == -1
 
 
 def test_split_conv_weight_packing_reconstructs_fp32():

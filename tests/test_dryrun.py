@@ -64,9 +64,19 @@ def test_rife_pipeline_plumbing(dry, monkeypatch):
     assert out2[0].shape == (1, 3, 64, 128)
     r = m.inference_ts(I[0], I[1], np.array([0.0, 0.5, 1.0]))
     assert r[0] is I[0] and r[2] is I[1]
-    for k in ("drba_conv3x3", "drba_deconv4x4s2", "drba_ifblock_input", "drba_ifblock_input_batch", "drba_ifblock_input_lds_batch",
-              "drba_ifblock_update", "drba_ifblock_update_batch", "drba_warp_blend_fold", "drba_flow_reverse",
+    # default pipeline: the running flow as terms (no flow tensor), the scale-1 stage input fused with conv0[0]
+    for k in ("drba_conv3x3", "drba_deconv4x4s2", "drba_ifblock_input", "drba_ifblock_input_batch", "drba_ifblock_input_lazy_batch",
+              "drba_stage_conv0_batch", "drba_warp_blend_lazy_batch", "drba_ifblock_update", "drba_flow_reverse",
               "drba_drm_rife_linear", "drba_softsplat", "drba_drm_retime"):
+        assert dry.calls.get(k, 0) > 0, k
+    assert dry.calls.get("drba_ifblock_update_batch", 0) == 0 and dry.calls.get("drba_warp_blend_fold", 0) == 0
+    # ... and the pipeline with the materialised flow (a model scale > 1 takes it; ops.LAZY_FLOW / STAGE_CONV_FUSED are its A/B switches)
+    monkeypatch.setattr(ops, "LAZY_FLOW", False)
+    out3, _ = m.inference_ts_drba(I[0], I[1], I[2], np.array([0.75, 1.25]), None, True)
+    assert out3[0].shape == (1, 3, 64, 128)
+    monkeypatch.setattr(ops, "STAGE_CONV_FUSED", False)
+    m.inference_ts_drba(I[0], I[1], I[2], np.array([0.75, 1.25]), None, True)
+    for k in ("drba_ifblock_input_lds_batch", "drba_ifblock_update_batch", "drba_warp_blend_fold"):
         assert dry.calls.get(k, 0) > 0, k
 
 
@@ -160,12 +170,19 @@ def test_rife_many_items_and_scale_plumbing(dry, scale, n_items):
     frames = net.forward_pairs(items, sl)
     assert len(frames) == n_items and all(x.shape == (1, 3, H, W) for x in frames)
     state = net.forward_pairs(items, sl, 0, 3)
-    assert len(state[0]) == n_items and state[1].shape[0] == n_items
+    lazy = state[3] == "lazy"  # the running flow as terms: state[0] = [(head output [B,13,h,w], scale)] of stages 0, 1
+    assert lazy == (scale <= 1)
+    if lazy:
+        assert len(state[0]) == 2 and all(t.shape[0] == n_items for t, _ in state[0]) and state[1].shape[0] == n_items
+    else:
+        assert len(state[0]) == n_items and state[1].shape[0] == n_items
     frames = net.forward_pairs(items, sl, 3, 5, state)
     assert len(frames) == n_items
+    groups = -(-n_items // _lib.MAX_STAGE_ITEMS)
     if n_items > _lib.MAX_STAGE_ITEMS:
-        assert dry.calls["drba_ifblock_input_batch"] >= 2 * -(-n_items // _lib.MAX_STAGE_ITEMS)
+        assert dry.calls["drba_ifblock_input_batch"] >= 2 * groups
     if scale > 1:
         assert dry.calls.get("drba_warp_blend", 0) == 2 * n_items and dry.calls.get("drba_warp_blend_fold", 0) == 0
-    else:
-        assert dry.calls.get("drba_warp_blend_fold", 0) == 2 * n_items
+    else:  # one launch per group of items, no flow update pass at all
+        assert dry.calls.get("drba_warp_blend_lazy_batch", 0) == 2 * groups and dry.calls.get("drba_ifblock_update_batch", 0) == 0
+        assert dry.calls.get("drba_ifblock_input_lazy_batch", 0) > 0

@@ -62,6 +62,10 @@ for n in (2, 8):
         xin = torch.empty(n, 52, int(H / s), int(W / s), device=dev)
         target(f"stage input s={s:.0f} with the folded flow update, {n} samples",
                lambda: ops.stage_inputs(items, flows, tprev, 2 * s, s, xin, fold=True))
+    tprev = torch.randn(n, 13, H // 2, W // 2, generator=g).to(dev)
+    conv00f = ops.Conv3x3(torch.randn(16, 52, 3, 3, generator=g) * 0.05, torch.zeros(16), 2, True, None, device=dev)
+    target(f"stage input s=1 + conv0[0] fused, folded flow update, {n} samples",
+           lambda: ops.stage_conv0(items, flows, tprev, 2.0, conv00f, fold=True))
     tprev = torch.randn(n, 13, H // 8, W // 8, generator=g).to(dev)
     xin4 = torch.empty(n, 52, H // 4, W // 4, device=dev)
     target(f"stage input s=4, {n} samples", lambda: ops.stage_inputs(items, flows, tprev, 8.0, 4.0, xin4))

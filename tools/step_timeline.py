@@ -13,7 +13,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from drba_amd import ops  # noqa: E402
 from drba_amd.models.rife import RIFE  # noqa: E402
 from drba_amd.utils import synth  # noqa: E402
 
@@ -25,31 +24,15 @@ a = ap.parse_args()
 (H, W), scale, _ = bench.CONFIGS[a.config]
 dev = torch.device("cuda:0")
 m = RIFE(weights=synth.ifnet_state_dict(0), scale=scale, device=dev)
-from drba_amd.models.utils import tools  # noqa: E402
-size = tools.get_valid_net_inp_size(np.zeros((H, W, 3), np.uint8), scale, div=64)
 clip = bench.DeviceClip(12, H, W, 1234, dev)
-TS = bench.TS
-state = {"I0": ops.to_inp(clip[0], size["dst_size"]), "I1": ops.to_inp(clip[1], size["dst_size"]), "reuse": None, "k": 2, "next": None}
-
-
-def step():
-    I2 = state["next"] if state["next"] is not None else ops.to_inp(clip[state["k"] % 12], size["dst_size"])
-    nxt = ops.to_inp(clip[(state["k"] + 1) % 12], size["dst_size"])
-    out, state["reuse"] = m.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], True, lookahead=(nxt, TS))
-    res = [ops.to_out(x, size["src_size"]) for x in out]
-    state["I0"], state["I1"], state["next"] = state["I1"], I2, nxt
-    state["k"] += 1
-    return res
-
-
-for _ in range(6):
-    step()
-torch.cuda.synchronize()
-ops.trace_begin()
-for _ in range(a.steps):
-    step()
-torch.cuda.synchronize()
-recs = ops.trace_end()
+frames = [clip[k] for k in range(len(clip))]
+# bench.py's own loop (groups of RIFE.GROUP steps, three streams), its instrumented steps traced launch by launch
+args = argparse.Namespace(steps=8, warmup=3, no_lookahead=False)
+_, _, recs, traced, _ = bench.step_loop(m, frames, 8, args, 1, trace=True)
+a.steps = traced
+t0 = min(r["start_ms"] for r in recs)
+for r in recs:
+    r["start_ms"] -= t0
 streams = sorted({r["stream"] for r in recs})
 names = {s: f"s{i}" for i, s in enumerate(streams)}
 t_end = max(r["start_ms"] + r["ms"] for r in recs)
