@@ -93,8 +93,13 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 // FMODE: 0 = the finished flow is read; 1 = FOLD (flow_prev + the previous stage's update, written to flow_out); 2 = LAZY
 // (the flow is the sum of the terms, flow_terms.hpp, + the previous stage's update; nothing but the convolution is written)
+#ifdef DRBA_SC_WPE  // experiment builds: cap the registers for this many waves per SIMD
+#define DRBA_SC_ATTR __attribute__((amdgpu_waves_per_eu(DRBA_SC_WPE)))
+#else
+#define DRBA_SC_ATTR
+#endif
 template <int FMODE, class G_>
-__global__ void __launch_bounds__(G_::THREADS)
+__global__ void __launch_bounds__(G_::THREADS) DRBA_SC_ATTR
 stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restrict__ wpk, const float *__restrict__ bias, int hp, int wp,
             float inv_prev_scale, float prev_scale, int H, int W, int Ho, int Wo, int tiles_x) {
   constexpr bool FOLD = FMODE != 0, WRITES = FMODE == 1, LAZY = FMODE == 2;

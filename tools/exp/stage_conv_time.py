@@ -29,12 +29,13 @@ for B in (2, 8):
         lo = torch.randn(1, 4, H // 16, W // 16, generator=g) * 5
         flows.append(torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear").to(dev).contiguous())
     tprev = torch.randn(B, 13, H // 2, W // 2, generator=g).to(dev)
+    terms = [(torch.randn(B, 13, H // st, W // st, generator=g).to(dev), float(st)) for st in (16, 8, 4)]  # the 1080p pyramid
     for _ in range(3):
-        ops.stage_conv0(items, flows, tprev, 2.0, conv, fold=True)
+        ops.stage_conv0(items, None, tprev, 2.0, conv, terms=terms)
     torch.cuda.synchronize()
     ops.trace_begin()
     for _ in range(reps):
-        ops.stage_conv0(items, flows, tprev, 2.0, conv, fold=True)
+        ops.stage_conv0(items, None, tprev, 2.0, conv, terms=terms)
     recs = [r for r in ops.trace_end() if "stage_conv0" in r["name"]]
     us = sum(r["ms"] for r in recs) / len(recs) * 1e3
     res.append("B%%d %%7.1f us (%%5.1f us/sample)" %% (B, us, us / B))

@@ -11,21 +11,9 @@ if [ "$2" != "skip-tests" ]; then
   echo "pytest exit $?" >> $OUT/pytest_gpu.txt
   tail -3 $OUT/pytest_gpu.txt
 fi
-timeout 900 python bench.py > $OUT/bench_1080p.json 2> $OUT/bench_1080p.err; echo "bench exit $?"
-for c in 4k 480p 4k_s1; do
-  timeout 600 python bench.py --config $c --no-extra --no-cpu-baseline > $OUT/bench_$c.json 2>> $OUT/bench_other.err
-done
-python tools/step_timeline.py --steps 2 > $OUT/timeline_1080p.txt 2>/dev/null
+# PMC passes first: bench.py reads profiles/pmc_traffic.json (written here) for roofline.traffic of the same build
 export TMPDIR=/tmp
 REPO=$(pwd)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $OUT/trace -o rife1080 -- python $REPO/bench.py --no-extra --no-cpu-baseline --no-roofline > $OUT/bench_1080p_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?")
-ls $OUT/trace | head
-DB=$(ls $OUT/trace/*_results.db 2>/dev/null | head -1)
-if [ -n "$DB" ]; then
-  python tools/rocpd_steady.py $DB 10 $OUT/steady_state.csv --rows 12
-  python tools/rocpd_steady.py $DB 10 $OUT/steady_state_by_grid.csv --by-grid --by-queue --rows 0 > /dev/null
-  python tools/rocpd_stats.py $DB $OUT/kernel_stats_whole_run.csv > /dev/null
-fi
 python tools/pmc_targets.py > /dev/null 2>&1   # autotune / warm outside the counter passes
 (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $REPO/tools/pmc_targets.py > /dev/null 2> $OUT/pmc_fetch.err; echo "pmc fetch exit $?")
 (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $REPO/tools/pmc_targets.py > /dev/null 2> $OUT/pmc_write.err; echo "pmc write exit $?")
@@ -41,4 +29,19 @@ if [ -n "$F" ] && [ -n "$Wc" ]; then
   python tools/pmc_traffic.py $F $Wc $OUT/pmc_manifest.json $OUT/pmc_traffic.md && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 fi
 rm -rf $OUT/pmc_fetch/*kernel_trace.csv $OUT/pmc_write/*kernel_trace.csv
+timeout 900 python bench.py > $OUT/bench_1080p.json 2> $OUT/bench_1080p.err; echo "bench exit $?"
+for c in 4k 480p 4k_s1; do
+  timeout 600 python bench.py --config $c --no-extra --no-cpu-baseline > $OUT/bench_$c.json 2>> $OUT/bench_other.err
+done
+python tools/step_timeline.py --steps 2 > $OUT/timeline_1080p.txt 2>/dev/null
+export TMPDIR=/tmp
+REPO=$(pwd)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $OUT/trace -o rife1080 -- python $REPO/bench.py --no-extra --no-cpu-baseline --no-roofline > $OUT/bench_1080p_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?")
+ls $OUT/trace | head
+DB=$(ls $OUT/trace/*_results.db 2>/dev/null | head -1)
+if [ -n "$DB" ]; then
+  python tools/rocpd_steady.py $DB 10 $OUT/steady_state.csv --rows 12
+  python tools/rocpd_steady.py $DB 10 $OUT/steady_state_by_grid.csv --by-grid --by-queue --rows 0 > /dev/null
+  python tools/rocpd_stats.py $DB $OUT/kernel_stats_whole_run.csv > /dev/null
+fi
 du -sh $OUT

@@ -69,6 +69,22 @@ for n in (2, 8):
     tprev = torch.randn(n, 13, H // 8, W // 8, generator=g).to(dev)
     xin4 = torch.empty(n, 52, H // 4, W // 4, device=dev)
     target(f"stage input s=4, {n} samples", lambda: ops.stage_inputs(items, flows, tprev, 8.0, 4.0, xin4))
+
+    # what the pipeline launches since the running flow is a list of terms (head outputs of the earlier stages: a refinement
+    # of a few pixels per stage on top of the coarse flow) -- the launch labels end in "+lazy"
+    def head(st, amp):
+        t = torch.randn(n, 13, int(H / st), int(W / st), generator=g)
+        t[:, :4] *= amp
+        return t.to(dev)
+    pyr = {16.0: head(16.0, 1.0), 8.0: head(8.0, 0.3), 4.0: head(4.0, 0.3), 2.0: head(2.0, 0.3)}
+    target(f"stage input s=1 + conv0[0] fused, flow as 3 terms, {n} samples",
+           lambda: ops.stage_conv0(items, None, pyr[2.0], 2.0, conv00f, terms=[(pyr[16.0], 16.0), (pyr[8.0], 8.0), (pyr[4.0], 4.0)]))
+    xl2 = torch.empty(n, 52, H // 2, W // 2, device=dev)
+    target(f"stage input s=2, flow as 2 terms, {n} samples",
+           lambda: ops.stage_inputs(items, None, pyr[4.0], 4.0, 2.0, xl2, terms=[(pyr[16.0], 16.0), (pyr[8.0], 8.0)]))
+    target(f"stage input s=4, flow as 1 term, {n} samples",
+           lambda: ops.stage_inputs(items, None, pyr[8.0], 8.0, 4.0, xin4, terms=[(pyr[16.0], 16.0)]))
+    del xl2, pyr
     for (c, h, w) in ((64, 136, 240), (32, 272, 480), (96, 68, 120), (128, 34, 60), (192, 17, 30)) + (((32, 544, 960),) if n == 2 else ()):
         x = torch.randn(n, c, h, w, generator=g).to(dev)
         layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, True, torch.ones(1, c, 1, 1), device=dev)
