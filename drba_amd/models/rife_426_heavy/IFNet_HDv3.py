@@ -33,6 +33,10 @@ class Head:
 
     def __call__(self, x, feat=False):
         if not feat:
+            if _ops.HEAD_FUSED and x.is_cuda:
+                f = _ops.head_fused(x, (self.cnn0, self.cnn1, self.cnn2, self.cnn3), self)  # one kernel, both feature layouts
+                if f is not None:
+                    return f
             return self.chain(x)
         x0 = self.cnn0(x)
         x1 = self.cnn1(x0)

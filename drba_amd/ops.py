@@ -570,6 +570,38 @@ class ConvChain:
 PAIR_FEATURES = True  # warped stages read the encoder features from a pair-interleaved copy (half the gather instructions)
 
 
+HEAD_FUSED = True  # IFNet's encoder as one kernel (drba_head_fused) instead of four layers + the pair-interleave copy (bench.py --no-head-fused: A/B)
+
+
+def head_fused(img, layers, holder):
+    """Head(img) (IFNet_HDv3.py:23-47) in one launch: layers = (cnn0, cnn1, cnn2 Conv3x3, cnn3 Deconv4x4); returns f [1,16,H,W]
+    with its pair-interleaved copy already attached (pair_interleaved(f) costs nothing afterwards).  `holder` keeps the packed
+    weights.  None when the shape is not one the kernel takes (odd sizes, a batch)."""
+    img = _f32(img)
+    n, c, H, W = img.shape
+    if n != 1 or c != 3 or H % 2 or W % 4:
+        return None
+    lib = _lib.load()
+    pk = getattr(holder, "_fused_pack", None)
+    if pk is None:
+        c0, c1, c2, c3 = layers
+        buf = torch.empty(lib.drba_head_fused_packed_floats(), dtype=torch.float32)
+        hb = [l.bias.detach().float().cpu().contiguous() for l in layers]
+        _lib.check(lib.drba_head_fused_pack(*(C.c_void_p(t.data_ptr()) for t in (c0.w_host, hb[0], c1.w_host, hb[1], c2.w_host, hb[2],
+                                                                                  c3.w_host, hb[3])), C.c_void_p(buf.data_ptr())),
+                   "drba_head_fused_pack")
+        pk = holder._fused_pack = buf.to(img.device)
+    f = torch.empty((1, 16, H, W), dtype=torch.float32, device=img.device)
+    fp = torch.empty((8, H, W, 2), dtype=torch.float32, device=img.device)
+    # algorithmic bytes: the frame read, the features written in both layouts; 9.5 GFLOP of fp32 MFMA work per 1080p frame
+    # ride along (61 us at the fp32 MFMA peak against 50 us of HBM time: the matrix cores are the binding roofline)
+    flop = 2.0 * (16 * 27 + 2 * 16 * 144) * (H // 2) * (W // 2) + 2.0 * 16 * 16 * 16 * (H // 2) * (W // 2)
+    _lib.check(_timed("head_fused", (H, W), flop, "flop", lambda: lib.drba_head_fused(_p(img), _p(pk), _p(f), _p(fp), 1, H, W, _stream())),
+               "drba_head_fused")
+    f._drba_pair = fp
+    return f
+
+
 def pair_interleaved(f):
     """[1,C,H,W] -> the [C/2,H,W,2] copy the stage-input gathers read; made once per feature tensor and kept on it."""
     fp = getattr(f, "_drba_pair", None)

@@ -226,6 +226,15 @@ int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, in
  * [16, (H-1)/2+1, (W-1)/2+1]; f0_pair / f1_pair and tmp_prev are required; flow_out non-NULL folds the previous stage's
  * flow update in exactly as drba_ifblock_input_lds_batch does; with `terms` the flow is the lazy sum.  prev_scale must be 2.  `packed_w`: device copy of
  * drba_stage_conv0_pack's output (HOST function: w [16,52,3,3] and packed are host memory). */
+/* IFNet's context encoder (IFNet_HDv3.py:23-47 `Head`: conv 3->16 stride 2, two convs 16->16, each + LeakyReLU(0.2), then
+ * ConvTranspose2d(16,16,4,2,1)) in one kernel, intermediates in LDS (head_fused.hip).  img [N,3,H,W] -> f_out [N,16,H,W] and
+ * f_pair_out, the same values pair-interleaved per sample ([8,H,W,2]: what drba_pair_interleave(f_out) would write).
+ * H even, W % 4 == 0, 16-byte aligned outputs.  drba_head_fused_pack is a HOST function (weights in the reference's
+ * layouts: w0 [16,3,3,3], w1 / w2 [16,16,3,3], w3 [16 in,16 out,4,4], biases [16]); packed_w is its output copied to the device. */
+size_t drba_head_fused_packed_floats(void);
+int drba_head_fused_pack(const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
+                         const float *w3, const float *b3, float *packed);
+int drba_head_fused(const float *img, const float *packed_w, float *f_out, float *f_pair_out, int N, int H, int W, void *stream);
 /* drba_ifblock_input_lds_batch with the flow given as terms (any scale of the pyramid; nothing but `out` is written). */
 int drba_ifblock_input_lazy_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int hp, int wp,
                                   float prev_scale, int H, int W, int h, int w, float scale, void *stream);

@@ -200,6 +200,37 @@ def check_conv_layers(dev):
         rows.append(("conv_chain vs layer-by-layer", _diff(second, first), 0.0, "bit-exact"))
     except Exception as e:  # noqa: BLE001
         rows.append(("conv_chain", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    # IFNet's encoder as one kernel (head_fused.hip) against the reference's four layers (IFNet_HDv3.py:23-47) in fp64 and
+    # against the layer-by-layer HIP path: whole tiles, tiles cut by the border, a frame smaller than one tile
+    try:
+        from drba_amd.models.rife_426_heavy.IFNet_HDv3 import Head
+        sd = {"encode.cnn0.weight": torch.randn(16, 3, 3, 3, generator=g) / 27 ** 0.5, "encode.cnn0.bias": torch.randn(16, generator=g) * 0.1,
+              "encode.cnn1.weight": torch.randn(16, 16, 3, 3, generator=g) / 12, "encode.cnn1.bias": torch.randn(16, generator=g) * 0.1,
+              "encode.cnn2.weight": torch.randn(16, 16, 3, 3, generator=g) / 12, "encode.cnn2.bias": torch.randn(16, generator=g) * 0.1,
+              "encode.cnn3.weight": torch.randn(16, 16, 4, 4, generator=g) / 8, "encode.cnn3.bias": torch.randn(16, generator=g) * 0.1}
+        head = Head(sd, "encode.", dev)
+        for (h, w) in ((64, 128), (72, 136), (16, 24), (128, 320)):
+            x = torch.rand(1, 3, h, w, generator=g)
+            d = {k: v.double() for k, v in sd.items()}
+            y = F.leaky_relu(F.conv2d(x.double(), d["encode.cnn0.weight"], d["encode.cnn0.bias"], stride=2, padding=1), 0.2)
+            y = F.leaky_relu(F.conv2d(y, d["encode.cnn1.weight"], d["encode.cnn1.bias"], padding=1), 0.2)
+            y = F.leaky_relu(F.conv2d(y, d["encode.cnn2.weight"], d["encode.cnn2.bias"], padding=1), 0.2)
+            ref = F.conv_transpose2d(y, d["encode.cnn3.weight"], d["encode.cnn3.bias"], stride=2, padding=1).float()
+            ops.HEAD_FUSED = True
+            f = head(x.to(dev))
+            fp = getattr(f, "_drba_pair", None)
+            ops.HEAD_FUSED = False
+            f_layers = head(x.to(dev))
+            ops.HEAD_FUSED = True
+            tol = 2e-5 * max(1.0, float(ref.abs().max()))
+            rows.append((f"head_fused {h}x{w} vs fp64 reference layers", _diff(f, ref), tol, ""))
+            rows.append((f"head_fused {h}x{w} vs layer-by-layer HIP path", _diff(f, f_layers.cpu()), tol, ""))
+            want_pair = ref[0].reshape(8, 2, h, w).permute(0, 2, 3, 1).contiguous()
+            rows.append((f"head_fused {h}x{w} pair-interleaved copy", float("inf") if fp is None else _diff(fp, want_pair), tol, ""))
+    except Exception as e:  # noqa: BLE001
+        rows.append(("head_fused", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    finally:
+        ops.HEAD_FUSED = True
     return rows
 
 
