@@ -3,12 +3,12 @@
 // 25 + 33 | 33 + 33 | 33 + 33 | 33 + 134 MB per 1080p frame through HBM at 33-38 % of the fp32 MFMA peak, plus the
 // pair-interleave copy of the result (268 MB) the warped gathers read: 225 us per frame, 9 % of a 1080p step and a quarter
 // of a 4K scale-0.5 step (the encoder runs at the frame's full resolution whatever the flow scale).  Here a workgroup
-// (8 waves) owns a 32 x 64 tile of the output = 16 x 32 half-resolution positions and keeps everything between the frame
+// (8 waves) owns a 16 x 64 tile of the output = 8 x 32 half-resolution positions and keeps everything between the frame
 // and the features in LDS:
-//   IN  [3][45][77]   the frame under the tile with the 3 + 3 + 3 (+1) half-resolution rings the three 3x3 convolutions and
+//   IN  [3][29][77]   the frame under the tile with the 3 + 3 + 3 (+1) half-resolution rings the three 3x3 convolutions and
 //                     the transposed one reach (zero outside the image: the first convolution's padding)
-//   X0  [16][22][38]  cnn0 + LeakyReLU        X1 [16][20][36]  cnn1 + LeakyReLU        X2 [16][18][34]  cnn2 + LeakyReLU
-//   (all three in one 22 x 40 "region" coordinate system, channel stride 880 = 16 mod 32: A fragments are conflict-free;
+//   X0  [16][14][38]  cnn0 + LeakyReLU        X1 [16][12][36]  cnn1 + LeakyReLU        X2 [16][10][34]  cnn2 + LeakyReLU
+//   (all three in one 14 x 40 "region" coordinate system, channel stride 560 = 16 mod 32: A fragments are conflict-free;
 //    positions outside the half-resolution map are stored as zero -- the next layer's padding; X1 overlays IN, X2 X0)
 // and every layer is exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: 16 pixels x 16 output channels x 4 input channels of one
 // tap), M tiles taken from the flattened region so that a tile's taps are one LDS read at a constant offset; a layer's
@@ -16,12 +16,13 @@
 // two to four independent accumulator chains per wave.  The transposed convolution runs as its four output phases
 // (2 x 2 taps each) and writes BOTH layouts from registers: [16, H, W] (what the unwarped first stage, tests and callers
 // read) and the pair-interleaved [8, H, W, 2] the warped gathers read (lanes of a channel pair exchange halves).
-// Redundant work for the rings: 1.30 x the MFMAs of the four layers; HBM traffic: the frame once, the features once per
-// layout.  LDS: two 56 KB buffers, one workgroup per CU.  Results differ from the layer-by-layer path only by the
-// accumulation order.  Measured alone (tools/exp/head_time.py): 189 us per 1080p frame against 215 for the four layers +
-// the copy, 735 against 817 at 4K; in the step +1.2 / +1.4 % (1080p / 4K scale 0.5).  The matrix cores are 47 % busy: with
-// one workgroup per CU the window load and the feature stores of a tile do not overlap another tile's MFMAs; 16 x 64 tiles
-// with two workgroups per CU (1.13 x more ring work) measured 200 us.
+// Redundant work for the rings: 1.47 x the MFMAs of the four layers; HBM traffic: the frame once, the features once per
+// layout.  LDS: two 35 KB buffers, two workgroups per CU.  Results differ from the layer-by-layer path only by the
+// accumulation order.  Measured alone (tools/exp/head_time.py): 200 us per 1080p frame against 215 for the four layers +
+// the copy, 755 against 817 at 4K; 32 x 64 tiles (one 114 KB workgroup per CU, 1.30 x ring work) are faster alone (189 /
+// 735) but the same in the step (826-837 frames/s either way, +1.2 % over the layers): their workgroups wait for a CU with
+// 114 KB of LDS free while the main stream's kernels run, the kernel's launches stretch to 610 us in the step and hold
+// stage_conv0's workgroups off in turn.  The matrix cores are 45 % busy.
 #include "common.hpp"
 
 #include <string.h>
@@ -33,20 +34,20 @@ namespace drba_head {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C = 16;                       // feature channels
-constexpr int H2 = 16, W2 = 32;             // half-resolution positions per workgroup (output tile 32 x 64)
+constexpr int H2 = 8, W2 = 32;              // half-resolution positions per workgroup (output tile 16 x 64)
 constexpr int RR = H2 + 6, RC = W2 + 6;     // region: 22 x 38 positions (cnn0's outputs)
 constexpr int RS = 40;                      // region row stride
-constexpr int CS = RR * RS;                 // 880: channel stride, = 16 (mod 32)
-constexpr int IR = 2 * RR + 1, IC = 2 * RC + 1;  // frame window: 45 x 77
+constexpr int CS = RR * RS;                 // 560: channel stride, = 16 (mod 32)
+constexpr int IR = 2 * RR + 1, IC = 2 * RC + 1;  // frame window: 29 x 77
 constexpr int IRS = 80, ICS = IR * IRS;     // its row / channel stride (3600)
 constexpr int GUARD = 64;                   // floats in front of / behind each buffer (taps of discarded edge positions)
-constexpr int BUF = C * CS;                 // 14080 floats >= 3 * ICS = 10800
+constexpr int BUF = C * CS;                 // 8960 floats >= 3 * ICS = 6960
 constexpr int THREADS = 512;
 // packed weights: cnn0 [7][64], cnn1 [9 taps][4 groups][64], cnn2 likewise, deconv [4 phases][4 taps][4 groups][64], biases [4][16]
 constexpr int W0 = 7 * 64, W1 = 36 * 64, W3 = 64 * 64, WB = 4 * 16;
 constexpr int OFF_W1 = W0, OFF_W2 = W0 + W1, OFF_W3 = W0 + 2 * W1, OFF_B = W0 + 2 * W1 + W3;
 constexpr int W_FLOATS = OFF_B + WB;        // 9216
-constexpr int LDS_FLOATS = 2 * (BUF + 2 * GUARD);  // 113.7 KB (the weights go from L2 to registers)
+constexpr int LDS_FLOATS = 2 * (BUF + 2 * GUARD);  // 72.7 KB: two workgroups per CU (the weights go from L2 to registers)
 
 static_assert(CS % 32 == 16, "channel stride");
 static_assert(3 * ICS <= BUF, "frame window fits the region buffer it shares");
