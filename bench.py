@@ -116,6 +116,7 @@ def parse():
     p.add_argument("--no-stage-conv", action="store_true",
                    help="A/B runs: the scale-1 stage input and conv0[0] as two kernels (ops.STAGE_CONV_FUSED = False)")
     p.add_argument("--no-head-fused", action="store_true", help="A/B runs: IFNet's encoder layer by layer (ops.HEAD_FUSED = False)")
+    p.add_argument("--prefetch-priority", type=int, default=None, help="A/B runs: HIP priority of the encoder / prefetch stream (-1 = high)")
     p.add_argument("--no-lazy-flow", action="store_true",
                    help="A/B runs: IFNet's running flow as a full-resolution tensor updated after every stage (ops.LAZY_FLOW = False)")
     p.add_argument("--selftest-sharded", action="store_true",
@@ -801,6 +802,9 @@ def main():
     if args.no_lazy_flow:
         from drba_amd import ops as _ops1
         _ops1.LAZY_FLOW = False
+    if args.prefetch_priority is not None:
+        from drba_amd.models import lookahead as _la
+        _la.PRIORITY["prefetch"] = int(args.prefetch_priority)
     if args.no_head_fused:
         from drba_amd import ops as _ops2
         _ops2.HEAD_FUSED = False

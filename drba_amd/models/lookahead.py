@@ -12,6 +12,9 @@ import torch
 _STREAMS = {}
 
 
+PRIORITY = {}  # role -> HIP stream priority (-1 = high); experiments only (bench.py --prefetch-priority)
+
+
 def shared_stream(device, role):
     """ONE extra HIP stream per (device, role) for every model instance of the process ("side": the lookahead's chain,
     "prefetch": encoders / coarse flows of frames read ahead).  HIP multiplexes streams onto a handful of hardware queues;
@@ -21,7 +24,7 @@ def shared_stream(device, role):
     key = (device.index, role)
     s = _STREAMS.get(key)
     if s is None:
-        s = _STREAMS[key] = torch.cuda.Stream(device=device)
+        s = _STREAMS[key] = torch.cuda.Stream(device=device, priority=PRIORITY.get(role, 0))
     return s
 
 
