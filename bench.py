@@ -330,6 +330,10 @@ def standalone_of(roof, dev, reps=30):
     import re
     geo = sorted((roof or {}).get("by_geometry") or [], key=lambda g: -g["algorithmic_per_launch"])  # most work first
     for g in geo:
+        m = re.match(r"stage_conv0\+lazy \(52, 16, (\d+), (\d+), (\d+)\)$", g["launch"])
+        if m:
+            return _standalone_stage_conv0(roof, dev, g, *(int(v) for v in m.groups()), reps=reps)
+    for g in geo:
         m = re.match(r"conv3x3 \((\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)$", g["launch"])
         if not m:
             continue
@@ -360,6 +364,38 @@ def standalone_of(roof, dev, reps=30):
                 "what": f"{reps} back-to-back launches of this layer alone (events around the run: includes the ~5 us between "
                         "dependent launches)"}
     return None
+
+
+def _standalone_stage_conv0(roof, dev, g, H, W, n, reps=30):
+    """drba_stage_conv0_batch alone on the idle GPU: the launch geometry of the loop (n samples, the flow as the terms of
+    the four earlier stages -- a coarse flow of a few pixels plus sub-pixel refinements, i.e. smooth, as a trained net's)."""
+    from drba_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    items = []
+    for _ in range(n):
+        i0, i1 = torch.rand(1, 3, H, W, generator=gen).to(dev), torch.rand(1, 3, H, W, generator=gen).to(dev)
+        f0, f1 = torch.randn(1, 16, H, W, generator=gen).to(dev), torch.randn(1, 16, H, W, generator=gen).to(dev)
+        items.append((i0, i1, torch.rand(1, 1, H, W, generator=gen).to(dev), f0, f1))
+
+    def head(st, amp):
+        t = torch.randn(n, 13, H // st, W // st, generator=gen)
+        t[:, :4] *= amp
+        return t.to(dev)
+    terms = [(head(16, 1.0), 16.0), (head(8, 0.3), 8.0), (head(4, 0.3), 4.0)]
+    tprev = head(2, 0.3)
+    conv = ops.Conv3x3(torch.randn(16, 52, 3, 3, generator=gen) * 0.05, torch.zeros(16), 2, True, None, device=dev)
+    run = lambda: ops.stage_conv0(items, None, tprev, 2.0, conv, terms=terms)  # noqa: E731
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    ops.trace_begin()
+    for _ in range(reps):
+        run()
+    recs = [r for r in ops.trace_end() if "stage_conv0" in r["name"]]
+    us = sum(r["ms"] for r in recs) / max(len(recs), 1) * 1e3
+    ach = g["algorithmic_per_launch"] / us / 1e3  # GB/s
+    return {"launch": g["launch"], "avg_us": round(us, 2), "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / roof["peak"], 4),
+            "what": f"{reps} launches of this geometry alone (synthetic smooth flows), the kernel's own dispatch times"}
 
 
 def _rocprof_table():
@@ -654,7 +690,7 @@ def gpu_leg(args, rank, world):
     r["roofline"] = roofline_from_trace(recs, traced, _traffic_table(), serial) if recs else None
     if world == 1:
         r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps})
-        if r["roofline"] and r["roofline"].get("bound") == "mfma":
+        if r["roofline"] and (r["roofline"].get("bound") == "mfma" or "stage_conv0" in r["roofline"].get("kernel", "")):
             torch.cuda.synchronize()
             r["roofline"]["standalone"] = standalone_of(r["roofline"], dev)
             r["roofline"]["frac_standalone"] = (r["roofline"]["standalone"] or {}).get("frac")
