@@ -35,11 +35,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C = 16;                       // feature channels
 constexpr int H2 = 8, W2 = 32;              // half-resolution positions per workgroup (output tile 16 x 64)
-constexpr int RR = H2 + 6, RC = W2 + 6;     // region: 22 x 38 positions (cnn0's outputs)
+constexpr int RR = H2 + 6, RC = W2 + 6;     // region: 14 x 38 positions (cnn0's outputs)
 constexpr int RS = 40;                      // region row stride
 constexpr int CS = RR * RS;                 // 560: channel stride, = 16 (mod 32)
 constexpr int IR = 2 * RR + 1, IC = 2 * RC + 1;  // frame window: 29 x 77
-constexpr int IRS = 80, ICS = IR * IRS;     // its row / channel stride (3600)
+constexpr int IRS = 80, ICS = IR * IRS;     // its row / channel stride (2320)
 constexpr int GUARD = 64;                   // floats in front of / behind each buffer (taps of discarded edge positions)
 constexpr int BUF = C * CS;                 // 8960 floats >= 3 * ICS = 6960
 constexpr int THREADS = 512;
@@ -75,8 +75,7 @@ head_fused(const float *__restrict__ img, const float *__restrict__ wpk, float *
   // ---- weights and the frame window (zero outside the image)
   {
     // all of a lane's loads are issued before the first is parked (unconditional loads at clamped addresses: a guarded
-    // load per iteration serialises one memory latency per element, 21 of them -- with one workgroup per CU nothing else
-    // runs meanwhile)
+    // load per iteration serialises one memory latency per element, 14 of them per lane: 30 us per 1080p frame)
     const int y0 = 2 * rm - 1, x0 = 2 * rn - 1;
     constexpr int NI = (3 * IR * IRS + THREADS - 1) / THREADS;
     float v[NI];
