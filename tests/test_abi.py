@@ -76,6 +76,35 @@ def test_stage_conv0_weight_packing_and_argument_checks():
     assert lib.drba_stage_conv0_batch(None, 1, None, 4, 4, 2.0, 8, 8, None, None, None) == -1
 
 
+def test_lazy_flow_and_head_entry_points_validate_arguments_without_gpu():
+    """The entry points that take the running flow as terms (drba_flow_terms_t) and the fused encoder reject malformed calls
+    before any launch; the fused encoder's weight pack holds every weight exactly once."""
+    lib = _lib.load()
+    ft = _lib.FlowTerms()
+    ft.n = 5  # more than DRBA_MAX_FLOW_TERMS
+    item = (_lib.StageItem * 1)()
+    p = C.cast(C.pointer(ft), C.c_void_p)
+    assert lib.drba_ifblock_input_lazy_batch(None, 1, p, 4, 4, 2.0, 8, 8, 8, 8, 1.0, None) == -1
+    assert lib.drba_ifblock_input_lazy_batch(C.cast(item, C.c_void_p), 1, None, 4, 4, 2.0, 8, 8, 8, 8, 1.0, None) == -1  # no terms: not the lazy call
+    assert lib.drba_warp_blend_lazy_batch(None, 1, p, 8, 8, 1.0, 8, 8, None) == -1
+    assert lib.drba_head_fused(None, None, None, None, 1, 8, 8, None) == -1
+    n = lib.drba_head_fused_packed_floats()
+    assert n == 7 * 64 + 2 * 36 * 64 + 64 * 64 + 64
+    g = torch.Generator().manual_seed(3)
+    w0, w1, w2, w3 = (torch.rand(16, 3, 3, 3, generator=g) + 1, torch.rand(16, 16, 3, 3, generator=g) + 3,
+                      torch.rand(16, 16, 3, 3, generator=g) + 5, torch.rand(16, 16, 4, 4, generator=g) + 7)
+    bs = [torch.rand(16, generator=g) + 9 + k for k in range(4)]
+    buf = torch.full((n,), -1.0)
+    args = [w0, bs[0], w1, bs[1], w2, bs[2], w3, bs[3]]
+    assert lib.drba_head_fused_pack(*(C.c_void_p(t.data_ptr()) for t in args), C.c_void_p(buf.data_ptr())) == 0
+    pk = buf.numpy()
+    assert (pk >= 0).all()
+    for lo, hi, w in ((1, 2, w0), (3, 4, w1), (5, 6, w2), (7, 8, w3)):
+        got = np.sort(pk[(pk >= lo) & (pk < hi)])
+        assert np.array_equal(got, np.sort(w.numpy().reshape(-1)))  # every weight of the layer exactly once
+    assert np.array_equal(pk[-64:], torch.cat(bs).numpy())
+
+
 def test_split_conv_weight_packing_reconstructs_fp32():
     """conv_split.hip packs every weight as three bf16 terms h + m + l (cfg ids after the fp32 table): their sum must be
     the fp32 weight up to its last mantissa bit, every weight exactly once, and a layer the family cannot run
