@@ -271,10 +271,10 @@ def test_feature_splat_quad_source(hip_backend):
     _assert_rows(gpu_checks.check_splat_quad(hip_backend.dev))
 
 
-@pytest.mark.parametrize("scale,n_ts", [(1.0, 7), (2.0, 2), (2.0, 5)])
+@pytest.mark.parametrize("scale,n_ts", [(1.0, 7), (1.0, 10), (2.0, 2), (2.0, 5)])
 def test_rife_many_timesteps_and_model_scale_above_one(hip_backend, oracle_backend, scale, n_ts):
-    """A step with more frames to synthesise than one batched glue launch takes (DRBA_MAX_STAGE_ITEMS = 4: `-t 8` has 7)
-    runs as independent groups, and with a model scale > 1 (scale_list ends at 0.5: the last stage runs ABOVE the frame
+    """A step with more frames to synthesise than one batched glue launch takes (DRBA_MAX_STAGE_ITEMS = 8: the 10-timestep case;
+    `-t 8` has 7) runs as independent groups whose carried state -- the flow terms -- is re-joined, and with a model scale > 1 (scale_list ends at 0.5: the last stage runs ABOVE the frame
     resolution) the frame is finished by the plain flow update + warp_blend pair; both against the oracle at 1e-3, cold
     and warm step (reference rife.py:77-109 takes any number of timesteps and any scale)."""
     from drba_amd.utils import synth
