@@ -117,6 +117,7 @@ def parse():
                    help="A/B runs: the scale-1 stage input and conv0[0] as two kernels (ops.STAGE_CONV_FUSED = False)")
     p.add_argument("--no-head-fused", action="store_true", help="A/B runs: IFNet's encoder layer by layer (ops.HEAD_FUSED = False)")
     p.add_argument("--prefetch-priority", type=int, default=None, help="A/B runs: HIP priority of the encoder / prefetch stream (-1 = high)")
+    p.add_argument("--enc-main", action="store_true", help="A/B runs: RIFE.ENC_ON_MAIN, the encoders in the main stream")
     p.add_argument("--side-stages", type=int, default=None, help="A/B runs: RIFE.SIDE_STAGES, IFNet stages of the next group staged on the side stream")
     p.add_argument("--no-lazy-flow", action="store_true",
                    help="A/B runs: IFNet's running flow as a full-resolution tensor updated after every stage (ops.LAZY_FLOW = False)")
@@ -842,6 +843,9 @@ def main():
     if args.prefetch_priority is not None:
         from drba_amd.models import lookahead as _la
         _la.PRIORITY["prefetch"] = int(args.prefetch_priority)
+    if args.enc_main:
+        from drba_amd.models.rife import RIFE as _R3
+        _R3.ENC_ON_MAIN = True
     if args.side_stages is not None:
         from drba_amd.models.rife import RIFE as _R2
         _R2.SIDE_STAGES = int(args.side_stages)

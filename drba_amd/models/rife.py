@@ -135,7 +135,7 @@ class RIFE:
         dev = I.device
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_enc_stream", None) is None:
-            self._enc_stream = shared_stream(dev, "prefetch")
+            self._enc_stream = main if self.ENC_ON_MAIN else shared_stream(dev, "prefetch")
         ready = torch.cuda.Event()
         ready.record(main)  # the frame was produced (to_inp) on the caller's stream
         with torch.cuda.stream(self._enc_stream):
@@ -200,6 +200,7 @@ class RIFE:
         flow_ab, flow_ba, fa, fb = self.calc_flow(Ia, Ib)
         return (flow_ba, flow_ab, fb, fa)
 
+    ENC_ON_MAIN = False  # A/B runs: the frames' encoders in the caller's stream (right behind to_inp) instead of the prefetch stream
     SIDE_STAGES = 3  # IFNet stages of the NEXT step run by the lookahead on the side stream (class attribute: A/B runs set it)
 
     def _items(self, I0, I1, I2, ts, linear, flow10, flow12, f0, f1, f2):
