@@ -93,10 +93,21 @@ head_fused(const float *__restrict__ img, const float *__restrict__ wpk, float *
       if (tid + k * THREADS < 3 * IR * IRS) bufA[tid + k * THREADS] = v[k];
   }
   __syncthreads();
-  auto inside = [&](int q) -> bool {  // is region position q (row-major, stride RS) inside the half-resolution map?
-    const int r = q / RS, c = q - r * RS;
-    const int y = rm + r, x = rn + c;
-    return y >= 0 && y < Hh && x >= 0 && x < Wh;
+  // Positions outside the half-resolution map are stored as zero.  Only border tiles have any (a workgroup-uniform test);
+  // there the four positions a lane stores (q .. q+3, q % 4 == 0, RS % 4 == 0: one region row) share one row test.
+  const bool interior = rm >= 0 && rm + RR <= Hh && rn >= 0 && rn + RS <= Wh;
+  auto store4 = [&](float *dst, int q, const f32x4 &acc, float bias, int ncol) {  // ncol: valid columns of the region row (RC or RS)
+    f32x4 o;
+    if (interior && ncol == RS) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) o[v] = lrelu02(acc[v] + bias);
+    } else {
+      const int r = q / RS, c = q - r * RS;
+      const bool rowok = (unsigned)(rm + r) < (unsigned)Hh;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) o[v] = (rowok && c + v < ncol && (unsigned)(rn + c + v) < (unsigned)Wh) ? lrelu02(acc[v] + bias) : 0.f;
+    }
+    *reinterpret_cast<f32x4 *>(dst + q) = o;
   };
 
   // ---- cnn0: 3 -> 16, stride 2, + LeakyReLU: IN -> X0 (bufB).  K = 27 as 7 groups of 4 (k = 4 i + kq -> channel, tap)
@@ -117,12 +128,7 @@ head_fused(const float *__restrict__ img, const float *__restrict__ wpk, float *
 #pragma unroll
       for (int i = 0; i < 7; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[off[i]], b[i], acc, 0, 0, 0);
       const int c = c0 + 4 * kq;                    // this lane: positions c .. c+3 of row r, output channel m
-      if (c < RS) {
-        f32x4 o;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) o[v] = (c + v < RC && inside(r * RS + c + v)) ? lrelu02(acc[v] + bias) : 0.f;
-        *reinterpret_cast<f32x4 *>(bufB + m * CS + r * RS + c) = o;
-      }
+      if (c < RS) store4(bufB + m * CS, r * RS + c, acc, bias, RC);
     }
   }
   __syncthreads();
@@ -147,15 +153,8 @@ head_fused(const float *__restrict__ img, const float *__restrict__ wpk, float *
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[o], b[t * 4 + g], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[o], b[t * 4 + g], acc1, 0, 0, 0);
         }
-      auto put = [&](int qq, const f32x4 &acc) {
-        const int q = qq + 4 * kq;
-        f32x4 o;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) o[v] = inside(q + v) ? lrelu02(acc[v] + bias) : 0.f;
-        *reinterpret_cast<f32x4 *>(dst + m * CS + q) = o;
-      };
-      put(q0, acc0);
-      if (two) put(q1, acc1);
+      store4(dst + m * CS, q0 + 4 * kq, acc0, bias, RS);
+      if (two) store4(dst + m * CS, q1 + 4 * kq, acc1, bias, RS);
     }
   };
   conv16(bufB, bufA, OFF_W1, 16, 1 * RS, (RR - 1) * RS);   // X0 -> X1: region rows 1..20
