@@ -8,6 +8,21 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrba_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "drba_hip.h")
+
+
+def _header_abi_version():
+    """DRBA_ABI_VERSION of include/drba_hip.h: the header is the one place the number is written down (the library
+    returns the macro, the entry point and the tests compare with this)."""
+    import re
+    with open(HEADER_PATH) as f:
+        m = re.search(r"^#define\s+DRBA_ABI_VERSION\s+(\d+)", f.read(), flags=re.M)
+    if m is None:
+        raise RuntimeError(f"{HEADER_PATH} does not define DRBA_ABI_VERSION")
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()
 
 _p = C.c_void_p
 _i = C.c_int
@@ -154,6 +169,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    got = lib.drba_abi_version()
+    if got != ABI_VERSION:
+        raise DrbaHipError(f"{LIB_PATH} reports ABI version {got}, include/drba_hip.h declares {ABI_VERSION}: "
+                           "stale build, run `make -C drba_amd/csrc`")
     _lib = lib
     return lib
 

@@ -78,7 +78,7 @@ TimedLaunch trace_launch(const void *host_fn, const char *fallback, dim3 grid, h
 
 extern "C" {
 
-int drba_abi_version(void) { return 3; }
+int drba_abi_version(void) { return DRBA_ABI_VERSION; }
 
 int drba_trace_begin(void) {
   // events are created here, outside any timed region (hipEventCreate costs tens of microseconds each)

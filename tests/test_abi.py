@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in include/drba_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in drba_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.drba_abi_version() == 3
+    assert lib.drba_abi_version() == _lib.ABI_VERSION
     assert lib.drba_error_string(-1) == b"invalid argument"
 
 
@@ -215,3 +215,23 @@ def test_library_is_mapped_after_torch():
             "assert 'torch' in sys.modules\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_graft_entry_build_succeeds():
+    """`python -c "import __graft_entry__ as g; g.build()"` (README, the driver's build check) in a fresh process on this
+    tree: make (a no-op when the objects are current), the library loads, its ABI version equals the header's
+    DRBA_ABI_VERSION and the package imports.  Round 3 shipped a build() that asserted a stale literal."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=3000)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_abi_version_has_one_source():
+    """The number is written once (the header's macro); nothing else in the tree compares against a literal."""
+    assert _lib.ABI_VERSION == _lib.load().drba_abi_version()
+    hdr = open(os.path.join(ROOT, "include", "drba_hip.h")).read()
+    assert re.search(r"ABI version\.\s+%d:" % _lib.ABI_VERSION, hdr), "the header's version history lacks the current version"
+    for fn in ("__graft_entry__.py", "bench.py", os.path.join("drba_amd", "csrc", "api_misc.hip")):
+        assert not re.search(r"abi_version\(\)\s*(==|!=|>=)\s*\d", open(os.path.join(ROOT, fn)).read()), fn

@@ -30,7 +30,7 @@ def test_native_library_is_what_runs():
     """The product must be the HIP library: it is loaded from the tree and there is no fallback."""
     from drba_amd import _lib
     lib = _lib.load()
-    assert lib.drba_abi_version() == 3
+    assert lib.drba_abi_version() == _lib.ABI_VERSION
     with open("/proc/self/maps") as f:
         assert "libdrba_hip.so" in f.read()
 
