@@ -10,7 +10,7 @@ Decode/encode and PCIe are outside the metric; `pcie_inclusive`
 starting and ending in pinned host memory.  value = model-generated frames of ALL ranks / max-rank time.
 As in drba_amd.infer.interpolate_stream the loop reads two frames ahead: the next step's coarse flow and
 low-resolution stages run on a side stream under this step's full-resolution stages, and the frame after that has its
-context encoder and the coarse flow of the pair it forms with its predecessor started on a third stream (`--no-lookahead` disables both); every frame is converted and encoded exactly
+context encoder and the coarse flow of the pair it forms with its predecessor started on a third stream (`tools/ab_bench.py --no-lookahead` disables both); every frame is converted and encoded exactly
 once either way, one new frame per step, and the K timed steps contain K steps of work.
 
 N = 1: the K-step loop above.
@@ -84,8 +84,13 @@ kClipWarmup = 24
 SRC_FPS = 24.0
 
 
+# A/B switches between kernel variants / schedules of THIS library live in tools/ab_bench.py (it fills AB and calls main()):
+# the benchmark's own command line carries the contract's flags only.
+AB = {}
+
 _T0 = time.perf_counter()
 LAST_SHARD = {"rank_dt": None}  # this rank's own wall time of the last sharded_leg (the line reports every rank's)
+LAST_PATH = {}  # RIFE.stats over the timed region of the last step_loop: which path the K timed calls took (reported on the line)
 LAST_SETTLE = {"steps": 0}  # untimed settling steps the last step_loop ran after its W warm-up steps (reported on the line)
 
 
@@ -108,23 +113,12 @@ def parse():
                         "< 0.013: oneDNN/OpenMP oversubscription), profiles/r02_cpu_threads.txt (tools/cpu_threads.py)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip extra_configs / pcie_inclusive (configs 3-5 at N = 1)")
-    p.add_argument("--no-lookahead", action="store_true", help="do not overlap the next step's coarse flow (A/B runs)")
-    p.add_argument("--group", type=int, default=None, help="A/B runs: RIFE.GROUP, consecutive steps per stacked IFNet pass (1: off)")
-    p.add_argument("--conv-families", default=None,
-                   help="A/B runs: comma-separated kernel families the conv autotuner may pick from (0 fp32 MFMA, 1 split-bf16, "
-                        "2 LDS-DMA 32-channel, 3 K-split); default all")
-    p.add_argument("--no-stage-conv", action="store_true",
-                   help="A/B runs: the scale-1 stage input and conv0[0] as two kernels (ops.STAGE_CONV_FUSED = False)")
-    p.add_argument("--no-head-fused", action="store_true", help="A/B runs: IFNet's encoder layer by layer (ops.HEAD_FUSED = False)")
-    p.add_argument("--prefetch-priority", type=int, default=None, help="A/B runs: HIP priority of the encoder / prefetch stream (-1 = high)")
-    p.add_argument("--enc-main", action="store_true", help="A/B runs: RIFE.ENC_ON_MAIN, the encoders in the main stream")
-    p.add_argument("--side-stages", type=int, default=None, help="A/B runs: RIFE.SIDE_STAGES, IFNet stages of the next group staged on the side stream")
-    p.add_argument("--no-lazy-flow", action="store_true",
-                   help="A/B runs: IFNet's running flow as a full-resolution tensor updated after every stage (ops.LAZY_FLOW = False)")
     p.add_argument("--selftest-sharded", action="store_true",
                    help="N = 1 only: run the N > 1 legs' code (sharded warm-up + sharded run of the headline clip and of the "
                         "config-5 clip) on one GPU without a process group and print their rates; not the metric")
-    return p.parse_args()
+    args = p.parse_args()
+    args.no_lookahead = bool(AB.get("no_lookahead", False))  # (the single-stream roofline block sets it on a copy of args)
+    return args
 
 
 def make_frames_u8(n, h, w, seed, cut_at=None):
@@ -218,6 +212,56 @@ def _dev_hooks():
     return to_inp, to_out
 
 
+class AnnouncedLoop:
+    """The read-ahead of the shipped driver (drba_amd.infer.interpolate_stream) over a random-access clip, without its
+    head / tail / scene logic: step k = inference_ts_drba(F[k], F[k+1], F[k+2], ts(k), reuse, linear=True, lookahead=...).
+    The frames of the next steps are fetched (`get_frame(k)`: the network input of source frame k, None past the end) as
+    far ahead as the model's groups need -- 2 GROUP - 1 frames --, their context encoders and coarse flows are started on
+    the prefetch stream (`prefetch_frame` / `prefetch_pair`) and the model is told the frames and timesteps of the
+    following calls; it computes RIFE.GROUP consecutive steps in one stacked pass and stages the low-resolution part of
+    the group after them on a side stream.  Every frame is fetched / encoded exactly once, one per step.
+    THE loop of the timed region (step_loop), of `max_abs_vs_oracle` (cpu_leg) and of tests/test_gpu_fullsize.py: what is
+    checked against the oracle is what is timed."""
+
+    def __init__(self, model, get_frame, get_ts, lookahead=True, reuse=None, first=0):
+        self.model, self.get_frame, self.get_ts = model, get_frame, get_ts
+        self.lookahead = lookahead
+        self.prefetch = getattr(model, "prefetch_frame", None) if lookahead else None
+        self.prefetch_pair = getattr(model, "prefetch_pair", None) if lookahead else None
+        self.I0, self.I1 = get_frame(first), get_frame(first + 1)
+        self.k, self.reuse = first, reuse  # step k uses frames k, k + 1, k + 2
+        self.next, self.ahead, self.eof = None, [], False
+
+    def step(self):
+        """-> (outputs of step k, its timesteps); advances to step k + 1."""
+        model, k = self.model, self.k
+        I2 = self.next if self.next is not None else self.get_frame(k + 2)
+        ahead = self.ahead  # network inputs of frames k + 3, k + 4, ...
+        if self.lookahead:
+            depth = max(3, 2 * int(getattr(model, "GROUP", 1)) - 1) if self.prefetch is not None else 1
+            while len(ahead) < depth and not self.eof:
+                x = self.get_frame(k + 3 + len(ahead))
+                if x is None:
+                    self.eof = True
+                    break
+                if self.prefetch is not None:
+                    self.prefetch(x)
+                    if self.prefetch_pair is not None:
+                        self.prefetch_pair(ahead[-1] if ahead else I2, x)
+                ahead.append(x)
+        ts = self.get_ts(k)
+        look = None
+        if ahead:
+            look = (ahead[0], self.get_ts(k + 1))
+            if len(ahead) >= 3:  # (frame, ts) of the following steps: all of them DRBA steps (no scene detection in this loop)
+                look = tuple(v for j, x in enumerate(ahead) for v in (x, self.get_ts(k + 1 + j)))
+        out, self.reuse = model.inference_ts_drba(self.I0, self.I1, I2, ts, self.reuse, linear=True, lookahead=look)
+        self.I0, self.I1 = self.I1, I2
+        self.next = ahead.pop(0) if ahead else None
+        self.k += 1
+        return out, ts
+
+
 # ------------------------------------------------------------------------------------------------- roofline
 def _peak(name, unit):
     if unit == "byte":
@@ -242,7 +286,7 @@ def _symbol_totals(recs, n_steps):
             for k, v in acc.items()}
 
 
-def roofline_from_trace(recs, n_steps, traffic=None, serial=None):
+def roofline_from_trace(recs, n_steps, traffic=None, serial=None, workload=None):
     """recs: ops.trace_end() records of `n_steps` instrumented steps of the loop as it is timed (three streams).
     serial: _symbol_totals of the same steps run on ONE stream (no lookahead, no prefetch): a kernel's duration there is its
     own execution -- in the three-stream loop a launch of a small side-stream kernel also spans the time its workgroups wait
@@ -304,14 +348,19 @@ def roofline_from_trace(recs, n_steps, traffic=None, serial=None):
     # the same symbols under rocprofv3's kernel trace of this command (profiles/rocprof_frac.json, written by
     # tools/rocprof_frac.py from the steady-state table of the round's trace): the loop runs ~13 % slower and less
     # overlapped there, so a kernel reads shorter than in the step and longer than alone
+    # -- ONLY when that table was taken on this workload (its "__workload__" entry): a 1080p duration under a 4K launch's
+    # work is not evidence (round 3 printed fractions above 1 that way); otherwise null
     rp = _rocprof_table()
+    same = workload is not None and (rp.get("__workload__") or {}).get("config") == workload
     for e in [roof] + roof["others"]:
-        r = rp.get(e["kernel"])
+        r = rp.get(e["kernel"]) if same else None
         e["frac_rocprof"] = None
         if r and e.get("algorithmic_per_launch") and e.get("peak"):
             ach = e["algorithmic_per_launch"] / (r["avg_us"] * 1e-6) / (1e9 if e["unit"] == "GB/s" else 1e12)
-            e["frac_rocprof"] = round(ach / e["peak"], 4)
-            e["rocprof_avg_us"] = r["avg_us"]
+            if ach <= e["peak"]:  # (a symbol whose launches differ in work between the two runs: no figure rather than a wrong one)
+                e["frac_rocprof"] = round(ach / e["peak"], 4)
+                e["rocprof_avg_us"] = r["avg_us"]
+                e["rocprof_source"] = r.get("source")
     roof["step_kernels_ms"] = round(total_ms / n_steps, 3)
     if all("start_ms" in r for r in recs):  # how many kernels share the chip on average while these durations were taken
         span = max(r["start_ms"] + r["ms"] for r in recs) - min(r["start_ms"] for r in recs)
@@ -445,7 +494,7 @@ def _quiet_gc():
     gc.freeze()
 
 
-def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False, settle=True):
+def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False, settle=True, check_path=True):
     """The N = 1 loop of the module docstring over `frames` (sequence of uint8 HWC frames: device tensors, or -- with
     pcie=True -- pinned host tensors with the outputs copied back to pinned host buffers).
     -> (seconds for args.steps steps, host-side enqueue seconds, trace records, instrumented steps)."""
@@ -473,41 +522,12 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
             n_out[0] += 1
         return y
 
-    state = {"I0": to_inp(0), "I1": to_inp(1), "reuse": None, "k": 2}
     lookahead = not args.no_lookahead
-
-    prefetch = getattr(model, "prefetch_frame", None) if lookahead else None
-    prefetch_pair = getattr(model, "prefetch_pair", None) if lookahead else None
+    loop = AnnouncedLoop(model, to_inp, lambda k: TS, lookahead=lookahead)
 
     def step():
-        # the driver reads ahead (as drba_amd.infer.interpolate_stream does): the next steps' frames are converted -- and
-        # their context encoders and coarse flows started on a third stream -- three frames ahead, the model is told the
-        # frames and timesteps of the next iterations (it computes RIFE.GROUP consecutive steps in one stacked pass and stages the
-        # low-resolution part of the group after them on a side stream); every frame is still converted / encoded exactly
-        # once, one per step, and K timed steps contain K steps of work (K a multiple of the group size: 20 = 5 x 4)
-        I2 = state.pop("next", None)
-        if I2 is None:
-            I2 = to_inp(state["k"])
-        ahead = state.setdefault("ahead", [])  # frames k+1, k+2, k+3 (network inputs)
-        if lookahead:
-            while len(ahead) < (max(3, 2 * int(getattr(model, "GROUP", 1)) - 1) if prefetch is not None else 1):
-                x = to_inp(state["k"] + 1 + len(ahead))
-                if prefetch is not None:
-                    prefetch(x)
-                    if prefetch_pair is not None:
-                        prefetch_pair(ahead[-1] if ahead else I2, x)
-                ahead.append(x)
-        look = None
-        if ahead:
-            look = (ahead[0], TS)
-            if len(ahead) >= 3:  # (frame, ts) of the following steps: all of them DRBA steps (no scene detection in this loop)
-                look = tuple(v for x in ahead for v in (x, TS))
-        out, state["reuse"] = model.inference_ts_drba(state["I0"], state["I1"], I2, TS, state["reuse"], linear=True, lookahead=look)
-        res = [to_out(x) for x in out]
-        state["I0"], state["I1"] = state["I1"], I2
-        state["next"] = ahead.pop(0) if ahead else None
-        state["k"] += 1
-        return res
+        out, _ = loop.step()
+        return [to_out(x) for x in out]
 
     for _ in range(args.warmup):
         step()
@@ -528,6 +548,7 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
     LAST_SETTLE["steps"] = settled
     _quiet_gc()
     _fence(world)
+    stats0 = dict(getattr(model, "stats", {}))
     t0 = time.perf_counter()
     per_step = []
     for k in range(args.steps):
@@ -536,6 +557,15 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
     t_host = time.perf_counter() - t0  # all launches enqueued: the host side of a step (the GPU may still be working)
     _fence(world)
     dt = time.perf_counter() - t0
+    LAST_PATH.clear()
+    LAST_PATH.update({k: v - stats0.get(k, 0) for k, v in getattr(model, "stats", {}).items()})
+    grp = int(getattr(model, "GROUP", 1))
+    if check_path and settle and lookahead and grp > 1 and args.steps and hasattr(model, "stats"):
+        # the timed calls must have taken the grouped, side-stream-staged path the number is quoted for: a silent fall-back to
+        # the one-step path (frames cloned on the way, a stale lookahead) would read as a kernel regression
+        want = -(-args.steps // grp)
+        if LAST_PATH["groups_formed"] != want or LAST_PATH["staged_groups"] != want or LAST_PATH["single_steps"]:
+            raise RuntimeError(f"timed region did not run the grouped path: {LAST_PATH} (expected {want} staged groups)")
     recs, traced = None, 0
     if trace:  # the roofline block: same loop, same state, every launch traced
         ops.trace_begin()
@@ -678,6 +708,7 @@ def gpu_leg(args, rank, world):
     dt, t_host, recs, traced, dst = step_loop(model, frames, n_total, args, world, trace=not args.no_roofline)
     r["dst_size"] = dst
     r["settle_steps"] = LAST_SETTLE["steps"]
+    r["path"] = dict(LAST_PATH, group=int(getattr(model, "GROUP", 1)), what="RIFE.stats over the K timed calls of this rank")
     serial = None
     if recs and world == 1 and not args.no_lookahead:
         # the same steps on ONE stream (no lookahead / prefetch), every launch traced: each kernel's own duration, the
@@ -689,7 +720,7 @@ def gpu_leg(args, rank, world):
             inst = _symbol_totals(recs, traced)
             for k, (ms, n, us, _) in sorted(serial.items(), key=lambda kv: -kv[1][0]):
                 log(f"serial {ms:7.4f} ms/step {n:5.1f} x {us:7.1f} us | in-step {inst.get(k, (0, 0, 0))[2]:7.1f} us | {k[:110]}")
-    r["roofline"] = roofline_from_trace(recs, traced, _traffic_table(), serial) if recs else None
+    r["roofline"] = roofline_from_trace(recs, traced, _traffic_table(), serial, workload=args.config) if recs else None
     if world == 1:
         r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps})
         if r["roofline"] and (r["roofline"].get("bound") == "mfma" or "stage_conv0" in r["roofline"].get("kernel", "")):
@@ -713,7 +744,7 @@ def gpu_leg(args, rank, world):
         n5 = 8 * args.steps + 2  # fixed clip whatever N is: strong scaling
         c5 = DeviceClip(n5, 2160, 3840, 1234, dev, cut_at=n5 // 2)
         warm = [c5[k] for k in range(min(12, n5))]
-        step_loop(m5, warm, 0, argparse.Namespace(**{**vars(args), "steps": 2, "warmup": 2}), world, trace=False)  # autotune / allocator warm-up
+        step_loop(m5, warm, 0, argparse.Namespace(**{**vars(args), "steps": 2, "warmup": 2}), world, trace=False, check_path=False)  # autotune / allocator warm-up
         sharded_warmup(m5, 2160, 3840, 60.0, -1, True, rank, world, dev, cut=True)
         sdt5, gen5, got5 = sharded_leg(m5, c5, 60.0, -1, True, rank, world, dev)
         r["config5_sharded"] = {"value": round(gen5 / sdt5, 3), "unit": "frames/s", "scaling": "strong", "seconds": round(sdt5, 4),
@@ -747,7 +778,8 @@ def cpu_leg(args, model):
     ora = oracle.rife.RifeOracle(synth.ifnet_state_dict(seed=0), scale)
     from drba_amd.models.utils.tools import get_valid_net_inp_size
     dst = get_valid_net_inp_size(np.zeros((H, W, 3), np.uint8), scale, div=64)["dst_size"]
-    fr = make_frames_u8(3 + args.cpu_steps, H, W, seed=1234)
+    n_ahead = 2 * int(getattr(model, "GROUP", 1)) - 1  # frames beyond the compared steps, so that the HIP side forms the groups it is timed with
+    fr = make_frames_u8(3 + args.cpu_steps + max(n_ahead, 0), H, W, seed=1234)
 
     def to_inp(f):
         return oracle.ops.resize(torch.from_numpy(f.transpose(2, 0, 1)).unsqueeze(0).float() / 255.0, dst)
@@ -759,7 +791,7 @@ def cpu_leg(args, model):
 
     def run(threads, steps, keep):
         torch.set_num_threads(threads)
-        I = [to_inp(f) for f in fr]
+        I = [to_inp(f) for f in fr[:steps + 3]]
         with torch.no_grad():
             if not state:  # untimed, once: what the previous step would have left behind + oneDNN primitive creation
                 flow12, flow21, f1, f2 = ora.calc_flow(I[1], I[2])
@@ -785,21 +817,26 @@ def cpu_leg(args, model):
             "sample": f"{args.cpu_steps} warm inference_ts_drba step(s) = {n} frames at {dst[0]}x{dst[1]} incl. to_inp/to_out, after an "
                       f"untimed warm-up; torch {torch.__version__} CPU fp32, {cores} threads of {avail} available",
             "single_thread": {"value": round(n1 / dt1, 4), "unit": "frames/s", "cores": 1, "sample": f"1 warm step = {n1} frames"}}
-    # ---- parity on the same frames: HIP path, same uint8 inputs, same step sequence
+    # ---- parity on the same frames: HIP path, same uint8 inputs, same step sequence, driven by THE loop of the timed region
+    # (AnnouncedLoop: frames read ahead, encoders / coarse flows prefetched, the steps computed in groups of RIFE.GROUP)
     dev = model.device
     g = [ops.to_inp(torch.from_numpy(f).to(dev), dst) for f in fr]
-    reuse = model.warm_reuse(g[1], g[2])
+    stats0 = dict(model.stats)
+    loop = AnnouncedLoop(model, lambda k: g[k] if k < len(g) else None, lambda k: TS, reuse=model.warm_reuse(g[1], g[2]), first=1)
     worst, worst_lsb, n_cmp = 0.0, 0, 0
     for k, (want, want_u8) in enumerate(kept):
-        out, reuse = model.inference_ts_drba(g[k + 1], g[k + 2], g[k + 3], TS, reuse, True)
+        out, _ = loop.step()
         for a, b, bu in zip(out, want, want_u8):
             worst = max(worst, float((a.cpu() - b).abs().max()))
             au = ops.to_out(a, (H, W)).cpu().numpy()
             worst_lsb = max(worst_lsb, int(np.abs(au.astype(np.int32) - bu.astype(np.int32)).max()))
             n_cmp += 1
-    parity = {"value": worst, "frames": n_cmp, "u8_max_lsb": worst_lsb, "tolerance": 1e-3,
+    torch.cuda.synchronize()
+    path = {k: v - stats0[k] for k, v in model.stats.items()}
+    parity = {"value": worst, "frames": n_cmp, "u8_max_lsb": worst_lsb, "tolerance": 1e-3, "path": path,
               "what": "max |HIP - CPU oracle| over the synthesised fp32 frames of the cpu_baseline steps (same uint8 inputs, to_inp "
-                      "on each side); u8_max_lsb = largest difference of the written uint8 frames"}
+                      "on each side), the HIP side driven by the timed region's loop (frames announced ahead: `path` counts the "
+                      "groups it formed); u8_max_lsb = largest difference of the written uint8 frames"}
     return base, parity
 
 
@@ -830,31 +867,6 @@ def describe_job(rank, world, r):
 
 def main():
     args = parse()
-    if args.group is not None:
-        from drba_amd.models.rife import RIFE as _R
-        _R.GROUP = abs(int(args.group))
-        _R.BATCH_COARSE = int(args.group) > 0  # (negative: groups without the batched coarse flows)
-    if args.no_stage_conv:
-        from drba_amd import ops as _ops0
-        _ops0.STAGE_CONV_FUSED = False
-    if args.no_lazy_flow:
-        from drba_amd import ops as _ops1
-        _ops1.LAZY_FLOW = False
-    if args.prefetch_priority is not None:
-        from drba_amd.models import lookahead as _la
-        _la.PRIORITY["prefetch"] = int(args.prefetch_priority)
-    if args.enc_main:
-        from drba_amd.models.rife import RIFE as _R3
-        _R3.ENC_ON_MAIN = True
-    if args.side_stages is not None:
-        from drba_amd.models.rife import RIFE as _R2
-        _R2.SIDE_STAGES = int(args.side_stages)
-    if args.no_head_fused:
-        from drba_amd import ops as _ops2
-        _ops2.HEAD_FUSED = False
-    if args.conv_families is not None:
-        from drba_amd import ops as _ops
-        _ops.CONV_FAMILIES = {int(x) for x in args.conv_families.split(",")}
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -921,6 +933,7 @@ def main():
             "config": {"workload": wl, "net_size": list(r["dst_size"]), "frames_per_step": len(TS),
                        "weights": "seeded random IFNet 4.26-heavy", "parallelism": f"frame-sharded dp{world}"},
             "max_abs_vs_oracle": parity, "roofline": r["roofline"], "cpu_baseline": cpu,
+            "path": r.get("path"),
         }
         line["dist"] = dist_info
         if pcie is not None:

@@ -4,6 +4,8 @@
 #include <cxxabi.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -73,6 +75,19 @@ TimedLaunch trace_launch(const void *host_fn, const char *fallback, dim3 grid, h
   t.start = g_ev[slot][0];
   t.stop = g_ev[slot][1];
   return t;
+}
+hipError_t max_dynamic_lds(const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, hipError_t> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(kernel, dev);
+  auto it = done.find(key);
+  if (it != done.end()) return it->second;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.emplace(key, e);
+  return e;
 }
 }  // namespace drba
 

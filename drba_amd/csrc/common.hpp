@@ -38,6 +38,11 @@ TimedLaunch trace_launch(const void *host_fn, const char *fallback_name, dim3 gr
   } while (0)
 #define DRBA_LAUNCH_TIMED DRBA_LAUNCH
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: raised once per (kernel, device), not once
+// per process -- a process that drives a second GPU (RIFE(device="cuda:1")) would otherwise launch > 64 KB-LDS kernels there
+// without it.  Thread-safe; the answer of the first call per (kernel, device) is remembered (api_misc.hip).
+hipError_t max_dynamic_lds(const void *kernel, int bytes);
+
 // Environment switches select between kernel variants of THIS library for A/B measurements (never another backend).  The
 // release build -- the Makefile's default -- compiles them out: env_int() returns the default without reading the
 // environment; `make TUNING=1` (-DDRBA_TUNING_SWITCHES) builds the measuring library the tools/ scripts may use.

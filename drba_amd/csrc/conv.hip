@@ -461,13 +461,11 @@ const CfgInfo kConv[kNumConvCfg] = {cfg_info<C0>(), cfg_info<C1>(), cfg_info<C2>
 const CfgInfo kDeconv[kNumDeconvCfg] = {cfg_info<D0>(), cfg_info<D1>(), cfg_info<D2>(),
                                         cfg_info<D3>(), cfg_info<D4>(), cfg_info<D5>()};
 
-// Raises the kernel's dynamic-LDS limit past the default 64 KB (gfx950: 160 KB per CU); once per kernel instantiation.
+// Raises the kernel's dynamic-LDS limit past the default 64 KB (gfx950: 160 KB per CU); once per kernel instantiation and device.
 template <class Cfg, bool PRE>
 hipError_t lds_limit() {
   if (Cfg::LDS_FLOATS * sizeof(float) <= 64 * 1024) return hipSuccess;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma<Cfg, PRE>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_FLOATS * (int)sizeof(float));
-  return e;
+  return max_dynamic_lds(reinterpret_cast<const void *>(conv_mfma<Cfg, PRE>), Cfg::LDS_FLOATS * (int)sizeof(float));
 }
 
 template <class Cfg>

@@ -29,8 +29,9 @@
 
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
-#include <unordered_map>
 #include <utility>
 
 using namespace drba;
@@ -530,33 +531,46 @@ constexpr int kNum = 1;
 
 template <bool PRE, bool RL>
 hipError_t lds_limit() {
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_dma1<PRE, RL>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  return e;
+  return max_dynamic_lds(reinterpret_cast<const void *>(conv_dma1<PRE, RL>), LDS_BYTES);
 }
 
-// The work counters of a launch: 8 ints, one per XCD band, zero when the launch starts.  Two sets per stream, used in
-// turn -- launches on one stream run one after the other, and each zeroes the set of its successor.  Allocated on a
-// stream's first launch (the library is driven from one host thread; the autotuner's first call of a layer is where
-// this happens).  mine: the set this launch counts in; next: the set it clears.
-bool counters_for(hipStream_t s, int *&mine, int *&next) {
-  struct Slot {
-    int *base;
-    unsigned parity;
-  };
-  static std::unordered_map<hipStream_t, Slot> tab;
-  auto it = tab.find(s);
-  if (it == tab.end()) {
+// The work counters of a launch: 8 ints, one per XCD band, zero when the launch starts.  Two sets per (device, stream), used
+// in turn -- launches on one stream run one after the other, and each zeroes the set of its successor.  Allocated on a
+// stream's first launch on its device (torch's default stream is handle 0 on EVERY device: the key holds the device, and the
+// counters live in that device's memory); the table is mutex-protected.  mine: the set this launch counts in; next: the set it
+// clears.  The sets change roles only after the launch was issued (counters_commit): a launch that fails before it reaches
+// the queue (the LDS attribute, a bad configuration) leaves the stream's next launch on a zeroed set.
+// Not capturable: the first launch on a stream allocates and synchronises (drba_hip.h, "one exception").
+struct CounterSlot {
+  int *base;
+  unsigned parity;
+};
+static std::mutex g_counter_mu;
+static std::map<std::pair<int, hipStream_t>, CounterSlot> g_counter_tab;
+
+CounterSlot *counters_for(hipStream_t s, int *&mine, int *&next) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_counter_mu);
+  const auto key = std::make_pair(dev, s);
+  auto it = g_counter_tab.find(key);
+  if (it == g_counter_tab.end()) {
     int *p = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&p), 64) != hipSuccess) return false;
-    if (hipMemset(p, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
-    it = tab.emplace(s, Slot{p, 0u}).first;
+    if (hipMalloc(reinterpret_cast<void **>(&p), 64) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    it = g_counter_tab.emplace(key, CounterSlot{p, 0u}).first;
   }
-  Slot &sl = it->second;
+  CounterSlot &sl = it->second;  // (std::map: the address of an element is stable)
   mine = sl.base + 8 * (sl.parity & 1u);
   next = sl.base + 8 * ((sl.parity & 1u) ^ 1u);
-  sl.parity ^= 1u;
-  return true;
+  return &sl;
+}
+void counters_commit(CounterSlot *sl) {
+  std::lock_guard<std::mutex> lock(g_counter_mu);
+  sl->parity ^= 1u;
 }
 
 int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, const float *res2,
@@ -569,11 +583,14 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   dim3 g((unsigned)grid);
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(wpk);
   int *counters = nullptr, *counters_next = nullptr;
-  if (!counters_for(s, counters, counters_next)) return DRBA_ELAUNCH;
+  CounterSlot *slot = counters_for(s, counters, counters_next);
+  if (!slot) return DRBA_ELAUNCH;
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     DRBA_LAUNCH(kernel, g, dim3(NTHREADS), LDS_BYTES, s, in, wf, bias, beta, res, res2, out, H, W, Cout, act, post_slope,
                 pre_slope, nbx, nby, (int)total, counters, counters_next);
+    if (hipPeekAtLastError() != hipSuccess) return DRBA_ELAUNCH;  // not issued: the sets keep their roles
+    counters_commit(slot);
     return DRBA_OK;
   };
   const bool rl = res && res == in && !res2 && !pre_act && Cout == CK;

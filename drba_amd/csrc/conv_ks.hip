@@ -290,10 +290,8 @@ constexpr int kNum = 1;
 
 template <int KW, bool PRE, bool RL, bool DW>
 hipError_t lds_limit(int bytes) {
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ks<KW, PRE, RL, DW>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)bytes;
-  return e;
+  return max_dynamic_lds(reinterpret_cast<const void *>(conv_ks<KW, PRE, RL, DW>), 160 * 1024);
 }
 
 template <int KW>

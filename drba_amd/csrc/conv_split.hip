@@ -596,9 +596,7 @@ const Info kInfoT[kNumT] = {info<T0>(), info<T1>()};
 template <class Cfg, bool PRE, bool RL = false>
 hipError_t lds_limit() {
   if (Cfg::LDS_BYTES <= 64 * 1024) return hipSuccess;
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_split_mfma<Cfg, PRE, RL>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-  return e;
+  return max_dynamic_lds(reinterpret_cast<const void *>(conv_split_mfma<Cfg, PRE, RL>), Cfg::LDS_BYTES);
 }
 
 template <class Cfg>

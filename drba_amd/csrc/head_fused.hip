@@ -279,12 +279,7 @@ int drba_head_fused(const float *img, const float *packed_w, float *f_out, float
   if ((((uintptr_t)f_out | (uintptr_t)f_pair_out | (uintptr_t)packed_w) & 15) != 0) return DRBA_EINVAL;
   const int tiles_x = (W / 2 + W2 - 1) / W2, tiles_y = (H / 2 + H2 - 1) / H2;
   constexpr size_t lds_bytes = (size_t)LDS_FLOATS * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void *)head_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-      return DRBA_ELAUNCH;
-    attr_done = true;
-  }
+  if (max_dynamic_lds((const void *)head_fused, (int)lds_bytes) != hipSuccess) return DRBA_ELAUNCH;
   DRBA_LAUNCH(head_fused, dim3(tiles_x * tiles_y, N), dim3(THREADS), lds_bytes, (hipStream_t)stream, img, packed_w, f_out, f_pair_out, H, W,
               tiles_x);
   DRBA_CHECK_LAUNCH();

@@ -442,13 +442,7 @@ int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, const dr
   do {                                                                                                                     \
     using G_ = Geo<TT, R>;                                                                                                 \
     constexpr size_t lds_bytes = (size_t)G_::LDS_FLOATS * 4;                                                               \
-    static bool attr_done = false;                                                                                         \
-    if (!attr_done) {                                                                                                      \
-      if (hipFuncSetAttribute((const void *)stage_conv0<FO, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != \
-          hipSuccess)                                                                                                      \
-        return DRBA_ELAUNCH;                                                                                               \
-      attr_done = true;                                                                                                    \
-    }                                                                                                                      \
+    if (max_dynamic_lds((const void *)stage_conv0<FO, G_>, (int)lds_bytes) != hipSuccess) return DRBA_ELAUNCH;             \
     const int tiles_x = (Wo + TOW - 1) / TOW, tiles_y = (Ho + TT - 1) / TT;                                                \
     DRBA_LAUNCH((stage_conv0<FO, G_>), dim3(tiles_x * tiles_y, n_items), dim3(G_::THREADS), lds_bytes, s, its, T, packed_w, bias, \
                 hp, wp, ips, prev_scale, H, W, Ho, Wo, tiles_x);                                                           \

@@ -326,10 +326,9 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
   const int groups = (nwin + 7) / 8;
   const int ksplit = ws ? attn_ksplit(nwin, g.L) : 1;  // without a workspace every workgroup walks all keys
   const dim3 grid((unsigned)(groups * 8 * qtiles * ksplit));
-  static const hipError_t lds_ok =  // beyond the default 64 KB dynamic-LDS limit
-      hipFuncSetAttribute(reinterpret_cast<const void *>(drba_attn::window_attention_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, drba_attn::kLdsBytes);
-  if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
+  // beyond the default 64 KB dynamic-LDS limit
+  if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention_kernel), drba_attn::kLdsBytes) != hipSuccess)
+    return DRBA_ELAUNCH;
   DRBA_LAUNCH(drba_attn::window_attention_kernel, grid, dim3(kBlock), drba_attn::kLdsBytes, (hipStream_t)stream, q, k, v,
                     out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws);
   if (ksplit > 1)

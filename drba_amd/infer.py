@@ -9,6 +9,7 @@ module globals turned into arguments, so tests can drive it with any model objec
 import argparse
 import os
 import time
+import weakref
 
 from drba_amd.models.utils import tools as _tools
 
@@ -119,10 +120,25 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
         last[0] = x
         return raw, x
 
+    cuts = {}  # (id(a), id(b)) -> (decision, weakref(a), weakref(b)): every pair is tested ONCE, as in the reference loop
+
     def is_cut(a, b):
         if ahead_checks is not None and a.is_cuda:
             return ahead_checks.cut((id(a), id(b)), a, b)
-        return bool(check_scene(a, b, scdet_threshold))
+        # an injected check_scene (or CPU frames): called in place, but a pair that moves through the look-ahead window is
+        # still asked about in several iterations -- memoised here, so that a stateful / counting check sees each pair once
+        k = (id(a), id(b))
+        c = cuts.get(k)
+        if c is not None and c[1]() is a and c[2]() is b:
+            return c[0]
+        res = bool(check_scene(a, b, scdet_threshold))
+        try:
+            cuts[k] = (res, weakref.ref(a), weakref.ref(b))
+        except TypeError:  # frames that cannot be weakly referenced (plain ndarrays in a test double): not memoised
+            return res
+        while len(cuts) > 32:
+            cuts.pop(next(iter(cuts)))
+        return res
 
     # A model that can look ahead gets the loop reading THREE frames ahead (same frames, same order, same outputs): (i3, I3)
     # is the lookahead frame of this iteration; a model that can (RIFE: `prefetch_frame`) has the encoder and the coarse flow
@@ -158,7 +174,7 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
             out.extend([I1 for _ in ts[ts > 1] - 1])
         elif can_look and I3 is not None:
             look = (I3, _tools.calc_t(idx + 1, times, mapper))
-            if prefetch is not None:
+            if prefetch is not None and group > 1:
                 # the following iterations, as far as they are DRBA steps too (no cut up to the last frame named): the model may
                 # take them in one stacked pass with this one and stage the group after them
                 entries, prev = [], I2

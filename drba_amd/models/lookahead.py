@@ -12,7 +12,7 @@ import torch
 _STREAMS = {}
 
 
-PRIORITY = {}  # role -> HIP stream priority (-1 = high); experiments only (bench.py --prefetch-priority)
+PRIORITY = {}  # role -> HIP stream priority (-1 = high); experiments only (tools/ab_bench.py --prefetch-priority)
 
 
 def shared_stream(device, role):
@@ -70,6 +70,9 @@ class Lookahead:
             done.record(self.side)
         for t in _tensors(res):
             t.record_stream(main)  # consumed on the caller's stream by the next step
+            fp = getattr(t, "_drba_pair", None)  # the pair-interleaved copy hung on a feature tensor (ops.pair_interleaved):
+            if fp is not None:                   # allocated on the side / prefetch stream, read by the main stream's gathers
+                fp.record_stream(main)
         self.pending = (a, b, res, done)
 
     def take(self, a, b):

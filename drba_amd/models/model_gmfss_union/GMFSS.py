@@ -98,6 +98,10 @@ class Model:
         return flow01, flow10, metric0, metric1, feat0, feat1
 
     def inference(self, img0, img1, reuse_things, timestep0, timestep1, rife=None):
+        return _ops.clamp(self.fusionnet(*self.fusion_inputs(img0, img1, reuse_things, timestep0, timestep1, rife)), 0.0, 1.0)
+
+    def fusion_inputs(self, img0, img1, reuse_things, timestep0, timestep1, rife=None):
+        """GMFSS.py:80-152: the splat stage -> GridNet's inputs (x [1,9,h,w], [1,128,h,w], [1,256,h/2,w/2], [1,384,h/4,w/4])."""
         flow01, flow10, metric0, metric1, (f11, f12, f13), (f21, f22, f23) = reuse_things
         F1t, F2t = _times(timestep0, flow01), _times(timestep1, flow10)
         Z1t, Z2t = _times(timestep0, metric0), _times(timestep1, metric1)
@@ -123,5 +127,4 @@ class Model:
             a2, b2 = _ops.swap_select(a2, b2, _half(t0, 0.5), _half(t1, 0.5), 25.0)
             a3, b3 = _ops.swap_select(a3, b3, _half(t0, 0.25), _half(t1, 0.25), 25.0)
         x = torch.cat([I1t, rife, I2t], 1) if self.union else torch.cat([img0, I1t, I2t, img1], 1)
-        out = self.fusionnet(x, torch.cat([a1, b1], 1), torch.cat([a2, b2], 1), torch.cat([a3, b3], 1))
-        return _ops.clamp(out, 0.0, 1.0)
+        return x, torch.cat([a1, b1], 1), torch.cat([a2, b2], 1), torch.cat([a3, b3], 1)

@@ -22,6 +22,14 @@ from drba_amd.models.utils.tools import convert
 
 class RIFE:
     supports_lookahead = True  # inference_ts_drba(..., lookahead=next frame): see prefetch_flow
+    STAT_KEYS = ("groups_formed", "staged_groups", "group_collects", "groups_dropped", "single_steps", "encoder_prefetch_hits",
+                 "encoder_prefetch_misses", "pairflow_prefetch_hits", "lookahead_hits")
+    stats = None     # per instance: {key: count}, see __init__
+
+    def _count(self, key):
+        if self.stats is None:
+            self.stats = dict.fromkeys(self.STAT_KEYS, 0)
+        self.stats[key] += 1
     _look = None     # models/lookahead.Lookahead, created on first use
 
     def __init__(self, weights="weights/train_log_rife_426_heavy", scale=1.0, device=None):
@@ -38,6 +46,12 @@ class RIFE:
         self.scale = scale
         self.scale_list = [16 / scale, 8 / scale, 4 / scale, 2 / scale, 1 / scale]
         self.pad_size = 64
+        # which path the calls took (not in the reference): a caller that clones / slices frames loses the identity-keyed
+        # prefetches and groups silently -- correct results, slower -- so the hit counts are kept where bench.py and the
+        # tests can assert them (`groups_formed`, `staged_groups`: _drba_group; `group_collects`: calls that only collected
+        # a step computed ahead; `single_steps`: calls that ran the one-step path; `encoder_prefetch_hits` / `_misses`:
+        # _encoded; `pairflow_prefetch_hits`: _pair_flow; `lookahead_hits`: one-step lookahead results picked up)
+        self.stats = dict.fromkeys(self.STAT_KEYS, 0)
 
     def encode(self, img):
         return self.ifnet.encode(img[:, :3])
@@ -174,6 +188,7 @@ class RIFE:
         if c is not None and c[0]() is a and c[3] == id(self):
             cur = torch.cuda.current_stream(a.device)
             cur.wait_event(c[2])
+            self._count("pairflow_prefetch_hits")
             for t in c[1]:
                 t.record_stream(cur)
                 fp = getattr(t, "_drba_pair", None)
@@ -188,11 +203,13 @@ class RIFE:
         if c is not None and c[2] == id(self):
             cur = torch.cuda.current_stream(I.device)
             cur.wait_event(c[1])
+            self._count("encoder_prefetch_hits")
             c[0].record_stream(cur)
             fp = getattr(c[0], "_drba_pair", None)
             if fp is not None:
                 fp.record_stream(cur)
             return c[0]
+        self._count("encoder_prefetch_misses")
         return self.ifnet.encode(I)
 
     def warm_reuse(self, Ia, Ib):
@@ -246,6 +263,8 @@ class RIFE:
     def _flow_pair(self, a, b, fa):
         """(calc_flow(a, b), staged low-resolution stages or None), from a matching lookahead if there is one."""
         got = self._look.take(a, b) if self._look is not None else None
+        if got is not None:
+            self._count("lookahead_hits")
         return got if got is not None else (self._pair_flow(a, b, fa), None)
 
     BATCH_COARSE = True  # with GROUP > 1: calc_flow of a group's new frame pairs in one batched pass (A/B runs)
@@ -294,7 +313,9 @@ class RIFE:
         if not (staged is not None and len(staged["ts"]) == g and all(a is b for a, b in zip(staged["F"], F))
                 and staged["flow10"] is reuse[0] and all(np.array_equal(a, b) for a, b in zip(staged["ts"], ts_list))):
             staged = None
+        self._count("groups_formed")
         if staged is not None:
+            self._count("staged_groups")
             P, outs, counts, items, reuses = (staged[k] for k in ("P", "outs", "counts", "items", "reuses"))
         else:
             got = self._look.take(F[1], F[2]) if self._look is not None else None  # a one-step lookahead of the call before
@@ -325,8 +346,10 @@ class RIFE:
             po, self._group_out = self._group_out[0], self._group_out[1:]
             if (reuse and po[0] is I0 and po[1] is I1 and po[2] is I2 and po[4][0] is reuse[0]
                     and np.array_equal(po[3], np.asarray(ts, dtype=np.float64))):
+                self._count("group_collects")
                 return po[5], po[6]  # a later step of the group an earlier call computed
             self._group_out = ()     # another call pattern than announced: what was computed ahead is dropped
+            self._count("groups_dropped")
         if self.GROUP > 1 and linear and reuse and isinstance(lookahead, (tuple, list)) and len(lookahead) >= 4 and I0.is_cuda:
             # (frame, ts) of the following calls; two or more entries = the driver vouches that all of them are plain DRBA steps
             # (no scene cut up to the last frame it names); one entry alone is the one-step lookahead below
@@ -342,6 +365,7 @@ class RIFE:
                 rest = ahead[g - 1:]
                 more = ([a[0] for a in rest[:g]], [a[1] for a in rest[:g]]) if len(rest) >= g else None
                 return self._drba_group(F, ts_list, reuse, more)
+        self._count("single_steps")
         flow10, flow01, f1, f0 = self.calc_flow(I1, I0) if not reuse else reuse
         (flow12, flow21, f1, f2), staged = self._flow_pair(I1, I2, None if reuse is None else reuse[2])
         nxt, ts_nxt = split_lookahead(lookahead)

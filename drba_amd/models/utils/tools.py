@@ -7,6 +7,7 @@ CPU fallback in this module.
 """
 import json
 import math
+import weakref
 import os
 import subprocess
 import threading
@@ -92,20 +93,27 @@ class SceneChecks:
     """check_scene for frame pairs announced ahead of their use (not in the reference, same decisions): submit(key, x1, x2)
     enqueues the test when the driver has both frames, cut(key, x1, x2) returns the bool -- waiting only for that test's own
     event -- and remembers it (the drivers ask for the same pair in several iterations).  `key` identifies the pair for
-    the caller (frame indices, or object ids -- the entry keeps the frames, so an id cannot be recycled while it is here);
-    the last 32 pairs are kept."""
+    the caller (frame indices, or object ids).  Only the decision is kept once it is known, with WEAK references to the
+    two frames as the identity guard (an id can be recycled once a frame is gone: a dead or different referent is a miss):
+    a remembered pair must not keep its frames -- and the encoder features hung on them, 270 MB per 1080p frame -- alive.
+    A pending test holds its frames only until it is collected; the last 32 decisions are kept."""
 
     def __init__(self, scdet_threshold=0.3):
         self.thr, self.pending, self.done = scdet_threshold, {}, {}
 
     def submit(self, key, x1, x2):
-        if key not in self.pending and key not in self.done:
+        if key not in self.pending and not self._known(key, x1, x2):
             self.pending[key] = (_ops.ssim_thumb32_async(x1, x2), x1, x2)
+            while len(self.pending) > 32:  # tests nobody asked for (a driver that stopped early): do not pin their frames
+                self.pending.pop(next(iter(self.pending)))
+
+    def _known(self, key, x1, x2):
+        d = self.done.get(key)
+        return d is not None and d[1]() is x1 and d[2]() is x2
 
     def cut(self, key, x1, x2):
-        d = self.done.get(key)
-        if d is not None and d[1] is x1 and d[2] is x2:
-            return d[0]
+        if self._known(key, x1, x2):
+            return self.done[key][0]
         self.done.pop(key, None)
         p = self.pending.pop(key, None)
         if p is None or p[1] is not x1 or p[2] is not x2:
@@ -113,7 +121,7 @@ class SceneChecks:
         (host, ev), _, _ = p
         ev.synchronize()
         res = float(host.item()) < self.thr
-        self.done[key] = (res, x1, x2)
+        self.done[key] = (res, weakref.ref(x1), weakref.ref(x2))
         while len(self.done) > 32:
             self.done.pop(next(iter(self.done)))
         return res

@@ -334,7 +334,7 @@ def ssim_thumb32_async(x1, x2):
 # and keeps the fastest ("measure, don't guess").  Results are shared by all layers of the same shape.
 AUTOTUNE = True
 # kernel families the autotuner may choose from (drba_conv3x3_cfg_family: 0 fp32 MFMA, 1 split-bf16 register staging, 2 LDS-DMA
-# 32-channel, 3 K-split); A/B runs narrow it (bench.py --conv-families)
+# 32-channel, 3 K-split); A/B runs narrow it (tools/ab_bench.py --conv-families)
 CONV_FAMILIES = {0, 1, 2, 3}
 _tuned = {}
 
@@ -570,7 +570,7 @@ class ConvChain:
 PAIR_FEATURES = True  # warped stages read the encoder features from a pair-interleaved copy (half the gather instructions)
 
 
-HEAD_FUSED = True  # IFNet's encoder as one kernel (drba_head_fused) instead of four layers + the pair-interleave copy (bench.py --no-head-fused: A/B)
+HEAD_FUSED = True  # IFNet's encoder as one kernel (drba_head_fused) instead of four layers + the pair-interleave copy (tools/ab_bench.py --no-head-fused: A/B)
 
 
 def head_fused(img, layers, holder):
@@ -680,7 +680,7 @@ def _ptr(t):
 
 
 LAZY_FLOW = True  # IFNet's running flow as a list of terms (earlier head outputs) evaluated inside the consumers instead of a
-#                   full-resolution tensor updated after every stage (drba_hip.h drba_flow_terms_t; bench.py --no-lazy-flow: A/B)
+#                   full-resolution tensor updated after every stage (drba_hip.h drba_flow_terms_t; tools/ab_bench.py --no-lazy-flow: A/B)
 
 
 def _flow_terms(terms, B):
@@ -768,7 +768,7 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
     return [flow_out[k:k + 1] for k in range(B)] if fold else None
 
 
-STAGE_CONV_FUSED = True  # the scale-1 stage input and the IFBlock's first convolution in one kernel (bench.py --no-stage-conv: A/B)
+STAGE_CONV_FUSED = True  # the scale-1 stage input and the IFBlock's first convolution in one kernel (tools/ab_bench.py --no-stage-conv: A/B)
 
 
 def stage_conv0_ok(conv, H, W, scale, prev_scale):

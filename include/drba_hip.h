@@ -7,8 +7,11 @@
  * operator (or a fused group of them) and cites it.  Conventions for every function:
  *   - all pointers are DEVICE pointers to contiguous fp32 NCHW data unless noted;
  *   - caller owns all memory; the library never allocates, frees or synchronises -- one exception (ABI version 2):
- *     drba_conv3x3 with a family-2 configuration keeps 64 bytes of work counters per stream, allocated (hipMalloc +
- *     hipMemset + one device synchronisation) on that stream's first such launch and never freed;
+ *     drba_conv3x3 with a family-2 configuration keeps 64 bytes of work counters per (device, stream), allocated (hipMalloc +
+ *     hipMemset + one device synchronisation) on that stream's first such launch on the current device and never freed --
+ *     that first launch cannot be stream-captured; the table is mutex-protected;
+ *   - kernels that need more than 64 KB of LDS raise their limit once per (kernel, device) (hipFuncSetAttribute applies to
+ *     the current device): the library may be driven on several GPUs of one process;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*), re-entrant across streams;
  *   - returns 0 on success or a negative DRBA_E* code (see drba_error_string);
  *   - `ws` arguments are caller-provided scratch of at least the documented size.

@@ -122,6 +122,13 @@ class GmfssModel:
         """Model.inference (GMFSS.py:80-155): soft-splat the half-res frames and the 3-level feature pyramid to time
         t from both sides; with map timesteps (DRBA) also splat the timestep maps, fill holes with 1 and swap regions
         where one side's timestep is > 25x the other's; GridNet fusion; clamp."""
+        out = gridnet(self.fusion, *self.fusion_inputs(img0, img1, reuse, timestep0, timestep1, rife))
+        return torch.clamp(out, 0, 1)
+
+    def fusion_inputs(self, img0, img1, reuse, timestep0, timestep1, rife=None):
+        """GMFSS.py:80-152, everything of Model.inference before GridNet: -> (x [1,9,h,w], pyramid level 1 [1,128,h,w], level 2
+        [1,256,h/2,w/2], level 3 [1,384,h/4,w/4]).  Split out so that the tests can check the splat stage and GridNet each on
+        the other implementation's inputs (same operations in the same order as before the split)."""
         flow01, flow10, metric0, metric1, (f11, f12, f13), (f21, f22, f23) = reuse
         F1t, F2t = timestep0 * flow01, timestep1 * flow10
         Z1t, Z2t = timestep0 * metric0, timestep1 * metric1
@@ -167,8 +174,7 @@ class GmfssModel:
             x = torch.cat([I1t, rife, I2t], 1)
         else:
             x = torch.cat([img0, I1t, I2t, img1], 1)  # model_gmfss/GMFSS.py:162
-        out = gridnet(self.fusion, x, torch.cat([a1, b1], 1), torch.cat([a2, b2], 1), torch.cat([a3, b3], 1))
-        return torch.clamp(out, 0, 1)
+        return x, torch.cat([a1, b1], 1), torch.cat([a2, b2], 1), torch.cat([a3, b3], 1)
 
 
 class GmfssUnionOracle:

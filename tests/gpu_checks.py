@@ -429,6 +429,191 @@ def check_glue(dev):
     return rows
 
 
+def check_glue_n8_fullsize(dev, H=1088, W=1920, B=8, ref_items=(0, 3, 7)):
+    """The glue launches of the benchmarked path at ITS launch geometry: 8 items per launch at 1088x1920 (a group of 4 steps
+    x 2 frames), the running flow as the terms of the earlier stages (scales 16, 8, 4) + the newest head output:
+      * stage_conv0 (scale 1: gather fused with conv0[0], IFNet_HDv3.py:85-88 + :64-66) vs an fp64 convolution of the
+        reference's stage input,
+      * the lazy stage-input gather at scale 2 (terms 16, 8; newest head output at 4),
+      * warp_blend_lazy (IFNet_HDv3.py:163-167).
+    Every item has its own frames / features / timestep map / head outputs; the CPU reference is formed for `ref_items`
+    (first, middle, last: a wrong item pointer or stride shows there)."""
+    import oracle
+    from drba_amd import ops
+    g = torch.Generator().manual_seed(11)
+    D = lambda t: t.to(dev)  # noqa: E731
+    rows = []
+
+    def smooth(c, h, w, amp):  # a smooth field: low-resolution noise, bicubic
+        return F.interpolate(torch.randn(B, c, max(h // 8, 2), max(w // 8, 2), generator=g) * amp, size=(h, w), mode="bicubic", align_corners=False)
+
+    img0, img1 = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    f0, f1 = torch.randn(B, 16, H, W, generator=g), torch.randn(B, 16, H, W, generator=g)
+    tmap = torch.rand(B, 1, H, W, generator=g)
+    heads = {}
+    for st, amp in ((16.0, 1.0), (8.0, 0.4), (4.0, 0.3), (2.0, 0.3)):  # head outputs [B,13,H/st,W/st]: smooth flow deltas, random mask / feat
+        t = torch.randn(B, 13, int(H / st), int(W / st), generator=g)
+        t[:, :4] = smooth(4, int(H / st), int(W / st), amp)
+        heads[st] = t
+    dimg0, dimg1, df0, df1, dtm = D(img0), D(img1), D(f0), D(f1), D(tmap)
+    dheads = {st: D(t) for st, t in heads.items()}
+    items = [(dimg0[k:k + 1], dimg1[k:k + 1], dtm[k:k + 1], df0[k:k + 1], df1[k:k + 1]) for k in range(B)]
+
+    def up(t, st):
+        return F.interpolate(t, scale_factor=st, mode="bilinear", align_corners=False)
+
+    def ref_stage(k, s, term_scales, sp):
+        """the reference's stage input of item k at scale s (52 ch, fp32) and its flow"""
+        fl = None
+        for st in term_scales + (sp,):
+            d = up(heads[st][k:k + 1, :4], st) * st
+            fl = d if fl is None else fl + d
+        upp = up(heads[sp][k:k + 1], sp)
+        a, b = img0[k:k + 1], img1[k:k + 1]
+        w0, w1 = oracle.ops.backwarp(a, fl[:, :2]), oracle.ops.backwarp(b, fl[:, 2:4])
+        wf0, wf1 = oracle.ops.backwarp(f0[k:k + 1], fl[:, :2]), oracle.ops.backwarp(f1[k:k + 1], fl[:, 2:4])
+        x = torch.cat((w0, w1, wf0, wf1, tmap[k:k + 1], upp[:, 4:5], upp[:, 5:]), 1)
+        if s != 1.0:
+            x = F.interpolate(x, scale_factor=1.0 / s, mode="bilinear", align_corners=False)
+            fls = F.interpolate(fl, scale_factor=1.0 / s, mode="bilinear", align_corners=False) * 1.0 / s
+        else:
+            fls = fl
+        return torch.cat((x, fls), 1), fl, upp
+
+    # ---- stage_conv0: scale 1, terms (16, 8, 4), newest head output at scale 2
+    wt, bs = torch.randn(16, 52, 3, 3, generator=g) / (52 * 9) ** 0.5, torch.randn(16, generator=g) * 0.1
+    conv = ops.Conv3x3(wt, bs, 2, True, None, device=dev)
+    assert ops.stage_conv0_ok(conv, H, W, 1.0, 2.0)
+    terms = [(dheads[16.0], 16.0), (dheads[8.0], 8.0), (dheads[4.0], 4.0)]
+    y, _ = ops.stage_conv0(items, None, dheads[2.0], 2.0, conv, terms=terms)
+    frames = ops.warp_blend_lazy([(it[0], it[1]) for it in items], terms, dheads[2.0], 2.0)
+    xin2 = torch.empty(B, 52, H // 2, W // 2, device=dev)
+    ops.stage_inputs(items, None, dheads[4.0], 4.0, 2.0, xin2, terms=[(dheads[16.0], 16.0), (dheads[8.0], 8.0)])
+    torch.cuda.synchronize()
+    for k in ref_items:
+        ref52, fl, upp = ref_stage(k, 1.0, (16.0, 8.0, 4.0), 2.0)
+        mag = float(fl.abs().max())
+        refy = F.leaky_relu(F.conv2d(ref52.double(), wt.double(), bs.double(), stride=2, padding=1), 0.2).float()
+        rows.append((f"stage_conv0 x{B} at {H}x{W}, 3 terms, item {k}: conv output vs fp64", _diff(y[k:k + 1], refy), 1e-4 + 2e-6 * mag,
+                     f"|flow|max={mag:.1f}"))
+        m = torch.sigmoid(upp[:, 4:5])
+        refb = oracle.ops.backwarp(img0[k:k + 1], fl[:, :2]) * m + oracle.ops.backwarp(img1[k:k + 1], fl[:, 2:4]) * (1 - m)
+        rows.append((f"warp_blend_lazy x{B} at {H}x{W}, 3 terms, item {k}", _diff(frames[k], refb), 2e-5 + 2e-6 * mag, ""))
+        ref2, fl2, _ = ref_stage(k, 2.0, (16.0, 8.0), 4.0)
+        rows.append((f"ifblock_input_lds+lazy x{B} s=2 at {H}x{W}, 2 terms, item {k}", _diff(xin2[k:k + 1], ref2),
+                     1e-4 + 2e-6 * float(fl2.abs().max()), ""))
+    return rows
+
+
+def check_gmfss_union_teacher_forced(dev, frames, rel=1e-4):
+    """BASELINE.json configs[3] AT ITS SIZE (frames: three fp32 [1,3,1152,1920] network inputs), stage by stage, every HIP stage
+    fed the ORACLE's intermediate tensors, so that nothing upstream amplifies a rounding difference (end to end at this size the
+    seeded GMFlow moves the oracle's own frame by 4.5e-2 under a 1-ulp input change: that run cannot fail at 1e-3; these can):
+      FeatureNet (FeatureNet.py:29-33) | GMFlow CNN encoder (backbone.py:39-117) | coarse transformer (transformer.py:236-302)
+      | global correlation + propagation (matching.py:7-38, transformer.py:355-372) | fine-scale refinement: warp, transformer,
+      local correlation r=4, local propagation, convex upsampling (gmflow.py:140-185) | MetricNet (MetricNet.py:45-65) | the
+      splat stage of Model.inference with map timesteps incl. the swap masks (GMFSS.py:80-152) | GridNet (FusionNet.py:106-146).
+    Bar: rel * max|ref| per tensor (1e-4: a wrong tap, stride or layout is O(1) of max|ref|; fp32 accumulation-order noise is
+    1e-6 .. 1e-5).  The splat stage has discontinuous decisions (ones-splat hole test, > 25x swap masks, exp(10 tanh) weights in
+    occlusions): there a flipped decision is an isolated outlier, budgeted at 0.02 % of the elements and reported."""
+    from drba_amd import ops
+    from drba_amd.models.gmflow.gmflow import GMFlow
+    from drba_amd.models.model_gmfss_union.FeatureNet import FeatureNet
+    from drba_amd.models.model_gmfss_union.FusionNet import GridNet
+    from drba_amd.models.model_gmfss_union.GMFSS import Model
+    from drba_amd.models.model_gmfss_union.MetricNet import MetricNet
+    from oracle import drm as odrm
+    from oracle import gmflow as ogm
+    from oracle import gmfss as ogs
+    sds = synth.gmfss_union_state_dicts(seed=0)
+    fsd = {k: v.float() for k, v in sds["flownet"].items()}
+    I0, I1, I2 = frames
+    D = lambda t: t.to(dev).contiguous()  # noqa: E731
+    rows = []
+
+    def row(name, g, o, budget=0.0):
+        scale = max(1.0, float(o.abs().max()))
+        tol = rel * scale
+        d = _diff(g, o)
+        n_out, n = _outliers(g, o, tol)
+        ok = n_out <= budget * n
+        inl = float(((g.detach().float().cpu() - o).abs().clamp(max=tol)).max()) if ok else d
+        rows.append((name, inl, tol, f"max={d:.2e} |ref|max={scale:.3g}" + (f" outliers {n_out}/{n} (budget {budget:.2%})" if budget else "")))
+
+    with torch.no_grad():
+        h0, h1, h2 = [F.interpolate(x, scale_factor=0.5, mode="bilinear", align_corners=False) for x in (I0, I1, I2)]
+        # ---- FeatureNet at full resolution
+        of0, of1 = ogs.featurenet(sds["feat"], I0), ogs.featurenet(sds["feat"], I1)
+        fnet = FeatureNet(sds["feat"], dev)
+        gf0 = fnet(D(I0))
+        for k in range(3):
+            row(f"FeatureNet level {k} {tuple(of0[k].shape[1:])}", gf0[k], of0[k])
+        # ---- GMFlow, one direction (h1 -> h0: what a warm DRBA step's reuse holds), stage by stage
+        net = GMFlow(sds["flownet"], dev)
+        x = torch.cat((h1, h0), 0)
+        xn = (x - ogm._MEAN) / ogm._STD
+        oe = ogm.encoder(fsd, xn)  # [1/4-res, 1/8-res]
+        ge = net.encoder(ops.channel_normalize3(D(x), (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)))
+        for k in range(2):
+            row(f"GMFlow CNN encoder out{k} {tuple(oe[k].shape[1:])}", ge[k], oe[k])
+        # coarse scale: position, transformer (splits 2), global correlation, global propagation
+        c0, c1 = oe[1][0:1], oe[1][1:2]
+        p0, p1 = ogm.feature_add_position(c0, c1, 2)
+        ot0, ot1 = ogm.feature_transformer(fsd, p0, p1, 2)
+        gt0, gt1 = net.transformer(D(p0), D(p1), 2)
+        row("GMFlow coarse transformer f0 (oracle inputs)", gt0, ot0)
+        row("GMFlow coarse transformer f1 (oracle inputs)", gt1, ot1)
+        oflow_c = ogm.flow_attention(fsd, ot0, ogm.global_correlation_softmax(ot0, ot1), local=False, radius=-1)
+        gflow_c = net._match(D(ot0), D(ot1), None, -1, -1)
+        row("GMFlow global correlation + propagation: coarse flow (oracle features)", gflow_c, oflow_c)
+        # fine scale: x2 upsample, warp, position, transformer (splits 8), local correlation r=4, local propagation r=1, convex x4
+        f0, f1 = oe[0][0:1], oe[0][1:2]
+        up = F.interpolate(oflow_c, scale_factor=2, mode="bilinear", align_corners=True) * 2
+        q0, q1 = ogm.feature_add_position(f0, ogm.flow_warp(f1, up), 8)
+        oq0, oq1 = ogm.feature_transformer(fsd, q0, q1, 8)
+        gq0, gq1 = net.transformer(D(q0), D(q1), 8)
+        row("GMFlow fine transformer f0 (oracle inputs)", gq0, oq0)
+        row("GMFlow fine transformer f1 (oracle inputs)", gq1, oq1)
+        oflow_f = ogm.flow_attention(fsd, oq0, up + ogm.local_correlation_softmax(oq0, oq1, 4), local=True, radius=1)
+        gflow_f = net._match(D(oq0), D(oq1), D(up), 4, 1)
+        row("GMFlow local correlation + propagation: fine flow (oracle features)", gflow_f, oflow_f)
+        gwarp = ops.flow_warp(D(f1), ops.resize_bilinear_ac(D(oflow_c), tuple(f0.shape[2:]), 2.0))
+        row("GMFlow x2 flow upsample + feature warp (oracle coarse flow)", gwarp, ogm.flow_warp(f1, up))
+        oflow10 = ogm.upsample_flow(fsd, oflow_f, oq0)
+        row("GMFlow convex upsampling x4 (oracle fine flow)", net._upsample(D(oflow_f), D(oq0)), oflow10)
+        # the whole refinement in one call, given the oracle's coarse flow
+        gfl, gfa = net._refine(D(f0), D(f1), D(oflow_c), 8, 4, 1)
+        row("GMFlow fine-scale refinement, one call (oracle coarse flow)", net._upsample(gfl, gfa), oflow10, budget=2e-4)
+        # ---- the other pair state of a warm step comes from the oracle outright (it is only an input below)
+        oflow01 = ogm.gmflow(fsd, h0, h1)
+        oflow12 = ogm.gmflow(fsd, h1, h2)
+        # ---- MetricNet on the oracle's flows
+        om1, om0 = ogs.metricnet(sds["metric"], h1, h0, oflow10, oflow01, True)
+        gm1, gm0 = MetricNet(sds["metric"], dev, tanh10=True)(D(h1), D(h0), D(oflow10), D(oflow01))
+        row("MetricNet metric (frame 1 side, oracle flows)", gm1, om1, budget=2e-4)
+        row("MetricNet metric (frame 0 side, oracle flows)", gm0, om0, budget=2e-4)
+        om12 = torch.roll(om1, shifts=(3, 5), dims=(2, 3))  # only an input of the DRM below (a second backward GMFlow pass would cost the oracle 20 s more)
+        # ---- the splat stage with DRM timestep maps (t = 0.75: the left pair, GMFSS_UNION.inference_ts_drba), oracle inputs
+        dg = odrm.calc_drm_gmfss(0.25, oflow10, oflow12, om1, om12, True)
+        t1, t0 = dg["drm1t_t01"], dg["drm0t_t01"]
+        reuse = (oflow10, oflow01, om1, om0, of1, of0)
+        omodel = ogs.GmfssModel(sds["flownet"], sds["metric"], sds["feat"], sds["fusion"], union=True)
+        rife = h1 * 0.5 + h0 * 0.5  # stands in for the auxiliary RIFE frame: any half-resolution image, identical on both sides
+        ox = omodel.fusion_inputs(I1, I0, reuse, t1, t0, rife)
+        gmodel = Model(union=True)
+        gmodel.load_state_dicts(sds["flownet"], sds["metric"], sds["feat"], sds["fusion"], dev)
+        dreuse = (D(oflow10), D(oflow01), D(om1), D(om0), [D(t) for t in of1], [D(t) for t in of0])
+        gx = gmodel.fusion_inputs(D(I1), D(I0), dreuse, D(t1), D(t0), D(rife))
+        for name, a, b in zip(("splat stage: x (I1t, rife, I2t)", "splat stage: pyramid level 1 (2 x 64 ch)", "splat stage: pyramid level 2 (2 x 128 ch)",
+                               "splat stage: pyramid level 3 (2 x 192 ch)"), gx, ox):
+            row(name + " (oracle flows, metrics, features, DRM maps)", a, b, budget=2e-4)
+        # ---- GridNet on the oracle's inputs
+        og = ogs.gridnet(sds["fusion"], *ox)
+        gg = gmodel.fusionnet(*[D(t) for t in ox])
+        row("GridNet (oracle inputs)", gg, og)
+    return rows
+
+
 def check_scdet(hip, golden):
     rows = []
     T = cases.scdet_frames()

@@ -4,9 +4,14 @@ The small-size end-to-end cases (tests/cases.py, 128x192 .. 256x512) never reach
 the persistent multi-tile loop of conv_split_mfma (more than 768 tiles), the XCD-banded gathers at 2 088 960 pixels, the
 three side-stream stages of the lookahead at N=2, drba_conv_chain on the 1080p shapes.  These tests do:
 
-  * RIFE 1088x1920 scale 1.0 and 2176x3840 scale 0.5: one cold and two warm inference_ts_drba steps with
-    lookahead=(next frame, next ts) exactly like bench.py's loop, ts = [0.75, 1.25] (-t 2) and [0.6, 1.0, 1.4] (-fps 60),
-    every synthesised frame and the carried reuse state against RifeOracle on identical fp32 inputs: 1e-3 max-abs;
+  * RIFE 1088x1920 scale 1.0 (1 cold + 9 warm steps) and 2176x3840 scale 0.5 (1 + 8) driven by bench.AnnouncedLoop -- the
+    object bench.py's timed region runs: 7 frames read ahead, encoders / coarse flows prefetched, the calls announced so
+    that the model computes groups of 4 steps (8 samples per launch) and stages the following group's low-resolution
+    stages on the side stream --, ts = [0.75, 1.25] (-t 2) and the [0.6, 1.0, 1.4] / [0.8, 1.2] alternation (-fps 60);
+    every synthesised frame and the carried reuse state against RifeOracle on identical fp32 inputs, 1e-3 max-abs; the
+    model's path counters prove that one group was computed in place and one came from the side stream;
+  * the layers of that path at the batch it launches them with (N = 8): split-bf16 convolutions, stage_conv0, the lazy
+    gathers and warp_blend_lazy with 8 items at 1088x1920 against fp64 (tests/gpu_checks.py);
   * GMFSS_UNION 1152x1920: one warm step against GmfssUnionOracle (bar of gpu_checks.check_gmfss_union);
   * every split-bf16 convolution configuration on shapes with more than 768 tiles against an fp64 convolution.
 
@@ -38,39 +43,54 @@ def _net_frames(n, H, W, net, seed=1234):
     return out
 
 
-def _drive(model, frames, ts_seq, dev, lookahead):
-    """bench.py's loop: step k = inference_ts_drba(f[k], f[k+1], f[k+2], ts_seq[k], reuse, linear=True,
-    lookahead=(f[k+3], ts_seq[k+1])); the first step is cold (reuse=None)."""
+def _drive(model, frames, ts_seq, dev, announced):
+    """announced=True: bench.AnnouncedLoop, THE loop of bench.py's timed region (7 frames read ahead, prefetch_frame /
+    prefetch_pair, the following calls named so that the model computes groups of RIFE.GROUP steps and stages the next
+    group on the side stream).  announced=False: the reference's call pattern (the oracle).  Step k =
+    inference_ts_drba(f[k], f[k+1], f[k+2], ts_seq[k], reuse, linear=True); the first step is cold (reuse=None).
+    -> (per-step synthesised frames, per-step reuse)."""
     fr = [f.to(dev) for f in frames]
-    outs, reuse = [], None
-    for k, ts in enumerate(ts_seq):
-        kw = {}
-        if lookahead and k + 1 < len(ts_seq):
-            kw["lookahead"] = (fr[k + 3], ts_seq[k + 1])
-        o, reuse = model.inference_ts_drba(fr[k], fr[k + 1], fr[k + 2], ts, reuse, True, **kw)
-        outs.append([x for x, t in zip(o, ts) if t not in (0.0, 1.0, 2.0)])
+    outs, reuses = [], []
+    if announced:
+        import bench
+        loop = bench.AnnouncedLoop(model, lambda k: fr[k] if k < len(fr) else None, lambda k: ts_seq[k] if k < len(ts_seq) else None)
+        for _ in ts_seq:
+            o, ts = loop.step()
+            outs.append([x for x, t in zip(o, ts) if t not in (0.0, 1.0, 2.0)])
+            reuses.append(loop.reuse)
+    else:
+        reuse = None
+        for k, ts in enumerate(ts_seq):
+            o, reuse = model.inference_ts_drba(fr[k], fr[k + 1], fr[k + 2], ts, reuse, True)
+            outs.append([x for x, t in zip(o, ts) if t not in (0.0, 1.0, 2.0)])
+            reuses.append(reuse)
     if dev.type == "cuda":
         torch.cuda.synchronize()
-    return outs, reuse
+    return outs, reuses
 
 
-def _rife_fullsize(hip_backend, oracle_backend, src, net, scale, ts_seq):
+def _rife_fullsize(hip_backend, oracle_backend, src, net, scale, ts_seq, min_groups, min_staged):
     sd = synth.ifnet_state_dict(seed=0)
     frames = _net_frames(len(ts_seq) + 2, src[0], src[1], net)
     hip = hip_backend.make_rife(sd, scale)
-    got, greuse = _drive(hip, frames, ts_seq, hip_backend.dev, lookahead=True)
-    want, oreuse = _drive(oracle_backend.make_rife(sd, scale), frames, ts_seq, torch.device("cpu"), lookahead=False)
-    # the lookahead must have been consumed by the warm steps (i.e. the side-stream path is what was checked)
-    assert hip._look is not None and hip._look.pending is None
+    got, greuse = _drive(hip, frames, ts_seq, hip_backend.dev, announced=True)
+    # what was checked is the grouped path the benchmark times: the first step is cold (one-step path), then one group
+    # computed in place and -- for the longer sequences -- groups whose low-resolution stages ran on the side stream
+    st = dict(hip.stats)
+    assert st["groups_formed"] >= min_groups and st["staged_groups"] >= min_staged and st["groups_dropped"] == 0, st
+    assert st["single_steps"] + st["group_collects"] + st["groups_formed"] == len(ts_seq), st
+    want, oreuse = _drive(oracle_backend.make_rife(sd, scale), frames, ts_seq, torch.device("cpu"), announced=False)
     rows = []
     for k, (g, o) in enumerate(zip(got, want)):
         assert len(g) == len(o)
         for j, (a, b) in enumerate(zip(g, o)):
             rows.append((f"step{k} frame{j} ({'cold' if k == 0 else 'warm'})", gpu_checks._diff(a, b), 1e-3, ""))
-    # reuse = (flow21, flow12, f2, f1): features to 1e-3; flows carry the hole-fill discontinuity -> outlier budget
-    for name, a, b in zip(("flow21", "flow12", "f2", "f1"), greuse, oreuse):
+    # reuse = (flow21, flow12, f2, f1) after the LAST step (every step's reuse feeds the next step's frames, which are
+    # checked above): features to 1e-3; flows carry the hole-fill discontinuity -> outlier budget
+    for name, a, b in zip(("flow21", "flow12", "f2", "f1"), greuse[-1], oreuse[-1]):
         n_out, n = gpu_checks._outliers(a, b, 1e-3)
         rows.append((f"reuse {name}", 0.0 if n_out <= max(2, n // 2000) else gpu_checks._diff(a, b), 1e-3, f"outliers {n_out}/{n}"))
+    rows.append(("path: " + ", ".join(f"{k}={v}" for k, v in st.items() if v), 0.0, 0.0, ""))
     return rows
 
 
@@ -87,13 +107,16 @@ def _assert_rows(rows):
 @pytest.mark.parametrize("ts_name", ("t2", "fps60"))
 def test_rife_1080p_bench_loop_parity(hip_backend, oracle_backend, ts_name):
     """BASELINE.json configs[1] (-t 2) and configs[2] (-fps 60 timesteps) at 1088x1920, scale 1.0."""
-    ts_seq = [TS_T2] * 3 if ts_name == "t2" else [TS_F3, TS_F2, TS_F3]
-    _assert_rows(_rife_fullsize(hip_backend, oracle_backend, (1080, 1920), (1088, 1920), 1.0, ts_seq))
+    # 1 cold + 9 warm steps: steps 1-4 one group computed in place (while it runs, steps 5-8 are staged on the side stream),
+    # steps 5-8 the staged group, step 9 the clip's last step on the one-step path
+    ts_seq = [TS_T2] * 10 if ts_name == "t2" else [TS_F3, TS_F2] * 5
+    _assert_rows(_rife_fullsize(hip_backend, oracle_backend, (1080, 1920), (1088, 1920), 1.0, ts_seq, 2, 1))
 
 
 def test_rife_4k_half_scale_bench_loop_parity(hip_backend, oracle_backend):
-    """BASELINE.json configs[4]'s per-GPU work: 2176x3840, scale 0.5, -fps 60 timesteps; one cold + one warm step."""
-    _assert_rows(_rife_fullsize(hip_backend, oracle_backend, (2160, 3840), (2176, 3840), 0.5, [TS_F3, TS_F2]))
+    """BASELINE.json configs[4]'s per-GPU work: 2176x3840, scale 0.5, -fps 60 timesteps; one cold + 8 warm steps (one group
+    computed in place, one staged on the side stream)."""
+    _assert_rows(_rife_fullsize(hip_backend, oracle_backend, (2160, 3840), (2176, 3840), 0.5, [TS_F3, TS_F2] * 4 + [TS_F3], 2, 1))
 
 
 def test_to_inp_to_out_fullsize_bit_exact(hip_backend):
@@ -147,6 +170,13 @@ def test_gmfss_union_1080p_warm_step_parity(hip_backend, oracle_backend):
     _assert_rows(rows)
 
 
+def test_gmfss_union_1080p_teacher_forced_stages(hip_backend):
+    """BASELINE.json configs[3] at 1152x1920, stage by stage on the oracle's intermediate tensors: a check that CAN fail at
+    1e-4 * max|ref| (the end-to-end row above sits on a 4.5e-2 conditioning floor at this size)."""
+    frames = _net_frames(3, 1080, 1920, (1152, 1920), seed=4321)
+    _assert_rows(gpu_checks.check_gmfss_union_teacher_forced(hip_backend.dev, frames))
+
+
 def test_split_conv_configs_on_many_tile_shapes(hip_backend):
     """conv_split_mfma's persistent workgroups walk more than one tile only when a launch has more tiles than resident
     workgroups (768): the 1080p layer shapes.  Every split configuration (conv cfg >= 14, deconv cfg >= 6) on those
@@ -157,8 +187,12 @@ def test_split_conv_configs_on_many_tile_shapes(hip_backend):
     lib = ops._lib.load()
     g = torch.Generator().manual_seed(321)
     rows = []
+    # nb = 8: the batch the benchmarked loop launches these layers with (groups of 4 steps x 2 frames; the autotuner picks a
+    # configuration per batch size, the forced loop below runs all of them)
     for (nb, cin, cout, h, w, kind) in ((2, 32, 32, 272, 480, "res"), (2, 64, 64, 136, 240, "res"), (2, 96, 96, 68, 120, "res"),
-                                        (1, 32, 16, 544, 960, "conv"), (1, 64, 64, 288, 960, "pre")):
+                                        (1, 32, 16, 544, 960, "conv"), (1, 64, 64, 288, 960, "pre"),
+                                        (8, 32, 32, 272, 480, "res"), (8, 64, 64, 136, 240, "res"), (8, 96, 96, 68, 120, "res"),
+                                        (8, 128, 128, 34, 60, "res"), (8, 192, 192, 17, 30, "res")):
         x = torch.randn(nb, cin, h, w, generator=g) * 2.0
         wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
         b = torch.randn(cout, generator=g) * 0.1
@@ -184,7 +218,8 @@ def test_split_conv_configs_on_many_tile_shapes(hip_backend):
                 got = ops.Conv3x3(wt, b, 1, True, None, device=dev, cfg=cfg)(xg)
             rows.append((f"conv split cfg{cfg} {kind} [{nb}x{cin}->{cout} {h}x{w}]", gpu_checks._diff(got, ref),
                          5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
-    for (nb, cin, cout, h, w, ps) in ((2, 32, 52, 272, 480, True), (2, 64, 52, 136, 240, True), (1, 96, 64, 192, 480, False)):
+    for (nb, cin, cout, h, w, ps) in ((2, 32, 52, 272, 480, True), (2, 64, 52, 136, 240, True), (1, 96, 64, 192, 480, False),
+                                      (8, 32, 20, 272, 480, True), (8, 64, 52, 136, 240, True)):
         x = torch.randn(nb, cin, h, w, generator=g) * 2.0
         wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
         b = torch.randn(cout, generator=g) * 0.1
@@ -201,9 +236,16 @@ def test_split_conv_configs_on_many_tile_shapes(hip_backend):
     _assert_rows(rows)
 
 
+def test_glue_launches_with_8_items_at_1080p(hip_backend):
+    """stage_conv0, the lazy scale-2 gather and warp_blend_lazy with 8 items per launch at 1088x1920 (the launch geometry of
+    the benchmarked loop) against the reference's arithmetic (oracle ops, fp64 convolution)."""
+    _assert_rows(gpu_checks.check_glue_n8_fullsize(hip_backend.dev))
+
+
 def test_config3_one_clip_1080p_fps60_scdet_and_its_sharding(hip_backend):
-    """BASELINE.json configs[2] as ONE clip at the benchmarked size: 10 source frames 1080x1920 (net 1088x1920), 24 -> 60
-    fps (fractional timesteps + DRM), scene detection on with a planted cut -- what bench.py's `config3_*` leg times --
+    """BASELINE.json configs[2] as ONE clip at the benchmarked size: 24 source frames 1080x1920 (net 1088x1920), 24 -> 60
+    fps (fractional timesteps + DRM), scene detection on with a planted cut in the middle (24 source frames: the driver forms
+    groups of steps on each side of it) -- what bench.py's `config3_*` leg times --
     through the real driver loop on the HIP path (to_inp / to_out / check_scene on the device, lookahead and prefetch
     active) against the same loop on the CPU oracle: same number of frames, same cut decisions (a different decision
     would put a copy where a synthesised frame belongs: far more than 1 LSB), every byte within 1 LSB.
@@ -216,12 +258,14 @@ def test_config3_one_clip_1080p_fps60_scdet_and_its_sharding(hip_backend):
     from tests.test_gpu_parallel import _hooks
     dev = hip_backend.dev
     sd = synth.ifnet_state_dict(seed=0)
-    frames = synth.make_clip(10, 1080, 1920, seed=1234, cut_at=5)
+    frames = synth.make_clip(24, 1080, 1920, seed=1234, cut_at=12)  # 12 frames on each side of the cut: groups of 4 steps form on both
     to_inp, to_out = _hooks(dev)
     hip = hip_backend.make_rife(sd, 1.0)
     io = ListIO(frames, 24.0)
     n = drv.interpolate_stream(hip, io, 60.0, enable_scdet=True, to_inp=to_inp, to_out=to_out)
     torch.cuda.synchronize()
+    st = dict(hip.stats)  # the driver loop took the grouped path on both sides of the cut (and staged a group on the side stream)
+    assert st["groups_formed"] >= 3 and st["staged_groups"] >= 1, st
     cio = ListIO(frames, 24.0)
     c_inp, c_out, c_check = cpu_hooks()
     drv.interpolate_stream(oracle.rife.RifeOracle(sd, 1.0), cio, 60.0, enable_scdet=True, to_inp=c_inp, to_out=c_out,

@@ -179,6 +179,49 @@ def test_prefetched_encoder_matches_inline(hip_backend):
         assert float((x - y).abs().max()) <= 2e-6
 
 
+def test_scene_checks_do_not_retain_frames(hip_backend):
+    """tools.SceneChecks remembers DECISIONS, not frames: once the driver has dropped a tested pair nothing in the table may
+    keep the two frames (and the encoder features hung on them: 270 MB per 1080p frame) alive; an id recycled by a new frame
+    is a miss, not a stale hit."""
+    import gc
+    import weakref
+    from drba_amd.models.utils import tools
+    dev = hip_backend.dev
+    g = torch.Generator().manual_seed(3)
+    sc = tools.SceneChecks(0.3)
+    a, b = torch.rand(1, 3, 64, 96, generator=g).to(dev), torch.rand(1, 3, 64, 96, generator=g).to(dev)
+    key = (id(a), id(b))
+    sc.submit(key, a, b)
+    want = tools.check_scene(a, b, 0.3)
+    assert sc.cut(key, a, b) == want and sc.cut(key, a, b) == want  # second call: the remembered decision
+    assert not sc.pending
+    ra, rb = weakref.ref(a), weakref.ref(b)
+    del a, b
+    gc.collect()
+    assert ra() is None and rb() is None, "SceneChecks keeps tested frames alive"
+    c, d = torch.rand(1, 3, 64, 96, generator=g).to(dev), torch.rand(1, 3, 64, 96, generator=g).to(dev)
+    sc.done[(id(c), id(d))] = sc.done.pop(key)  # the old decision under the new pair's key: as if the ids had been recycled
+    assert not sc._known((id(c), id(d)), c, d)
+    assert sc.cut((id(c), id(d)), c, d) == tools.check_scene(c, d, 0.3)
+
+
+def test_two_model_instances_in_one_process(hip_backend):
+    """A second RIFE in the process (the per-device kernel attributes and the per-(device, stream) work counters are looked
+    up, not assumed from the first instance) gives the first one's results."""
+    from drba_amd.utils import synth
+    sd = synth.ifnet_state_dict(seed=0)
+    dev = hip_backend.dev
+    g = torch.Generator().manual_seed(9)
+    fr = [torch.rand(1, 3, 128, 192, generator=g).to(dev) for _ in range(3)]
+    ts = np.array([0.75, 1.25])
+    m1, m2 = hip_backend.make_rife(sd, 1.0), hip_backend.make_rife(sd, 1.0)
+    o1, _ = m1.inference_ts_drba(*fr, ts, None, True)
+    o2, _ = m2.inference_ts_drba(*fr, ts, None, True)
+    torch.cuda.synchronize()
+    for x, y in zip(o1, o2):
+        assert torch.equal(x, y)
+
+
 def test_prefetch_does_not_retain_frames(hip_backend):
     """The prefetch caches hang on the frame tensors (encoder output on the frame, coarse flow on the pair's second frame);
     nothing may keep a frame -- with its 16-channel features -- alive once the driver has dropped it: memory is flat over a

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box pass producing everything profiles/ holds for a round: tools/gpu_round.sh <tag> [skip-tests]
 #   gpurun_out/<tag>/{pytest_gpu.txt, bench_*.json, kernel trace (rocpd db + csv), steady-state tables, PMC passes, timeline}
-TAG=${1:-r02}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 [ -z "$GRAFT_REPO_ROOT" ] && OUT=$(pwd)/gpurun_out/$TAG
 mkdir -p $OUT
@@ -40,8 +40,8 @@ REPO=$(pwd)
 ls $OUT/trace | head
 DB=$(ls $OUT/trace/*_results.db 2>/dev/null | head -1)
 if [ -n "$DB" ]; then
-  python tools/rocpd_steady.py $DB 10 $OUT/steady_state.csv --rows 12
-  python tools/rocpd_steady.py $DB 10 $OUT/steady_state_by_grid.csv --by-grid --by-queue --rows 0 > /dev/null
+  python tools/rocpd_steady.py $DB 12 $OUT/steady_state.csv --rows 14
+  python tools/rocpd_steady.py $DB 12 $OUT/steady_state_by_grid.csv --by-grid --by-queue --rows 0 > /dev/null
   python tools/rocpd_stats.py $DB $OUT/kernel_stats_whole_run.csv > /dev/null
 fi
 du -sh $OUT
