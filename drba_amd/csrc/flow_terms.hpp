@@ -16,6 +16,7 @@
 namespace drba {
 
 constexpr int kMaxTerms = DRBA_MAX_FLOW_TERMS;
+typedef float f32x4t __attribute__((ext_vector_type(4)));
 
 struct FlowTermsArg {  // kernel-argument form of drba_flow_terms_t
   int n;
@@ -36,7 +37,9 @@ static inline bool flow_terms_arg(const drba_flow_terms_t *t, FlowTermsArg &a) {
 }
 
 // Footprints of the terms under a tile whose sample points span [Xa, Xb] x [Ya, Yb] (full resolution, in-image).
-// lds: [kMaxTerms][4][CAP_R * CAP_C]; org[i] = (rx0, ry0) of term i.  All threads of the workgroup call this (before a
+// lds (16-byte aligned): [kMaxTerms][CAP_R * CAP_C][4 channels] -- the four flow channels of a footprint pixel are one
+// 16-byte LDS word, so a sample point reads a term's 2 x 2 taps with 4 ds_read_b128 instead of 16 ds_read_b32 (round 4: the
+// final warp_blend evaluates 4 terms per pixel, 64 of its 84 LDS reads); org[i] = (rx0, ry0) of term i.  All threads of the workgroup call this (before a
 // barrier of their own).  CAP must cover (extent - 1) / s_i + 3 per axis; footprints are clipped to it defensively.
 template <int CAP_R, int CAP_C, int NTHREADS>
 __device__ __forceinline__ void terms_stage(float *lds, const FlowTermsArg &T, const float *const *ptr, int Xa, int Ya, int Xb, int Yb,
@@ -54,8 +57,10 @@ __device__ __forceinline__ void terms_stage(float *lds, const FlowTermsArg &T, c
         const int r = e / CAP_C, col = e - r * CAP_C;
         if (r < rh && col < rw) {
           const float *src = ptr[i] + (size_t)(ry0[i] + r) * T.w[i] + rx0[i] + col;
+          f32x4t v;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) lds[(i * 4 + c) * CAP + e] = src[(size_t)c * plane];
+          for (int c = 0; c < 4; ++c) v[c] = src[(size_t)c * plane];
+          *reinterpret_cast<f32x4t *>(lds + (size_t)(i * CAP + e) * 4) = v;
         }
       }
     }
@@ -75,10 +80,12 @@ __device__ __forceinline__ bool terms_flow(const float *lds, const FlowTermsArg 
       const int o01 = min(a.i0 - ry0[i], CAP_R - 1) * CAP_C + min(b.i1 - rx0[i], CAP_C - 1);
       const int o10 = min(a.i1 - ry0[i], CAP_R - 1) * CAP_C + min(b.i0 - rx0[i], CAP_C - 1);
       const int o11 = min(a.i1 - ry0[i], CAP_R - 1) * CAP_C + min(b.i1 - rx0[i], CAP_C - 1);
+      const float *p = lds + (size_t)i * CAP * 4;
+      const f32x4t q00 = *reinterpret_cast<const f32x4t *>(p + o00 * 4), q01 = *reinterpret_cast<const f32x4t *>(p + o01 * 4);
+      const f32x4t q10 = *reinterpret_cast<const f32x4t *>(p + o10 * 4), q11 = *reinterpret_cast<const f32x4t *>(p + o11 * 4);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float *p = lds + (i * 4 + c) * CAP;
-        const float term = __fmul_rn(lerp2_fma(a.w0, a.w1, b.w0, b.w1, p[o00], p[o01], p[o10], p[o11]), T.scale[i]);
+        const float term = __fmul_rn(lerp2_fma(a.w0, a.w1, b.w0, b.w1, q00[c], q01[c], q10[c], q11[c]), T.scale[i]);
         fl[c] = i == 0 ? term : __fadd_rn(fl[c], term);
       }
     }

@@ -69,7 +69,7 @@ head_fused(const float *__restrict__ img, const float *__restrict__ wpk, float *
   const int m0 = ty * H2, n0 = tx * W2;           // the tile's first half-resolution row / column
   const int rm = m0 - 3, rn = n0 - 3;             // region origin (half-resolution coordinates)
   img += (size_t)blockIdx.y * 3 * P;
-  f_out += (size_t)blockIdx.y * C * P;
+  if (f_out) f_out += (size_t)blockIdx.y * C * P;
   fp_out += (size_t)blockIdx.y * C * P;
 
   // ---- weights and the frame window (zero outside the image)
@@ -201,7 +201,8 @@ head_fused(const float *__restrict__ img, const float *__restrict__ wpk, float *
         for (int k = 0; k < 8; ++k) o8[k] = __shfl_xor(v8[k], 1, 64);  // the other channel of the pair (lane m ^ 1)
         if (M < Hh && x < W) {
           float *pf = f_out + (size_t)m * P + (size_t)y * W + x;
-          if (x + 7 < W) {
+          if (!f_out) {  // pair layout only (the hot path: every consumer reads the pair layout; -134 MB written per 1080p frame)
+          } else if (x + 7 < W) {
             *reinterpret_cast<f32x4 *>(pf) = (f32x4){v8[0], v8[1], v8[2], v8[3]};
             *reinterpret_cast<f32x4 *>(pf + 4) = (f32x4){v8[4], v8[5], v8[6], v8[7]};
           } else {
@@ -274,7 +275,7 @@ int drba_head_fused_pack(const float *w0, const float *b0, const float *w1, cons
 
 int drba_head_fused(const float *img, const float *packed_w, float *f_out, float *f_pair_out, int N, int H, int W, void *stream) {
   using namespace drba_head;
-  if (!img || !packed_w || !f_out || !f_pair_out || N <= 0 || H < 2 || W < 2) return DRBA_EINVAL;
+  if (!img || !packed_w || !f_pair_out || N <= 0 || H < 2 || W < 2) return DRBA_EINVAL;  // f_out may be NULL: pair layout only
   if ((H & 1) || (W & 3) || N > 65535) return DRBA_EUNSUPPORTED;  // even rows; 16-byte aligned rows in both layouts
   if ((((uintptr_t)f_out | (uintptr_t)f_pair_out | (uintptr_t)packed_w) & 15) != 0) return DRBA_EINVAL;
   const int tiles_x = (W / 2 + W2 - 1) / W2, tiles_y = (H / 2 + H2 - 1) / H2;

@@ -86,6 +86,60 @@ __global__ void __launch_bounds__(256) to_out_kernel(const float *__restrict__ i
   }
 }
 
+// The frame sizes of the 1080p / 4K configurations change the HEIGHT only (1080 -> 1088, 2160 -> 2176: the width is already a
+// multiple of the padding): the horizontal interpolation is the identity -- scale_x == 1 gives s = x, weights (1, 0), and
+// fma(1, a, 0 * b) == a for finite b -- so a lane takes FOUR consecutive pixels of a row with 16-byte loads / stores instead of
+// one pixel with 12 scalar loads and 3 byte (or 3 dword) stores: same values bit for bit, a third of the time (round 4: the
+// one-pixel kernels were 46 + 2 x 34 us of a 2.43 ms 1080p step at 0.9 TB/s).
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) to_inp_rows_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int Hin, int W, int Hout,
+                                                          float sy) {
+  const int W4 = W >> 2;
+  const size_t total = (size_t)W4 * Hout, P = (size_t)Hout * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / W4), x = (int)(i - (size_t)y * W4) * 4;
+    const Lerp ly = lerp_src_aten(y, sy, Hin);
+    // 4 pixels x 3 channels = 12 bytes per row, 4-byte aligned (W % 4 == 0)
+    const uint32_t *r0 = reinterpret_cast<const uint32_t *>(in + ((size_t)ly.i0 * W + x) * 3);
+    const uint32_t *r1 = reinterpret_cast<const uint32_t *>(in + ((size_t)ly.i1 * W + x) * 3);
+    const uint32_t a[3] = {r0[0], r0[1], r0[2]}, b[3] = {r1[0], r1[1], r1[2]};
+    f32x4g o[3];
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int k = px * 3 + c;
+        const float top = (float)((a[k >> 2] >> (8 * (k & 3))) & 0xffu) / 255.f, bot = (float)((b[k >> 2] >> (8 * (k & 3))) & 0xffu) / 255.f;
+        o[c][px] = __fmaf_rn(ly.w0, top, __fmul_rn(ly.w1, bot));
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4g *>(out + (size_t)c * P + (size_t)y * W + x) = o[c];
+  }
+}
+__global__ void __launch_bounds__(256) to_out_rows_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, int Hin, int W, int Hout,
+                                                          float sy, int rev) {
+  const int W4 = W >> 2;
+  const size_t total = (size_t)W4 * Hout, P = (size_t)Hin * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / W4), x = (int)(i - (size_t)y * W4) * 4;
+    const Lerp ly = lerp_src_aten(y, sy, Hin);
+    uint32_t bytes[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x4g t = *reinterpret_cast<const f32x4g *>(in + (size_t)c * P + (size_t)ly.i0 * W + x);
+      const f32x4g u = *reinterpret_cast<const f32x4g *>(in + (size_t)c * P + (size_t)ly.i1 * W + x);
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const float v = __fmul_rn(__fmaf_rn(ly.w0, t[px], __fmul_rn(ly.w1, u[px])), 255.f);
+        bytes[px * 3 + (rev ? 2 - c : c)] = (uint32_t)(uint8_t)(int)v;
+      }
+    }
+    uint32_t *o = reinterpret_cast<uint32_t *>(out + ((size_t)y * W + x) * 3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | (bytes[4 * k + 3] << 24);
+  }
+}
+
 // tools.py:33-34: HWC uint8 -> [1,3,H,W] fp32 / 255.
 __global__ void __launch_bounds__(256) u8_to_f32_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int H, int W) {
   const size_t P = (size_t)H * W;
@@ -253,10 +307,18 @@ ifblock_input_pixel(const StageItems items, int hp, int wp, float inv_prev_scale
         dst[(size_t)c * p_lo] = lerp4([&](int j, int i) { return pl0[q[j][i]]; });
         dst[(size_t)(3 + c) * p_lo] = lerp4([&](int j, int i) { return pl1[q[j][i]]; });
       }
-      for (int c = 0; c < 16; ++c) {
-        const float *pl0 = f0 + (size_t)c * P, *pl1 = f1 + (size_t)c * P;
-        dst[(size_t)(6 + c) * p_lo] = lerp4([&](int j, int i) { return pl0[q[j][i]]; });
-        dst[(size_t)(22 + c) * p_lo] = lerp4([&](int j, int i) { return pl1[q[j][i]]; });
+      if (f0p) {  // pair-interleaved features (the only layout head_fused writes on the hot path): channel c of pixel q at [c / 2][q][c % 2]
+        for (int c = 0; c < 16; ++c) {
+          const float *pl0 = f0p + (size_t)(c >> 1) * 2 * P + (c & 1), *pl1 = f1p + (size_t)(c >> 1) * 2 * P + (c & 1);
+          dst[(size_t)(6 + c) * p_lo] = lerp4([&](int j, int i) { return pl0[2 * q[j][i]]; });
+          dst[(size_t)(22 + c) * p_lo] = lerp4([&](int j, int i) { return pl1[2 * q[j][i]]; });
+        }
+      } else {
+        for (int c = 0; c < 16; ++c) {
+          const float *pl0 = f0 + (size_t)c * P, *pl1 = f1 + (size_t)c * P;
+          dst[(size_t)(6 + c) * p_lo] = lerp4([&](int j, int i) { return pl0[q[j][i]]; });
+          dst[(size_t)(22 + c) * p_lo] = lerp4([&](int j, int i) { return pl1[q[j][i]]; });
+        }
       }
       dst[(size_t)38 * p_lo] = lerp4([&](int j, int i) { return tmap ? tmap[q[j][i]] : tscalar; });
     }
@@ -371,12 +433,27 @@ ifblock_input_kernel(const StageItems items, int hp, int wp, float inv_prev_scal
           dst[(size_t)(3 + c) * p_lo] = v1;
         }
       }
+      if (f0p) {  // pair-interleaved features: both channels of a pair in one 8-byte load
 #pragma unroll UNR
-      for (int c = 0; c < 16; ++c) {
-        const float v0 = comb(f0[(size_t)c * P + q]), v1 = comb(f1[(size_t)c * P + q]);
-        if (writer) {
-          dst[(size_t)(6 + c) * p_lo] = v0;
-          dst[(size_t)(22 + c) * p_lo] = v1;
+        for (int c2 = 0; c2 < 8; ++c2) {
+          const f32x2u a = *reinterpret_cast<const f32x2u *>(f0p + ((size_t)c2 * P + q) * 2);
+          const f32x2u b = *reinterpret_cast<const f32x2u *>(f1p + ((size_t)c2 * P + q) * 2);
+          const float a0 = comb(a.x), a1 = comb(a.y), b0 = comb(b.x), b1 = comb(b.y);
+          if (writer) {
+            dst[(size_t)(6 + 2 * c2) * p_lo] = a0;
+            dst[(size_t)(7 + 2 * c2) * p_lo] = a1;
+            dst[(size_t)(22 + 2 * c2) * p_lo] = b0;
+            dst[(size_t)(23 + 2 * c2) * p_lo] = b1;
+          }
+        }
+      } else {
+#pragma unroll UNR
+        for (int c = 0; c < 16; ++c) {
+          const float v0 = comb(f0[(size_t)c * P + q]), v1 = comb(f1[(size_t)c * P + q]);
+          if (writer) {
+            dst[(size_t)(6 + c) * p_lo] = v0;
+            dst[(size_t)(22 + c) * p_lo] = v1;
+          }
         }
       }
       const float v = comb(tmap ? tmap[q] : tscalar);
@@ -416,7 +493,7 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   DRBA_UNPACK_STAGE_ITEM(items);
   float *__restrict__ flow_out = item_.flow_out;
   __shared__ float prev[13][kPrevRH][kPrevRW];
-  __shared__ float tl[LAZY ? kMaxTerms * 4 * kTermR * kTermC : 1];
+  __shared__ __attribute__((aligned(16))) float tl[LAZY ? kMaxTerms * 4 * kTermR * kTermC : 4];
   int trx0[kMaxTerms], try0[kMaxTerms];
   constexpr int STG = VS ? (SINGLE ? 4 * 64 : 52 * 16 + 4 * 64) : 1;  // floats per wave
   __shared__ __attribute__((aligned(16))) float stg_all[4 * STG];
@@ -647,7 +724,7 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   const float *__restrict__ flow = items.flow[blockIdx.y], *__restrict__ tmp = items.tmp[blockIdx.y];
   float *__restrict__ out = items.out[blockIdx.y];
   __shared__ float prev[5][10][36];
-  __shared__ float tl[LAZY ? kMaxTerms * 4 * kWbTermR * kWbTermC : 1];
+  __shared__ __attribute__((aligned(16))) float tl[LAZY ? kMaxTerms * 4 * kWbTermR * kWbTermC : 4];
   int trx0[kMaxTerms], try0[kMaxTerms];
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
   const int tiles_x = (W + kTileW - 1) / kTileW;
@@ -788,6 +865,12 @@ int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *str
 int drba_to_inp(const uint8_t *img_hwc, float *out, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
                 void *stream) {
   if (!img_hwc || !out || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
+  if (Win == Wout && scale_x == 1.f && (Wout & 3) == 0 && (((uintptr_t)img_hwc & 3) | ((uintptr_t)out & 15)) == 0) {
+    DRBA_LAUNCH(to_inp_rows_kernel, dim3(grid_for((size_t)(Wout >> 2) * Hout)), dim3(kBlock), 0, (hipStream_t)stream, img_hwc, out, Hin,
+                Wout, Hout, scale_y);
+    DRBA_CHECK_LAUNCH();
+    return DRBA_OK;
+  }
   DRBA_LAUNCH(to_inp_kernel, dim3(tiles_for(Wout, Hout)), dim3(kBlock), 0, (hipStream_t)stream, img_hwc, out, Hin, Win, Hout,
               Wout, scale_y, scale_x);
   DRBA_CHECK_LAUNCH();
@@ -797,6 +880,12 @@ int drba_to_inp(const uint8_t *img_hwc, float *out, int Hin, int Win, int Hout, 
 int drba_to_out(const float *in, uint8_t *out_hwc, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
                 int reverse_channels, void *stream) {
   if (!in || !out_hwc || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
+  if (Win == Wout && scale_x == 1.f && (Wout & 3) == 0 && (((uintptr_t)out_hwc & 3) | ((uintptr_t)in & 15)) == 0) {
+    DRBA_LAUNCH(to_out_rows_kernel, dim3(grid_for((size_t)(Wout >> 2) * Hout)), dim3(kBlock), 0, (hipStream_t)stream, in, out_hwc, Hin,
+                Wout, Hout, scale_y, reverse_channels);
+    DRBA_CHECK_LAUNCH();
+    return DRBA_OK;
+  }
   DRBA_LAUNCH(to_out_kernel, dim3(tiles_for(Wout, Hout)), dim3(kBlock), 0, (hipStream_t)stream, in, out_hwc, Hin, Win, Hout,
               Wout, scale_y, scale_x, reverse_channels);
   DRBA_CHECK_LAUNCH();
@@ -807,11 +896,13 @@ static int stage_items_ok(const drba_stage_item_t *items, int n, bool lds) {
   if (!items || n <= 0 || n > kMaxItems) return DRBA_EINVAL;
   for (int k = 0; k < n; ++k) {
     const drba_stage_item_t &I = items[k];
-    if (!I.img0 || !I.img1 || !I.f0 || !I.f1 || !I.out) return DRBA_EINVAL;
-    if ((I.f0_pair == nullptr) != (I.f1_pair == nullptr)) return DRBA_EINVAL;
+    if (!I.img0 || !I.img1 || !I.out) return DRBA_EINVAL;
+    if ((I.f0_pair == nullptr) != (I.f1_pair == nullptr) || (I.f0 == nullptr) != (I.f1 == nullptr)) return DRBA_EINVAL;
+    if (!I.f0 && !I.f0_pair) return DRBA_EINVAL;  // the features in one layout at least: planar [16,H,W] or pair-interleaved [8,H,W,2]
     // one kernel instantiation serves the batch: the items agree on what is optional
     if ((I.flow == nullptr) != (items[0].flow == nullptr) || (I.flow_out == nullptr) != (items[0].flow_out == nullptr) ||
-        (I.f0_pair == nullptr) != (items[0].f0_pair == nullptr) || (I.tmp_prev == nullptr) != (items[0].tmp_prev == nullptr))
+        (I.f0_pair == nullptr) != (items[0].f0_pair == nullptr) || (I.f0 == nullptr) != (items[0].f0 == nullptr) ||
+        (I.tmp_prev == nullptr) != (items[0].tmp_prev == nullptr))
       return DRBA_EINVAL;
     if (lds && !I.tmp_prev) return DRBA_EINVAL;
     if (lds && !I.flow_out && !I.flow) return DRBA_EINVAL;  // without the fold the finished flow must be given
@@ -879,8 +970,9 @@ static int ifblock_input_lds_launch(const drba_stage_item_t *items, int n_items,
   if (lazy) {
     for (int k = 0; k < n_items; ++k) {
       const drba_stage_item_t &I = items[k];
-      if (!I.img0 || !I.img1 || !I.f0 || !I.f1 || !I.out || !I.tmp_prev || I.flow || I.flow_out) return DRBA_EINVAL;
+      if (!I.img0 || !I.img1 || !I.out || !I.tmp_prev || I.flow || I.flow_out) return DRBA_EINVAL;
       if ((I.f0_pair == nullptr) != (I.f1_pair == nullptr) || (I.f0_pair == nullptr) != (items[0].f0_pair == nullptr)) return DRBA_EINVAL;
+      if ((I.f0 == nullptr) != (I.f1 == nullptr) || (!I.f0 && !I.f0_pair)) return DRBA_EINVAL;  // planar or pair-interleaved features
       for (int i = 0; i < terms->n && i < kMaxTerms; ++i)
         if (!I.term[i]) return DRBA_EINVAL;
     }

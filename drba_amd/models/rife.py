@@ -67,7 +67,7 @@ class RIFE:
                 output.append(I1)
             else:
                 if f0 is None:  # encode once per call, not once per t (same values)
-                    f0, f1 = self.ifnet.encode(I0), self.ifnet.encode(I1)
+                    f0, f1 = self.ifnet.encode(I0, planar=False), self.ifnet.encode(I1, planar=False)
                 output.append(len(items))  # placeholder: index into the batched pass below
                 items.append((I0, I1, float(t), f0, f1))
         return self._fill(output, items)
@@ -155,7 +155,7 @@ class RIFE:
         with torch.cuda.stream(self._enc_stream):
             self._enc_stream.wait_event(ready)
             I.record_stream(self._enc_stream)
-            f = self.ifnet.encode(I)
+            f = self.ifnet.encode(I, planar=False)
             if _ops.PAIR_FEATURES:
                 _ops.pair_interleaved(f)
             done = torch.cuda.Event()
@@ -210,7 +210,7 @@ class RIFE:
                 fp.record_stream(cur)
             return c[0]
         self._count("encoder_prefetch_misses")
-        return self.ifnet.encode(I)
+        return self.ifnet.encode(I, planar=False)  # the pair-interleaved layout only: what the kernels read (ops.head_fused)
 
     def warm_reuse(self, Ia, Ib):
         """The `reuse` a DRBA step ending on the pair (Ia, Ib) hands to the next step (rife.py:82-85,109)."""

@@ -31,10 +31,12 @@ class Head:
         self.cnn3 = _ops.Deconv4x4(g("cnn3.weight"), g("cnn3.bias"), pixel_shuffle=False, device=device)
         self.chain = _ops.ConvChain([(self.cnn0, False), (self.cnn1, False), (self.cnn2, False), (self.cnn3, False)])
 
-    def __call__(self, x, feat=False):
+    def __call__(self, x, feat=False, planar=True):
+        """planar=False (RIFE's own calls): the features in the pair-interleaved layout only (ops.head_fused), which is what
+        every kernel of the pipeline reads; the default returns the reference's [1,16,H,W]."""
         if not feat:
             if _ops.HEAD_FUSED and x.is_cuda:
-                f = _ops.head_fused(x, (self.cnn0, self.cnn1, self.cnn2, self.cnn3), self)  # one kernel, both feature layouts
+                f = _ops.head_fused(x, (self.cnn0, self.cnn1, self.cnn2, self.cnn3), self, planar=planar)  # one kernel
                 if f is not None:
                     return f
             return self.chain(x)
@@ -117,8 +119,8 @@ class IFNet:
         want_flows=False: only the frame is needed -> the pipeline of forward_pairs (flow updates folded into their
         consumers, the per-stage full-resolution flows are not all materialised); returns (frame, None)."""
         _, _, H, W = img0.shape
-        f0 = self.encode(img0) if f0 is None else f0
-        f1 = self.encode(img1) if f1 is None else f1
+        f0 = self.encode(img0, planar=False) if f0 is None else f0
+        f1 = self.encode(img1, planar=False) if f1 is None else f1
         if not want_flows:
             return self.forward_pairs([(img0, img1, timestep, f0, f1)], scale_list)[0], None
         flow = tmp = None

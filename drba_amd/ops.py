@@ -573,10 +573,13 @@ PAIR_FEATURES = True  # warped stages read the encoder features from a pair-inte
 HEAD_FUSED = True  # IFNet's encoder as one kernel (drba_head_fused) instead of four layers + the pair-interleave copy (tools/ab_bench.py --no-head-fused: A/B)
 
 
-def head_fused(img, layers, holder):
+def head_fused(img, layers, holder, planar=True):
     """Head(img) (IFNet_HDv3.py:23-47) in one launch: layers = (cnn0, cnn1, cnn2 Conv3x3, cnn3 Deconv4x4); returns f [1,16,H,W]
-    with its pair-interleaved copy already attached (pair_interleaved(f) costs nothing afterwards).  `holder` keeps the packed
-    weights.  None when the shape is not one the kernel takes (odd sizes, a batch)."""
+    with its pair-interleaved copy already attached (pair_interleaved(f) costs nothing afterwards).  planar=False (the hot
+    path: RIFE's own calls): ONLY the pair-interleaved layout [8,H,W,2] is written and returned, tagged as such -- every
+    kernel of the pipeline reads that layout, and the planar copy is 134 MB of HBM writes per 1080p frame nobody reads;
+    features_planar() converts where a caller wants the reference's [1,16,H,W].  `holder` keeps the packed weights.  None
+    when the shape is not one the kernel takes (odd sizes, a batch)."""
     img = _f32(img)
     n, c, H, W = img.shape
     if n != 1 or c != 3 or H % 2 or W % 4:
@@ -591,19 +594,46 @@ def head_fused(img, layers, holder):
                                                                                   c3.w_host, hb[3])), C.c_void_p(buf.data_ptr())),
                    "drba_head_fused_pack")
         pk = holder._fused_pack = buf.to(img.device)
-    f = torch.empty((1, 16, H, W), dtype=torch.float32, device=img.device)
+    f = torch.empty((1, 16, H, W), dtype=torch.float32, device=img.device) if planar else None
     fp = torch.empty((8, H, W, 2), dtype=torch.float32, device=img.device)
     # algorithmic bytes: the frame read, the features written in both layouts; 9.5 GFLOP of fp32 MFMA work per 1080p frame
     # ride along (61 us at the fp32 MFMA peak against 50 us of HBM time: the matrix cores are the binding roofline)
     flop = 2.0 * (16 * 27 + 2 * 16 * 144) * (H // 2) * (W // 2) + 2.0 * 16 * 16 * 16 * (H // 2) * (W // 2)
     _lib.check(_timed("head_fused", (H, W), flop, "flop", lambda: lib.drba_head_fused(_p(img), _p(pk), _p(f), _p(fp), 1, H, W, _stream())),
                "drba_head_fused")
+    if not planar:
+        fp._drba_is_pair = True
+        return fp
     f._drba_pair = fp
     return f
 
 
+def is_pair(f):
+    """Is `f` a feature tensor in the pair-interleaved layout [C/2,H,W,2] (head_fused(planar=False))?"""
+    return bool(getattr(f, "_drba_is_pair", False))
+
+
+def features_planar(f):
+    """The reference's layout [1,16,H,W] of a feature tensor (tests, callers that inspect `reuse`); pair-only tensors are
+    converted (a torch view + copy: not on the hot path)."""
+    if not is_pair(f):
+        return f
+    c2, h, w, _ = f.shape
+    return f.permute(0, 3, 1, 2).reshape(1, 2 * c2, h, w).contiguous()
+
+
+def _feat(f, want_pair=True):
+    """-> (planar tensor or None, pair-interleaved tensor or None) of a feature argument."""
+    if is_pair(f):
+        return None, f
+    f = _f32(f)
+    return f, (pair_interleaved(f) if want_pair and PAIR_FEATURES and f.shape[1] == 16 else None)
+
+
 def pair_interleaved(f):
     """[1,C,H,W] -> the [C/2,H,W,2] copy the stage-input gathers read; made once per feature tensor and kept on it."""
+    if is_pair(f):
+        return f
     fp = getattr(f, "_drba_pair", None)
     if fp is None:
         n, c, h, w = f.shape
@@ -618,7 +648,8 @@ def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scal
     """Stage input at 1/scale resolution (52 ch with flow, 39 without).  `timestep`: float or [1,1,H,W] map;
     `tmp_prev`: the previous stage's [1,13,hp,wp] head output (mask/feat are its x prev_scale upsample).
     `out`: optional [1,nch,h,w] destination (one sample of a stacked stage batch)."""
-    img0, img1, f0, f1 = _f32(img0), _f32(img1), _f32(f0), _f32(f1)
+    img0, img1 = _f32(img0), _f32(img1)
+    (f0, f0p), (f1, f1p) = _feat(f0, flow is not None), _feat(f1, flow is not None)
     _, _, H, W = img0.shape
     h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
     tmap, tsc = (None, float(timestep)) if not torch.is_tensor(timestep) else (_f32(timestep), 0.0)
@@ -636,9 +667,6 @@ def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scal
     pts = H * W if scale <= 2 else 4 * h * w
     nbytes = 4.0 * ((nch - (9 if flow is not None else 0)) * pts + nch * h * w)
     lib = _lib.load()
-    f0p = f1p = None
-    if flow is not None and PAIR_FEATURES and f0.shape[1] == 16:
-        f0p, f1p = pair_interleaved(f0), pair_interleaved(f1)
     _lib.check(_timed("ifblock_input", (nch, H, W, h, w), nbytes, "byte", lambda: lib.drba_ifblock_input(
         _p(img0), _p(img1), _p(f0), _p(f1), _p(f0p), _p(f1p), _p(tmap), tsc, _p(flow), _p(tmp_prev), hp, wp, ps, _p(out), H, W, h, w,
         float(scale), _stream())), "drba_ifblock_input")
@@ -652,7 +680,8 @@ def ifblock_input_lds(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, 
     """Warped stage input like ifblock_input(flow != None), previous head output staged through LDS.  fold=True: `flow` is
     the running flow BEFORE the previous stage's update (or None); the update flow + up(tmp_prev[:4]) * prev_scale is
     formed inside the kernel (scale <= 2 only) and returned as the second value."""
-    img0, img1, f0, f1, tmp_prev = _f32(img0), _f32(img1), _f32(f0), _f32(f1), _f32(tmp_prev)
+    img0, img1, tmp_prev = _f32(img0), _f32(img1), _f32(tmp_prev)
+    (f0, f0p), (f1, f1p) = _feat(f0), _feat(f1)
     _, _, H, W = img0.shape
     h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
     tmap, tsc = (None, float(timestep)) if not torch.is_tensor(timestep) else (_f32(timestep), 0.0)
@@ -665,9 +694,6 @@ def ifblock_input_lds(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, 
     hp, wp = tmp_prev.shape[2], tmp_prev.shape[3]
     pts = H * W if scale <= 2 else 4 * h * w
     nbytes = 4.0 * (43 * pts + 52 * h * w + (4 * pts if fold else 0))
-    f0p = f1p = None
-    if PAIR_FEATURES and f0.shape[1] == 16:
-        f0p, f1p = pair_interleaved(f0), pair_interleaved(f1)
     lib = _lib.load()
     _lib.check(_timed("ifblock_input_lds" + ("+fold" if fold else ""), (52, H, W, h, w), nbytes, "byte", lambda: lib.drba_ifblock_input_lds(
         _p(img0), _p(img1), _p(f0), _p(f1), _p(f0p), _p(f1p), _p(tmap), tsc, _p(flow), _p(tmp_prev), hp, wp, float(prev_scale),
@@ -732,12 +758,10 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
     arr = (_lib.StageItem * B)()
     keep = []
     for k, (i0, i1, t, f0, f1) in enumerate(items):
-        i0, i1, f0, f1 = _f32(i0), _f32(i1), _f32(f0), _f32(f1)
+        i0, i1 = _f32(i0), _f32(i1)
+        (f0, f0p), (f1, f1p) = _feat(f0, lds or has_flow), _feat(f1, lds or has_flow)
         tmap, tsc = (None, float(t)) if not torch.is_tensor(t) else (_f32(t), 0.0)
         fl = None if (flows is None or flows[k] is None) else _f32(flows[k])
-        f0p = f1p = None
-        if (lds or has_flow) and PAIR_FEATURES and f0.shape[1] == 16:
-            f0p, f1p = pair_interleaved(f0), pair_interleaved(f1)
         keep += [i0, i1, f0, f1, tmap, fl, f0p, f1p]
         a = arr[k]
         a.img0, a.img1, a.f0, a.f1, a.f0_pair, a.f1_pair = _ptr(i0), _ptr(i1), _ptr(f0), _ptr(f1), _ptr(f0p), _ptr(f1p)
@@ -805,10 +829,10 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
     arr = (_lib.StageItem * B)()
     keep = []
     for k, (i0, i1, t, f0, f1) in enumerate(items):
-        i0, i1, f0, f1 = _f32(i0), _f32(i1), _f32(f0), _f32(f1)
+        i0, i1 = _f32(i0), _f32(i1)
+        (f0, f0p), (f1, f1p) = _feat(f0), _feat(f1)
         tmap, tsc = (None, float(t)) if not torch.is_tensor(t) else (_f32(t), 0.0)
         fl = None if (flows is None or flows[k] is None) else _f32(flows[k])
-        f0p, f1p = pair_interleaved(f0), pair_interleaved(f1)
         keep += [i0, i1, f0, f1, tmap, fl, f0p, f1p]
         a = arr[k]
         a.img0, a.img1, a.f0, a.f1, a.f0_pair, a.f1_pair = _ptr(i0), _ptr(i1), _ptr(f0), _ptr(f1), _ptr(f0p), _ptr(f1p)

@@ -32,13 +32,15 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  3: drba_stage_item_t grew by term[DRBA_MAX_FLOW_TERMS]; drba_flow_terms_t and the entry points that take the
+/* ABI version.  4: the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
+ * NULL (nothing but f_pair_out is written), and every stage-input entry point accepts items with f0 == f1 == NULL when
+ * f0_pair / f1_pair are set (the first, unwarped stage reads the pair layout too).  3: drba_stage_item_t grew by term[DRBA_MAX_FLOW_TERMS]; drba_flow_terms_t and the entry points that take the
  * running flow as terms (drba_ifblock_input_lazy_batch, drba_warp_blend_lazy_batch); drba_stage_conv0_*.
  * 2: drba_timing_* and drba_softmax_expect2 removed; drba_flow_reverse and drba_drm_rife_linear take a
  * workspace that must be ZERO on entry (they leave it zero on return: self-cleaning accumulator) instead of clearing it
  * themselves; batched stage entry points added; drba_conv3x3_cfg_family added and configuration ids 19 (LDS-DMA, 32
  * channels) / 20 (K split across waves) behind drba_conv3x3; the allocation exception above.  1: the first release. */
-#define DRBA_ABI_VERSION 3  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
+#define DRBA_ABI_VERSION 4  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 
@@ -233,6 +235,7 @@ int drba_ifblock_input_lds_batch(const drba_stage_item_t *items, int n_items, in
 /* IFNet's context encoder (IFNet_HDv3.py:23-47 `Head`: conv 3->16 stride 2, two convs 16->16, each + LeakyReLU(0.2), then
  * ConvTranspose2d(16,16,4,2,1)) in one kernel, intermediates in LDS (head_fused.hip).  img [N,3,H,W] -> f_out [N,16,H,W] and
  * f_pair_out, the same values pair-interleaved per sample ([8,H,W,2]: what drba_pair_interleave(f_out) would write).
+ * f_out may be NULL (ABI 4): only the pair layout is written -- every kernel of the pipeline reads that one.
  * H even, W % 4 == 0, 16-byte aligned outputs.  drba_head_fused_pack is a HOST function (weights in the reference's
  * layouts: w0 [16,3,3,3], w1 / w2 [16,16,3,3], w3 [16 in,16 out,4,4], biases [16]); packed_w is its output copied to the device. */
 size_t drba_head_fused_packed_floats(void);

@@ -143,6 +143,15 @@ def rife_frames(H, W):
     return [torch.from_numpy(f.transpose(2, 0, 1)).unsqueeze(0).float().div(255.0) for f in clip]
 
 
+def planar(t):
+    """A feature tensor in the reference's [1,16,H,W] layout: the HIP path carries the encoder features pair-interleaved
+    ([8,H,W,2], tagged `_drba_is_pair`; drba_amd.ops.features_planar) wherever the caller does not ask for them."""
+    if getattr(t, "_drba_is_pair", False):
+        c2, h, w, _ = t.shape
+        return t.permute(0, 3, 1, 2).reshape(1, 2 * c2, h, w).contiguous()
+    return t
+
+
 def rife_run(b, sd, scale, H, W):
     """All end-to-end RIFE outputs for one (scale, size) as an ordered {name: tensor} dict."""
     m = b.make_rife(sd, scale)
@@ -174,7 +183,7 @@ def rife_run(b, sd, scale, H, W):
     if scale == 1.0:
         r, _ = m.inference_ts_drba(I0, I1, I2, np.array([0.75]), None, False)
         out["drba_nonlinear_0"] = r[0]
-    return out
+    return {k: planar(v) for k, v in out.items()}
 
 
 # ------------------------------------------------------------------------------------------ gmfss_union end to end

@@ -227,6 +227,9 @@ def check_conv_layers(dev):
             rows.append((f"head_fused {h}x{w} vs layer-by-layer HIP path", _diff(f, f_layers.cpu()), tol, ""))
             want_pair = ref[0].reshape(8, 2, h, w).permute(0, 2, 3, 1).contiguous()
             rows.append((f"head_fused {h}x{w} pair-interleaved copy", float("inf") if fp is None else _diff(fp, want_pair), tol, ""))
+            f2 = head(x.to(dev), planar=False)  # the hot path's form: the pair layout only
+            rows.append((f"head_fused {h}x{w} pair layout only", _diff(f2, want_pair) if ops.is_pair(f2) else float("inf"), tol, ""))
+            rows.append((f"head_fused {h}x{w} pair layout only -> features_planar", _diff(ops.features_planar(f2), ref), tol, ""))
     except Exception as e:  # noqa: BLE001
         rows.append(("head_fused", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     finally:

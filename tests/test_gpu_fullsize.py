@@ -87,7 +87,9 @@ def _rife_fullsize(hip_backend, oracle_backend, src, net, scale, ts_seq, min_gro
             rows.append((f"step{k} frame{j} ({'cold' if k == 0 else 'warm'})", gpu_checks._diff(a, b), 1e-3, ""))
     # reuse = (flow21, flow12, f2, f1) after the LAST step (every step's reuse feeds the next step's frames, which are
     # checked above): features to 1e-3; flows carry the hole-fill discontinuity -> outlier budget
+    from tests.cases import planar
     for name, a, b in zip(("flow21", "flow12", "f2", "f1"), greuse[-1], oreuse[-1]):
+        a = planar(a)  # (the HIP path carries the features pair-interleaved)
         n_out, n = gpu_checks._outliers(a, b, 1e-3)
         rows.append((f"reuse {name}", 0.0 if n_out <= max(2, n // 2000) else gpu_checks._diff(a, b), 1e-3, f"outliers {n_out}/{n}"))
     rows.append(("path: " + ", ".join(f"{k}={v}" for k, v in st.items() if v), 0.0, 0.0, ""))

@@ -218,8 +218,10 @@ def test_two_model_instances_in_one_process(hip_backend):
     o1, _ = m1.inference_ts_drba(*fr, ts, None, True)
     o2, _ = m2.inference_ts_drba(*fr, ts, None, True)
     torch.cuda.synchronize()
-    for x, y in zip(o1, o2):
-        assert torch.equal(x, y)
+    # (the fused splats sum a key's records in arrival order and the first instance's first call runs layer by layer while
+    # the autotuner decides, the second one through the chains: equal to rounding, not bit for bit)
+    err = max(float((x - y).abs().max()) for x, y in zip(o1, o2))
+    assert err <= 2e-5, err
 
 
 def test_prefetch_does_not_retain_frames(hip_backend):

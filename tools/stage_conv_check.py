@@ -63,6 +63,67 @@ for (B, H, W, tmap, with_flow, fold) in cases:
           f"{'ok' if ok else 'FAIL'}", flush=True)
 print("FAILED" if bad else "all ok", flush=True)
 
+# ---- the two paths of the kernel: source boxes in LDS (16-byte aligned frames, smooth flows) and per-lane gathers (frames
+# whose planes are not 16-byte aligned run it on every tile; so do tiles whose taps do not fit the boxes: the random flows)
+def misaligned(t):
+    buf = torch.empty(t.numel() + 1, device=t.device, dtype=t.dtype)
+    v = buf[1:].view(t.shape)
+    v.copy_(t)
+    return v
+
+
+def smooth_heads(B, H, W, amp16=1.0):
+    def head(st, amp):
+        t = torch.randn(B, 13, H // st, W // st, generator=g)
+        lo = torch.randn(B, 4, max(H // st // 8, 2), max(W // st // 8, 2), generator=g) * amp
+        t[:, :4] = torch.nn.functional.interpolate(lo, size=(H // st, W // st), mode="bicubic", align_corners=False)
+        return t.to(dev)
+    return [(head(16, amp16), 16.0), (head(8, 0.4), 8.0), (head(4, 0.3), 4.0)], head(2, 0.3)
+
+
+for (B, H, W) in ((2, 128, 256), (3, 96, 160), (2, 1088, 1920)):
+    items, _, _ = make(B, H, W, True, False)
+    for amp, tag in ((1.0, "smooth flows"), (30.0, "rough flows")):
+        terms, tprev = smooth_heads(B, H, W, amp)
+        y_box, _ = ops.stage_conv0(items, None, tprev, 2.0, conv, terms=terms)
+        items_g = [(misaligned(a), b, c, d, e) for a, b, c, d, e in items]
+        y_gat, _ = ops.stage_conv0(items_g, None, tprev, 2.0, conv, terms=terms)
+        xin = torch.empty(B, 52, H, W, device=dev)
+        ops.stage_inputs(items, None, tprev, 2.0, 1.0, xin, terms=terms)
+        y_ref = conv(xin)
+        torch.cuda.synchronize()
+        e1, e2 = float((y_box - y_ref).abs().max()), float((y_gat - y_ref).abs().max())
+        ok = max(e1, e2) <= 2e-5 * max(1.0, float(y_ref.abs().max())) and bool(torch.isfinite(y_box).all())
+        bad += not ok
+        print(f"lazy B{B} {H}x{W} {tag}: aligned frames (box path where the taps fit) err {e1:.3e}, misaligned frames (gather path) err {e2:.3e} "
+              f"{'ok' if ok else 'FAIL'}", flush=True)
+print("FAILED" if bad else "all ok (lazy / box vs gather)", flush=True)
+
+if "--no-time" not in sys.argv:
+    H, W = 1088, 1920
+    for B in (8,):
+        items, _, _ = make(B, H, W, True, False)
+        items_g = [(misaligned(a), b, c, d, e) for a, b, c, d, e in items]
+        for amp, tag in ((0.0, "zero"), (0.1, "gentle"), (1.0, "smooth"), (30.0, "rough")):
+            terms, tprev = smooth_heads(B, H, W, amp)
+            if amp <= 0.1:  # flows that certainly fit the boxes: every tile of the aligned run takes the box path
+                terms = [(t * (1.0 if amp else 0.0), sc) for t, sc in terms]
+                tprev = tprev.clone()
+                tprev[:, :4] *= amp
+                if amp:
+                    terms = [(torch.cat((t[:, :4] * 0.1, t[:, 4:]), 1).contiguous(), sc) for t, sc in terms]
+            for name, its in (("box path   ", items), ("gather path", items_g)):
+                for _ in range(3):
+                    ops.stage_conv0(its, None, tprev, 2.0, conv, terms=terms)
+                torch.cuda.synchronize()
+                ops.trace_begin()
+                for _ in range(reps):
+                    ops.stage_conv0(its, None, tprev, 2.0, conv, terms=terms)
+                recs = [r for r in ops.trace_end() if "stage_conv0" in r["name"]]
+                us = sum(r["ms"] for r in recs) / len(recs) * 1e3
+                alg = B * 4.0 * (39.0 * H * W + 16 * (H // 2) * (W // 2))
+                print(f"1080p B{B} lazy {tag} flows, {name}: {us:8.1f} us per launch = {us / B:6.1f} us per sample ({alg / us / 1e3:7.1f} GB/s algorithmic, "
+                      f"{alg / us / 1e3 / 8000:.3f} of HBM)", flush=True)
 if "--no-time" not in sys.argv:
     H, W = 1088, 1920
     for B in (2, 8):
