@@ -89,7 +89,7 @@ SRC_FPS = 24.0
 AB = {}
 
 _T0 = time.perf_counter()
-LAST_SHARD = {"rank_dt": None}  # this rank's own wall time of the last sharded_leg (the line reports every rank's)
+LAST_SHARD = {"rank_dt": None, "path": None}  # this rank's own wall time of the last sharded_leg (the line reports every rank's)
 LAST_PATH = {}  # RIFE.stats over the timed region of the last step_loop: which path the K timed calls took (reported on the line)
 LAST_SETTLE = {"steps": 0}  # untimed settling steps the last step_loop ran after its W warm-up steps (reported on the line)
 
@@ -666,6 +666,7 @@ def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
     counts = parallel.emission_counts(len(clip), SRC_FPS, dst_fps, times, world)
     _quiet_gc()
     _fence(world)
+    stats0 = dict(getattr(model, "stats", None) or {})
     t0 = time.perf_counter()
     sg = parallel.StreamedGather(rank, world, counts, chunk=4, device=_coll_device(dev), frame_shape=clip.shape)
     parallel.interpolate_shard(cm, clip, SRC_FPS, dst_fps, rank, world, times=times, enable_scdet=scdet,
@@ -674,6 +675,11 @@ def sharded_leg(model, clip, dst_fps, times, scdet, rank, world, dev):
     _fence(world)
     dt = time.perf_counter() - t0
     LAST_SHARD["rank_dt"] = dt
+    # which path this rank's shard took: a shard starts cold (halo reuse, the first group computed in place before a staged one
+    # exists), so its ramp-in -- steps outside staged groups -- separates the GROUP ramp from RCCL cost in a scaling record
+    st = {k: v - stats0.get(k, 0) for k, v in (getattr(model, "stats", None) or {}).items()}
+    grp = int(getattr(model, "GROUP", 1))
+    LAST_SHARD["path"] = dict(st, group=grp, ramp_in_steps=st.get("single_steps", 0) + grp * (st.get("groups_formed", 0) - st.get("staged_groups", 0))) if st else None
     if world == 1:  # (--selftest-sharded: the same code on one GPU, no process group)
         return dt, cm.generated, (len(allf) if allf is not None else 0)
     import torch.distributed as dist
@@ -738,7 +744,7 @@ def gpu_leg(args, rank, world):
     big = DeviceClip(world * args.steps + 2, H, W, 1234, dev)
     sharded_warmup(model, H, W, SRC_FPS * 2, 2, False, rank, world, dev)
     sdt, gen, got = sharded_leg(model, big, SRC_FPS * 2, 2, False, rank, world, dev)
-    r.update({"dt": sdt, "host_dt": None, "frames": gen, "writer_frames": got, "rank_dt": LAST_SHARD["rank_dt"]})
+    r.update({"dt": sdt, "host_dt": None, "frames": gen, "writer_frames": got, "rank_dt": LAST_SHARD["rank_dt"], "rank_path": LAST_SHARD["path"]})
     if not args.no_extra:
         m5 = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=0.5, device=dev)
         n5 = 8 * args.steps + 2  # fixed clip whatever N is: strong scaling
@@ -848,7 +854,8 @@ def describe_job(rank, world, r):
     me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", 0)), "device": f"cuda:{dev.index}", "name": prop.name,
           "arch": getattr(prop, "gcnArchName", None), "pci_bus_id": getattr(prop, "pci_bus_id", None),
           "uuid": str(getattr(prop, "uuid", "")) or None, "pid": os.getpid(),
-          "rank_seconds": None if r.get("rank_dt") is None else round(r["rank_dt"], 5)}
+          "rank_seconds": None if r.get("rank_dt") is None else round(r["rank_dt"], 5),
+          "rank_path": r.get("rank_path")}  # this rank's groups formed / staged and ramp-in steps in the timed sharded run
     info = {"backend": "none (single process)", "world_size": 1, "devices": [me], "rccl_version": None,
             "visible_gpus": torch.cuda.device_count()}
     try:
@@ -897,7 +904,8 @@ def main():
         model = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=scale, device=dev)
         sharded_warmup(model, H, W, SRC_FPS * 2, 2, False, 0, 1, dev)
         dt, gen, got = sharded_leg(model, DeviceClip(args.steps + 2, H, W, 1234, dev), SRC_FPS * 2, 2, False, 0, 1, dev)
-        out = {"selftest": "sharded legs at world 1", "headline_clip": {"frames_generated": gen, "writer_frames": got, "frames_per_s": round(gen / dt, 2)}}
+        out = {"selftest": "sharded legs at world 1", "headline_clip": {"frames_generated": gen, "writer_frames": got, "frames_per_s": round(gen / dt, 2),
+                                                                        "rank_path": LAST_SHARD["path"]}}
         m5 = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=0.5, device=dev)
         n5 = args.steps + 2
         sharded_warmup(m5, 2160, 3840, 60.0, -1, True, 0, 1, dev, cut=True)

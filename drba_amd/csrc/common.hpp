@@ -125,6 +125,17 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomic
 
 __device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
 
+// Lane exchanges inside a quad / a row of 16 as DPP operand modifiers of a VALU move (no LDS crossbar trip, no lgkmcnt wait):
+// __shfl_xor(v, 1 | 2 | 8) compiles to ds_bpermute_b32 -- the scale >= 2 stage-input gather issued 104 of them per lane for
+// the 2 x 2 downsample of its 52 channels, every one an LDS-pipe instruction with ~100 clocks of latency in front of a
+// dependent add.  All lanes of the quad / row must be active (a disabled source lane reads as 0).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_xor1(float v) { return dpp_f32<0xB1>(v); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ float quad_xor2(float v) { return dpp_f32<0x4E>(v); }  // quad_perm [2,3,0,1]
+
 // torch.linspace(-1, 1, n)[i] in fp32: symmetric two-sided formula (ATen RangeFactories).
 __device__ __forceinline__ float linspace_m1p1(int i, int n) {
   const float step = 2.0f / (float)(n - 1);

@@ -198,7 +198,7 @@ head_fused(const float *__restrict__ img, const float *__restrict__ wpk, float *
 #pragma unroll
         for (int v = 0; v < 4; ++v) v8[2 * v] = acc[0][v] + bias, v8[2 * v + 1] = acc[1][v] + bias;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o8[k] = __shfl_xor(v8[k], 1, 64);  // the other channel of the pair (lane m ^ 1)
+        for (int k = 0; k < 8; ++k) o8[k] = quad_xor1(v8[k]);  // the other channel of the pair (lane m ^ 1): a DPP move, not a bpermute
         if (M < Hh && x < W) {
           float *pf = f_out + (size_t)m * P + (size_t)y * W + x;
           if (!f_out) {  // pair layout only (the hot path: every consumer reads the pair layout; -134 MB written per 1080p frame)

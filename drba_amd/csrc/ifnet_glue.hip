@@ -357,9 +357,9 @@ ifblock_input_kernel(const StageItems items, int hp, int wp, float inv_prev_scal
     auto comb = [&](float v) -> float {
       if (SINGLE) return ly.w0 * (lx.w0 * v + lx.w1 * 0.f) + ly.w1 * 0.f;
       const float a = wx * v;
-      const float row = a + __shfl_xor(a, 1, 64);  // wx0*V_j0 + wx1*V_j1
+      const float row = a + quad_xor1(a);  // wx0*V_j0 + wx1*V_j1 (the quad's four lanes are the 2 x 2 sample points)
       const float b = wy * row;
-      return b + __shfl_xor(b, 2, 64);             // wy0*top + wy1*bot
+      return b + quad_xor2(b);             // wy0*top + wy1*bot
     };
     const bool writer = valid && sub == 0;
     float *dst = out + o;
@@ -492,7 +492,9 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   constexpr bool FOLD = FMODE != 0, WRITES = FMODE == 1, LAZY = FMODE == 2;
   DRBA_UNPACK_STAGE_ITEM(items);
   float *__restrict__ flow_out = item_.flow_out;
-  __shared__ float prev[13][kPrevRH][kPrevRW];
+  // [row][column][16]: the 13 channels of a footprint pixel (padded to 16) are four 16-byte LDS words, so a sample point
+  // reads its 2 x 2 taps of four channels with 4 ds_read_b128 (16 reads for all 13 channels instead of 52 ds_read_b32)
+  __shared__ __attribute__((aligned(16))) float prev[kPrevRH][kPrevRW][16];
   __shared__ __attribute__((aligned(16))) float tl[LAZY ? kMaxTerms * 4 * kTermR * kTermC : 4];
   int trx0[kMaxTerms], try0[kMaxTerms];
   constexpr int STG = VS ? (SINGLE ? 4 * 64 : 52 * 16 + 4 * 64) : 1;  // floats per wave
@@ -513,7 +515,7 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   const int rw = lerp_src(Xb, inv_prev_scale, wp).i1 - rx0 + 1, rh = lerp_src(Yb, inv_prev_scale, hp).i1 - ry0 + 1;
   for (int i = threadIdx.x; i < (13 - C0) * rh * rw; i += 256) {
     const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
-    prev[C0 + c][r][col] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
+    prev[r][col][C0 + c] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
   }
   if (LAZY) terms_stage<kTermR, kTermC, 256>(tl, T, item_.term, Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
@@ -533,9 +535,9 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   auto comb = [&](float v) -> float {
     if (SINGLE) return v;  // scale 1: the "downsample" has weights (1, 0) x (1, 0) -- v * 1 + 0 * 0 + 0 * 0, the identity
     const float a = wx * v;
-    const float row = a + __shfl_xor(a, 1, 64);
+    const float row = a + quad_xor1(a);
     const float b = wy * row;
-    return b + __shfl_xor(b, 2, 64);
+    return b + quad_xor2(b);
   };
   const bool writer = valid && sub == 0;
   float *dst = out + o;
@@ -570,9 +572,16 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   // taps of the previous head output's upsample at (X, Y), relative to the staged footprint
   const Lerp a = lerp_src(Y, inv_prev_scale, hp), b = lerp_src(X, inv_prev_scale, wp);
   const int r0 = a.i0 - ry0, r1 = a.i1 - ry0, c0 = b.i0 - rx0, c1 = b.i1 - rx0;
-  auto prev_up = [&](int c) -> float {
-    return lerp2_fma(a.w0, a.w1, b.w0, b.w1, prev[c][r0][c0], prev[c][r0][c1], prev[c][r1][c0], prev[c][r1][c1]);
+  auto prev_up4 = [&](int k) -> f32x4a {  // channels 4k .. 4k+3 of the previous head output, upsampled to (X, Y)
+    const f32x4a q00 = *reinterpret_cast<const f32x4a *>(&prev[r0][c0][4 * k]), q01 = *reinterpret_cast<const f32x4a *>(&prev[r0][c1][4 * k]);
+    const f32x4a q10 = *reinterpret_cast<const f32x4a *>(&prev[r1][c0][4 * k]), q11 = *reinterpret_cast<const f32x4a *>(&prev[r1][c1][4 * k]);
+    f32x4a v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = lerp2_fma(a.w0, a.w1, b.w0, b.w1, q00[j], q01[j], q10[j], q11[j]);
+    return v;
   };
+  const f32x4a pu0 = FOLD ? prev_up4(0) : (f32x4a){0.f, 0.f, 0.f, 0.f};  // flow delta
+  auto prev_up = [&](int c) -> float { return pu0[c & 3]; };                // c < 4; mask / feat are read where they are emitted (registers)
   float fls[4];
   const bool have_terms = LAZY && terms_flow<kTermR, kTermC>(tl, T, trx0, try0, X, Y, fls);
 #pragma unroll
@@ -637,7 +646,7 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
     flush_out(g4 < 3 ? g4 : 38);
 #pragma unroll
     for (int c = 0; c < 3; ++c) park(c, comb(sample(img1 + (size_t)c * P, W, k1)));
-    park(3, comb(prev_up(4)));
+    park(3, comb(prev_up4(1)[0]));  // mask = channel 4
     flush_out(g4 < 3 ? 3 + g4 : 39);
 #pragma unroll 1
     for (int c2 = 0; c2 < 8; ++c2) {
@@ -652,11 +661,15 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
       park(0, comb(a0)), park(1, comb(a1)), park(2, comb(b0)), park(3, comb(b1));
       flush_out(6 + 2 * c2 + (g4 & 1) + (g4 >> 1) * 16);
     }
+    {
+      const f32x4a p1 = prev_up4(1), p2 = prev_up4(2), p3 = prev_up4(3);  // channels 4..15: feat = 5..12
+      const float ft[8] = {p1[1], p1[2], p1[3], p2[0], p2[1], p2[2], p2[3], p3[0]};
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) park(c, comb(prev_up(5 + 4 * half + c)));
-      flush_out(40 + 4 * half + g4);
+        for (int c = 0; c < 4; ++c) park(c, comb(ft[4 * half + c]));
+        flush_out(40 + 4 * half + g4);
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) park(c, (comb(fls[c]) * 1.f) / scale);  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
@@ -690,8 +703,12 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
     }
   }
   emit(38, tmv);
+  {
+    const f32x4a p1 = prev_up4(1), p2 = prev_up4(2), p3 = prev_up4(3);  // mask (tmp[4]) and feat (tmp[5:13])
+    const float mf[9] = {p1[0], p1[1], p1[2], p1[3], p2[0], p2[1], p2[2], p2[3], p3[0]};
 #pragma unroll
-  for (int c = 0; c < 9; ++c) emit(39 + c, comb(prev_up(4 + c)));  // mask (tmp[4]) and feat (tmp[5:13])
+    for (int c = 0; c < 9; ++c) emit(39 + c, comb(mf[c]));
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) emit(48 + c, (comb(fls[c]) * 1.f) / scale);  // interpolate(flow) * 1. / scale (IFNet_HDv3.py:87)
   if (VS && !SINGLE) {
@@ -723,7 +740,7 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   const float *__restrict__ img0 = items.img0[blockIdx.y], *__restrict__ img1 = items.img1[blockIdx.y];
   const float *__restrict__ flow = items.flow[blockIdx.y], *__restrict__ tmp = items.tmp[blockIdx.y];
   float *__restrict__ out = items.out[blockIdx.y];
-  __shared__ float prev[5][10][36];
+  __shared__ __attribute__((aligned(16))) float prev[10][36][8];  // [row][column][flow 0..3 | mask, 3 x padding]: 16-byte LDS words
   __shared__ __attribute__((aligned(16))) float tl[LAZY ? kMaxTerms * 4 * kWbTermR * kWbTermC : 4];
   int trx0[kMaxTerms], try0[kMaxTerms];
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
@@ -735,7 +752,7 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
   for (int i = threadIdx.x; i < 5 * rh * rw; i += 256) {
     const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
-    prev[c][r][col] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
+    prev[r][col][c] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
   }
   if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[blockIdx.y], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
@@ -744,8 +761,12 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   const size_t p = (size_t)y * W + x;
   const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
   const int r0 = ly.i0 - ry0, r1 = ly.i1 - ry0, c0 = lx.i0 - rx0, c1 = lx.i1 - rx0;
+  typedef float f32x4w __attribute__((ext_vector_type(4)));
+  const f32x4w q00 = *reinterpret_cast<const f32x4w *>(&prev[r0][c0][0]), q01 = *reinterpret_cast<const f32x4w *>(&prev[r0][c1][0]);
+  const f32x4w q10 = *reinterpret_cast<const f32x4w *>(&prev[r1][c0][0]), q11 = *reinterpret_cast<const f32x4w *>(&prev[r1][c1][0]);
   auto up = [&](int c) -> float {
-    return lerp2_fma(ly.w0, ly.w1, lx.w0, lx.w1, prev[c][r0][c0], prev[c][r0][c1], prev[c][r1][c0], prev[c][r1][c1]);
+    if (c < 4) return lerp2_fma(ly.w0, ly.w1, lx.w0, lx.w1, q00[c & 3], q01[c & 3], q10[c & 3], q11[c & 3]);
+    return lerp2_fma(ly.w0, ly.w1, lx.w0, lx.w1, prev[r0][c0][4], prev[r0][c1][4], prev[r1][c0][4], prev[r1][c1][4]);
   };
   float fl[4];
   const bool have_terms = LAZY && terms_flow<kWbTermR, kWbTermC>(tl, T, trx0, try0, x, y, fl);

@@ -129,6 +129,9 @@ def test_bench_sharded_legs_run_at_world_1():
     h, c5 = d["headline_clip"], d["config5_clip"]
     # -t 2 over 6 source frames: head (1 synthesised, 1 copy) + 4 DRBA steps x 2 + tail (1): 12 written, 10 generated
     assert (h["frames_generated"], h["writer_frames"]) == (10, 12), h
+    # the rank reports which path its shard took (groups formed / staged, ramp-in steps): 4 DRBA steps = 1 cold + a group or single steps
+    rp = h["rank_path"]
+    assert rp is not None and rp["single_steps"] + rp["group_collects"] + rp["groups_formed"] == 4 and rp["ramp_in_steps"] >= 1, rp
     # 24 -> 60 fps over 6 source frames with a cut: every written frame is accounted for, copies replace synthesised ones
     assert c5["writer_frames"] >= c5["frames_generated"] > 0, c5
 
