@@ -53,7 +53,7 @@ struct Geo {
   static constexpr int WV = (WG_FLOATS + THREADS - 1) / THREADS;  // streamed weights: floats per lane and group
   static constexpr int TR = TOH / 2 + 4, TC = 12;  // term footprint capacity: (2 TOH + 1 rows, 33 columns) at >= 1/4 resolution
   static constexpr int TERM_FLOATS = kMaxTerms * 4 * TR * TC;
-  static constexpr int LDS_FLOATS = WL + 2 * 4 * CS + 13 * PR * PC + TERM_FLOATS;
+  static constexpr int LDS_FLOATS = WL + 2 * 4 * CS + 16 * PR * PC + TERM_FLOATS;
   static_assert(32 + WR <= 64, "upper row + left column on one wave");
 };
 
@@ -108,8 +108,8 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *wl = lds;                         // WRES: [13][9][64]; else [2][9][64]
   float *win = lds + G_::WL;               // [2][4][CS]
-  float *prev = win + 2 * 4 * CS;          // [13][PR][PC]
-  float *tl = prev + 13 * PR * PC;         // [kMaxTerms][4][TR * TC]
+  float *prev = win + 2 * 4 * CS;          // [PR][PC][16]: a footprint pixel's 13 channels as four 16-byte words (flow | mask | feat 0..3 | feat 4..7)
+  float *tl = prev + 16 * PR * PC;         // [kMaxTerms][TR * TC][4]
   // the item is picked by blockIdx.y out of the by-value argument: the compiler does not see that its fields are
   // wave-uniform (it would address every load per lane and wrap every buffer load in a waterfall loop) -- state it
   typedef __attribute__((address_space(1))) float *gptr;
@@ -204,7 +204,7 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
   }
   if (pr_on) {
 #pragma unroll
-    for (int c = C0; c < 13; ++c) prev[(c * PR + pr_r) * PC + pr_c] = pv[c];
+    for (int c = C0; c < 13; ++c) prev[(pr_r * PC + pr_c) * 16 + (c < 5 ? c : c + 3)] = pv[c];  // words: flow | mask, - | feat 0..3 | feat 4..7
   }
   int trx0[kMaxTerms], try0[kMaxTerms];
   if (LAZY) terms_stage<G_::TR, G_::TC, THREADS>(tl, T, item.term, Xa, Ya, Xb, Yb, tid, trx0, try0);
@@ -213,10 +213,17 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
   // taps of the previous head output's upsample at (X, Y), relative to the staged footprint
   const Lerp la = lerp_src(Y, inv_prev_scale, hp), lb = lerp_src(X, inv_prev_scale, wp);
   const int pr0 = (la.i0 - ry0) * PC, pr1 = (la.i1 - ry0) * PC, pc0 = lb.i0 - rx0, pc1 = lb.i1 - rx0;
-  auto prev_up = [&](int c) -> float {
-    const float *pp = prev + c * PR * PC;
-    return lerp2_fma(la.w0, la.w1, lb.w0, lb.w1, pp[pr0 + pc0], pp[pr0 + pc1], pp[pr1 + pc0], pp[pr1 + pc1]);
+  // channels 4k .. 4k+3 of the previous head output, upsampled to (X, Y) with row weights (wy0, wy1): four ds_read_b128
+  auto prev_up4 = [&](int k, float wy0, float wy1) -> f32x4 {
+    const f32x4 q00 = *reinterpret_cast<const f32x4 *>(prev + (pr0 + pc0) * 16 + 4 * k), q01 = *reinterpret_cast<const f32x4 *>(prev + (pr0 + pc1) * 16 + 4 * k);
+    const f32x4 q10 = *reinterpret_cast<const f32x4 *>(prev + (pr1 + pc0) * 16 + 4 * k), q11 = *reinterpret_cast<const f32x4 *>(prev + (pr1 + pc1) * 16 + 4 * k);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = lerp2_fma(wy0, wy1, lb.w0, lb.w1, q00[j], q01[j], q10[j], q11[j]);
+    return v;
   };
+  const f32x4 pu0 = FOLD ? prev_up4(0, la.w0, la.w1) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto prev_up = [&](int c) -> float { return pu0[c]; };  // c < 4: the flow delta
   float fls[4];
   const bool have_terms = LAZY && terms_flow<G_::TR, G_::TC>(tl, T, trx0, try0, X, Y, fls);
 #pragma unroll
@@ -263,10 +270,7 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
     k1.w00 = k1.w01 = k1.w10 = k1.w11 = 0.f;
   }
   const float uw0 = la.w0 * zin, uw1 = la.w1 * zin;  // prev_up's row weights for the PARKED mask / feat (the flow fold used the true ones)
-  auto prev_up_z = [&](int c) -> float {
-    const float *pp = prev + c * PR * PC;
-    return lerp2_fma(uw0, uw1, lb.w0, lb.w1, pp[pr0 + pc0], pp[pr0 + pc1], pp[pr1 + pc0], pp[pr1 + pc1]);
-  };
+  auto prev_up_z4 = [&](int k) -> f32x4 { return prev_up4(k, uw0, uw1); };  // mask / feat (channels 4..12), zero outside the image
   const uint32_t img_bytes = (uint32_t)(3 * P * 4), feat_bytes = (uint32_t)(16 * P * 4);
   const __amdgpu_buffer_rsrc_t r_i0 = __builtin_amdgcn_make_buffer_rsrc((void *)item.img0, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_i1 = __builtin_amdgcn_make_buffer_rsrc((void *)item.img1, 0, img_bytes, 0x00020000);
@@ -307,7 +311,7 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
         const float bx = __uint_as_float(r.h[2 * c + 1].x), by = __uint_as_float(r.h[2 * c + 1].y);
         v[c] = ax * k.w00 + ay * k.w01 + bx * k.w10 + by * k.w11;
       }
-      v[3] = g == 0 ? (inimg ? tmv : 0.f) : prev_up_z(4);
+      v[3] = g == 0 ? (inimg ? tmv : 0.f) : prev_up_z4(1)[0];
     } else if constexpr (g < 10) {
       auto pair = [&](const u32x4 &a, const u32x4 &b, const TapW &k, float &v0, float &v1) {
         v0 = __uint_as_float(a.x) * k.w00 + __uint_as_float(a.z) * k.w01 + __uint_as_float(b.x) * k.w10 + __uint_as_float(b.z) * k.w11;
@@ -316,8 +320,11 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
       pair(r.q[0], r.q[1], k0, v[0], v[1]);
       pair(r.q[2], r.q[3], k1, v[2], v[3]);
     } else if constexpr (g < 12) {
+      {
+        const f32x4 ft = prev_up_z4(g - 8);  // word 2: feat 0..3, word 3: feat 4..7
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = prev_up_z(5 + 4 * (g - 10) + c);
+        for (int c = 0; c < 4; ++c) v[c] = ft[c];
+      }
     } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = inimg ? fls[c] : 0.f;  // interpolate(flow) * 1. / scale at scale 1: the flow itself

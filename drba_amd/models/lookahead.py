@@ -12,6 +12,8 @@ import torch
 _STREAMS = {}
 
 
+ONE_STREAM = False  # measurement only (tools/step_timeline.py --one-stream): side / prefetch work on the caller's stream, so that a
+#                     traced launch's duration is the kernel's own at the loop's launch geometry (8 samples per launch)
 PRIORITY = {}  # role -> HIP stream priority (-1 = high); experiments only (tools/ab_bench.py --prefetch-priority)
 
 
@@ -21,6 +23,8 @@ def shared_stream(device, role):
     a process that builds several models (bench.py's extra configs, a test session) would otherwise create streams until
     a side stream shares its queue with the main stream and the overlap is silently gone (measured: GMFSS_UNION 41.6 ->
     35.0 frames/s as the 7th stream of the process)."""
+    if ONE_STREAM:
+        return torch.cuda.current_stream(device)
     key = (device.index, role)
     s = _STREAMS.get(key)
     if s is None:

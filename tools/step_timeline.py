@@ -20,7 +20,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--config", default="1080p")
 ap.add_argument("--brief", action="store_true")
+ap.add_argument("--one-stream", action="store_true", help="side / prefetch work on the main stream: every duration is the kernel's own")
+ap.add_argument("--table", action="store_true", help="per (symbol, launch label) totals instead of the timeline")
 a = ap.parse_args()
+if a.one_stream:
+    from drba_amd.models import lookahead as _la
+    _la.ONE_STREAM = True
 (H, W), scale, _ = bench.CONFIGS[a.config]
 dev = torch.device("cuda:0")
 m = RIFE(weights=synth.ifnet_state_dict(0), scale=scale, device=dev)
@@ -37,6 +42,18 @@ streams = sorted({r["stream"] for r in recs})
 names = {s: f"s{i}" for i, s in enumerate(streams)}
 t_end = max(r["start_ms"] + r["ms"] for r in recs)
 print(f"{a.steps} traced steps: {len(recs)} launches, span {t_end:.3f} ms = {t_end / a.steps:.3f} ms/step (traced)")
+if a.table:
+    agg = {}
+    for r in recs:
+        k = (r["name"].replace("drba_conv_split::", "").replace("drba_conv::", "")[:70], r["label"] or "")
+        v = agg.setdefault(k, [0, 0.0])
+        v[0] += 1
+        v[1] += r["ms"]
+    tot = sum(v[1] for v in agg.values())
+    print(f"{a.steps} traced steps, {len(recs)} launches, kernel time {tot / a.steps:.3f} ms per step, span {t_end / a.steps:.3f} ms per step")
+    for (nm, lab), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{ms / a.steps * 1e3:8.1f} us/step {100 * ms / tot:5.1f} %  {n / a.steps:5.2f} x {ms / n * 1e3:8.1f} us  {nm} {lab}")
+    sys.exit(0)
 busy = {s: sum(r["ms"] for r in recs if r["stream"] == s) for s in streams}
 for s in streams:
     print(f"  stream {names[s]}: {sum(1 for r in recs if r['stream'] == s)} launches, {busy[s]:.3f} ms of kernels")
