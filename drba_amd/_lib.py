@@ -49,6 +49,7 @@ SIGNATURES = {
     "drba_error_string": (C.c_char_p, [_i]),
     "drba_softsplat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "drba_softsplat_ws_floats": (_z, [_i, _i, _i, _i]),
+    "drba_softsplat_again": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "drba_backwarp": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "drba_flow_distance": (_i, [_p, _p, _i, _i, _i, _p]),
     "drba_flow_reverse": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -651,6 +651,41 @@ size_t drba_softsplat_ws_floats(int N, int C, int H, int W) {
          (splat_quad(C) ? (size_t)N * C * H * W : 0);
 }
 
+// ws layout: [cnt: L][start: L + 1][block sums: nb][rec: N * P][quad-interleaved copy of the input: N*C*P, feature tensors only]
+struct SplatWs {
+  int *cnt, *start, *bsum;
+  SplatRec *rec;
+  float *inq;
+  size_t L;
+  int nb;
+};
+static SplatWs splat_ws(float *ws, int N, int H, int W) {
+  SplatWs w;
+  w.L = sort_keys(N, H, W);
+  w.nb = (int)((w.L + kScanPerBlock - 1) / kScanPerBlock);
+  w.cnt = (int *)ws;
+  w.start = w.cnt + w.L;                                  // L + 1 entries
+  w.bsum = w.start + ((w.L + 1 + 3) & ~(size_t)3);        // nb entries
+  w.rec = (SplatRec *)(((uintptr_t)(w.bsum + w.nb) + 15) & ~(uintptr_t)15);
+  w.inq = (float *)(((uintptr_t)(w.rec + (size_t)N * H * W) + 15) & ~(uintptr_t)15);
+  return w;
+}
+// the gather of one input through the index in ws
+static int splat_gather(const float *in, float *out, const SplatWs &w, int N, int C, int H, int W, int mode, int eps, hipStream_t s) {
+  const size_t P = (size_t)H * W;
+  const int chunks = (C + kChunk - 1) / kChunk;
+  if (splat_quad(C)) {
+    DRBA_LAUNCH(quad_interleave_kernel, dim3(grid_for((size_t)N * (C / 4) * P)), dim3(kBlock), 0, s, in, w.inq, N * (C / 4), P);
+    DRBA_LAUNCH(splat_sorted_gather_quad, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, w.inq, w.start, w.rec, out, C,
+                       H, W, mode, eps, chunks);
+  } else {
+    DRBA_LAUNCH(splat_sorted_gather, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, in, w.start, w.rec, out, C, H,
+                       W, mode, eps, chunks);
+  }
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
 int drba_softsplat(const float *in, const float *flow, const float *metric, float *out, float *ws, int N, int C,
                    int H, int W, int mode, int eps, void *stream) {
   if (!in || !flow || !out || !ws || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
@@ -659,30 +694,20 @@ int drba_softsplat(const float *in, const float *flow, const float *metric, floa
   if ((size_t)N * (H + 1) * (W + 1) >= (1u << 31)) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t P = (size_t)H * W;
-  const size_t L = sort_keys(N, H, W);
-  const int nb = (int)((L + kScanPerBlock - 1) / kScanPerBlock);
-  int *cnt = (int *)ws;
-  int *start = cnt + L;                                // L + 1 entries
-  int *bsum = start + ((L + 1 + 3) & ~(size_t)3);      // nb entries
-  SplatRec *rec = (SplatRec *)(((uintptr_t)(bsum + nb) + 15) & ~(uintptr_t)15);
-  if (hipMemsetAsync(cnt, 0, L * sizeof(int), s) != hipSuccess) return DRBA_ELAUNCH;
-  DRBA_LAUNCH(splat_sort_count, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, cnt, H, W);
-  DRBA_LAUNCH(scan_block, dim3(nb), dim3(kBlock), 0, s, cnt, start, bsum, L);
-  DRBA_LAUNCH(scan_sums, dim3(1), dim3(kBlock), 0, s, bsum, nb, start + L);
-  DRBA_LAUNCH(scan_add, dim3((unsigned)((L + 255) / 256)), dim3(kBlock), 0, s, start, bsum, L);
-  DRBA_LAUNCH(splat_sort_fill, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, metric, start, cnt, rec, H, W, mode);
-  const int chunks = (C + kChunk - 1) / kChunk;
-  if (splat_quad(C)) {
-    float *inq = (float *)(((uintptr_t)(rec + (size_t)N * P) + 15) & ~(uintptr_t)15);
-    DRBA_LAUNCH(quad_interleave_kernel, dim3(grid_for((size_t)N * (C / 4) * P)), dim3(kBlock), 0, s, in, inq, N * (C / 4), P);
-    DRBA_LAUNCH(splat_sorted_gather_quad, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, inq, start, rec, out, C,
-                       H, W, mode, eps, chunks);
-  } else {
-    DRBA_LAUNCH(splat_sorted_gather, dim3(tiles_for(W, H), N * chunks), dim3(kBlock), 0, s, in, start, rec, out, C, H,
-                       W, mode, eps, chunks);
-  }
-  DRBA_CHECK_LAUNCH();
-  return DRBA_OK;
+  const SplatWs w = splat_ws(ws, N, H, W);
+  if (hipMemsetAsync(w.cnt, 0, w.L * sizeof(int), s) != hipSuccess) return DRBA_ELAUNCH;
+  DRBA_LAUNCH(splat_sort_count, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, w.cnt, H, W);
+  DRBA_LAUNCH(scan_block, dim3(w.nb), dim3(kBlock), 0, s, w.cnt, w.start, w.bsum, w.L);
+  DRBA_LAUNCH(scan_sums, dim3(1), dim3(kBlock), 0, s, w.bsum, w.nb, w.start + w.L);
+  DRBA_LAUNCH(scan_add, dim3((unsigned)((w.L + 255) / 256)), dim3(kBlock), 0, s, w.start, w.bsum, w.L);
+  DRBA_LAUNCH(splat_sort_fill, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, metric, w.start, w.cnt, w.rec, H, W, mode);
+  return splat_gather(in, out, w, N, C, H, W, mode, eps, s);
+}
+
+int drba_softsplat_again(const float *in, float *out, float *ws, int N, int C, int H, int W, int mode, int eps, void *stream) {
+  if (!in || !out || !ws || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  if (mode < 0 || mode > 3 || eps < 0 || eps > 2) return DRBA_EINVAL;
+  return splat_gather(in, out, splat_ws(ws, N, H, W), N, C, H, W, mode, eps, (hipStream_t)stream);
 }
 
 int drba_backwarp(const float *in, const float *flow, float *out, int N, int C, int H, int W, int padding,

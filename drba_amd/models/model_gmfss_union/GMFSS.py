@@ -106,25 +106,48 @@ class Model:
         F1t, F2t = _times(timestep0, flow01), _times(timestep1, flow10)
         Z1t, Z2t = _times(timestep0, metric0), _times(timestep1, metric1)
         img0, img1 = _half(img0), _half(img1)
-        I1t, I2t = warp(img0, F1t, Z1t, "soft"), warp(img1, F2t, Z2t, "soft")
-        a1, b1 = warp(f11, F1t, Z1t, "soft"), warp(f21, F2t, Z2t, "soft")
+        _, _, h, w = img0.shape
+        dev = img0.device
+        maps = self.union and torch.is_tensor(timestep0)  # DRBA: timestep maps -> the swap masks (GMFSS.py:112-150)
+        # GridNet's inputs are written where they are consumed: slices of the concatenation buffers (no torch.cat copies)
+        x = torch.empty((1, 9 if self.union else 12, h, w), dtype=torch.float32, device=dev)
+        p1 = torch.empty((1, 2 * f11.shape[1], h, w), dtype=torch.float32, device=dev)
+        p2 = torch.empty((1, 2 * f12.shape[1], h // 2, w // 2), dtype=torch.float32, device=dev)
+        p3 = torch.empty((1, 2 * f13.shape[1], h // 4, w // 4), dtype=torch.float32, device=dev)
+        c1, c2, c3 = f11.shape[1], f12.shape[1], f13.shape[1]
+        xa, xb = (x[:, 0:3], x[:, 6:9]) if self.union else (x[:, 3:6], x[:, 6:9])
+        dst = lambda t: None if maps else t  # noqa: E731  (with maps the splats go to temporaries, swap_select writes the slices)
 
         def down(flow, z, s):
             return _ops.affine(_half(flow, s), s, 0.0), _half(z, s)
 
-        a2 = warp(f12, *down(F1t, Z1t, 0.5), "soft")
-        b2 = warp(f22, *down(F2t, Z2t, 0.5), "soft")
-        a3 = warp(f13, *down(F1t, Z1t, 0.25), "soft")
-        b3 = warp(f23, *down(F2t, Z2t, 0.25), "soft")
-        if self.union and torch.is_tensor(timestep0):
-            t0 = warp(timestep0, F1t, Z1t, "soft")
-            t1 = warp(timestep1, F2t, Z2t, "soft")
-            cov0 = warp(_ops.affine(t0, 0.0, 1.0), F1t, Z1t, "soft")  # t.clone()*0+1 splatted (GMFSS.py:116-117)
-            cov1 = warp(_ops.affine(t1, 0.0, 1.0), F2t, Z2t, "soft")
-            t0, t1 = _ops.timestep_fix(t0, t1, cov0, cov1)
-            I1t, I2t = _ops.swap_select(I1t, I2t, t0, t1, 25.0)
-            a1, b1 = _ops.swap_select(a1, b1, t0, t1, 25.0)
-            a2, b2 = _ops.swap_select(a2, b2, _half(t0, 0.5), _half(t1, 0.5), 25.0)
-            a3, b3 = _ops.swap_select(a3, b3, _half(t0, 0.25), _half(t1, 0.25), 25.0)
-        x = torch.cat([I1t, rife, I2t], 1) if self.union else torch.cat([img0, I1t, I2t, img1], 1)
-        return x, torch.cat([a1, b1], 1), torch.cat([a2, b2], 1), torch.cat([a3, b3], 1)
+        # one sorted index per (flow, metric): the frame, its 64-channel features, the timestep map and the ones-mask of a side
+        # are four gathers through it (the reference: four independent softsplat calls, GMFSS.py:92-117)
+        def side(img, f1, ts, F, Z, xd, pd):
+            ins, outs = [img, f1], [dst(xd), dst(pd)]
+            if maps:
+                ins.append(ts)
+                outs.append(None)
+            r = _ops.softsplat_many(ins, F, Z, "soft", outs)
+            cov = None
+            if maps:  # t.clone() * 0 + 1 splatted along the same flow (GMFSS.py:116-117)
+                cov = _ops.softsplat_many([_ops.affine(r[2], 0.0, 1.0)], F, Z, "soft", reuse_index=True)[0]
+            return r, cov
+        (I1t, a1, *ta), cov0 = side(img0, f11, timestep0, F1t, Z1t, xa, p1[:, :c1])
+        (I2t, b1, *tb), cov1 = side(img1, f21, timestep1, F2t, Z2t, xb, p1[:, c1:])
+        a2 = warp(f12, *down(F1t, Z1t, 0.5), "soft", out=dst(p2[:, :c2]))
+        b2 = warp(f22, *down(F2t, Z2t, 0.5), "soft", out=dst(p2[:, c2:]))
+        a3 = warp(f13, *down(F1t, Z1t, 0.25), "soft", out=dst(p3[:, :c3]))
+        b3 = warp(f23, *down(F2t, Z2t, 0.25), "soft", out=dst(p3[:, c3:]))
+        if maps:
+            t0, t1 = _ops.timestep_fix(ta[0], tb[0], cov0, cov1)
+            _ops.swap_select(I1t, I2t, t0, t1, 25.0, out=(xa, xb))
+            _ops.swap_select(a1, b1, t0, t1, 25.0, out=(p1[:, :c1], p1[:, c1:]))
+            _ops.swap_select(a2, b2, _half(t0, 0.5), _half(t1, 0.5), 25.0, out=(p2[:, :c2], p2[:, c2:]))
+            _ops.swap_select(a3, b3, _half(t0, 0.25), _half(t1, 0.25), 25.0, out=(p3[:, :c3], p3[:, c3:]))
+        if self.union:
+            x[:, 3:6].copy_(rife)
+        else:  # model_gmfss/GMFSS.py:162: cat([img0, I1t, I2t, img1])
+            x[:, 0:3].copy_(img0)
+            x[:, 9:12].copy_(img1)
+        return x, p1, p2, p3

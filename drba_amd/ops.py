@@ -130,7 +130,17 @@ def _trace_pos():
 
 
 # ----------------------------------------------------------------------------- splat / warp / drm
-def softsplat(tenIn, tenFlow, tenMetric, strMode):
+def softsplat(tenIn, tenFlow, tenMetric, strMode, out=None):
+    """`out` (not in the reference): a contiguous [N,C,H,W] destination, e.g. a channel slice of a concatenation buffer."""
+    return softsplat_many([tenIn], tenFlow, tenMetric, strMode, None if out is None else [out])[0]
+
+
+def softsplat_many(inputs, tenFlow, tenMetric, strMode, outs=None, reuse_index=False):
+    """softsplat(x, tenFlow, tenMetric, strMode) for every x of `inputs` (same N, H, W; any channel counts): the sorted
+    index of the (flow, metric, mode) is built once and every input is gathered through it (drba_softsplat_again) -- the
+    count / scan / fill launches of the reference's one-call-per-tensor form are not repeated.  -> list of outputs.
+    reuse_index=True: the caller vouches that the LAST splat on this stream used the same (flow, metric, mode, N, H, W) and
+    channel counts no larger than before (the index is still in the stream's workspace): not even the first input rebuilds it."""
     parts = strMode.split("-")
     main, sub = parts[0], (parts[1] if len(parts) > 1 else None)
     assert main in ("sum", "avg", "linear", "soft")
@@ -138,15 +148,29 @@ def softsplat(tenIn, tenFlow, tenMetric, strMode):
         assert tenMetric is None
     if main in ("linear", "soft"):
         assert tenMetric is not None
-    x, f = _f32(tenIn, "tenIn"), _f32(tenFlow, "tenFlow")
+    f = _f32(tenFlow, "tenFlow")
     m = None if tenMetric is None else _f32(tenMetric, "tenMetric")
-    n, c, h, w = x.shape
-    out = torch.empty_like(x)
+    xs = [_f32(x, "tenIn") for x in inputs]
+    n, _, h, w = xs[0].shape
     lib = _lib.load()
-    ws = _workspace(x.device, lib.drba_softsplat_ws_floats(n, c, h, w))
-    _lib.check(lib.drba_softsplat(_p(x), _p(f), _p(m), _p(out), _p(ws), n, c, h, w, _MODES[main], _EPS.get(sub, 0),
-                                  _stream()), "drba_softsplat")
-    return out
+    ws = _workspace(f.device, max(lib.drba_softsplat_ws_floats(n, x.shape[1], h, w) for x in xs))
+    res = []
+    for k, x in enumerate(xs):
+        assert x.shape[0] == n and tuple(x.shape[2:]) == (h, w), (tuple(x.shape), (n, h, w))
+        c = x.shape[1]
+        out = None if outs is None else outs[k]
+        if out is None:
+            out = torch.empty_like(x)
+        elif tuple(out.shape) != tuple(x.shape) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise _lib.DrbaHipError("softsplat: out must be a contiguous float32 tensor of the input's shape")
+        if k == 0 and not reuse_index:
+            _lib.check(lib.drba_softsplat(_p(x), _p(f), _p(m), _p(out), _p(ws), n, c, h, w, _MODES[main], _EPS.get(sub, 0),
+                                          _stream()), "drba_softsplat")
+        else:
+            _lib.check(lib.drba_softsplat_again(_p(x), _p(out), _p(ws), n, c, h, w, _MODES[main], _EPS.get(sub, 0), _stream()),
+                       "drba_softsplat_again")
+        res.append(out)
+    return res
 
 
 def backwarp(x, flow, padding="border"):
@@ -970,11 +994,14 @@ def timestep_fix(t0, t1, cover0, cover1):
     return o0, o1
 
 
-def swap_select(x, y, t0, t1, thr=25.0):
+def swap_select(x, y, t0, t1, thr=25.0, out=None):
+    """`out`: optional (ox, oy) destinations (contiguous, e.g. channel slices of a concatenation buffer)."""
     x, y, t0, t1 = _f32(x), _f32(y), _f32(t0), _f32(t1)
     n, c, h, w = x.shape
     assert n == 1 and t0.shape[2:] == x.shape[2:]
-    ox, oy = torch.empty_like(x), torch.empty_like(y)
+    ox, oy = (torch.empty_like(x), torch.empty_like(y)) if out is None else out
+    if tuple(ox.shape) != tuple(x.shape) or tuple(oy.shape) != tuple(y.shape) or not (ox.is_contiguous() and oy.is_contiguous()):
+        raise _lib.DrbaHipError("swap_select: out must be contiguous tensors of the inputs' shapes")
     _lib.check(_lib.load().drba_swap_select(_p(x), _p(y), _p(t0), _p(t1), _p(ox), _p(oy), c, h, w, float(thr),
                                             _stream()), "drba_swap_select")
     return ox, oy

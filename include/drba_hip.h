@@ -32,7 +32,7 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  4: the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
+/* ABI version.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
  * NULL (nothing but f_pair_out is written), and every stage-input entry point accepts items with f0 == f1 == NULL when
  * f0_pair / f1_pair are set (the first, unwarped stage reads the pair layout too).  3: drba_stage_item_t grew by term[DRBA_MAX_FLOW_TERMS]; drba_flow_terms_t and the entry points that take the
  * running flow as terms (drba_ifblock_input_lazy_batch, drba_warp_blend_lazy_batch); drba_stage_conv0_*.
@@ -67,6 +67,11 @@ int drba_trace_get_start(int i, float *ms_since_first, unsigned long long *strea
 int drba_softsplat(const float *in, const float *flow, const float *metric, float *out, float *ws,
                    int N, int C, int H, int W, int mode, int eps, void *stream);
 size_t drba_softsplat_ws_floats(int N, int C, int H, int W);
+/* ABI 4: ANOTHER input [N,C,H,W] splatted along the same flow with the same metric and mode: the sorted index the last
+ * drba_softsplat call left in `ws` (same N, H, W; ws sized for the largest C of the calls that share it) is reused -- the
+ * count / scan / fill launches are not repeated.  GMFSS_UNION splats a frame, its 64-channel features, the timestep map and
+ * the ones-mask along one (flow, metric) pair (model_gmfss_union/GMFSS.py:92-117). */
+int drba_softsplat_again(const float *in, float *out, float *ws, int N, int C, int H, int W, int mode, int eps, void *stream);
 
 /* ---- backward warp -----------------------------------------------------------------------
  * replaces: models/rife_426_heavy/warplayer.py:8-22 (padding 0 = border) and
