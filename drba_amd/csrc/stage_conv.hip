@@ -448,8 +448,9 @@ int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, const dr
 #define DRBA_SC_GO(FO, TT, R)                                                                                            \
   do {                                                                                                                     \
     using G_ = Geo<TT, R>;                                                                                                 \
-    constexpr size_t lds_bytes = (size_t)G_::LDS_FLOATS * 4;                                                               \
-    if (max_dynamic_lds((const void *)stage_conv0<FO, G_>, (int)lds_bytes) != hipSuccess) return DRBA_ELAUNCH;             \
+    static const int lds_pad = env_int("DRBA_SC_LDS_PAD", 0); /* TUNING builds: extra LDS bytes per workgroup (occupancy probe) */ \
+    const size_t lds_bytes = (size_t)G_::LDS_FLOATS * 4 + (size_t)lds_pad;                                                 \
+    if (max_dynamic_lds((const void *)stage_conv0<FO, G_>, 160 * 1024) != hipSuccess) return DRBA_ELAUNCH;                 \
     const int tiles_x = (Wo + TOW - 1) / TOW, tiles_y = (Ho + TT - 1) / TT;                                                \
     DRBA_LAUNCH((stage_conv0<FO, G_>), dim3(tiles_x * tiles_y, n_items), dim3(G_::THREADS), lds_bytes, s, its, T, packed_w, bias, \
                 hp, wp, ips, prev_scale, H, W, Ho, Wo, tiles_x);                                                           \

@@ -97,6 +97,26 @@ for n in (2, 8):
     last = ops.Deconv4x4(torch.randn(32, 52, 4, 4, generator=g) * 0.05, torch.zeros(52), pixel_shuffle=True, device=dev)
     target(f"block4 lastconv 32->52 deconv + PixelShuffle 272x480 N{n}", lambda: last(x32))
     del x52, xin, x32
+# the context encoder as the pipeline runs it (pair-interleaved features only), and the final synthesis of a group of 4 steps
+from drba_amd.models.rife_426_heavy.IFNet_HDv3 import Head  # noqa: E402
+hsd = {"encode.cnn0.weight": torch.randn(16, 3, 3, 3, generator=g) / 27 ** 0.5, "encode.cnn0.bias": torch.zeros(16),
+       "encode.cnn1.weight": torch.randn(16, 16, 3, 3, generator=g) / 12, "encode.cnn1.bias": torch.zeros(16),
+       "encode.cnn2.weight": torch.randn(16, 16, 3, 3, generator=g) / 12, "encode.cnn2.bias": torch.zeros(16),
+       "encode.cnn3.weight": torch.randn(16, 16, 4, 4, generator=g) / 8, "encode.cnn3.bias": torch.zeros(16)}
+head_net = Head(hsd, "encode.", dev)
+target("head_fused 1088x1920, pair layout only", lambda: head_net(img0, planar=False))
+
+
+def head8(st, amp):
+    t = torch.randn(8, 13, int(H / st), int(W / st), generator=g)
+    t[:, :4] *= amp
+    return t.to(dev)
+
+
+wb_terms = [(head8(16.0, 1.0), 16.0), (head8(8.0, 0.3), 8.0), (head8(4.0, 0.3), 4.0), (head8(2.0, 0.3), 2.0)]
+wb_last = head8(1.0, 0.3)[:, :5].contiguous() if False else head8(1.0, 0.3)
+target("warp_blend_lazy, 4 terms, 8 samples", lambda: ops.warp_blend_lazy([(img1, img0)] * 8, wb_terms, wb_last, 1.0))
+del wb_terms, wb_last
 # GMFSS_UNION's matrix-core kernels at 1080p (1152x1920 -> 576x960 working resolution, GMFlow at 1/8: 72x120 = 8640 tokens,
 # fine scale 144x240 = 34560 tokens x 2 directions): fused window attention, the MLP's 256 -> 1024 linear, GridNet's
 # full-resolution 32-channel layer
