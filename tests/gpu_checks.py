@@ -696,6 +696,14 @@ def check_gmfss_parts(dev, size=(128, 256)):
             floor = float((ogm.local_correlation_softmax(a, b, 4).double() - ref64).abs().max())  # the fp32 oracle's own error
             rows.append((f"local_corr_flow r4 {hh_}x{ww_} (vs fp64)", _diff(ops.local_corr_flow(a.to(dev), b.to(dev), 4), ref64.float()),
                          max(2e-5, 3.0 * floor), f"fp32_oracle_vs_fp64={floor:.2e}"))
+        # 1x1 convolutions on the matrix cores (conv1x1_mfma_kernel behind drba_conv_direct): GMFlow's shapes and ragged ones
+        for (nb, cin, cout, hh_, ww_, st, has_b) in ((2, 96, 128, 36, 60, 1, True), (1, 256, 144, 144, 240, 1, True), (2, 64, 96, 37, 61, 2, True),
+                                                     (1, 8, 20, 5, 7, 1, False), (3, 12, 70, 9, 13, 2, True)):
+            xx, ww1 = cases.rnd((nb, cin, hh_, ww_), 71, 1.0), cases.rnd((cout, cin, 1, 1), 72, 0.2)
+            bb = cases.rnd((cout,), 73, 0.1) if has_b else None
+            ref = F.conv2d(xx.double(), ww1.double(), None if bb is None else bb.double(), stride=st).float()
+            got = ops.conv_direct(xx.to(dev), ww1.to(dev), None if bb is None else bb.to(dev), st, 0)
+            rows.append((f"conv 1x1 {cin}->{cout} stride {st} [{nb}x{hh_}x{ww_}] (vs fp64)", _diff(got, ref), 1e-5 * max(1.0, float(ref.abs().max())), ""))
         oflow = ogm.gmflow(sds["flownet"], h0, h1)
         gflow = net(h0.to(dev), h1.to(dev))
         row("gmflow flow01", gflow, oflow, 1e-3)

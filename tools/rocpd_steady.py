@@ -35,7 +35,7 @@ def main():
     db = sqlite3.connect(argv[0])
     K = int(argv[1])
     rows = db.execute("select name, start, end, queue_id, grid_x, grid_y, grid_z, workgroup_x from kernels order by start").fetchall()
-    ends = [i for i, r in enumerate(rows) if "to_out_kernel" in r[0]]
+    ends = [i for i, r in enumerate(rows) if "to_out_" in r[0]]  # to_out_kernel / to_out_rows_kernel
     assert len(ends) >= 2 * K + 1, (len(ends), K)
     first = ends[-(2 * K) - 1] + 1
     sel = rows[first:ends[-1] + 1]
