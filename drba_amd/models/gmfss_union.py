@@ -54,6 +54,14 @@ class GMFSS_UNION:
         r = self.model.reuse(Ia, Ib, self.scale)
         return [v for pair in zip(r[1::2], r[0::2]) for v in pair]
 
+    def _half_of(self, frame):
+        """F.interpolate(frame, 0.5) (gmfss_union.py:72-74), once per frame tensor."""
+        return self.model._cached(frame, "_drba_half", None, lambda: _half(frame))
+
+    def _aux_enc(self, half):
+        """The auxiliary IFNet's context encoding of a half-resolution frame, once per tensor (pair-interleaved layout)."""
+        return self.model._cached(half, "_drba_auxenc", None, lambda: self.ifnet.encode(half, planar=False))
+
     def _pair_state(self, a, b):
         """model.reuse(a, b), taken from a matching lookahead if there is one (models/lookahead.py)."""
         res = self._look.take(a, b) if self._look is not None else None
@@ -72,8 +80,11 @@ class GMFSS_UNION:
             self._look.start(I2, lookahead, lambda: self.model.reuse(I2, lookahead, self.scale))
         flow10, metric10 = reuseI1I0[0], reuseI1I0[2]
         flow12, metric12 = reuseI1I2[0], reuseI1I2[2]
-        I0s, I1s, I2s = _half(I0), _half(I1), _half(I2)
-        output = []
+        # the auxiliary RIFE frames of ALL timesteps of the step in one stacked IFNet pass (the reference runs the half-resolution
+        # IFNet once per frame, gmfss_union.py:77-93: ~100 latency-bound launches each), every frame's half-resolution copy and
+        # context encoding made once per frame tensor (a frame is I2, then I1, then I0 of consecutive steps)
+        I0s, I1s, I2s = self._half_of(I0), self._half_of(I1), self._half_of(I2)
+        output, jobs, items = [], [], []
         for t in ts:
             if t == 0:
                 output.append(I0)
@@ -87,12 +98,17 @@ class GMFSS_UNION:
                 dg = calc_drm_gmfss(tt, flow10, flow12, metric10, metric12, linear)
                 dr = calc_drm_rife_auxiliary(tt, flow10, flow12, metric10, metric12, linear)
                 dr = {k: resize(v, I0s.shape[2:]) for k, v in dr.items()}
+                a, b = (I1s, I0s) if left else (I1s, I2s)
+                items.append((a, b, dr["drm_t1_t01"] if left else dr["drm_t1_t12"], self._aux_enc(a), self._aux_enc(b)))
+                jobs.append((len(output), left, dg))
+                output.append(None)
+        if items:
+            rifes = self.ifnet.forward_pairs(items, self.scale_list)
+            for (slot, left, dg), rife in zip(jobs, rifes):
                 if left:
-                    rife = self.ifnet.forward_pair(I1s, I0s, dr["drm_t1_t01"], self.scale_list, want_flows=False)[0]
-                    output.append(self.model.inference(I1, I0, reuseI1I0, dg["drm1t_t01"], dg["drm0t_t01"], rife))
+                    output[slot] = self.model.inference(I1, I0, reuseI1I0, dg["drm1t_t01"], dg["drm0t_t01"], rife)
                 else:
-                    rife = self.ifnet.forward_pair(I1s, I2s, dr["drm_t1_t12"], self.scale_list, want_flows=False)[0]
-                    output.append(self.model.inference(I1, I2, reuseI1I2, dg["drm1t_t12"], dg["drm2t_t12"], rife))
+                    output[slot] = self.model.inference(I1, I2, reuseI1I2, dg["drm1t_t12"], dg["drm2t_t12"], rife)
         # next step's (I1, I0) state = this step's (I1, I2) state with the roles swapped (gmfss_union.py:95-98)
         new_reuse = [v for pair in zip(reuseI1I2[1::2], reuseI1I2[0::2]) for v in pair]
         return output, new_reuse

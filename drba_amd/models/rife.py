@@ -66,8 +66,8 @@ class RIFE:
             elif t == 1:
                 output.append(I1)
             else:
-                if f0 is None:  # encode once per call, not once per t (same values)
-                    f0, f1 = self.ifnet.encode(I0, planar=False), self.ifnet.encode(I1, planar=False)
+                if f0 is None:  # encode once per call, not once per t (same values); from prefetch_frame where the driver started it
+                    f0, f1 = self._encoded(I0), self._encoded(I1)
                 output.append(len(items))  # placeholder: index into the batched pass below
                 items.append((I0, I1, float(t), f0, f1))
         return self._fill(output, items)
