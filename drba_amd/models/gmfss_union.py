@@ -104,11 +104,10 @@ class GMFSS_UNION:
                 output.append(None)
         if items:
             rifes = self.ifnet.forward_pairs(items, self.scale_list)
-            for (slot, left, dg), rife in zip(jobs, rifes):
-                if left:
-                    output[slot] = self.model.inference(I1, I0, reuseI1I0, dg["drm1t_t01"], dg["drm0t_t01"], rife)
-                else:
-                    output[slot] = self.model.inference(I1, I2, reuseI1I2, dg["drm1t_t12"], dg["drm2t_t12"], rife)
+            work = [((I1, I0, reuseI1I0, dg["drm1t_t01"], dg["drm0t_t01"], rife) if left
+                     else (I1, I2, reuseI1I2, dg["drm1t_t12"], dg["drm2t_t12"], rife)) for (_, left, dg), rife in zip(jobs, rifes)]
+            for (slot, _, _), frame in zip(jobs, self.model.inference_many(work)):  # one GridNet pass over the step's frames
+                output[slot] = frame
         # next step's (I1, I0) state = this step's (I1, I2) state with the roles swapped (gmfss_union.py:95-98)
         new_reuse = [v for pair in zip(reuseI1I2[1::2], reuseI1I2[0::2]) for v in pair]
         return output, new_reuse

@@ -100,8 +100,27 @@ class Model:
     def inference(self, img0, img1, reuse_things, timestep0, timestep1, rife=None):
         return _ops.clamp(self.fusionnet(*self.fusion_inputs(img0, img1, reuse_things, timestep0, timestep1, rife)), 0.0, 1.0)
 
-    def fusion_inputs(self, img0, img1, reuse_things, timestep0, timestep1, rife=None):
-        """GMFSS.py:80-152: the splat stage -> GridNet's inputs (x [1,9,h,w], [1,128,h,w], [1,256,h/2,w/2], [1,384,h/4,w/4])."""
+    # One GridNet pass over the stacked frames of a step: measured SLOWER in the step (same box, tools/gmfss_bench.py: 42.3 / 42.4
+    # against 43.2 / 42.9 frames/s per frame -- alone the N = 2 layers are 10 % faster per FLOP, beside the lookahead stream's GMFlow
+    # the longer launches overlap worse), so the frames go through GridNet one by one; True is kept for A/B runs (--batch-fusion).
+    BATCH_FUSION = False
+
+    def inference_many(self, jobs):
+        """inference(*job) for every job of a step -- [(img0, img1, reuse_things, timestep0, timestep1, rife), ...], frames of one
+        size -- with ONE GridNet pass over the stacked fusion inputs (the samples are independent, FusionNet.py:106-146): the
+        splat stage of each job writes its slice of the [B, ...] buffers.  -> list of [1,3,H,W] frames."""
+        B = len(jobs)
+        if B == 1 or not self.BATCH_FUSION:
+            return [self.inference(*j) for j in jobs]
+        bufs = None
+        for k, job in enumerate(jobs):
+            bufs = self.fusion_inputs(*job, bufs=bufs, k=k, B=B)
+        out = _ops.clamp(self.fusionnet(*bufs), 0.0, 1.0)
+        return [out[k:k + 1] for k in range(B)]
+
+    def fusion_inputs(self, img0, img1, reuse_things, timestep0, timestep1, rife=None, bufs=None, k=0, B=1):
+        """GMFSS.py:80-152: the splat stage -> GridNet's inputs (x [1,9,h,w], [1,128,h,w], [1,256,h/2,w/2], [1,384,h/4,w/4]).
+        bufs / k / B: sample k of B stacked inputs (inference_many): the [B, ...] buffers are made by the first job and returned."""
         flow01, flow10, metric0, metric1, (f11, f12, f13), (f21, f22, f23) = reuse_things
         F1t, F2t = _times(timestep0, flow01), _times(timestep1, flow10)
         Z1t, Z2t = _times(timestep0, metric0), _times(timestep1, metric1)
@@ -110,10 +129,12 @@ class Model:
         dev = img0.device
         maps = self.union and torch.is_tensor(timestep0)  # DRBA: timestep maps -> the swap masks (GMFSS.py:112-150)
         # GridNet's inputs are written where they are consumed: slices of the concatenation buffers (no torch.cat copies)
-        x = torch.empty((1, 9 if self.union else 12, h, w), dtype=torch.float32, device=dev)
-        p1 = torch.empty((1, 2 * f11.shape[1], h, w), dtype=torch.float32, device=dev)
-        p2 = torch.empty((1, 2 * f12.shape[1], h // 2, w // 2), dtype=torch.float32, device=dev)
-        p3 = torch.empty((1, 2 * f13.shape[1], h // 4, w // 4), dtype=torch.float32, device=dev)
+        if bufs is None:
+            bufs = (torch.empty((B, 9 if self.union else 12, h, w), dtype=torch.float32, device=dev),
+                    torch.empty((B, 2 * f11.shape[1], h, w), dtype=torch.float32, device=dev),
+                    torch.empty((B, 2 * f12.shape[1], h // 2, w // 2), dtype=torch.float32, device=dev),
+                    torch.empty((B, 2 * f13.shape[1], h // 4, w // 4), dtype=torch.float32, device=dev))
+        x, p1, p2, p3 = (t[k:k + 1] for t in bufs)
         c1, c2, c3 = f11.shape[1], f12.shape[1], f13.shape[1]
         xa, xb = (x[:, 0:3], x[:, 6:9]) if self.union else (x[:, 3:6], x[:, 6:9])
         dst = lambda t: None if maps else t  # noqa: E731  (with maps the splats go to temporaries, swap_select writes the slices)
@@ -150,4 +171,4 @@ class Model:
         else:  # model_gmfss/GMFSS.py:162: cat([img0, I1t, I2t, img1])
             x[:, 0:3].copy_(img0)
             x[:, 9:12].copy_(img1)
-        return x, p1, p2, p3
+        return bufs

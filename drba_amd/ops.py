@@ -980,9 +980,10 @@ def metric_input(img0, img1, flow01, flow10):
 def pixel_shuffle2(x):
     x = _f32(x)
     n, c4, h, w = x.shape
-    assert n == 1 and c4 % 4 == 0
-    out = torch.empty((1, c4 // 4, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().drba_pixel_shuffle2(_p(x), _p(out), c4 // 4, h, w, _stream()), "drba_pixel_shuffle2")
+    assert c4 % 4 == 0
+    out = torch.empty((n, c4 // 4, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    # (the samples of a batch are just more groups of 4 channels: [N, 4C, h, w] -> [N * C] output planes)
+    _lib.check(_lib.load().drba_pixel_shuffle2(_p(x), _p(out), n * (c4 // 4), h, w, _stream()), "drba_pixel_shuffle2")
     return out
 
 

@@ -29,7 +29,13 @@ def main():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--no-lookahead", action="store_true")
+    p.add_argument("--table", action="store_true",
+                   help="after the timed steps: 2 more steps on ONE stream with every launch traced -> per-symbol kernel time per step")
+    p.add_argument("--batch-fusion", action="store_true", help="A/B: one GridNet pass over the frames of a step instead of one per frame")
     a = p.parse_args()
+    if a.batch_fusion:
+        from drba_amd.models.model_gmfss_union.GMFSS import Model
+        Model.BATCH_FUSION = True
     dev = torch.device("cuda", 0)
     sds = synth.gmfss_union_state_dicts(0)
     if a.model == "gmfss_union":
@@ -59,6 +65,29 @@ def main():
         I0, I1, k = I1, I2, k + 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if a.table:
+        from drba_amd.models import lookahead as la
+        la.ONE_STREAM = True
+        model._look = None
+        for traced in (False, True):  # one untraced step settles the one-stream state
+            if traced:
+                ops.trace_begin()
+            for _ in range(2):
+                I2 = to_inp(k)
+                out, reuse = model.inference_ts_drba(I0, I1, I2, ts, reuse, True, lookahead=None)
+                sink = [ops.to_out(x, src_size) for x in out]
+                I0, I1, k = I1, I2, k + 1
+            torch.cuda.synchronize()
+        recs = ops.trace_end()
+        agg = {}
+        for r in recs:
+            v = agg.setdefault(r["name"][:90], [0, 0.0])
+            v[0] += 1
+            v[1] += r["ms"]
+        tot = sum(v[1] for v in agg.values())
+        print(f"one stream, 2 traced steps: {len(recs) / 2:.0f} launches and {tot / 2:.2f} ms of kernel time per step", file=sys.stderr)
+        for nm, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            print(f"{ms / 2:8.3f} ms/step {100 * ms / tot:5.1f} %  {n / 2:6.1f} x {ms / n * 1e3:8.1f} us  {nm}", file=sys.stderr)
     print(json.dumps({"model": a.model, "size": a.size, "net_size": list(dst_size), "scale": a.scale,
                       "frames_per_s": round(2 * a.steps / dt, 3), "ms_per_step": round(dt / a.steps * 1e3, 2),
                       "steps": a.steps, "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
