@@ -100,6 +100,26 @@ __device__ __forceinline__ void xcd_strip_tile(int b, int nblocks, int tiles_x, 
   tx = col;
   ty = j * RB + row;
 }
+// A launch over (tiles x items) as ONE grid dimension with the items of a tile back to back on ONE XCD (round 4).  The items of
+// a group of DRBA steps read the same six source frames -- frame I(k) is img0 of two items and img1 of up to two more, at
+// sample points a few pixels apart --, but launched as blockIdx.y = item the whole frame of item 0 was gathered before
+// item 1 started: every item fetched its 159 MB per source from HBM again.  XCD x (= linear workgroup id % 8) walks its band
+// of tiles and runs all n items of a tile consecutively, so the later items find the neighbourhood in the XCD's L2.
+// vb = the block id xcd_strip_tile() expects (over `ntiles`), item = which item.  Falls back to item-major order when the
+// tile count is not a multiple of 8 (the XCD bands would not be equal).
+__device__ __forceinline__ void tile_item_block(int n_items, int &vb, int &item, int &ntiles) {
+  const int b = blockIdx.x;
+  ntiles = gridDim.x / n_items;
+  if ((ntiles & 7) == 0 && n_items > 1) {
+    const int xcd = b & 7, k = b >> 3;
+    item = k % n_items;
+    vb = (k / n_items) * 8 + xcd;
+  } else {
+    item = b / ntiles;
+    vb = b - item * ntiles;
+  }
+}
+
 constexpr int kTileW = 32, kTileH = 8;  // pixels per 256-thread workgroup: a wave covers 32 x 2
 
 struct Tile2D {

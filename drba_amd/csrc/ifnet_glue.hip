@@ -178,8 +178,9 @@ struct UpdateItems {
   float *flow_out[kMaxItems];
 };
 // the kernels' bodies keep their single-item names
-#define DRBA_UNPACK_STAGE_ITEM(items)                                                                             \
-  const drba_stage_item_t &item_ = (items).it[blockIdx.y];                                                        \
+#define DRBA_UNPACK_STAGE_ITEM(items) DRBA_UNPACK_STAGE_ITEM_AT(items, blockIdx.y)
+#define DRBA_UNPACK_STAGE_ITEM_AT(items, which)                                                                   \
+  const drba_stage_item_t &item_ = (items).it[which];                                                             \
   const float *__restrict__ img0 = item_.img0, *__restrict__ img1 = item_.img1, *__restrict__ f0 = item_.f0,      \
                            *__restrict__ f1 = item_.f1, *__restrict__ f0p = item_.f0_pair,                        \
                            *__restrict__ f1p = item_.f1_pair, *__restrict__ tmap = item_.timestep_map,            \
@@ -488,9 +489,11 @@ constexpr int kTermR = 5, kTermC = 12;  // term footprint capacity under a tile 
 template <bool SINGLE, int FMODE, bool VS>
 __global__ void __launch_bounds__(256)
 ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, float inv_prev_scale, float prev_scale, int H, int W,
-                  int h, int w, float scale) {
+                  int h, int w, float scale, int n_items) {
   constexpr bool FOLD = FMODE != 0, WRITES = FMODE == 1, LAZY = FMODE == 2;
-  DRBA_UNPACK_STAGE_ITEM(items);
+  int vb_, vitem_, ntiles_;
+  tile_item_block(n_items, vb_, vitem_, ntiles_);  // one grid dimension: the items of a tile back to back on one XCD
+  DRBA_UNPACK_STAGE_ITEM_AT(items, vitem_);
   float *__restrict__ flow_out = item_.flow_out;
   // [row][column][16]: the 13 channels of a footprint pixel (padded to 16) are four 16-byte LDS words, so a sample point
   // reads its 2 x 2 taps of four channels with 4 ds_read_b128 (16 reads for all 13 channels instead of 52 ds_read_b32)
@@ -505,7 +508,7 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w, p_prev = (size_t)hp * wp;
   const int tiles_x = (w + TWo - 1) / TWo;
   int tx, ty;
-  xcd_strip_tile(blockIdx.x, gridDim.x, tiles_x, tx, ty);
+  xcd_strip_tile(vb_, ntiles_, tiles_x, tx, ty);
   // footprint of this workgroup's sample points in tmp_prev (same for every lane: computed from the tile corners)
   const int ox_a = tx * TWo, oy_a = ty * THo;
   const int ox_b = min(ox_a + TWo - 1, w - 1), oy_b = min(oy_a + THo - 1, h - 1);
@@ -736,17 +739,19 @@ struct BlendItems {
 };
 template <bool LAZY>
 __global__ void __launch_bounds__(256)
-warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int w, float inv_scale, float scale, int H, int W) {
-  const float *__restrict__ img0 = items.img0[blockIdx.y], *__restrict__ img1 = items.img1[blockIdx.y];
-  const float *__restrict__ flow = items.flow[blockIdx.y], *__restrict__ tmp = items.tmp[blockIdx.y];
-  float *__restrict__ out = items.out[blockIdx.y];
+warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int w, float inv_scale, float scale, int H, int W, int n_items) {
+  int vb_, vitem_, ntiles_;
+  tile_item_block(n_items, vb_, vitem_, ntiles_);  // one grid dimension: the items of a tile back to back on one XCD
+  const float *__restrict__ img0 = items.img0[vitem_], *__restrict__ img1 = items.img1[vitem_];
+  const float *__restrict__ flow = items.flow[vitem_], *__restrict__ tmp = items.tmp[vitem_];
+  float *__restrict__ out = items.out[vitem_];
   __shared__ __attribute__((aligned(16))) float prev[10][36][8];  // [row][column][flow 0..3 | mask, 3 x padding]: 16-byte LDS words
   __shared__ __attribute__((aligned(16))) float tl[LAZY ? kMaxTerms * 4 * kWbTermR * kWbTermC : 4];
   int trx0[kMaxTerms], try0[kMaxTerms];
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
   const int tiles_x = (W + kTileW - 1) / kTileW;
   int tx, ty;
-  xcd_strip_tile(blockIdx.x, gridDim.x, tiles_x, tx, ty);
+  xcd_strip_tile(vb_, ntiles_, tiles_x, tx, ty);
   const int Xa = tx * kTileW, Ya = ty * kTileH, Xb = min(Xa + kTileW - 1, W - 1), Yb = min(Ya + kTileH - 1, H - 1);
   const int rx0 = lerp_src(Xa, inv_scale, w).i0, ry0 = lerp_src(Ya, inv_scale, h).i0;
   const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
@@ -754,7 +759,7 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
     const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
     prev[r][col][c] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
   }
-  if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[blockIdx.y], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
+  if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[vitem_], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
   const int x = Xa + (threadIdx.x & (kTileW - 1)), y = Ya + (threadIdx.x >> 5);
   if (x >= W || y >= H) return;
@@ -1026,7 +1031,7 @@ static int ifblock_input_lds_launch(const drba_stage_item_t *items, int n_items,
     vs = vs && ((uintptr_t)items[k].out & 15) == 0 &&
          (!fold || (((uintptr_t)items[k].flow_out & 15) == 0 && (single || (W == 2 * w && H == 2 * h))));
 #define DRBA_IFL(SG, FM, VS_) \
-  DRBA_LAUNCH((ifblock_input_lds<SG, FM, VS_>), dim3(tiles, n_items), dim3(kBlock), 0, s, its, T, hp, wp, ips, prev_scale, H, W, h, w, scale)
+  DRBA_LAUNCH((ifblock_input_lds<SG, FM, VS_>), dim3(tiles * n_items), dim3(kBlock), 0, s, its, T, hp, wp, ips, prev_scale, H, W, h, w, scale, n_items)
 #define DRBA_IFL2(SG, FM) \
   do {                    \
     if (vs) DRBA_IFL(SG, FM, true); \
@@ -1076,7 +1081,7 @@ int drba_warp_blend_fold(const float *img0, const float *img1, const float *flow
   FlowTermsArg T;
   flow_terms_arg(nullptr, T);
   DRBA_LAUNCH((warp_blend_fold_kernel<false>), dim3(tiles_for(W, H)), dim3(kBlock), 0, (hipStream_t)stream, its, T, h, w,
-              (float)(1.0 / (double)scale), scale, H, W);
+              (float)(1.0 / (double)scale), scale, H, W, 1);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
@@ -1099,8 +1104,8 @@ int drba_warp_blend_lazy_batch(const drba_stage_item_t *items, int n_items, cons
       its.term[k][i] = I.term[i];
     }
   }
-  DRBA_LAUNCH((warp_blend_fold_kernel<true>), dim3(tiles_for(W, H), n_items), dim3(kBlock), 0, (hipStream_t)stream, its, T, h, w,
-              (float)(1.0 / (double)scale), scale, H, W);
+  DRBA_LAUNCH((warp_blend_fold_kernel<true>), dim3(tiles_for(W, H) * n_items), dim3(kBlock), 0, (hipStream_t)stream, its, T, h, w,
+              (float)(1.0 / (double)scale), scale, H, W, n_items);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

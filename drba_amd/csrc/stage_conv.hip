@@ -101,7 +101,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <int FMODE, class G_>
 __global__ void __launch_bounds__(G_::THREADS) DRBA_SC_ATTR
 stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restrict__ wpk, const float *__restrict__ bias, int hp, int wp,
-            float inv_prev_scale, float prev_scale, int H, int W, int Ho, int Wo, int tiles_x) {
+            float inv_prev_scale, float prev_scale, int H, int W, int Ho, int Wo, int tiles_x, int n_items) {
   constexpr bool FOLD = FMODE != 0, WRITES = FMODE == 1, LAZY = FMODE == 2;
   constexpr int TOH = G_::TOH, WR = G_::WR, CS = G_::CS, THREADS = G_::THREADS, PR = G_::PR;
   constexpr bool WRES = G_::WRES;
@@ -110,7 +110,9 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
   float *win = lds + G_::WL;               // [2][4][CS]
   float *prev = win + 2 * 4 * CS;          // [PR][PC][16]: a footprint pixel's 13 channels as four 16-byte words (flow | mask | feat 0..3 | feat 4..7)
   float *tl = prev + 16 * PR * PC;         // [kMaxTerms][TR * TC][4]
-  // the item is picked by blockIdx.y out of the by-value argument: the compiler does not see that its fields are
+  int vb_, vitem_, ntiles_;
+  tile_item_block(n_items, vb_, vitem_, ntiles_);  // one grid dimension: the items of a tile back to back on one XCD (common.hpp)
+  // the item is picked by the block id out of the by-value argument: the compiler does not see that its fields are
   // wave-uniform (it would address every load per lane and wrap every buffer load in a waterfall loop) -- state it
   typedef __attribute__((address_space(1))) float *gptr;
   typedef __attribute__((address_space(1))) const float *cgptr;
@@ -126,7 +128,7 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
     const float *term[kMaxTerms];
   } item;
   {
-    const drba_stage_item_t &src = items.it[blockIdx.y];
+    const drba_stage_item_t &src = items.it[vitem_];
     item.img0 = uniform(src.img0), item.img1 = uniform(src.img1), item.f0_pair = uniform(src.f0_pair), item.f1_pair = uniform(src.f1_pair);
     item.timestep_map = uniform(src.timestep_map), item.flow = uniform(src.flow), item.tmp_prev = uniform(src.tmp_prev);
     item.flow_out = uniform(src.flow_out), item.out = uniform(src.out);
@@ -137,7 +139,7 @@ stage_conv0(const StageItems items, const FlowTermsArg T, const float *__restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t P = (size_t)H * W, p_prev = (size_t)hp * wp;
   int tx, ty;
-  xcd_strip_tile(blockIdx.x, gridDim.x, tiles_x, tx, ty);
+  xcd_strip_tile(vb_, ntiles_, tiles_x, tx, ty);
   const int ox0 = tx * TOW, oy0 = ty * TOH;
   const int X0 = 2 * ox0 - 1, Y0 = 2 * oy0 - 1;  // full-resolution coordinates of window (row 0, column 0)
 
@@ -452,8 +454,8 @@ int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, const dr
     const size_t lds_bytes = (size_t)G_::LDS_FLOATS * 4 + (size_t)lds_pad;                                                 \
     if (max_dynamic_lds((const void *)stage_conv0<FO, G_>, 160 * 1024) != hipSuccess) return DRBA_ELAUNCH;                 \
     const int tiles_x = (Wo + TOW - 1) / TOW, tiles_y = (Ho + TT - 1) / TT;                                                \
-    DRBA_LAUNCH((stage_conv0<FO, G_>), dim3(tiles_x * tiles_y, n_items), dim3(G_::THREADS), lds_bytes, s, its, T, packed_w, bias, \
-                hp, wp, ips, prev_scale, H, W, Ho, Wo, tiles_x);                                                           \
+    DRBA_LAUNCH((stage_conv0<FO, G_>), dim3(tiles_x * tiles_y * n_items), dim3(G_::THREADS), lds_bytes, s, its, T, packed_w, bias, \
+                hp, wp, ips, prev_scale, H, W, Ho, Wo, tiles_x, n_items);                                                           \
   } while (0)
 #define DRBA_SC_GO2(T_, R)       \
   do {                           \
