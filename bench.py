@@ -422,15 +422,20 @@ def _standalone_stage_conv0(roof, dev, g, H, W, n, reps=30):
     the four earlier stages -- a coarse flow of a few pixels plus sub-pixel refinements, i.e. smooth, as a trained net's)."""
     from drba_amd import ops
     gen = torch.Generator().manual_seed(0)
+    # the items of a group share their frames as the pipeline's do: step j = (I[j+1], I[j]) and (I[j+1], I[j+2])
+    fr = [(torch.rand(1, 3, H, W, generator=gen).to(dev), torch.randn(1, 16, H, W, generator=gen).to(dev)) for _ in range(n // 2 + 2)]
     items = []
-    for _ in range(n):
-        i0, i1 = torch.rand(1, 3, H, W, generator=gen).to(dev), torch.rand(1, 3, H, W, generator=gen).to(dev)
-        f0, f1 = torch.randn(1, 16, H, W, generator=gen).to(dev), torch.randn(1, 16, H, W, generator=gen).to(dev)
-        items.append((i0, i1, torch.rand(1, 1, H, W, generator=gen).to(dev), f0, f1))
+    for j in range(n // 2):
+        (a, fa), (b, fb), (c, fc) = fr[j], fr[j + 1], fr[j + 2]
+        items.append((b, a, torch.rand(1, 1, H, W, generator=gen).to(dev), fb, fa))
+        items.append((b, c, torch.rand(1, 1, H, W, generator=gen).to(dev), fb, fc))
+    items = items[:n] if len(items) >= n else items + items[:n - len(items)]
 
-    def head(st, amp):
-        t = torch.randn(n, 13, H // st, W // st, generator=gen)
-        t[:, :4] *= amp
+    def head(st, amp):  # smooth flow channels (low-resolution noise, bicubic): a coarse flow of a few pixels plus refinements
+        hh, ww = H // st, W // st
+        t = torch.randn(n, 13, hh, ww, generator=gen)
+        lo = torch.randn(n, 4, max(hh // 8, 2), max(ww // 8, 2), generator=gen) * amp
+        t[:, :4] = torch.nn.functional.interpolate(lo, size=(hh, ww), mode="bicubic", align_corners=False)
         return t.to(dev)
     terms = [(head(16, 1.0), 16.0), (head(8, 0.3), 8.0), (head(4, 0.3), 4.0)]
     tprev = head(2, 0.3)
@@ -446,7 +451,7 @@ def _standalone_stage_conv0(roof, dev, g, H, W, n, reps=30):
     us = sum(r["ms"] for r in recs) / max(len(recs), 1) * 1e3
     ach = g["algorithmic_per_launch"] / us / 1e3  # GB/s
     return {"launch": g["launch"], "avg_us": round(us, 2), "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / roof["peak"], 4),
-            "what": f"{reps} launches of this geometry alone (synthetic smooth flows), the kernel's own dispatch times"}
+            "what": f"{reps} launches of this geometry alone (items sharing six frames as in the loop, smooth synthetic flows), the kernel's own dispatch times"}
 
 
 def _rocprof_table():

@@ -55,8 +55,20 @@ items2 = [(img1, img0, tmap, f1, f0), (img1, img2, tmap, f1, f2)]
 flows2 = [flow, (flow * 0.9).contiguous()]
 # N = 2: the samples of one `-t 2` step (what a step-by-step driver launches); N = 8: a group of 4 steps (RIFE.GROUP, what
 # bench.py's loop launches) -- the launch label ends in N, so both geometries get their own row
+# a group of 4 steps (8 items) reads SIX distinct frames the way the pipeline's items do -- step j: (I[j+1], I[j]) and (I[j+1], I[j+2]) --
+# so that what the items share in L2 (round 4: the items of a tile run back to back on one XCD) is what the pipeline shares
+frames6 = [(img0, f0), (img1, f1), (img2, f2)]
+for _ in range(3):
+    im, ft = torch.rand(1, 3, H, W, generator=g).to(dev), torch.randn(1, 16, H, W, generator=g).to(dev)
+    ops.pair_interleaved(ft)
+    frames6.append((im, ft))
+items8 = []
+for j in range(4):
+    (a, fa), (b, fb), (c, fc) = frames6[j], frames6[j + 1], frames6[j + 2]
+    items8 += [(b, a, tmap, fb, fa), (b, c, tmap, fb, fc)]
+flows8 = [flow, (flow * 0.9).contiguous()] * 4
 for n in (2, 8):
-    items, flows = items2 * (n // 2), flows2 * (n // 2)
+    items, flows = (items2, flows2) if n == 2 else (items8, flows8)
     for s in (1.0, 2.0):
         tprev = torch.randn(n, 13, int(H / (2 * s)), int(W / (2 * s)), generator=g).to(dev)
         xin = torch.empty(n, 52, int(H / s), int(W / s), device=dev)
@@ -72,9 +84,11 @@ for n in (2, 8):
 
     # what the pipeline launches since the running flow is a list of terms (head outputs of the earlier stages: a refinement
     # of a few pixels per stage on top of the coarse flow) -- the launch labels end in "+lazy"
-    def head(st, amp):
-        t = torch.randn(n, 13, int(H / st), int(W / st), generator=g)
-        t[:, :4] *= amp
+    def head(st, amp):  # a head output whose flow channels are SMOOTH (low-resolution noise, bicubic), as a trained stage's are
+        hh, ww = int(H / st), int(W / st)
+        t = torch.randn(n, 13, hh, ww, generator=g)
+        lo = torch.randn(n, 4, max(hh // 8, 2), max(ww // 8, 2), generator=g) * amp
+        t[:, :4] = torch.nn.functional.interpolate(lo, size=(hh, ww), mode="bicubic", align_corners=False)
         return t.to(dev)
     pyr = {16.0: head(16.0, 1.0), 8.0: head(8.0, 0.3), 4.0: head(4.0, 0.3), 2.0: head(2.0, 0.3)}
     target(f"stage input s=1 + conv0[0] fused, flow as 3 terms, {n} samples",
@@ -108,14 +122,16 @@ target("head_fused 1088x1920, pair layout only", lambda: head_net(img0, planar=F
 
 
 def head8(st, amp):
-    t = torch.randn(8, 13, int(H / st), int(W / st), generator=g)
-    t[:, :4] *= amp
+    hh, ww = int(H / st), int(W / st)
+    t = torch.randn(8, 13, hh, ww, generator=g)
+    lo = torch.randn(8, 4, max(hh // 8, 2), max(ww // 8, 2), generator=g) * amp
+    t[:, :4] = torch.nn.functional.interpolate(lo, size=(hh, ww), mode="bicubic", align_corners=False)
     return t.to(dev)
 
 
 wb_terms = [(head8(16.0, 1.0), 16.0), (head8(8.0, 0.3), 8.0), (head8(4.0, 0.3), 4.0), (head8(2.0, 0.3), 2.0)]
 wb_last = head8(1.0, 0.3)[:, :5].contiguous() if False else head8(1.0, 0.3)
-target("warp_blend_lazy, 4 terms, 8 samples", lambda: ops.warp_blend_lazy([(img1, img0)] * 8, wb_terms, wb_last, 1.0))
+target("warp_blend_lazy, 4 terms, 8 samples", lambda: ops.warp_blend_lazy([(it[0], it[1]) for it in items8], wb_terms, wb_last, 1.0))
 del wb_terms, wb_last
 # GMFSS_UNION's matrix-core kernels at 1080p (1152x1920 -> 576x960 working resolution, GMFlow at 1/8: 72x120 = 8640 tokens,
 # fine scale 144x240 = 34560 tokens x 2 directions): fused window attention, the MLP's 256 -> 1024 linear, GridNet's

@@ -72,7 +72,7 @@ def main():
         print(f"  queue {q}: {c / K:.0f} launches/step, {ns / 1e6 / K:.3f} ms/step of kernel time")
     lines = ["Name,CallsPerStep,AverageUs,MsPerStep,Percentage,MinUs,MaxUs"]
     for nm, (c, ns, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        lines.append(f"\"{nm}\",{c / K:.1f},{ns / c / 1e3:.1f},{ns / 1e6 / K:.3f},{100.0 * ns / busy:.1f},{mn / 1e3:.1f},{mx / 1e3:.1f}")
+        lines.append(f"\"{nm}\",{c / K:.2f},{ns / c / 1e3:.1f},{ns / 1e6 / K:.3f},{100.0 * ns / busy:.1f},{mn / 1e3:.1f},{mx / 1e3:.1f}")
     print("\n".join(lines[:nrows]))
     if len(argv) > 2:
         open(argv[2], "w").write("\n".join(lines) + "\n")
