@@ -633,8 +633,12 @@ def head_fused(img, layers, holder, planar=True):
 
 
 def is_pair(f):
-    """Is `f` a feature tensor in the pair-interleaved layout [C/2,H,W,2] (head_fused(planar=False))?"""
-    return bool(getattr(f, "_drba_is_pair", False))
+    """Is `f` a feature tensor in the pair-interleaved layout [C/2,H,W,2] (head_fused(planar=False))?  The tag does not survive
+    a .clone() / slice of a carried `reuse` entry, so the SHAPE decides as well: [8,H,W,2] cannot be the reference's
+    [1,16,H,W] (a planar tensor handed to the kernels as pairs, or the reverse, would be read in the wrong layout silently)."""
+    if getattr(f, "_drba_is_pair", False):
+        return True
+    return bool(torch.is_tensor(f) and f.dim() == 4 and f.shape[0] == 8 and f.shape[3] == 2 and f.shape[1] > 2 and f.shape[2] > 2)
 
 
 def features_planar(f):
@@ -649,9 +653,35 @@ def features_planar(f):
 def _feat(f, want_pair=True):
     """-> (planar tensor or None, pair-interleaved tensor or None) of a feature argument."""
     if is_pair(f):
+        if not (f.is_cuda and f.dtype == torch.float32 and f.is_contiguous()):
+            raise _lib.DrbaHipError("pair-interleaved features must be a contiguous float32 CUDA tensor [8,H,W,2]")
         return None, f
     f = _f32(f)
+    if f.dim() != 4 or f.shape[0] != 1:
+        raise _lib.DrbaHipError(f"features must be [1,C,H,W] (or pair-interleaved [8,H,W,2]), got {tuple(f.shape)}")
     return f, (pair_interleaved(f) if want_pair and PAIR_FEATURES and f.shape[1] == 16 else None)
+
+
+def _feat2(f0, f1, want_pair=True):
+    """_feat of both feature arguments of an item, in ONE layout: when one of them exists pair-interleaved only (the hot path's
+    tensors) and the other is planar (a reference / oracle `reuse` entry), the planar one is given its pair copy and the
+    kernels read pairs -- the C entry points take the planar pointers of an item both or not at all."""
+    (a, ap), (b, bp) = _feat(f0, want_pair), _feat(f1, want_pair)
+    if a is None or b is None:
+        ap = ap if ap is not None else pair_interleaved(a)
+        bp = bp if bp is not None else pair_interleaved(b)
+        a = b = None
+    return (a, ap), (b, bp)
+
+
+def _feat_batch(items, want_pair=True):
+    """_feat2 for every (.., f0, f1) item of a batched launch, all items in ONE layout (the C entry points want the items of a
+    launch to agree on which pointers are given): if any item is pair-only, every item is read as pairs."""
+    fs = [_feat2(it[3], it[4], want_pair) for it in items]
+    if any(a is None for (a, _), _ in fs):
+        fs = [((None, ap if ap is not None else pair_interleaved(a)), (None, bp if bp is not None else pair_interleaved(b)))
+              for (a, ap), (b, bp) in fs]
+    return fs
 
 
 def pair_interleaved(f):
@@ -673,7 +703,7 @@ def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scal
     `tmp_prev`: the previous stage's [1,13,hp,wp] head output (mask/feat are its x prev_scale upsample).
     `out`: optional [1,nch,h,w] destination (one sample of a stacked stage batch)."""
     img0, img1 = _f32(img0), _f32(img1)
-    (f0, f0p), (f1, f1p) = _feat(f0, flow is not None), _feat(f1, flow is not None)
+    (f0, f0p), (f1, f1p) = _feat2(f0, f1, flow is not None)
     _, _, H, W = img0.shape
     h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
     tmap, tsc = (None, float(timestep)) if not torch.is_tensor(timestep) else (_f32(timestep), 0.0)
@@ -705,7 +735,7 @@ def ifblock_input_lds(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, 
     the running flow BEFORE the previous stage's update (or None); the update flow + up(tmp_prev[:4]) * prev_scale is
     formed inside the kernel (scale <= 2 only) and returned as the second value."""
     img0, img1, tmp_prev = _f32(img0), _f32(img1), _f32(tmp_prev)
-    (f0, f0p), (f1, f1p) = _feat(f0), _feat(f1)
+    (f0, f0p), (f1, f1p) = _feat2(f0, f1)
     _, _, H, W = img0.shape
     h, w = int(np.floor(H * (1.0 / scale))), int(np.floor(W * (1.0 / scale)))
     tmap, tsc = (None, float(timestep)) if not torch.is_tensor(timestep) else (_f32(timestep), 0.0)
@@ -781,9 +811,10 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
         hp, wp, ps = tmp_prev.shape[2], tmp_prev.shape[3], float(prev_scale)
     arr = (_lib.StageItem * B)()
     keep = []
-    for k, (i0, i1, t, f0, f1) in enumerate(items):
+    feats = _feat_batch(items, lds or has_flow)
+    for k, (i0, i1, t, _f0, _f1) in enumerate(items):
         i0, i1 = _f32(i0), _f32(i1)
-        (f0, f0p), (f1, f1p) = _feat(f0, lds or has_flow), _feat(f1, lds or has_flow)
+        (f0, f0p), (f1, f1p) = feats[k]
         tmap, tsc = (None, float(t)) if not torch.is_tensor(t) else (_f32(t), 0.0)
         fl = None if (flows is None or flows[k] is None) else _f32(flows[k])
         keep += [i0, i1, f0, f1, tmap, fl, f0p, f1p]
@@ -852,9 +883,10 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
     flow_out = torch.empty((B, 4, H, W), dtype=torch.float32, device=dev) if fold else None
     arr = (_lib.StageItem * B)()
     keep = []
-    for k, (i0, i1, t, f0, f1) in enumerate(items):
+    feats = _feat_batch(items)
+    for k, (i0, i1, t, _f0, _f1) in enumerate(items):
         i0, i1 = _f32(i0), _f32(i1)
-        (f0, f0p), (f1, f1p) = _feat(f0), _feat(f1)
+        (f0, f0p), (f1, f1p) = feats[k]
         tmap, tsc = (None, float(t)) if not torch.is_tensor(t) else (_f32(t), 0.0)
         fl = None if (flows is None or flows[k] is None) else _f32(flows[k])
         keep += [i0, i1, f0, f1, tmap, fl, f0p, f1p]

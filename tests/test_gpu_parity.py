@@ -224,6 +224,30 @@ def test_two_model_instances_in_one_process(hip_backend):
     assert err <= 2e-5, err
 
 
+def test_cloned_reuse_features_keep_their_layout(hip_backend):
+    """The carried encoder features are pair-interleaved [8,H,W,2] tensors (ops.head_fused(planar=False)); a caller that
+    clones the `reuse` tuple loses the tag on them, and a planar [1,16,H,W] tensor (the reference's layout, e.g. an oracle's
+    reuse) may come in as well: both must be read in the layout they are in."""
+    from drba_amd import ops
+    from drba_amd.utils import synth
+    sd = synth.ifnet_state_dict(seed=0)
+    dev = hip_backend.dev
+    g = torch.Generator().manual_seed(13)
+    fr = [torch.rand(1, 3, 128, 192, generator=g).to(dev) for _ in range(4)]
+    ts = np.array([0.75, 1.25])
+    m = hip_backend.make_rife(sd, 1.0)
+    _, reuse = m.inference_ts_drba(fr[0], fr[1], fr[2], ts, None, True)
+    assert ops.is_pair(reuse[2]) and tuple(reuse[2].shape) == (8, 128, 192, 2)
+    want, _ = m.inference_ts_drba(fr[1], fr[2], fr[3], ts, reuse, True)
+    cloned = tuple(t.clone() for t in reuse)                                             # tags gone, shapes tell
+    planar = (reuse[0], reuse[1], ops.features_planar(reuse[2]), ops.features_planar(reuse[3]))  # the reference's layout
+    for name, r in (("cloned", cloned), ("planar", planar)):
+        got, _ = hip_backend.make_rife(sd, 1.0).inference_ts_drba(fr[1], fr[2], fr[3], ts, r, True)
+        torch.cuda.synchronize()
+        err = max(float((a - b).abs().max()) for a, b in zip(got, want))
+        assert err <= 2e-5, (name, err)
+
+
 def test_prefetch_does_not_retain_frames(hip_backend):
     """The prefetch caches hang on the frame tensors (encoder output on the frame, coarse flow on the pair's second frame);
     nothing may keep a frame -- with its 16-channel features -- alive once the driver has dropped it: memory is flat over a
