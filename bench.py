@@ -266,9 +266,20 @@ class AnnouncedLoop:
 def _peak(name, unit):
     if unit == "byte":
         return HBM_PEAK_GBS, "GB/s", "hbm", "HBM3E 8 TB/s"
-    if "split" in name or "conv_dma" in name or "conv_ks" in name:  # fp32 operands as three bf16 terms, six MFMA products
+    if "split" in name or "conv_dma" in name or "conv_ks" in name:
+        if _two_term(name):  # fp32 operands as two fp16 terms (22 bits), three MFMA products
+            return round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1), "TFLOP/s", "mfma", "dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 multiply"
+        # fp32 operands as three bf16 terms, six MFMA products
         return round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), "TFLOP/s", "mfma", "dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32 multiply"
     return FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma", "dense fp32 MFMA"
+
+
+def _two_term(name):
+    """True for the two-term fp16 instantiations of the split families (the last template argument, PL, is 2):
+    conv_split_mfma<SplitCfg<M, RW, MW, NT, 2>, ...>, conv_dma1<PRE, RL, 2>, conv_ks<KW, PRE, RL, DW, 2>."""
+    import re
+    return bool(re.search(r"SplitCfg<[^<>]*, 2>", name) or re.search(r"conv_dma1<[^<>]*, 2>", name)
+                or re.search(r"conv_ks<\d+, \w+, \w+, \w+, 2>", name))
 
 
 def _symbol_totals(recs, n_steps):

@@ -69,6 +69,7 @@ SIGNATURES = {
     "drba_conv3x3_num_cfgs": (_i, []),
     "drba_conv3x3_cfg_stride": (_i, [_i]),
     "drba_conv3x3_cfg_family": (_i, [_i]),
+    "drba_deconv4x4_cfg_family": (_i, [_i]),
     "drba_deconv4x4_num_cfgs": (_i, []),
     "drba_conv3x3_packed_floats": (_z, [_i, _i, _i]),
     "drba_conv3x3_pack": (_i, [_p, _p, _i, _i, _i]),
@@ -109,11 +110,11 @@ SIGNATURES = {
     "drba_gelu": (_i, [_p, _p, _z, _p]),
     "drba_window_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p, _p]),
     "drba_window_attention_ws_floats": (_z, [_i, _i, _i, _i]),
-    "drba_linear_split_packed_floats": (_z, [_i, _i]),
-    "drba_linear_split_pack": (_i, [_p, _p, _i, _i]),
-    "drba_linear_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "drba_linear_split_cat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "drba_linear_split_layernorm": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "drba_linear_split_packed_floats": (_z, [_i, _i, _i]),
+    "drba_linear_split_pack": (_i, [_p, _p, _i, _i, _i]),
+    "drba_linear_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_linear_split_cat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_linear_split_layernorm": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
     "drba_softmax_rows": (_i, [_p, _p, _z, _i, _i, _i, _f, _p]),
     "drba_global_expect2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
     "drba_global_expect2_ws_floats": (_z, [_i]),

@@ -543,16 +543,25 @@ static bool split_enabled() {
 static int first_dma_cfg() { return kNumConvCfg + (split_enabled() ? conv_split_num_cfgs() : 0); }
 // ... then the K-split family of conv_ks.hip (Cin = 64 / 96 / 128 / 192)
 static int first_ks_cfg() { return first_dma_cfg() + (split_enabled() ? conv_dma_num_cfgs() : 0); }
-int drba_conv3x3_num_cfgs(void) { return first_ks_cfg() + (split_enabled() ? conv_ks_num_cfgs() : 0); }
+// ... then the two-term fp16 family (family 4; conv_split.hip "Two-term form"): 22-bit operands instead of 24, half the
+// matrix-core work.  A caller opts in by offering these ids to its tuner; none of the ids before them changes meaning.
+static int first_f16_cfg() { return first_ks_cfg() + (split_enabled() ? conv_ks_num_cfgs() : 0); }
+static int first_f16_dma_cfg() { return first_f16_cfg() + (split_enabled() ? conv_split_num_cfgs() : 0); }
+static int first_f16_ks_cfg() { return first_f16_dma_cfg() + (split_enabled() ? conv_dma_num_cfgs() : 0); }
+int drba_conv3x3_num_cfgs(void) { return first_f16_ks_cfg() + (split_enabled() ? conv_ks_num_cfgs() : 0); }
 int drba_conv3x3_cfg_stride(int cfg) {
   if (cfg >= kNumConvCfg && cfg < drba_conv3x3_num_cfgs()) return 1;
   return (cfg < 0 || cfg >= kNumConvCfg) ? DRBA_EINVAL : kConv[cfg].S;
 }
 int drba_conv3x3_cfg_family(int cfg) {
   if (cfg < 0 || cfg >= drba_conv3x3_num_cfgs()) return DRBA_EINVAL;
-  return cfg < kNumConvCfg ? 0 : (cfg < first_dma_cfg() ? 1 : (cfg < first_ks_cfg() ? 2 : 3));
+  return cfg < kNumConvCfg ? 0 : (cfg < first_dma_cfg() ? 1 : (cfg < first_ks_cfg() ? 2 : (cfg < first_f16_cfg() ? 3 : 4)));
 }
-int drba_deconv4x4_num_cfgs(void) { return kNumDeconvCfg + (split_enabled() ? deconv_split_num_cfgs() : 0); }
+int drba_deconv4x4_num_cfgs(void) { return kNumDeconvCfg + (split_enabled() ? 2 * deconv_split_num_cfgs() : 0); }
+int drba_deconv4x4_cfg_family(int cfg) {
+  if (cfg < 0 || cfg >= drba_deconv4x4_num_cfgs()) return DRBA_EINVAL;
+  return cfg < kNumDeconvCfg ? 0 : (cfg - kNumDeconvCfg < deconv_split_f16_first() ? 1 : 4);
+}
 
 // DRBA_CONV_CFG=<id> / DRBA_DECONV_CFG=<id> in the environment override the choice (experiments only).
 int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride) {
@@ -564,7 +573,11 @@ int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride) {
 }
 
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
-  if (cfg >= first_ks_cfg()) return cfg < drba_conv3x3_num_cfgs() ? conv_ks_packed_floats(Cin, Cout, cfg - first_ks_cfg()) : 0;
+  if (cfg >= first_f16_ks_cfg())
+    return cfg < drba_conv3x3_num_cfgs() ? conv_ks_packed_floats(Cin, Cout, cfg - first_f16_ks_cfg() + conv_ks_f16_first()) : 0;
+  if (cfg >= first_f16_dma_cfg()) return conv_dma_packed_floats(Cin, Cout, cfg - first_f16_dma_cfg() + conv_dma_f16_first());
+  if (cfg >= first_f16_cfg()) return conv_split_packed_floats(Cin, Cout, cfg - first_f16_cfg() + conv_split_f16_first());
+  if (cfg >= first_ks_cfg()) return conv_ks_packed_floats(Cin, Cout, cfg - first_ks_cfg());
   if (cfg >= first_dma_cfg()) return conv_dma_packed_floats(Cin, Cout, cfg - first_dma_cfg());
   if (cfg >= kNumConvCfg) return conv_split_packed_floats(Cin, Cout, cfg - kNumConvCfg);
   if (cfg < 0 || cfg >= kNumConvCfg || Cin <= 0 || Cout <= 0) return 0;
@@ -574,7 +587,13 @@ size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
 // fragment order: packed[(((cz*nchunks + q)*9 + tap)*CG + cg)*NT + nt][lane] =
 //   w[cz*NTC + nt*16 + (lane&15)][q*CK + cg*4 + (lane>>4)][tap], zero outside Cout/Cin
 int drba_conv3x3_pack(const float *w, float *packed, int Cin, int Cout, int cfg) {
-  if (cfg >= first_ks_cfg() && cfg < drba_conv3x3_num_cfgs()) return conv_ks_pack(w, packed, Cin, Cout, cfg - first_ks_cfg());
+  if (cfg >= first_f16_ks_cfg() && cfg < drba_conv3x3_num_cfgs())
+    return conv_ks_pack(w, packed, Cin, Cout, cfg - first_f16_ks_cfg() + conv_ks_f16_first());
+  if (cfg >= first_f16_dma_cfg() && cfg < first_f16_ks_cfg())
+    return conv_dma_pack(w, packed, Cin, Cout, cfg - first_f16_dma_cfg() + conv_dma_f16_first());
+  if (cfg >= first_f16_cfg() && cfg < first_f16_dma_cfg())
+    return conv_split_pack(w, packed, Cin, Cout, cfg - first_f16_cfg() + conv_split_f16_first());
+  if (cfg >= first_ks_cfg() && cfg < first_f16_cfg()) return conv_ks_pack(w, packed, Cin, Cout, cfg - first_ks_cfg());
   if (cfg >= first_dma_cfg() && cfg < first_ks_cfg()) return conv_dma_pack(w, packed, Cin, Cout, cfg - first_dma_cfg());
   if (cfg >= kNumConvCfg && cfg < first_dma_cfg()) return conv_split_pack(w, packed, Cin, Cout, cfg - kNumConvCfg);
   if (!w || !packed || cfg < 0 || cfg >= kNumConvCfg || Cin <= 0 || Cout <= 0) return DRBA_EINVAL;
@@ -602,7 +621,22 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
   if (beta && !residual) return DRBA_EINVAL;
   if (residual2 && !residual) return DRBA_EINVAL;
   if (act < 0 || act > 4) return DRBA_EINVAL;
-  if (cfg >= first_ks_cfg() && cfg < drba_conv3x3_num_cfgs()) {
+  if (cfg >= first_f16_ks_cfg() && cfg < drba_conv3x3_num_cfgs()) {
+    if (stride != 1) return DRBA_EINVAL;
+    return conv_ks_launch(cfg - first_f16_ks_cfg() + conv_ks_f16_first(), in, packed_w, bias, beta, residual, residual2, out, N, Cin,
+                          H, W, Cout, act, post_slope, pre_act, pre_slope, stream);
+  }
+  if (cfg >= first_f16_dma_cfg() && cfg < first_f16_ks_cfg()) {
+    if (stride != 1) return DRBA_EINVAL;
+    return conv_dma_launch(cfg - first_f16_dma_cfg() + conv_dma_f16_first(), in, packed_w, bias, beta, residual, residual2, out, N,
+                           Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream);
+  }
+  if (cfg >= first_f16_cfg() && cfg < first_f16_dma_cfg()) {
+    if (stride != 1) return DRBA_EINVAL;
+    return conv_split_launch(cfg - first_f16_cfg() + conv_split_f16_first(), in, packed_w, bias, beta, residual, residual2, out,
+                             N, Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream);
+  }
+  if (cfg >= first_ks_cfg() && cfg < first_f16_cfg()) {
     if (stride != 1) return DRBA_EINVAL;
     return conv_ks_launch(cfg - first_ks_cfg(), in, packed_w, bias, beta, residual, residual2, out, N, Cin, H, W, Cout, act,
                           post_slope, pre_act, pre_slope, stream);

@@ -40,6 +40,7 @@ namespace drba_conv_dma {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lds_ptr;
 
@@ -50,13 +51,13 @@ constexpr int WR = TH + 2, WC = TW + 8;  // window: rows y0-1 .. y0+8, columns x
 constexpr int CS = WR * WC;              // 400 dwords per channel, == 16 (mod 32)
 constexpr int A_BYTES = CK * CS * 4;     // 51200
 [[maybe_unused]] constexpr int A_INSTR = A_BYTES / 1024;  // 50 wave-level DMA instructions of 64 lanes x 16 B
-constexpr int W_BYTES = 9 * NT * 3 * 1024;  // 55296
-[[maybe_unused]] constexpr int W_INSTR = W_BYTES / 1024;
+// PL = number of 16-bit terms per operand: 3 = bf16 h + m + l, 2 = the two-term fp16 form (conv_split.hip "Two-term form")
+constexpr int w_bytes(int PL) { return 9 * NT * PL * 1024; }  // 55296 / 36864
 constexpr int OFF_W = 2 * A_BYTES;
-constexpr int OFF_IDX = OFF_W + W_BYTES;      // 2 x {x0, y0, image, tile number}: what the loader publishes per item
-constexpr int LDS_BYTES = OFF_IDX + 32;
+constexpr int off_idx(int PL) { return OFF_W + w_bytes(PL); }  // 2 x {x0, y0, image, tile number}: what the loader publishes per item
+constexpr int lds_bytes(int PL) { return off_idx(PL) + 32; }
 constexpr int NTHREADS = 9 * 64;         // 8 MFMA waves + the loader
-static_assert(CS % 32 == 16 && A_BYTES % 1024 == 0 && LDS_BYTES <= 160 * 1024, "window layout");
+static_assert(CS % 32 == 16 && A_BYTES % 1024 == 0 && lds_bytes(3) <= 160 * 1024, "window layout");
 [[maybe_unused]] constexpr unsigned kOOB = 0x7FFFFFF0u;  // beyond any num_records: the load returns 0 (zero padding), never faults
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N - 1>) -- the block schedule below is a table indexed by
@@ -85,7 +86,7 @@ struct Item {  // scalar (wave-uniform) description of a work item
 #define DRBA_CLK_ADD(slot, a, b)
 #endif
 
-template <bool PRE, bool RL>
+template <bool PRE, bool RL, int PL = 3>
 __global__ void __launch_bounds__(NTHREADS, 1)
 conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
           const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
@@ -93,6 +94,9 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
           int total, int *__restrict__ counters, int *__restrict__ counters_next) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // the ONLY LDS object of the kernel
+  constexpr int W_BYTES = w_bytes(PL), W_INSTR = W_BYTES / 1024, OFF_IDX = off_idx(PL);
+  constexpr int NM = (PL == 3 ? 6 : 3) * NT;  // MFMAs of a group = slots of the block program
+  constexpr int NSPLIT = PL == 3 ? 11 : 6;    // instruction groups of one block's split
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -317,9 +321,10 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
   }
 
   f32x4 acc[2][NT];    // [output row of the pair][cout tile]
+  f32x4 acl[2][NT];    // PL = 2: the h*l + l*h products (weight 2^-11), joined in the epilogue
   float rawr[2][8];    // ring: raw A dwords of block b in rawr[b & 1]
-  u32x4 pl[2][3];      // h / m / l operands of block b in pl[b & 1]
-  u32x4 bw[2][NT][3];  // weight fragments of MFMA group g in bw[g & 1]
+  u32x4 pl[2][PL];     // h / m / l (PL = 2: h / l) operands of block b in pl[b & 1]
+  u32x4 bw[2][NT][PL]; // weight fragments of MFMA group g in bw[g & 1]
   float sa[4], sb[4], ta[4], tb[4];  // split in flight: remainders (sa, sb) and unpacked terms (ta, tb) of the 4 pairs
   // Blocks of a tile, b = 0..11: window row ir = b / 3 of the wave's four, tap column dx = b % 3.  Block b feeds the output
   // rows o with 0 <= ir - o <= 2 (kernel row dy = ir - o): one MFMA group (12 MFMAs) for ir = 0, 3, two for ir = 1, 2.
@@ -348,6 +353,44 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
       }
     return;
 #endif
+    if constexpr (PL == 2) {
+      // two-term fp16 form: x' = x * 2^-shift, h = fp16(x'), l = fp16((x' - h) * 2^11), in 6 groups
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      auto pkh = [](float x, float y) -> unsigned {
+        return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x, y}, f16x2));
+      };
+      auto unpackh = [&](int p) {
+        const unsigned u = pl[s][0][p];  // (through a scalar: bit_cast of a vector ELEMENT reads element 0 with hipcc 7.2)
+        const f16x2 hv = __builtin_bit_cast(f16x2, u);
+        ta[p] = (float)hv[0], tb[p] = (float)hv[1];
+      };
+      constexpr float kScale = 1.f / (float)(1 << kSplitActShift);
+      if (q == 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          sa[p] = rawr[s][2 * p], sb[p] = rawr[s][2 * p + 1];
+          if (PRE) {
+            sa[p] = sa[p] > 0.f ? sa[p] : sa[p] * pre_slope;
+            sb[p] = sb[p] > 0.f ? sb[p] : sb[p] * pre_slope;
+          }
+          sa[p] *= kScale, sb[p] *= kScale;
+          pl[s][0][p] = pkh(sa[p], sb[p]);
+        }
+      } else if (q == 1 || q == 2) {
+        unpackh(2 * (q - 1)), unpackh(2 * (q - 1) + 1);
+      } else if (q == 3) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sa[p] -= ta[p], sb[p] -= tb[p];
+      } else if (q == 4) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sa[p] *= 2048.f, sb[p] *= 2048.f;
+      } else if (q == 5) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) pl[s][1][p] = pkh(sa[p], sb[p]);
+      }
+      return;
+    }
     if (q == 0) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -379,13 +422,19 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
   // group table (compile-time after unrolling): block, output row, kernel row of group g
   auto g_block = [](int g) { return g < 3 ? g : (g < 9 ? 3 + (g - 3) / 2 : (g < 15 ? 6 + (g - 9) / 2 : 9 + (g - 15))); };
   auto g_out = [](int g) { return g < 3 ? 0 : (g < 15 ? (g - 3) & 1 : 1); };
-  auto read_B1 = [&](int g, int k) {  // k-th (0 .. 3 NT - 1) 16-byte fragment of group g's tap (dy, dx)
+  auto read_B1 = [&](int g, int k) {  // k-th (0 .. PL NT - 1) 16-byte fragment of group g's tap (dy, dx)
     const int b = g_block(g), dy = b / 3 - g_out(g), dx = b % 3;
-    bw[g & 1][k / 3][k % 3] = ldsq[w_lane + (((dy * 3 + dx) * NT) * 3 + k) * 64];
+    bw[g & 1][k / PL][k % PL] = ldsq[w_lane + (((dy * 3 + dx) * NT) * PL + k) * 64];
   };
   // MFMA t (0 .. 6 NT - 1) of group g: term t / NT of cout tile t % NT (smallest terms first; the accumulators alternate)
   auto mma1 = [&](int g, int t) {
     const int s = g_block(g) & 1, o = g_out(g), nt = t % NT, term = t / NT;
+    if constexpr (PL == 2) {  // al bh, ah bl -> acl; ah bh -> acc
+      const f16x8 a = __builtin_bit_cast(f16x8, pl[s][term == 0 ? 1 : 0]), b = __builtin_bit_cast(f16x8, bw[g & 1][nt][term == 1 ? 1 : 0]);
+      if (term < 2) acl[o][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acl[o][nt], 0, 0, 0);
+      else acc[o][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[o][nt], 0, 0, 0);
+      return;
+    }
     constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};  // al bh, ah bl, am bm, am bh, ah bm, ah bh
 #ifdef DRBA_EXP_NOMFMA  // experiment (wrong results): operands consumed by one VALU instruction instead of the MFMA
     acc[o][nt][term & 3] += __uint_as_float(pl[s][ia[term]][term & 3] ^ bw[g & 1][nt][ib[term]][term & 3]);
@@ -409,16 +458,16 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-      for (int c = 0; c < NT; ++c) acc[o][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < NT; ++c) acc[o][c] = acl[o][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // head: the first two blocks' reads, the first split, the first fragments
     read_raw(ab, 0, 0, 8);
     read_raw(ab, 1, 0, 8);
 #pragma unroll
-    for (int k = 0; k < 3 * NT; ++k) read_B1(0, k);
+    for (int k = 0; k < PL * NT; ++k) read_B1(0, k);
 #pragma unroll
-    for (int q = 0; q < 11; ++q) split_group(0, q);
+    for (int q = 0; q < NSPLIT; ++q) split_group(0, q);
     DRBA_CLK(t2);
-    // 18 groups x 12 slots: [MFMA, 4 split instructions of the next block, one LDS read]
+    // 18 groups x NM (12 / 6) slots: [MFMA, 4 split instructions of the next block, one LDS read]
     static_for<18>([&](auto G) {
       constexpr int g = decltype(G)::value;
       constexpr int b = g < 3 ? g : (g < 9 ? 3 + (g - 3) / 2 : (g < 15 ? 6 + (g - 9) / 2 : 9 + (g - 15)));
@@ -432,23 +481,24 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
         if (wave >= 4) __builtin_amdgcn_s_setprio(0);
       }
 #endif
-      static_for<6 * NT>([&](auto T) {
+      static_for<NM>([&](auto T) {
         constexpr int t = decltype(T)::value;
         __builtin_amdgcn_sched_barrier(0);
         mma1(g, t);
-        // split of block b + 1: 11 groups over the 12 slots of a one-group block, over the even slots of a two-group one
+        // split of block b + 1: its NSPLIT groups over the slots of a one-group block, over the even slots of a two-group one
         if constexpr (b + 1 < 12) {
           if constexpr (!two) {
-            if constexpr (t < 11) split_group(b + 1, t);
+            if constexpr (t < NSPLIT) split_group(b + 1, t);
           } else if constexpr ((t & 1) == 0) {
-            constexpr int q = (first ? 0 : 6) + (t >> 1);
-            if constexpr (q < 11) split_group(b + 1, q);
+            constexpr int q = (first ? 0 : NM / 2) + (t >> 1);
+            if constexpr (q < NSPLIT) split_group(b + 1, q);
           }
         }
         // LDS reads: the raw dwords of block b + 2 (two per slot, slots 0..3 of the block's first group) ...
         if constexpr (first && b + 2 < 12 && t < 4) read_raw(ab, b + 2, 2 * t, 2 * t + 2);
-        // ... and the next group's weight fragments (slots 4 .. 4 + 3 NT - 1)
-        if constexpr (g + 1 < 18 && t >= 4 && t - 4 < 3 * NT) read_B1(g + 1, t - 4);
+        // ... and the next group's weight fragments (slots B0 .. B0 + PL NT - 1)
+        constexpr int B0 = PL == 3 ? 4 : 2;
+        if constexpr (g + 1 < 18 && t >= B0 && t - B0 < PL * NT) read_B1(g + 1, t - B0);
       });
     });
     __builtin_amdgcn_sched_barrier(0);
@@ -475,6 +525,7 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
             const int co = nt * 16 + m, y = cur.y0 + 2 * rp + o;
             const unsigned off = (y < H && xb < W && co < Cout) ? (unsigned)(((co * H + y) * W + xb) * 4) : 0xffffffffu;
             f32x4 v = acc[o][nt], x1 = (f32x4){0.f, 0.f, 0.f, 0.f}, x2 = x1;
+            if constexpr (PL == 2) v = (v + acl[o][nt] * (1.f / 2048.f)) * (float)(1 << kSplitActShift);  // exact powers of two
             if (RL) {  // the layer's input IS the residual: channel co of the window, row 2 rp + o + 1, columns 4 + 16 mw + 4 kq ..
               x1 = *reinterpret_cast<const f32x4 *>(ldsf + ab * (A_BYTES / 4) + co * CS + (2 * rp + o + 1) * WC + 4 + 16 * mw + 4 * kq);
             } else if (res) {
@@ -527,11 +578,11 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
 }
 
 // ------------------------------------------------------------------------------------------ host side
-constexpr int kNum = 1;
+constexpr int kNum = 1;  // ids 0 .. kNum-1: three bf16 terms; kNum .. 2 kNum-1: the same kernel on two fp16 terms
 
-template <bool PRE, bool RL>
+template <bool PRE, bool RL, int PL>
 hipError_t lds_limit() {
-  return max_dynamic_lds(reinterpret_cast<const void *>(conv_dma1<PRE, RL>), LDS_BYTES);
+  return max_dynamic_lds(reinterpret_cast<const void *>(conv_dma1<PRE, RL, PL>), lds_bytes(PL));
 }
 
 // The work counters of a launch: 8 ints, one per XCD band, zero when the launch starts.  Two sets per (device, stream), used
@@ -573,6 +624,7 @@ void counters_commit(CounterSlot *sl) {
   sl->parity ^= 1u;
 }
 
+template <int PL>
 int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, const float *res2,
            float *out, int N, int H, int W, int Cout, int act, float post_slope, int pre_act, float pre_slope, hipStream_t s) {
   const int nbx = (W + TW - 1) / TW, nby = (H + TH - 1) / TH;
@@ -587,33 +639,19 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   if (!slot) return DRBA_ELAUNCH;
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
-    DRBA_LAUNCH(kernel, g, dim3(NTHREADS), LDS_BYTES, s, in, wf, bias, beta, res, res2, out, H, W, Cout, act, post_slope,
+    DRBA_LAUNCH(kernel, g, dim3(NTHREADS), lds_bytes(PL), s, in, wf, bias, beta, res, res2, out, H, W, Cout, act, post_slope,
                 pre_slope, nbx, nby, (int)total, counters, counters_next);
     if (hipPeekAtLastError() != hipSuccess) return DRBA_ELAUNCH;  // not issued: the sets keep their roles
     counters_commit(slot);
     return DRBA_OK;
   };
   const bool rl = res && res == in && !res2 && !pre_act && Cout == CK;
-  const int rc = rl ? go(conv_dma1<false, true>, lds_limit<false, true>())
-                    : (pre_act ? go(conv_dma1<true, false>, lds_limit<true, false>()) : go(conv_dma1<false, false>, lds_limit<false, false>()));
+  const int rc = rl ? go(conv_dma1<false, true, PL>, lds_limit<false, true, PL>())
+                    : (pre_act ? go(conv_dma1<true, false, PL>, lds_limit<true, false, PL>())
+                               : go(conv_dma1<false, false, PL>, lds_limit<false, false, PL>()));
   if (rc != DRBA_OK) return rc;
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
-}
-
-static inline float bf16_round(float x) {  // round-to-nearest-even fp32 -> bf16 (finite inputs), as the fp32 value it represents
-  unsigned u;
-  memcpy(&u, &x, 4);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  u &= 0xffff0000u;
-  float r;
-  memcpy(&r, &u, 4);
-  return r;
-}
-static inline unsigned short bf16_bits(float exact) {
-  unsigned u;
-  memcpy(&u, &exact, 4);
-  return (unsigned short)(u >> 16);
 }
 
 }  // namespace drba_conv_dma
@@ -621,21 +659,24 @@ static inline unsigned short bf16_bits(float exact) {
 namespace drba {
 
 int conv_dma_num_cfgs() { return drba_conv_dma::kNum; }
+int conv_dma_f16_first() { return drba_conv_dma::kNum; }
+static int planes_of(int id) { return id < drba_conv_dma::kNum ? 3 : 2; }
 
 bool conv_dma_supports(int Cin, int Cout, int id) {
-  return id >= 0 && id < drba_conv_dma::kNum && Cin == drba_conv_dma::CK && Cout > 0 && Cout <= drba_conv_dma::NTC;
+  return id >= 0 && id < 2 * drba_conv_dma::kNum && Cin == drba_conv_dma::CK && Cout > 0 && Cout <= drba_conv_dma::NTC;
 }
 
 size_t conv_dma_packed_floats(int Cin, int Cout, int id) {
-  return conv_dma_supports(Cin, Cout, id) ? (size_t)drba_conv_dma::W_BYTES / 4 : 0;
+  return conv_dma_supports(Cin, Cout, id) ? (size_t)drba_conv_dma::w_bytes(planes_of(id)) / 4 : 0;
 }
 
-// packed (16-byte units): [dy][dx][nt][plane h/m/l][lane] = 8 bf16, element i =
+// packed (16-byte units): [dy][dx][nt][plane h/m/l or h/l][lane] = 8 x 16 bit (split_weight_terms), element i =
 //   w[nt*16 + (lane & 15)][4*i + (lane >> 4)][3*dy + dx], zero outside Cout
 int conv_dma_pack(const float *w, float *packed, int Cin, int Cout, int id) {
   using namespace drba_conv_dma;
   if (!w || !packed || !conv_dma_supports(Cin, Cout, id)) return DRBA_EINVAL;
-  memset(packed, 0, W_BYTES);
+  const int PL = planes_of(id);
+  memset(packed, 0, w_bytes(PL));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   for (int tap = 0; tap < 9; ++tap)
     for (int nt = 0; nt < NT; ++nt)
@@ -644,12 +685,11 @@ int conv_dma_pack(const float *w, float *packed, int Cin, int Cout, int id) {
         if (co >= Cout) continue;
         for (int i = 0; i < 8; ++i) {
           const int ci = 4 * i + (lane >> 4);
-          const float x = w[((size_t)co * Cin + ci) * 9 + tap];
-          const float h = bf16_round(x), m = bf16_round(x - h), l = bf16_round(x - h - m);
-          const float term[3] = {h, m, l};
-          for (int pl = 0; pl < 3; ++pl) {
-            const size_t unit = ((size_t)tap * NT + nt) * 3 + pl;
-            dst[(unit * 64 + lane) * 8 + i] = bf16_bits(term[pl]);
+          unsigned short term[3];
+          split_weight_terms(w[((size_t)co * Cin + ci) * 9 + tap], PL, term);
+          for (int pl = 0; pl < PL; ++pl) {
+            const size_t unit = ((size_t)tap * NT + nt) * PL + pl;
+            dst[(unit * 64 + lane) * 8 + i] = term[pl];
           }
         }
       }
@@ -663,8 +703,10 @@ int conv_dma_launch(int id, const float *in, const float *packed_w, const float 
   if (!conv_dma_supports(Cin, Cout, id)) return DRBA_EUNSUPPORTED;
   if ((W & 3) != 0) return DRBA_EUNSUPPORTED;  // the window moves in 16-byte units
   if ((size_t)Cin * H * W * 4 >= (1ull << 31) - 64) return DRBA_EUNSUPPORTED;  // 32-bit byte offsets inside an image, below kOOB
-  return launch(in, packed_w, bias, beta, residual, residual2, out, N, H, W, Cout, act, post_slope, pre_act, pre_slope,
-                (hipStream_t)stream);
+  return planes_of(id) == 3 ? launch<3>(in, packed_w, bias, beta, residual, residual2, out, N, H, W, Cout, act, post_slope, pre_act,
+                                        pre_slope, (hipStream_t)stream)
+                            : launch<2>(in, packed_w, bias, beta, residual, residual2, out, N, H, W, Cout, act, post_slope, pre_act,
+                                        pre_slope, (hipStream_t)stream);
 }
 
 }  // namespace drba

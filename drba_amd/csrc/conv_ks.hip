@@ -34,11 +34,13 @@ namespace drba_conv_ks {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lds_ptr;
 
 constexpr int CK = 32, NT = 2, NTC = 32;
-constexpr int FRAG_U4 = 9 * NT * 3 * 64;  // 16-byte units of packed weights per (cout tile, chunk)
+// PL = 16-bit terms per operand: 3 = bf16 h + m + l, 2 = the two-term fp16 form (conv_split.hip "Two-term form")
+constexpr int frag_u4(int PL) { return 9 * NT * PL * 64; }  // 16-byte units of packed weights per (cout tile, chunk)
 [[maybe_unused]] constexpr unsigned kOOB = 0x7FFFFFF0u;
 
 template <class F, int... I>
@@ -62,7 +64,7 @@ struct Geo {
   static_assert(CS % 32 == 16 && CS >= 4 * WCOL && (A_DW * 4) % (64 * UNIT) == 0, "window layout");
 };
 
-template <int KW, bool PRE, bool RL, bool DW>
+template <int KW, bool PRE, bool RL, bool DW, int PL = 3>
 __global__ void __launch_bounds__(KW * 64)
 conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
         const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2, float *__restrict__ out,
@@ -70,6 +72,7 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = Geo<DW>;
   constexpr int CS = G::CS, WCOL = G::WCOL;
+  constexpr int NM = (PL == 3 ? 6 : 3) * NT, NSPLIT = PL == 3 ? 11 : 6, B0 = PL == 3 ? 4 : 2;  // conv_dma.hip
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [KW windows][KW x 4 partial accumulators]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = the chunk this wave contracts
@@ -103,18 +106,18 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
     }
   }
   // per-lane epilogue constants (cout nt*16 + m of the tile) and the first weight fragments ride under the window's latency
-  const u32x4 *wq = wfrag + ((size_t)cz * KW + wave) * FRAG_U4 + lane;
+  const u32x4 *wq = wfrag + ((size_t)cz * KW + wave) * frag_u4(PL) + lane;
 
-  f32x4 acc[2][NT];
+  f32x4 acc[2][NT], acl[2][NT];  // acl (PL = 2): the h*l + l*h products, weight 2^-11
   float rawr[2][8];
-  u32x4 pl[2][3];
-  constexpr int D = 3;  // weight fragments are requested D - 1 groups ahead of their MFMAs (an L2 round trip ~ 2 groups)
-  u32x4 bw[D][NT][3];
+  u32x4 pl[2][PL];
+  constexpr int D = PL == 3 ? 3 : 4;  // weight fragments are requested D - 1 groups ahead of their MFMAs (an L2 round trip ~ 2 bf16 groups)
+  u32x4 bw[D][NT][PL];
   float sa[4], sb[4], ta[4], tb[4];
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
-    for (int c = 0; c < NT; ++c) acc[o][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NT; ++c) acc[o][c] = acl[o][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // Blocks b = 0..11: window row ir = b / 3, tap column dx = b % 3; block b feeds the output rows o with 0 <= ir - o <= 2
   // (kernel row dy = ir - o): 18 MFMA groups of 12 (conv_dma.hip).
@@ -133,7 +136,42 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
   auto split_group = [&](int b, int q) {  // group q (0..10) of the split of block b (conv_dma.hip)
     const int s = b & 1;
     auto unpack = [&](const u32x4 &v, int p) { ta[p] = __uint_as_float(v[p] << 16), tb[p] = __uint_as_float(v[p] & 0xffff0000u); };
-    if (q == 0) {
+    if constexpr (PL == 2) {  // two-term fp16 form, 6 groups (conv_dma.hip)
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      auto pkh = [](float x, float y) -> unsigned {
+        return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x, y}, f16x2));
+      };
+      auto unpackh = [&](int p) {
+        const unsigned u = pl[s][0][p];  // (through a scalar: bit_cast of a vector ELEMENT reads element 0 with hipcc 7.2)
+        const f16x2 hv = __builtin_bit_cast(f16x2, u);
+        ta[p] = (float)hv[0], tb[p] = (float)hv[1];
+      };
+      constexpr float kScale = 1.f / (float)(1 << kSplitActShift);
+      if (q == 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          sa[p] = rawr[s][2 * p], sb[p] = rawr[s][2 * p + 1];
+          if (PRE) {
+            sa[p] = sa[p] > 0.f ? sa[p] : sa[p] * pre_slope;
+            sb[p] = sb[p] > 0.f ? sb[p] : sb[p] * pre_slope;
+          }
+          sa[p] *= kScale, sb[p] *= kScale;
+          pl[s][0][p] = pkh(sa[p], sb[p]);
+        }
+      } else if (q == 1 || q == 2) {
+        unpackh(2 * (q - 1)), unpackh(2 * (q - 1) + 1);
+      } else if (q == 3) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sa[p] -= ta[p], sb[p] -= tb[p];
+      } else if (q == 4) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sa[p] *= 2048.f, sb[p] *= 2048.f;
+      } else if (q == 5) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) pl[s][1][p] = pkh(sa[p], sb[p]);
+      }
+    } else if (q == 0) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         sa[p] = rawr[s][2 * p], sb[p] = rawr[s][2 * p + 1];
@@ -163,12 +201,18 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
   };
   auto g_block = [](int g) { return g < 3 ? g : (g < 9 ? 3 + (g - 3) / 2 : (g < 15 ? 6 + (g - 9) / 2 : 9 + (g - 15))); };
   auto g_out = [](int g) { return g < 3 ? 0 : (g < 15 ? (g - 3) & 1 : 1); };
-  auto load_B1 = [&](int g, int k) {  // k-th (0 .. 3 NT - 1) fragment of group g's tap (dy, dx): one 16-byte load from L2
+  auto load_B1 = [&](int g, int k) {  // k-th (0 .. PL NT - 1) fragment of group g's tap (dy, dx): one 16-byte load from L2
     const int b = g_block(g), dy = b / 3 - g_out(g), dx = b % 3;
-    bw[g % D][k / 3][k % 3] = wq[(((dy * 3 + dx) * NT) * 3 + k) * 64];
+    bw[g % D][k / PL][k % PL] = wq[(((dy * 3 + dx) * NT) * PL + k) * 64];
   };
   auto mma1 = [&](int g, int tt) {
     const int s = g_block(g) & 1, o = g_out(g), nt = tt % NT, term = tt / NT;
+    if constexpr (PL == 2) {  // al bh, ah bl -> acl; ah bh -> acc
+      const f16x8 a = __builtin_bit_cast(f16x8, pl[s][term == 0 ? 1 : 0]), b = __builtin_bit_cast(f16x8, bw[g % D][nt][term == 1 ? 1 : 0]);
+      if (term < 2) acl[o][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acl[o][nt], 0, 0, 0);
+      else acc[o][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[o][nt], 0, 0, 0);
+      return;
+    }
     constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};  // al bh, ah bl, am bm, am bh, ah bm, ah bh
     acc[o][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pl[s][ia[term]]),
                                                          __builtin_bit_cast(bf16x8, bw[g % D][nt][ib[term]]), acc[o][nt], 0, 0, 0);
@@ -178,7 +222,7 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
 #pragma unroll
   for (int g = 0; g < D - 1; ++g)
 #pragma unroll
-    for (int k = 0; k < 3 * NT; ++k) load_B1(g, k);
+    for (int k = 0; k < PL * NT; ++k) load_B1(g, k);
   // (separate scalars, not arrays: the epilogue picks by a runtime cout tile, and a dynamically indexed array goes to scratch)
   const int co0 = cz * NTC + m, co1 = co0 + 16;
   const float bs0 = (bias && co0 < Cout) ? bias[co0] : 0.f, bs1 = (bias && co1 < Cout) ? bias[co1] : 0.f;
@@ -187,27 +231,27 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
   read_raw(0, 0, 8);
   read_raw(1, 0, 8);
 #pragma unroll
-  for (int q = 0; q < 11; ++q) split_group(0, q);
+  for (int q = 0; q < NSPLIT; ++q) split_group(0, q);
 
   static_for<18>([&](auto GG) {
     constexpr int g = decltype(GG)::value;
     constexpr int b = g < 3 ? g : (g < 9 ? 3 + (g - 3) / 2 : (g < 15 ? 6 + (g - 9) / 2 : 9 + (g - 15)));
     constexpr bool two = b >= 3 && b < 9;
     constexpr bool first = !two || ((g - 3) & 1) == 0;
-    static_for<6 * NT>([&](auto T) {
+    static_for<NM>([&](auto T) {
       constexpr int tt = decltype(T)::value;
       __builtin_amdgcn_sched_barrier(0);
       mma1(g, tt);
       if constexpr (b + 1 < 12) {
         if constexpr (!two) {
-          if constexpr (tt < 11) split_group(b + 1, tt);
+          if constexpr (tt < NSPLIT) split_group(b + 1, tt);
         } else if constexpr ((tt & 1) == 0) {
-          constexpr int q = (first ? 0 : 6) + (tt >> 1);
-          if constexpr (q < 11) split_group(b + 1, q);
+          constexpr int q = (first ? 0 : NM / 2) + (tt >> 1);
+          if constexpr (q < NSPLIT) split_group(b + 1, q);
         }
       }
       if constexpr (first && b + 2 < 12 && tt < 4) read_raw(b + 2, 2 * tt, 2 * tt + 2);
-      if constexpr (g + D - 1 < 18 && tt >= 4 && tt - 4 < 3 * NT) load_B1(g + D - 1, tt - 4);
+      if constexpr (g + D - 1 < 18 && tt >= B0 && tt - B0 < PL * NT) load_B1(g + D - 1, tt - B0);
     });
   });
   __builtin_amdgcn_sched_barrier(0);
@@ -217,7 +261,10 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) red[(wave * 4 + o * 2 + nt) * 64 + lane] = acc[o][nt];
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (PL == 2) acc[o][nt] = (acc[o][nt] + acl[o][nt] * (1.f / 2048.f)) * (float)(1 << kSplitActShift);  // exact powers of two
+      red[(wave * 4 + o * 2 + nt) * 64 + lane] = acc[o][nt];
+    }
   __syncthreads();
 
   // ---- epilogue, shared by the waves: accumulator (o, nt) = c is finished by wave c % KW.  y = sum + bias; ResConv:
@@ -286,15 +333,15 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
 }
 
 // ------------------------------------------------------------------------------------------ host side
-constexpr int kNum = 1;
+constexpr int kNum = 1;  // ids 0 .. kNum-1: three bf16 terms; kNum .. 2 kNum-1: two fp16 terms
 
-template <int KW, bool PRE, bool RL, bool DW>
+template <int KW, bool PRE, bool RL, bool DW, int PL>
 hipError_t lds_limit(int bytes) {
   (void)bytes;
-  return max_dynamic_lds(reinterpret_cast<const void *>(conv_ks<KW, PRE, RL, DW>), 160 * 1024);
+  return max_dynamic_lds(reinterpret_cast<const void *>(conv_ks<KW, PRE, RL, DW, PL>), 160 * 1024);
 }
 
-template <int KW>
+template <int KW, int PL>
 int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, const float *res2,
            float *out, int N, int H, int W, int Cout, int act, float post_slope, int pre_act, float pre_slope, hipStream_t s) {
   const int n_ct = (Cout + NTC - 1) / NTC, ncb = (W + 15) / 16, nrp = (H + 1) / 2;
@@ -312,7 +359,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   };
   const bool rl = res && res == in && !res2 && !pre_act && Cout == KW * CK;
   int rc;
-#define DRBA_GO(PRE_, RL_, DW_) go(conv_ks<KW, PRE_, RL_, DW_>, lds_limit<KW, PRE_, RL_, DW_>(lds_bytes))
+#define DRBA_GO(PRE_, RL_, DW_) go(conv_ks<KW, PRE_, RL_, DW_, PL>, lds_limit<KW, PRE_, RL_, DW_, PL>(lds_bytes))
   if (dw) rc = rl ? DRBA_GO(false, true, true) : (pre_act ? DRBA_GO(true, false, true) : DRBA_GO(false, false, true));
   else rc = rl ? DRBA_GO(false, true, false) : (pre_act ? DRBA_GO(true, false, false) : DRBA_GO(false, false, false));
 #undef DRBA_GO
@@ -321,44 +368,31 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   return DRBA_OK;
 }
 
-static inline float bf16_round(float x) {  // round-to-nearest-even fp32 -> bf16 (finite inputs), as the fp32 value it represents
-  unsigned u;
-  memcpy(&u, &x, 4);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  u &= 0xffff0000u;
-  float r;
-  memcpy(&r, &u, 4);
-  return r;
-}
-static inline unsigned short bf16_bits(float exact) {
-  unsigned u;
-  memcpy(&u, &exact, 4);
-  return (unsigned short)(u >> 16);
-}
-
 }  // namespace drba_conv_ks
 
 namespace drba {
 
 int conv_ks_num_cfgs() { return drba_conv_ks::kNum; }
+int conv_ks_f16_first() { return drba_conv_ks::kNum; }
+static int ks_planes(int id) { return id < drba_conv_ks::kNum ? 3 : 2; }
 
 bool conv_ks_supports(int Cin, int Cout, int id) {
   const int kw = Cin / drba_conv_ks::CK;
-  return id >= 0 && id < drba_conv_ks::kNum && Cout > 0 && Cin % drba_conv_ks::CK == 0 && (kw == 2 || kw == 3 || kw == 4 || kw == 6);
+  return id >= 0 && id < 2 * drba_conv_ks::kNum && Cout > 0 && Cin % drba_conv_ks::CK == 0 && (kw == 2 || kw == 3 || kw == 4 || kw == 6);
 }
 
 size_t conv_ks_packed_floats(int Cin, int Cout, int id) {
   if (!conv_ks_supports(Cin, Cout, id)) return 0;
   const size_t n_ct = (Cout + drba_conv_ks::NTC - 1) / drba_conv_ks::NTC, nch = Cin / drba_conv_ks::CK;
-  return n_ct * nch * drba_conv_ks::FRAG_U4 * 4;
+  return n_ct * nch * drba_conv_ks::frag_u4(ks_planes(id)) * 4;
 }
 
-// packed (16-byte units): [cout tile][chunk][dy][dx][nt][plane h/m/l][lane] = 8 bf16, element i =
+// packed (16-byte units): [cout tile][chunk][dy][dx][nt][plane h/m/l or h/l][lane] = 8 x 16 bit (split_weight_terms), element i =
 //   w[cz*32 + nt*16 + (lane & 15)][q*32 + 4*i + (lane >> 4)][3*dy + dx], zero outside Cout
 int conv_ks_pack(const float *w, float *packed, int Cin, int Cout, int id) {
   using namespace drba_conv_ks;
   if (!w || !packed || !conv_ks_supports(Cin, Cout, id)) return DRBA_EINVAL;
-  const int n_ct = (Cout + NTC - 1) / NTC, nch = Cin / CK;
+  const int n_ct = (Cout + NTC - 1) / NTC, nch = Cin / CK, PL = ks_planes(id);
   memset(packed, 0, sizeof(float) * conv_ks_packed_floats(Cin, Cout, id));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   for (int cz = 0; cz < n_ct; ++cz)
@@ -370,12 +404,11 @@ int conv_ks_pack(const float *w, float *packed, int Cin, int Cout, int id) {
             if (co >= Cout) continue;
             for (int i = 0; i < 8; ++i) {
               const int ci = q * CK + 4 * i + (lane >> 4);
-              const float x = w[((size_t)co * Cin + ci) * 9 + tap];
-              const float h = bf16_round(x), m = bf16_round(x - h), l = bf16_round(x - h - m);
-              const float term[3] = {h, m, l};
-              for (int pl = 0; pl < 3; ++pl) {
-                const size_t unit = ((((size_t)cz * nch + q) * 9 + tap) * NT + nt) * 3 + pl;
-                dst[(unit * 64 + lane) * 8 + i] = bf16_bits(term[pl]);
+              unsigned short term[3];
+              split_weight_terms(w[((size_t)co * Cin + ci) * 9 + tap], PL, term);
+              for (int pl = 0; pl < PL; ++pl) {
+                const size_t unit = ((((size_t)cz * nch + q) * 9 + tap) * NT + nt) * PL + pl;
+                dst[(unit * 64 + lane) * 8 + i] = term[pl];
               }
             }
           }
@@ -390,9 +423,11 @@ int conv_ks_launch(int id, const float *in, const float *packed_w, const float *
   if ((size_t)Cin * H * W * 4 >= (1ull << 31) - 64) return DRBA_EUNSUPPORTED;  // 32-bit byte offsets inside an image, below kOOB
   if ((size_t)Cout * H * W * 4 >= (1ull << 31) - 64) return DRBA_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-#define DRBA_CASE(K) \
-  case K:            \
-    return launch<K>(in, packed_w, bias, beta, residual, residual2, out, N, H, W, Cout, act, post_slope, pre_act, pre_slope, s);
+#define DRBA_CASE(K)                                                                                                          \
+  case K:                                                                                                                     \
+    return ks_planes(id) == 3                                                                                                 \
+               ? launch<K, 3>(in, packed_w, bias, beta, residual, residual2, out, N, H, W, Cout, act, post_slope, pre_act, pre_slope, s) \
+               : launch<K, 2>(in, packed_w, bias, beta, residual, residual2, out, N, H, W, Cout, act, post_slope, pre_act, pre_slope, s);
   switch (Cin / CK) {
     DRBA_CASE(2)
     DRBA_CASE(3)

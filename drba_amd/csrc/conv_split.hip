@@ -31,25 +31,27 @@ namespace drba_conv_split {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 32;  // channels per chunk = the K of one bf16 MFMA
 
 // MODE 0: conv3x3 stride 1.  MODE 1: one row phase py (both column phases px) of ConvTranspose2d(k=4, s=2, p=1), a
 // 2x2-tap convolution over the same haloed window (tap offsets and phase algebra as in conv.hip).
-template <int MODE_, int RW_, int MW_, int NT_>
+// PL = 3: the three-term bf16 split above.  PL = 2: the two-term fp16 split (header comment "Two-term form").
+template <int MODE_, int RW_, int MW_, int NT_, int PL_ = 3>
 struct SplitCfg {
-  static constexpr int MODE = MODE_, RW = RW_, MW = MW_, NT = NT_;
+  static constexpr int MODE = MODE_, RW = RW_, MW = MW_, NT = NT_, PL = PL_;
   static constexpr int NTAP = MODE == 0 ? 9 : 4, NPX = MODE == 0 ? 1 : 2;
   static constexpr int TH = 4 * RW, TW = 16 * MW, NTC = 16 * NT;
   static constexpr int TR = TH + 2, TC = TW + 2, NPIX = TR * TC;
-  // LDS: [plane 3][group 4][NPIXP][8 bf16]; NPIXP*16 bytes == 64 (mod 256) spreads the four channel groups of a wave
+  // LDS: [plane PL][group 4][NPIXP][8 x 16 bit]; NPIXP*16 bytes == 64 (mod 256) spreads the four channel groups of a wave
   // read over distinct banks
   static constexpr int NPIXP = ((NPIX + 15) / 16) * 16 + 4;
-  static constexpr int LDS_BYTES = 3 * 4 * NPIXP * 16;
+  static constexpr int LDS_BYTES = PL * 4 * NPIXP * 16;
   static constexpr int ITEMS = NPIX * 4;                 // (pixel, channel group) staging items per chunk
   static constexpr int LIT = (ITEMS + 255) / 256;        // per thread
-  static constexpr int FRAG_U4 = NTAP * NT * 3 * 64;     // 16-byte units of packed weights per (cout tile[, phase], chunk)
+  static constexpr int FRAG_U4 = NTAP * NT * PL * 64;    // 16-byte units of packed weights per (cout tile[, phase], chunk)
 #ifndef DRBA_SPLIT_BDEPTH_BIG
 #define DRBA_SPLIT_BDEPTH_BIG 2
 #endif
@@ -58,7 +60,7 @@ struct SplitCfg {
 #define DRBA_SPLIT_MINB3 1
 #endif
   // workgroups per CU the register allocation aims at: the 4x32x32 tile needs 170 registers, two short of three per CU
-  static constexpr int MINB = (DRBA_SPLIT_MINB3 && MODE == 0 && RW * MW * NT <= 4) ? 3 : 2;
+  static constexpr int MINB = (DRBA_SPLIT_MINB3 && MODE == 0 && RW * MW * NT <= 4 && PL == 3) ? 3 : 2;
 };
 
 // fp32 -> (h, m, l) bf16 with round-to-nearest-even at every step; returns the three terms of 2 values packed
@@ -73,6 +75,25 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &h, unsigned &
   const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
   m = pk(ra, rb);
   l = pk(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
+
+// Two-term form (PL = 2): x * 2^-kActShift = h + 2^-11 * l with h = fp16(x'), l = fp16((x' - h) * 2^11): the remainder is
+// exact in fp32 (13 bits), l keeps 11 of them, so h + 2^-11 l carries 22 bits of x (relative error <= 2^-22; values
+// below fp16's normal range keep an absolute error <= 2^-25 * 2^kActShift whether or not denormals are flushed, because
+// the remainder then holds the whole value).  l is kept scaled by 2^11 so that it sits in fp16's normal range; the
+// products therefore go to two accumulators -- h*h, and (h*l + l*h) whose weight is 2^-11 -- joined in the epilogue.
+// l*l (2^-22 of the product) is dropped.  Three v_mfma_f32_16x16x32_f16 per fragment pair instead of six bf16 ones.
+// The activations are pre-scaled by 2^-kActShift (undone exactly in the epilogue): finite up to 65504 * 2^kActShift.
+constexpr int kActShift = drba::kSplitActShift;
+__device__ __forceinline__ void split2_f16(float a, float b, unsigned &h, unsigned &l) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = (f32x2){a, b} * (1.f / (float)(1 << kActShift));
+  const f16x2 hh = __builtin_convertvector(v, f16x2);
+  const f32x2 r = (v - __builtin_convertvector(hh, f32x2)) * 2048.f;
+  const f16x2 ll = __builtin_convertvector(r, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, ll);
 }
 
 struct TileCtx {
@@ -115,7 +136,8 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MODE = Cfg::MODE, NTAP = Cfg::NTAP, NPX = Cfg::NPX;
   constexpr int RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, TH = Cfg::TH, TW = Cfg::TW, TC = Cfg::TC;
-  constexpr int NPIX = Cfg::NPIX, NPIXP = Cfg::NPIXP, LIT = Cfg::LIT;
+  constexpr int NPIX = Cfg::NPIX, NPIXP = Cfg::NPIXP, LIT = Cfg::LIT, PL = Cfg::PL;
+  static_assert(PL == 3 || !RL, "the residual is rebuilt exactly only from the three bf16 planes");
   extern __shared__ __attribute__((aligned(16))) u32x4 tile[];  // [plane][group][NPIXP]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -184,13 +206,14 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
           a = a > 0.f ? a : a * pre_slope;
           b = b > 0.f ? b : b * pre_slope;
         }
-        unsigned hh, hm, hl;
-        split2(a, b, hh, hm, hl);
+        unsigned hh, hm = 0, hl;
+        if constexpr (PL == 3) split2(a, b, hh, hm, hl);
+        else split2_f16(a, b, hh, hl);
         h[i] = hh, mm[i] = hm, l[i] = hl;
       }
       tile[slot] = h;
-      tile[4 * NPIXP + slot] = mm;
-      tile[8 * NPIXP + slot] = l;
+      if constexpr (PL == 3) tile[4 * NPIXP + slot] = mm;
+      tile[4 * (PL - 1) * NPIXP + slot] = l;
     }
   };
 
@@ -213,6 +236,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   fetch(ctx, first_chunk(ctx));
   while (true) {
     f32x4 acc[NPX][RW][MW][NT];
+    f32x4 acl[PL == 2 ? NPX : 1][RW][MW][NT];  // PL = 2: the sum of the h*l + l*h products (weight 2^-11)
 #pragma unroll
     for (int p = 0; p < NPX; ++p)
 #pragma unroll
@@ -220,7 +244,10 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 #pragma unroll
         for (int b = 0; b < MW; ++b)
 #pragma unroll
-          for (int c = 0; c < NT; ++c) acc[p][a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int c = 0; c < NT; ++c) {
+            acc[p][a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (PL == 2) acl[p][a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
     const int next = work + (int)gridDim.x;
     TileCtx nctx = ctx;
     if (next < total) nctx = decode(next);
@@ -253,13 +280,13 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       const int px_bytes = nchunks * (Cfg::FRAG_U4 * 16);
       auto wload = [&](int step, int pl) -> u32x4 {
         const int p = step / (NTAP * NT), r = step - p * (NTAP * NT);  // r = tap * NT + nt
-        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wq + p * px_bytes + (r * 3 + pl) * 1024, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wq + p * px_bytes + (r * PL + pl) * 1024, 0);
       };
-      u32x4 bw[D][3];
+      u32x4 bw[D][PL];
 #pragma unroll
       for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bw[d][pl] = wload(d, pl);
+        for (int pl = 0; pl < PL; ++pl) bw[d][pl] = wload(d, pl);
       DRBA_CLK(c_s0);
       lds_barrier();  // every wave is done reading the previous chunk
       stage();
@@ -280,14 +307,14 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       // -- half the registers of a whole-slot double buffer (48 instead of 96 for the 8x32 tile, which spilled).
       // Transposed conv, tap = 2a + b: window row rw + dro[a] with dro = {1, 0} (py = 0) / {2, 1} (py = 1), window
       // column x + dco[px][b] with dco = {{1, 0}, {2, 1}} (conv.hip).
-      u32x4 af[RW][MW][3];
+      u32x4 af[RW][MW][PL];
       auto load_piece = [&](int ts, int rw, int mw) {
         const int p = ts / NTAP, tap = ts - p * NTAP;
         const int ro = MODE == 0 ? tap / 3 : ((tap >> 1) ? 0 : 1) + ctx.py;
         const int co = MODE == 0 ? tap % 3 : ((tap & 1) ? 0 : 1) + p;
         const int slot = kq * NPIXP + (row0 + rw + ro) * TC + mw * 16 + m + co;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[rw][mw][pl] = tile[4 * pl * NPIXP + slot];
+        for (int pl = 0; pl < PL; ++pl) af[rw][mw][pl] = tile[4 * pl * NPIXP + slot];
       };
 #pragma unroll
       for (int rw = 0; rw < RW; ++rw)
@@ -299,24 +326,34 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int step = ts * NT + nt;
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[step % D][0]);
-          const bf16x8 bm = __builtin_bit_cast(bf16x8, bw[step % D][1]);
-          const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[step % D][2]);
 #pragma unroll
           for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
             for (int mw = 0; mw < MW; ++mw) {
-              const bf16x8 ah = __builtin_bit_cast(bf16x8, af[rw][mw][0]);
-              const bf16x8 am = __builtin_bit_cast(bf16x8, af[rw][mw][1]);
-              const bf16x8 al = __builtin_bit_cast(bf16x8, af[rw][mw][2]);
-              f32x4 c = acc[p][rw][mw][nt];
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);  // smallest terms first
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-              acc[p][rw][mw][nt] = c;
+              if constexpr (PL == 3) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[step % D][0]);
+                const bf16x8 bm = __builtin_bit_cast(bf16x8, bw[step % D][1]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[step % D][PL - 1]);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, af[rw][mw][0]);
+                const bf16x8 am = __builtin_bit_cast(bf16x8, af[rw][mw][1]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, af[rw][mw][PL - 1]);
+                f32x4 c = acc[p][rw][mw][nt];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);  // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                acc[p][rw][mw][nt] = c;
+              } else {
+                const f16x8 bh = __builtin_bit_cast(f16x8, bw[step % D][0]), bl = __builtin_bit_cast(f16x8, bw[step % D][1]);
+                const f16x8 ah = __builtin_bit_cast(f16x8, af[rw][mw][0]), al = __builtin_bit_cast(f16x8, af[rw][mw][1]);
+                f32x4 c = acl[p][rw][mw][nt];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+                acl[p][rw][mw][nt] = c;
+                acc[p][rw][mw][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[p][rw][mw][nt], 0, 0, 0);
+              }
 #ifndef DRBA_EXP_NOALOAD
               if (nt == NT - 1 && ts + 1 < NTS) load_piece(ts + 1, rw, mw);
 #endif
@@ -324,7 +361,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 #ifndef DRBA_EXP_NOWLOAD
           if (step + D < STEPS) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bw[step % D][pl] = wload(step + D, pl);
+            for (int pl = 0; pl < PL; ++pl) bw[step % D][pl] = wload(step + D, pl);
           }
 #endif
 
@@ -335,6 +372,17 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       DRBA_CLK_ADD(1, c_s1, c_m1);
     }
     DRBA_CLK(c_e0);
+    if constexpr (PL == 2) {  // join the two sums and undo the activation pre-scale (both exact powers of two)
+#pragma unroll
+      for (int p = 0; p < NPX; ++p)
+#pragma unroll
+        for (int a = 0; a < RW; ++a)
+#pragma unroll
+          for (int b = 0; b < MW; ++b)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+              acc[p][a][b][c] = (acc[p][a][b][c] + acl[p][a][b][c] * (1.f / 2048.f)) * (float)(1 << kActShift);
+    }
 
     // ---- epilogue (conv.hip MODE 0): y = acc + bias; ResConv: y = y*beta + res; otherwise y += res (+ res2); then
     // the post activation: act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10.  The activation is
@@ -583,15 +631,25 @@ constexpr int kNum = 5;
 using T0 = SplitCfg<1, 1, 2, 2>;  // transposed: 4x32 input px x 32 cout (both column phases)
 using T1 = SplitCfg<1, 1, 2, 4>;  // 4x32 x 64 (8x32 and 4x64 tiles need > 256 registers with two phases' accumulators)
 constexpr int kNumT = 2;
+// the same tiles in the two-term fp16 form: ids kNum.. / kNumT.. of this file, exposed by conv.hip as the LAST family of
+// the cfg tables (drba_conv3x3_cfg_family 4) so that a caller opts into them
+using F0 = SplitCfg<0, 1, 2, 2, 2>;
+using F1 = SplitCfg<0, 1, 2, 4, 2>;
+using F2 = SplitCfg<0, 1, 2, 6, 2>;
+using F3 = SplitCfg<0, 1, 4, 2, 2>;
+using F4 = SplitCfg<0, 2, 2, 2, 2>;
+using G0 = SplitCfg<1, 1, 2, 2, 2>;
+using G1 = SplitCfg<1, 1, 2, 4, 2>;
 struct Info {
-  int NT, NTC, frag_u4;
+  int NT, NTC, frag_u4, PL;
 };
 template <class C>
 constexpr Info info() {
-  return {C::NT, C::NTC, C::FRAG_U4};
+  return {C::NT, C::NTC, C::FRAG_U4, C::PL};
 }
-const Info kInfo[kNum] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>()};
-const Info kInfoT[kNumT] = {info<T0>(), info<T1>()};
+const Info kInfo[2 * kNum] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>(),
+                              info<F0>(), info<F1>(), info<F2>(), info<F3>(), info<F4>()};
+const Info kInfoT[2 * kNumT] = {info<T0>(), info<T1>(), info<G0>(), info<G1>()};
 
 template <class Cfg, bool PRE, bool RL = false>
 hipError_t lds_limit() {
@@ -621,7 +679,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
     return DRBA_OK;
   };
   int rc;
-  if constexpr (Cfg::MODE == 0 && Cfg::NTC == CK) {
+  if constexpr (Cfg::MODE == 0 && Cfg::NTC == CK && Cfg::PL == 3) {
     // ResConv shape (the residual is the layer's own input): rebuilt from the bf16 planes in LDS, no second read
     const bool rl = res && res == in && !res2 && !pre_act && Cin == Cout && (W & 3) == 0;
     rc = rl ? go(conv_split_mfma<Cfg, false, true>, lds_limit<Cfg, false, true>())
@@ -634,30 +692,16 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   return DRBA_OK;
 }
 
-// round-to-nearest-even fp32 -> bf16 (finite inputs), returned as the fp32 value it represents
-static inline float bf16_round(float x) {
-  unsigned u;
-  memcpy(&u, &x, 4);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  u &= 0xffff0000u;
-  float r;
-  memcpy(&r, &u, 4);
-  return r;
-}
-static inline unsigned short bf16_bits(float exact) {
-  unsigned u;
-  memcpy(&u, &exact, 4);
-  return (unsigned short)(u >> 16);
-}
-
 }  // namespace drba_conv_split
 
 namespace drba {
 
+// ids 0 .. kNum-1: three-term bf16; kNum .. 2*kNum-1: the same tiles in the two-term fp16 form
 int conv_split_num_cfgs() { return drba_conv_split::kNum; }
+int conv_split_f16_first() { return drba_conv_split::kNum; }
 
 bool conv_split_supports(int Cin, int Cout, int id) {
-  return id >= 0 && id < drba_conv_split::kNum && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
+  return id >= 0 && id < 2 * drba_conv_split::kNum && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
 }
 
 size_t conv_split_packed_floats(int Cin, int Cout, int id) {
@@ -685,12 +729,11 @@ int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id) {
             if (co >= Cout) continue;
             for (int i = 0; i < 8; ++i) {
               const int ci = q * CK + 8 * (lane >> 4) + i;
-              const float x = w[((size_t)co * Cin + ci) * 9 + tap];
-              const float h = bf16_round(x), m = bf16_round(x - h), l = bf16_round(x - h - m);
-              const float term[3] = {h, m, l};
-              for (int pl = 0; pl < 3; ++pl) {
-                const size_t unit = ((((size_t)cz * nch + q) * 9 + tap) * c.NT + nt) * 3 + pl;
-                dst[(unit * 64 + lane) * 8 + i] = bf16_bits(term[pl]);
+              unsigned short term[3];
+              split_weight_terms(w[((size_t)co * Cin + ci) * 9 + tap], c.PL, term);
+              for (int pl = 0; pl < c.PL; ++pl) {
+                const size_t unit = ((((size_t)cz * nch + q) * 9 + tap) * c.NT + nt) * c.PL + pl;
+                dst[(unit * 64 + lane) * 8 + i] = term[pl];
               }
             }
           }
@@ -715,6 +758,11 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
     DRBA_CASE(2, S2)
     DRBA_CASE(3, S3)
     DRBA_CASE(4, S4)
+    DRBA_CASE(5, F0)
+    DRBA_CASE(6, F1)
+    DRBA_CASE(7, F2)
+    DRBA_CASE(8, F3)
+    DRBA_CASE(9, F4)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;
@@ -723,8 +771,10 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
 // ---- transposed convolution (ConvTranspose2d k=4, s=2, p=1), cfg ids after conv.hip's fp32 deconv table
 int deconv_split_num_cfgs() { return drba_conv_split::kNumT; }
 
+int deconv_split_f16_first() { return drba_conv_split::kNumT; }
+
 bool deconv_split_supports(int Cin, int Cout, int id) {
-  return id >= 0 && id < drba_conv_split::kNumT && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
+  return id >= 0 && id < 2 * drba_conv_split::kNumT && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
 }
 
 size_t deconv_split_packed_floats(int Cin, int Cout, int id) {
@@ -757,12 +807,11 @@ int deconv_split_pack(const float *w, float *packed, int Cin, int Cout, int id) 
               if (co >= Cout) continue;
               for (int i = 0; i < 8; ++i) {
                 const int ci = q * CK + 8 * (lane >> 4) + i;
-                const float x = w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
-                const float h = bf16_round(x), m = bf16_round(x - h), l = bf16_round(x - h - m);
-                const float term[3] = {h, m, l};
-                for (int pl = 0; pl < 3; ++pl) {
-                  const size_t unit = ((((((size_t)cz * 4 + phase) * nch + q) * 4 + tap) * c.NT + nt) * 3 + pl);
-                  dst[(unit * 64 + lane) * 8 + i] = bf16_bits(term[pl]);
+                unsigned short term[3];
+                split_weight_terms(w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx], c.PL, term);
+                for (int pl = 0; pl < c.PL; ++pl) {
+                  const size_t unit = ((((((size_t)cz * 4 + phase) * nch + q) * 4 + tap) * c.NT + nt) * c.PL + pl);
+                  dst[(unit * 64 + lane) * 8 + i] = term[pl];
                 }
               }
             }
@@ -784,6 +833,8 @@ int deconv_split_launch(int id, const float *in, const float *packed_w, const fl
   switch (id) {
     DRBA_CASE(0, T0)
     DRBA_CASE(1, T1)
+    DRBA_CASE(2, G0)
+    DRBA_CASE(3, G1)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;

@@ -18,6 +18,7 @@
 //   Epilogue: + bias, then optionally the exact GELU (erf form, as nn.GELU()) or -- for the 128-feature layers, where
 //   a wave holds whole output rows -- LayerNorm(128) with its affine and the residual add.
 #include "common.hpp"
+#include "conv_split.hpp"
 
 #include <string.h>
 
@@ -29,6 +30,7 @@ namespace drba_linear {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 32;    // K per chunk = the K of one bf16 MFMA
@@ -45,17 +47,29 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &h, unsigned &
   l = pk(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
 }
 
+// two-term fp16 form (conv_split.hip "Two-term form"): x * 2^-shift = h + 2^-11 l
+__device__ __forceinline__ void split2_f16(float a, float b, unsigned &h, unsigned &l) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = (f32x2){a, b} * (1.f / (float)(1 << drba::kSplitActShift));
+  const f16x2 hh = __builtin_convertvector(v, f16x2);
+  const f32x2 r = (v - __builtin_convertvector(hh, f32x2)) * 2048.f;
+  const f16x2 ll = __builtin_convertvector(r, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
 typedef __attribute__((address_space(3))) void *lds_ptr;
 
-template <int MTW_, int NT_>
+template <int MTW_, int NT_, int PL_ = 3>  // PL: 16-bit terms per operand (3 bf16 / 2 fp16)
 struct LinCfg {
-  static constexpr int MTW = MTW_, NT = NT_;
+  static constexpr int MTW = MTW_, NT = NT_, PL = PL_;
   static constexpr int TM = 64 * MTW, TN = 16 * NT;
-  static constexpr int WBUF = NT * 3 * 64;  // 16-byte units of weight fragments per chunk
+  static constexpr int WBUF = NT * PL * 64;  // 16-byte units of weight fragments per chunk
 };
 
 // EPI 0: + bias.  EPI 1: + bias, GELU.  EPI 2 (N == the workgroup's 128 features): + bias, LayerNorm over the row
@@ -67,7 +81,7 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
                      const float *__restrict__ ln_b, const float *__restrict__ residual, float eps,
                      const float *__restrict__ x2, int ldx2, int q_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int MTW = Cfg::MTW, NT = Cfg::NT, TM = Cfg::TM, WBUF = Cfg::WBUF;
+  constexpr int MTW = Cfg::MTW, NT = Cfg::NT, TM = Cfg::TM, WBUF = Cfg::WBUF, PL = Cfg::PL;
   __shared__ __attribute__((aligned(16))) u32x4 wl[2 * WBUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,18 +91,18 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
   const int m0 = bm * TM + wave * (16 * MTW), ft0 = bn * NT;
   const int nchunks = K / CK, n_ftiles = (N + 15) >> 4;
 
-  // weights: fragment (nt, plane) of chunk q lives at 16-byte unit ((ft0 + nt) * nchunks + q) * 3 * 64 + plane * 64 + lane
+  // weights: fragment (nt, plane) of chunk q lives at 16-byte unit ((ft0 + nt) * nchunks + q) * PL * 64 + plane * 64 + lane
   const __amdgpu_buffer_rsrc_t wrs =
-      __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, n_ftiles * nchunks * 3 * 1024, 0x00020000);
-  auto wissue = [&](int q, int buf) {  // NT * 3 one-KB fragments, round-robin over the 4 waves
+      __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, n_ftiles * nchunks * PL * 1024, 0x00020000);
+  auto wissue = [&](int q, int buf) {  // NT * PL one-KB fragments, round-robin over the 4 waves
 #pragma unroll
-    for (int i = 0; i < (NT * 3 + 3) / 4; ++i) {
-      const int f = wave + 4 * i;  // fragment index nt * 3 + plane (wave-uniform)
-      if (f < NT * 3) {
-        const int nt = f / 3, pl = f - nt * 3;
+    for (int i = 0; i < (NT * PL + 3) / 4; ++i) {
+      const int f = wave + 4 * i;  // fragment index nt * PL + plane (wave-uniform)
+      if (f < NT * PL) {
+        const int nt = f / PL, pl = f - nt * PL;
         const int ft = min(ft0 + nt, n_ftiles - 1);  // tiles past N: any valid fragment, their results are not stored
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(wl + buf * WBUF + f * 64), 16, (unsigned)lane * 16u,
-                                                 (unsigned)(((ft * nchunks + q) * 3 + pl) * 1024), 0, 0);
+                                                 (unsigned)(((ft * nchunks + q) * PL + pl) * 1024), 0, 0);
       }
     }
   };
@@ -114,11 +128,14 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
     }
   };
 
-  f32x4 acc[MTW][NT];
+  f32x4 acc[MTW][NT], acl[MTW][PL == 2 ? NT : 1];  // acl (PL = 2): the h*l + l*h products, weight 2^-11
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (PL == 2) acl[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
   xfetch(0);
   wissue(0, 0);
@@ -127,18 +144,19 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
   auto chunk = [&](int q, auto curc) {
     constexpr int cur = decltype(curc)::value;
     // split this chunk's activations, then put the next chunk's loads in flight under the MFMAs
-    bf16x8 xh[MTW], xm[MTW], xl[MTW];
+    u32x4 xh[MTW], xm[MTW], xl[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-      u32x4 h, mm, l;
+      u32x4 h, mm = (u32x4){0u, 0u, 0u, 0u}, l;
       const float v[8] = {ra[mt][0], ra[mt][1], ra[mt][2], ra[mt][3], rb[mt][0], rb[mt][1], rb[mt][2], rb[mt][3]};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        unsigned hh, hm, hl;
-        split2(v[2 * i], v[2 * i + 1], hh, hm, hl);
+        unsigned hh, hm = 0u, hl;
+        if constexpr (PL == 3) split2(v[2 * i], v[2 * i + 1], hh, hm, hl);
+        else split2_f16(v[2 * i], v[2 * i + 1], hh, hl);
         h[i] = hh, mm[i] = hm, l[i] = hl;
       }
-      xh[mt] = __builtin_bit_cast(bf16x8, h), xm[mt] = __builtin_bit_cast(bf16x8, mm), xl[mt] = __builtin_bit_cast(bf16x8, l);
+      xh[mt] = h, xm[mt] = mm, xl[mt] = l;
     }
     if (q + 1 < nchunks) {
       xfetch(q + 1);
@@ -147,19 +165,33 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
     const u32x4 *wb = wl + cur * WBUF + lane;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 0) * 64]);
-      const bf16x8 wm = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 1) * 64]);
-      const bf16x8 wlo = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 2) * 64]);
+      if constexpr (PL == 3) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 0) * 64]);
+        const bf16x8 wm = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 1) * 64]);
+        const bf16x8 wlo = __builtin_bit_cast(bf16x8, wb[(nt * 3 + 2) * 64]);
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) {
-        f32x4 c = acc[mt][nt];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[mt], c, 0, 0, 0);  // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[mt], c, 0, 0, 0);
-        acc[mt][nt] = c;
+        for (int mt = 0; mt < MTW; ++mt) {
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, xh[mt]), am = __builtin_bit_cast(bf16x8, xm[mt]), al = __builtin_bit_cast(bf16x8, xl[mt]);
+          f32x4 c = acc[mt][nt];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ah, c, 0, 0, 0);  // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, c, 0, 0, 0);
+          acc[mt][nt] = c;
+        }
+      } else {
+        const f16x8 wh = __builtin_bit_cast(f16x8, wb[(nt * 2 + 0) * 64]), wlo = __builtin_bit_cast(f16x8, wb[(nt * 2 + 1) * 64]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, xh[mt]), al = __builtin_bit_cast(f16x8, xl[mt]);
+          f32x4 c = acl[mt][nt];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, ah, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, c, 0, 0, 0);
+          acl[mt][nt] = c;
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[mt][nt], 0, 0, 0);
+        }
       }
     }
     if (q + 1 < nchunks) {
@@ -172,6 +204,12 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
     if (q + 1 < nchunks) chunk(q + 1, std::integral_constant<int, 1>{});
   }
 
+  if constexpr (PL == 2) {  // join the two sums, undo the activation pre-scale (exact powers of two)
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (acc[mt][nt] + acl[mt][nt] * (1.f / 2048.f)) * (float)(1 << drba::kSplitActShift);
+  }
   if constexpr (EPI == 2) {
     // a lane holds 32 of its token's 128 outputs (features 16*nt + 4*kq + i); the other 96 sit in the lanes with the
     // same token and the other three kq -> two xor-shuffles complete a row sum
@@ -242,35 +280,21 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
 #endif
 }
 
-static inline float bf16_round(float x) {
-  unsigned u;
-  memcpy(&u, &x, 4);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  u &= 0xffff0000u;
-  float r;
-  memcpy(&r, &u, 4);
-  return r;
-}
-static inline unsigned short bf16_bits(float exact) {
-  unsigned u;
-  memcpy(&u, &exact, 4);
-  return (unsigned short)(u >> 16);
-}
-
 }  // namespace drba_linear
 
 extern "C" {
 
-size_t drba_linear_split_packed_floats(int K, int N) {
-  if (K <= 0 || N <= 0 || K % drba_linear::CK) return 0;
-  return (size_t)((N + 15) / 16) * (K / drba_linear::CK) * 3 * 64 * 4;
+size_t drba_linear_split_packed_floats(int K, int N, int terms) {
+  if (K <= 0 || N <= 0 || K % drba_linear::CK || (terms != 2 && terms != 3)) return 0;
+  return (size_t)((N + 15) / 16) * (K / drba_linear::CK) * terms * 64 * 4;
 }
 
-// packed (16-byte units): [feature tile][chunk][plane h/m/l][lane] = 8 bf16 of w[16*tile + (lane & 15)][32*chunk + 8*(lane >> 4) + i]
-int drba_linear_split_pack(const float *w, float *packed, int K, int N) {
+// packed (16-byte units): [feature tile][chunk][plane h/m/l or h/l][lane] = 8 x 16 bit (split_weight_terms) of
+// w[16*tile + (lane & 15)][32*chunk + 8*(lane >> 4) + i]
+int drba_linear_split_pack(const float *w, float *packed, int K, int N, int terms) {
   using namespace drba_linear;
-  if (!w || !packed || drba_linear_split_packed_floats(K, N) == 0) return DRBA_EINVAL;
-  memset(packed, 0, sizeof(float) * drba_linear_split_packed_floats(K, N));
+  if (!w || !packed || drba_linear_split_packed_floats(K, N, terms) == 0) return DRBA_EINVAL;
+  memset(packed, 0, sizeof(float) * drba_linear_split_packed_floats(K, N, terms));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   const int nft = (N + 15) / 16, nch = K / CK;
   for (int ft = 0; ft < nft; ++ft)
@@ -279,56 +303,61 @@ int drba_linear_split_pack(const float *w, float *packed, int K, int N) {
         const int n = ft * 16 + (lane & 15);
         if (n >= N) continue;
         for (int i = 0; i < 8; ++i) {
-          const float x = w[(size_t)n * K + q * CK + 8 * (lane >> 4) + i];
-          const float h = bf16_round(x), m = bf16_round(x - h), l = bf16_round(x - h - m);
-          const float term[3] = {h, m, l};
-          for (int pl = 0; pl < 3; ++pl) dst[(((((size_t)ft * nch + q) * 3 + pl) * 64) + lane) * 8 + i] = bf16_bits(term[pl]);
+          unsigned short term[3];
+          drba::split_weight_terms(w[(size_t)n * K + q * CK + 8 * (lane >> 4) + i], terms, term);
+          for (int pl = 0; pl < terms; ++pl) dst[(((((size_t)ft * nch + q) * terms + pl) * 64) + lane) * 8 + i] = term[pl];
         }
       }
   return DRBA_OK;
 }
 
 static int linear_launch(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
-                         int epi, const float *ln_w, const float *ln_b, const float *residual, float eps, void *stream,
+                         int epi, const float *ln_w, const float *ln_b, const float *residual, float eps, int terms, void *stream,
                          const float *x2 = nullptr, int ldx2 = 0, int K1 = 0) {
   using namespace drba_linear;
-  if (!x || !packed_w || !out || M <= 0 || K <= 0 || N <= 0) return DRBA_EINVAL;
+  if (!x || !packed_w || !out || M <= 0 || K <= 0 || N <= 0 || (terms != 2 && terms != 3)) return DRBA_EINVAL;
   if (K % CK) return DRBA_EUNSUPPORTED;
   if ((ldx & 3) || ldx < (x2 ? K1 : K)) return DRBA_EINVAL;  // rows are read as 16-byte vectors
   if (x2 && (K1 <= 0 || K1 >= K || K1 % CK || (ldx2 & 3) || ldx2 < K - K1)) return DRBA_EINVAL;
   const int q_split = x2 ? K1 / CK : K / CK;
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(packed_w);
-  using Cfg = LinCfg<1, 8>;
+  using Cfg = LinCfg<1, 8>;  // (tile geometry: the same for both forms)
   const int n_ntiles = (N + Cfg::TN - 1) / Cfg::TN, n_mtiles = (M + Cfg::TM - 1) / Cfg::TM;
   const dim3 grid((unsigned)(n_ntiles * n_mtiles));
-#define DRBA_LIN(E)                                                                                                      \
-  DRBA_LAUNCH((linear_split_kernel<Cfg, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
+#define DRBA_LIN(E, P)                                                                                                      \
+  DRBA_LAUNCH((linear_split_kernel<LinCfg<1, 8, P>, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
                     ldx, n_ntiles, ln_w, ln_b, residual, eps, x2, ldx2, q_split)
-  if (epi == 2) DRBA_LIN(2);
-  else if (epi == 1) DRBA_LIN(1);
-  else DRBA_LIN(0);
+  if (terms == 3) {
+    if (epi == 2) DRBA_LIN(2, 3);
+    else if (epi == 1) DRBA_LIN(1, 3);
+    else DRBA_LIN(0, 3);
+  } else {
+    if (epi == 2) DRBA_LIN(2, 2);
+    else if (epi == 1) DRBA_LIN(1, 2);
+    else DRBA_LIN(0, 2);
+  }
 #undef DRBA_LIN
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
 
 int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
-                      int gelu, void *stream) {
-  return linear_launch(x, packed_w, bias, out, M, K, N, ldx, gelu ? 1 : 0, nullptr, nullptr, nullptr, 0.f, stream);
+                      int gelu, int terms, void *stream) {
+  return linear_launch(x, packed_w, bias, out, M, K, N, ldx, gelu ? 1 : 0, nullptr, nullptr, nullptr, 0.f, terms, stream);
 }
 
 int drba_linear_split_cat(const float *x1, const float *x2, const float *packed_w, const float *bias, float *out, int M,
-                          int K1, int K2, int N, int ldx1, int ldx2, int gelu, void *stream) {
+                          int K1, int K2, int N, int ldx1, int ldx2, int gelu, int terms, void *stream) {
   if (!x2) return DRBA_EINVAL;
-  return linear_launch(x1, packed_w, bias, out, M, K1 + K2, N, ldx1, gelu ? 1 : 0, nullptr, nullptr, nullptr, 0.f, stream, x2,
+  return linear_launch(x1, packed_w, bias, out, M, K1 + K2, N, ldx1, gelu ? 1 : 0, nullptr, nullptr, nullptr, 0.f, terms, stream, x2,
                        ldx2, K1);
 }
 
 int drba_linear_split_layernorm(const float *x, const float *packed_w, const float *bias, const float *ln_w,
                                 const float *ln_b, const float *residual, float *out, int M, int K, int ldx, float eps,
-                                void *stream) {
+                                int terms, void *stream) {
   if (!ln_w || !ln_b || !(eps > 0.f)) return DRBA_EINVAL;
-  return linear_launch(x, packed_w, bias, out, M, K, 128, ldx, 2, ln_w, ln_b, residual, eps, stream);
+  return linear_launch(x, packed_w, bias, out, M, K, 128, ldx, 2, ln_w, ln_b, residual, eps, terms, stream);
 }
 
 }  // extern "C"

@@ -358,8 +358,10 @@ def ssim_thumb32_async(x1, x2):
 # and keeps the fastest ("measure, don't guess").  Results are shared by all layers of the same shape.
 AUTOTUNE = True
 # kernel families the autotuner may choose from (drba_conv3x3_cfg_family: 0 fp32 MFMA, 1 split-bf16 register staging, 2 LDS-DMA
-# 32-channel, 3 K-split); A/B runs narrow it (tools/ab_bench.py --conv-families)
-CONV_FAMILIES = {0, 1, 2, 3}
+# 32-channel, 3 K-split, 4 the two-term fp16 split: 22-bit operands, half the matrix-core work, errors against fp64 at
+# the same fp32-accumulation floor as the others); A/B runs narrow it (tools/ab_bench.py --conv-families), and
+# CONV_FAMILIES = {0, 1, 2, 3} before the first call keeps every operand at 24 bits
+CONV_FAMILIES = {0, 1, 2, 3, 4}
 _tuned = {}
 
 
@@ -486,7 +488,8 @@ class Deconv4x4:
         if self.force_cfg is not None:
             cfg = self.force_cfg
         elif AUTOTUNE and x.is_cuda:
-            cands = [c for c in range(lib.drba_deconv4x4_num_cfgs()) if lib.drba_deconv4x4_packed_floats(cin, self.cout, c) > 0]
+            cands = [c for c in range(lib.drba_deconv4x4_num_cfgs()) if lib.drba_deconv4x4_cfg_family(c) in CONV_FAMILIES
+                     and lib.drba_deconv4x4_packed_floats(cin, self.cout, c) > 0]
             cfg = _tune(("deconv4x4", n, cin, self.cout, h, w, self.ps), cands,
                         lambda c: lib.drba_deconv4x4s2(_p(x), _p(self._pack(c)), _p(self.bias), _p(out), n, cin, h, w,
                                                        self.cout, self.ps, pre, ps_, c, _stream()))
@@ -1110,15 +1113,18 @@ def gelu(x):
 class LinearSplit:
     """nn.Linear on token-major activations ([..., K] -> [..., N]) through drba_linear_split; optional fused GELU."""
 
-    def __init__(self, weight, bias=None, gelu=False, device=None):
+    def __init__(self, weight, bias=None, gelu=False, device=None, terms=None):
+        """terms: 3 = three bf16 terms per operand, 2 = two fp16 terms (kernel family 4); default: 2 when CONV_FAMILIES
+        allows family 4 at construction time."""
         w = weight.detach().float().cpu().contiguous()
         self.n, self.k = w.shape
+        self.terms = int(terms) if terms is not None else (2 if 4 in CONV_FAMILIES else 3)
         lib = _lib.load()
-        n = lib.drba_linear_split_packed_floats(self.k, self.n)
+        n = lib.drba_linear_split_packed_floats(self.k, self.n, self.terms)
         if n == 0:
-            raise _lib.DrbaHipError(f"drba_linear_split needs K % 32 == 0 (K={self.k})")
+            raise _lib.DrbaHipError(f"drba_linear_split needs K % 32 == 0 (K={self.k}) and terms in (2, 3)")
         buf = torch.empty(n, dtype=torch.float32)
-        _lib.check(lib.drba_linear_split_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr()), self.k, self.n),
+        _lib.check(lib.drba_linear_split_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr()), self.k, self.n, self.terms),
                    "drba_linear_split_pack")
         self.packed = buf.to(device)
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
@@ -1136,7 +1142,7 @@ class LinearSplit:
         m = x2.shape[0]
         out = torch.empty((m, self.n), dtype=torch.float32, device=x2.device)
         _lib.check(_timed("linear_split", (m, self.k, self.n, self.gelu), 2.0 * m * self.k * self.n, "flop", lambda: _lib.load().drba_linear_split(
-            _p(x2), _p(self.packed), _p(self.bias), _p(out), m, self.k, self.n, x2.stride(0), self.gelu, _stream())), "drba_linear_split")
+            _p(x2), _p(self.packed), _p(self.bias), _p(out), m, self.k, self.n, x2.stride(0), self.gelu, self.terms, _stream())), "drba_linear_split")
         return out.view(*lead, self.n)
 
     def cat(self, x1, x2):
@@ -1154,7 +1160,7 @@ class LinearSplit:
         out = torch.empty((m, self.n), dtype=torch.float32, device=a.device)
         _lib.check(_timed("linear_split_cat", (m, k1, k2, self.n, self.gelu), 2.0 * m * (k1 + k2) * self.n, "flop",
                           lambda: _lib.load().drba_linear_split_cat(_p(a), _p(b), _p(self.packed), _p(self.bias), _p(out), m, k1, k2, self.n,
-                                                                    a.stride(0), b.stride(0), self.gelu, _stream())), "drba_linear_split_cat")
+                                                                    a.stride(0), b.stride(0), self.gelu, self.terms, _stream())), "drba_linear_split_cat")
         return out.view(*lead, self.n)
 
     def layernorm(self, x, ln_w, ln_b, residual=None, eps=1e-5):
@@ -1167,7 +1173,7 @@ class LinearSplit:
         lw, lb = _f32(ln_w), _f32(ln_b)
         _lib.check(_timed("linear_split_layernorm", (m, self.k, 128), 2.0 * m * self.k * 128, "flop",
                           lambda: _lib.load().drba_linear_split_layernorm(_p(x2), _p(self.packed), _p(self.bias), _p(lw), _p(lb),
-                                                                          _p(res), _p(out), m, self.k, x2.stride(0), float(eps), _stream())),
+                                                                          _p(res), _p(out), m, self.k, x2.stride(0), float(eps), self.terms, _stream())),
                    "drba_linear_split_layernorm")
         return out.view(*lead, 128)
 

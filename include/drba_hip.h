@@ -32,7 +32,9 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
+/* ABI version.  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
+ * drba_deconv4x4s2, so no earlier id changes meaning), drba_deconv4x4_cfg_family, and a `terms` argument (3 or 2) on the
+ * drba_linear_split_* entry points.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
  * NULL (nothing but f_pair_out is written), and every stage-input entry point accepts items with f0 == f1 == NULL when
  * f0_pair / f1_pair are set (the first, unwarped stage reads the pair layout too).  3: drba_stage_item_t grew by term[DRBA_MAX_FLOW_TERMS]; drba_flow_terms_t and the entry points that take the
  * running flow as terms (drba_ifblock_input_lazy_batch, drba_warp_blend_lazy_batch); drba_stage_conv0_*.
@@ -40,7 +42,7 @@ extern "C" {
  * workspace that must be ZERO on entry (they leave it zero on return: self-cleaning accumulator) instead of clearing it
  * themselves; batched stage entry points added; drba_conv3x3_cfg_family added and configuration ids 19 (LDS-DMA, 32
  * channels) / 20 (K split across waves) behind drba_conv3x3; the allocation exception above.  1: the first release. */
-#define DRBA_ABI_VERSION 4  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
+#define DRBA_ABI_VERSION 5  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 
@@ -145,7 +147,12 @@ int drba_conv3x3_cfg_stride(int cfg);    /* the stride (1 or 2) a config was bui
 /* kernel family of a config: 0 = fp32 MFMA (conv.hip), 1 = split-bf16 with register staging (conv_split.hip: stride 1,
  * Cin % 32 == 0), 2 = split-bf16 with every operand streamed by LDS-DMA (conv_dma.hip: additionally W % 4 == 0; the
  * launch returns DRBA_EUNSUPPORTED otherwise: Cin == 32, Cout <= 32), 3 = split-bf16 with K split across the waves of a
- * workgroup (conv_ks.hip: Cin = 64 / 96 / 128 / 192, small maps) */
+ * workgroup (conv_ks.hip: Cin = 64 / 96 / 128 / 192, small maps), 4 = the two-term fp16 split (the tiles of families
+ * 1 - 3 with each fp32 operand taken as h + 2^-11 l, two fp16 terms = 22 significand bits, three matrix-core products
+ * instead of six, fp32 accumulation; activations must stay below 65504 * 16 in magnitude).  Families 1 - 3 reproduce the fp32 product to the
+ * last bit of the operands; family 4 drops operand bits 23 - 24, which the fp32 accumulation over 9 Cin terms hides
+ * (measured against fp64: tests/gpu_checks.py check_conv_layers, the same bound for all families).  A host that wants
+ * 24-bit operands everywhere leaves family 4 out of the ids it offers to its tuner. */
 int drba_conv3x3_cfg_family(int cfg);
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg);
 int drba_conv3x3_pack(const float *w /*[Cout,Cin,3,3] host or device-visible*/, float *packed,
@@ -159,6 +166,7 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
  * PixelShuffle(2) of the result directly (IFNet_HDv3.py:79-82), else plain [Cout,2H,2W]. */
 int drba_deconv4x4_pick_cfg(int Cin, int Cout, int H, int W);
 int drba_deconv4x4_num_cfgs(void);
+int drba_deconv4x4_cfg_family(int cfg);  /* 0 fp32 MFMA, 1 three-term bf16 split, 4 two-term fp16 split (as above) */
 size_t drba_deconv4x4_packed_floats(int Cin, int Cout, int cfg);
 int drba_deconv4x4_pack(const float *w /*[Cin,Cout,4,4] host*/, float *packed, int Cin, int Cout, int cfg);
 int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, float *out,
@@ -325,22 +333,24 @@ size_t drba_window_attention_ws_floats(int B, int H, int W, int splits);
 /* ldq / ldk / ldv: row strides in floats (>= C, multiples of 4; 16-byte aligned bases): q, k, v may be column slices
  * of one fused projection output [B*H*W, 3C]; out rows are C apart */
 /* nn.Linear on token-major activations (transformer.py:142-208: q/k/v/merge projections, MLP 256 -> 1024 -> GELU -> 128):
- * out[M, N] = x[M, K] (row stride ldx floats) . w[N, K]^T (+ bias) (, exact GELU).  fp32 operands evaluated as three bf16
- * terms each on the bf16 matrix cores with fp32-level error (conv_split); K % 32 == 0.  The weight is packed
- * once with drba_linear_split_pack (host buffers; drba_linear_split_packed_floats floats). */
-size_t drba_linear_split_packed_floats(int K, int N);
-int drba_linear_split_pack(const float *w /*[N,K] host*/, float *packed, int K, int N);
+ * out[M, N] = x[M, K] (row stride ldx floats) . w[N, K]^T (+ bias) (, exact GELU).  fp32 operands evaluated on the 16-bit
+ * matrix cores with fp32 accumulation, `terms` = 3: three bf16 terms each (24 bits, six products), `terms` = 2: two fp16
+ * terms (22 bits, three products; kernel family 4 of drba_conv3x3_cfg_family) -- the value a weight was PACKED with must
+ * be the one it is used with; K % 32 == 0.  The weight is packed once with drba_linear_split_pack (host buffers;
+ * drba_linear_split_packed_floats floats). */
+size_t drba_linear_split_packed_floats(int K, int N, int terms);
+int drba_linear_split_pack(const float *w /*[N,K] host*/, float *packed, int K, int N, int terms);
 int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,
-                      int gelu, void *stream);
+                      int gelu, int terms, void *stream);
 /* the same on cat(x1, x2) along the features without materialising it (transformer.py:201: mlp(cat(source, message))):
  * x1 [M, K1], x2 [M, K2], w [N, K1 + K2]; K1, K2 multiples of 32 */
 int drba_linear_split_cat(const float *x1, const float *x2, const float *packed_w, const float *bias, float *out, int M,
-                          int K1, int K2, int N, int ldx1, int ldx2, int gelu, void *stream);
+                          int K1, int K2, int N, int ldx1, int ldx2, int gelu, int terms, void *stream);
 /* the same for N = 128 with the layer's norm fused (transformer.py:178-185, :203-207):
  * out[M,128] = (residual ? residual : 0) + LayerNorm_128(x . w^T + bias) * ln_w + ln_b */
 int drba_linear_split_layernorm(const float *x, const float *packed_w, const float *bias, const float *ln_w,
                                 const float *ln_b, const float *residual, float *out, int M, int K, int ldx, float eps,
-                                void *stream);
+                                int terms, void *stream);
 /* in-place row softmax of x/scale + mask[(row/rows_per_mat) % n_masks][row % rows_per_mat] (transformer.py:91-96) */
 int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int rows_per_mat, int n_masks,
                       float scale, void *stream);

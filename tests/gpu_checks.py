@@ -114,7 +114,8 @@ def check_conv_layers(dev):
         # move in 16-byte units -- still ragged in tiles)
         # the K-split family: 2 / 3 / 4 / 6 chunks of 32 input channels, any width (dword windows when it is not a multiple of 4)
         fam = lib.drba_conv3x3_cfg_family(cfg)
-        dma = fam == 2
+        # (family 4 = the two-term fp16 form of the families' tiles: the LDS-DMA member is the one that refuses Cout = 40)
+        dma = fam == 2 or (fam == 4 and lib.drba_conv3x3_packed_floats(32, 40, cfg) == 0)
         shapes = (((1, 32, 24, 11, 44, "conv"), (2, 32, 32, 9, 72, "res"), (1, 32, 32, 5, 132, "pre"), (2, 32, 32, 19, 36, "res"),
                    (1, 32, 32, 8, 32, "conv")) if dma else
                   ((1, 64, 40, 11, 45, "conv"), (2, 96, 32, 9, 70, "res"), (1, 64, 16, 5, 130, "pre"), (2, 64, 64, 19, 36, "res"),
@@ -872,16 +873,19 @@ def check_linear_split(dev):
         ref = F.linear(x[:, 32:32 + k].double() if sliced else x.double(), w.double(), None if b is None else b.double())
         if gelu:
             ref = F.gelu(ref)
-        got = ops.LinearSplit(w, b, gelu=gelu, device=dev)(xin.view(2, m // 2, k) if (m % 2 == 0 and not sliced) else xin)
         scale = float(ref.abs().max())
-        rows.append((f"linear_split [{m}x{k}] -> {n} gelu={int(gelu)} bias={int(bias)} sliced={int(sliced)}",
-                     _diff(got.reshape(m, n), ref.float()), 5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+        for terms in (3, 2):  # three bf16 terms / two fp16 terms per operand: the same bound
+            got = ops.LinearSplit(w, b, gelu=gelu, device=dev, terms=terms)(xin.view(2, m // 2, k) if (m % 2 == 0 and not sliced) else xin)
+            rows.append((f"linear_split terms={terms} [{m}x{k}] -> {n} gelu={int(gelu)} bias={int(bias)} sliced={int(sliced)}",
+                         _diff(got.reshape(m, n), ref.float()), 5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
     # cat(x1, x2) read in place
     x1, x2 = torch.randn(1234, 128, generator=g), torch.randn(1234, 128, generator=g)
     w = torch.randn(1024, 256, generator=g) / 16.0
     ref = F.gelu(F.linear(torch.cat((x1, x2), -1).double(), w.double()))
-    got = ops.LinearSplit(w, None, gelu=True, device=dev).cat(x1.to(dev), x2.to(dev))
-    rows.append(("linear_split on cat(x1, x2) without the copy, GELU", _diff(got, ref.float()), 5e-6 * max(1.0, float(ref.abs().max())), ""))
+    for terms in (3, 2):
+        got = ops.LinearSplit(w, None, gelu=True, device=dev, terms=terms).cat(x1.to(dev), x2.to(dev))
+        rows.append((f"linear_split terms={terms} on cat(x1, x2) without the copy, GELU", _diff(got, ref.float()),
+                     5e-6 * max(1.0, float(ref.abs().max())), ""))
     # LayerNorm(128) (+ residual) in the epilogue, against fp64
     for (m, k, bias, with_res) in ((1000, 128, False, True), (4111, 1024, True, False), (69120, 128, False, True)):
         x = torch.randn(m, k, generator=g) * 2.0
@@ -893,10 +897,11 @@ def check_linear_split(dev):
         ref = F.layer_norm(y, (128,), lw.double(), lb.double(), 1e-5)
         if with_res:
             ref = res.double() + ref
-        got = ops.LinearSplit(w, b, device=dev).layernorm(x.to(dev), lw.to(dev), lb.to(dev), None if res is None else res.to(dev))
         scale = float(ref.abs().max())
-        rows.append((f"linear_split + LayerNorm [{m}x{k}] bias={int(bias)} residual={int(with_res)}", _diff(got, ref.float()),
-                     1e-5 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+        for terms in (3, 2):
+            got = ops.LinearSplit(w, b, device=dev, terms=terms).layernorm(x.to(dev), lw.to(dev), lb.to(dev), None if res is None else res.to(dev))
+            rows.append((f"linear_split terms={terms} + LayerNorm [{m}x{k}] bias={int(bias)} residual={int(with_res)}", _diff(got, ref.float()),
+                         1e-5 * max(1.0, scale), f"|ref|max={scale:.2f}"))
     return rows
 
 

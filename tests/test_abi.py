@@ -106,29 +106,45 @@ def test_lazy_flow_and_head_entry_points_validate_arguments_without_gpu():
 
 
 def test_split_conv_weight_packing_reconstructs_fp32():
-    """conv_split.hip packs every weight as three bf16 terms h + m + l (cfg ids after the fp32 table): their sum must be
-    the fp32 weight up to its last mantissa bit, every weight exactly once, and a layer the family cannot run
-    (Cin not a multiple of 32) reports 0 packed floats so that hosts skip it."""
+    """The split families pack every weight as three bf16 terms h + m + l (families 1 - 3: their sum must be the fp32 weight
+    up to its last mantissa bit) or as two fp16 terms h, (w - h) * 2^11 (family 4: h + 2^-11 l carries 22 bits), every weight
+    exactly once, and a layer a family cannot run (Cin not a multiple of 32) reports 0 packed floats so that hosts skip it."""
     lib = _lib.load()
     n_fp32 = 14
     assert lib.drba_conv3x3_num_cfgs() > n_fp32
     g = torch.Generator().manual_seed(5)
+    seen = set()
     for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
+        fam = lib.drba_conv3x3_cfg_family(cfg)
+        seen.add(fam)
         assert lib.drba_conv3x3_cfg_stride(cfg) == 1
         assert lib.drba_conv3x3_packed_floats(20, 32, cfg) == 0
-        cin, cout = (32, 24) if lib.drba_conv3x3_cfg_family(cfg) == 2 else (64, 40)  # (the LDS-DMA family: 32 -> <= 32 channels)
+        # (the LDS-DMA kernels, three- and two-term: 32 -> <= 32 channels)
+        cin, cout = (32, 24) if lib.drba_conv3x3_packed_floats(64, 40, cfg) == 0 else (64, 40)
         n = lib.drba_conv3x3_packed_floats(cin, cout, cfg)
         assert n > 0
-        w = torch.randn(cout, cin, 3, 3, generator=g) * torch.logspace(-3, 3, cout).view(-1, 1, 1, 1)
+        spread = torch.logspace(-3, 3, cout) if fam != 4 else torch.logspace(-2, 2, cout)  # (two-term: finite below 65504)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * spread.view(-1, 1, 1, 1)
         buf = torch.full((n,), float("nan"))
         assert lib.drba_conv3x3_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr()), cin, cout, cfg) == 0
-        bits = buf.view(torch.int16).numpy().astype(np.uint16).astype(np.uint32) << 16  # bf16 -> fp32 bit patterns
-        vals = bits.view(np.float32).astype(np.float64).reshape(-1, 3, 64, 8)            # [fragment][plane][lane][i]
-        total = vals.sum(1).reshape(-1)
-        nz = np.sort(total[total != 0])
         ref = np.sort(w.numpy().astype(np.float64).reshape(-1))
+        if fam != 4:
+            bits = buf.view(torch.int16).numpy().astype(np.uint16).astype(np.uint32) << 16  # bf16 -> fp32 bit patterns
+            vals = bits.view(np.float32).astype(np.float64).reshape(-1, 3, 64, 8)            # [fragment][plane][lane][i]
+            total = vals.sum(1).reshape(-1)
+            bound = 2.0 ** -23  # 8 + 8 + 8 mantissa bits
+        else:
+            vals = buf.view(torch.float16).numpy().astype(np.float64).reshape(-1, 2, 64, 8)
+            total = (vals[:, 0] + vals[:, 1] / 2048.0).reshape(-1)
+            bound = 2.0 ** -21  # 11 + 11 bits, round-to-nearest at both steps
+        nz = np.sort(total[total != 0])
         assert nz.size == ref.size
-        assert np.max(np.abs(nz - ref) / np.abs(ref)) < 2.0 ** -23  # 8 + 8 + 8 mantissa bits
+        # (two-term: a weight below fp16's normal range, 6.1e-5, leaves h subnormal and the remainder's 11 bits bound the
+        # error absolutely instead: 2^-11 of a remainder <= 2^-25)
+        floor = 0.0 if fam != 4 else 2.0 ** -35
+        assert np.all(np.abs(nz - ref) <= bound * np.abs(ref) + floor)
+    assert seen == {1, 2, 3, 4}
+    assert {lib.drba_deconv4x4_cfg_family(c) for c in range(lib.drba_deconv4x4_num_cfgs())} == {0, 1, 4}
 
 
 def test_autotune_skips_configurations_that_refuse_the_shape(monkeypatch):
