@@ -116,7 +116,13 @@ def parse():
     p.add_argument("--selftest-sharded", action="store_true",
                    help="N = 1 only: run the N > 1 legs' code (sharded warm-up + sharded run of the headline clip and of the "
                         "config-5 clip) on one GPU without a process group and print their rates; not the metric")
+    p.add_argument("--conv-families", default=None,
+                   help="kernel families the conv autotuner may pick from (default 0,1,2,3,4); 0,1,2,3 keeps every MFMA operand "
+                        "at 24 bits (three bf16 terms) instead of the two-term fp16 form -- the number of the previous rounds")
     args = p.parse_args()
+    if args.conv_families is not None:
+        from drba_amd import ops
+        ops.CONV_FAMILIES = {int(x) for x in args.conv_families.split(",")}
     args.no_lookahead = bool(AB.get("no_lookahead", False))  # (the single-stream roofline block sets it on a copy of args)
     return args
 
@@ -272,6 +278,19 @@ def _peak(name, unit):
         # fp32 operands as three bf16 terms, six MFMA products
         return round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), "TFLOP/s", "mfma", "dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32 multiply"
     return FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma", "dense fp32 MFMA"
+
+
+def _arithmetic_note():
+    """What `dtype` "f32" stands for on this run: which kernel families the conv autotuner was allowed (drba_amd.ops.CONV_FAMILIES)."""
+    from drba_amd import ops
+    two = 4 in ops.CONV_FAMILIES
+    return {"tensors": "fp32 in HBM, fp32 accumulation, fp32 outputs",
+            "mfma_operands": ("stride-1 / transposed convolutions and GMFlow linears: each fp32 operand as two fp16 terms h + 2^-11 l "
+                              "(22 significand bits, 3 MFMA products, kernel family 4); stride-2 convolutions, the encoder, stage_conv0, "
+                              "attention: fp32 MFMA" if two else
+                              "stride-1 / transposed convolutions and GMFlow linears: each fp32 operand as three bf16 terms (24 bits, 6 MFMA "
+                              "products); the rest fp32 MFMA"),
+            "conv_families": sorted(ops.CONV_FAMILIES)}
 
 
 def _two_term(name):
@@ -956,6 +975,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "net_size": list(r["dst_size"]), "frames_per_step": len(TS),
                        "weights": "seeded random IFNet 4.26-heavy", "parallelism": f"frame-sharded dp{world}"},
+            "arithmetic": _arithmetic_note(),
             "max_abs_vs_oracle": parity, "roofline": r["roofline"], "cpu_baseline": cpu,
             "path": r.get("path"),
         }

@@ -114,12 +114,14 @@ def check_conv_layers(dev):
         # move in 16-byte units -- still ragged in tiles)
         # the K-split family: 2 / 3 / 4 / 6 chunks of 32 input channels, any width (dword windows when it is not a multiple of 4)
         fam = lib.drba_conv3x3_cfg_family(cfg)
-        # (family 4 = the two-term fp16 form of the families' tiles: the LDS-DMA member is the one that refuses Cout = 40)
-        dma = fam == 2 or (fam == 4 and lib.drba_conv3x3_packed_floats(32, 40, cfg) == 0)
+        # (family 4 = the two-term fp16 form of the three families' kernels: told apart by the layers they accept -- the LDS-DMA
+        # member refuses Cout = 40, the K-split member Cin = 32)
+        dma = fam == 2 or (fam == 4 and lib.drba_conv3x3_packed_floats(32, 40, cfg) == 0 and lib.drba_conv3x3_packed_floats(32, 32, cfg) > 0)
+        ks = fam == 3 or (fam == 4 and lib.drba_conv3x3_packed_floats(32, 32, cfg) == 0)
         shapes = (((1, 32, 24, 11, 44, "conv"), (2, 32, 32, 9, 72, "res"), (1, 32, 32, 5, 132, "pre"), (2, 32, 32, 19, 36, "res"),
                    (1, 32, 32, 8, 32, "conv")) if dma else
                   ((1, 64, 40, 11, 45, "conv"), (2, 96, 32, 9, 70, "res"), (1, 64, 16, 5, 130, "pre"), (2, 64, 64, 19, 36, "res"),
-                   (2, 192, 192, 17, 30, "res"), (1, 128, 128, 7, 33, "res")) if fam == 3 else
+                   (2, 192, 192, 17, 30, "res"), (1, 128, 128, 7, 33, "res")) if ks else
                   ((1, 32, 40, 11, 45, "conv"), (2, 96, 32, 9, 70, "res"), (1, 64, 16, 5, 130, "pre"), (2, 64, 64, 19, 36, "res")))
         for (nb, cin, cout, h, w, kind) in shapes:
             try:

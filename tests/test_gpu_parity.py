@@ -224,6 +224,33 @@ def test_two_model_instances_in_one_process(hip_backend):
     assert err <= 2e-5, err
 
 
+def test_two_term_and_three_term_conv_families_agree(hip_backend, monkeypatch):
+    """The conv autotuner's default candidate set includes kernel family 4 (fp32 operands as two fp16 terms, 22 bits); with
+    CONV_FAMILIES = {0, 1, 2, 3} every MFMA operand keeps 24 bits (three bf16 terms).  One DRBA step both ways: the frames
+    agree to the rounding level of two instances of ONE setting (test_two_model_instances_in_one_process) -- the operand
+    bits family 4 drops are below the fp32 accumulation's own error."""
+    from drba_amd import ops
+    from drba_amd.utils import synth
+    sd = synth.ifnet_state_dict(seed=0)
+    dev = hip_backend.dev
+    g = torch.Generator().manual_seed(21)
+    fr = [torch.rand(1, 3, 256, 448, generator=g).to(dev) for _ in range(3)]
+    ts = np.array([0.75, 1.25])
+    outs = {}
+    for name, fams in (("three-term", {0, 1, 2, 3}), ("two-term", {0, 1, 2, 3, 4})):
+        monkeypatch.setattr(ops, "CONV_FAMILIES", fams)
+        monkeypatch.setattr(ops, "_tuned", {})
+        m = hip_backend.make_rife(sd, 1.0)
+        m.inference_ts_drba(*fr, ts, None, True)          # tunes layer by layer
+        o, _ = m.inference_ts_drba(*fr, ts, None, True)   # the chains, with the winners
+        torch.cuda.synchronize()
+        outs[name] = [x.clone() for x in o]
+        fams_used = {ops._lib.load().drba_conv3x3_cfg_family(c) for k, c in ops._tuned.items() if k[0] == "conv3x3"}
+        assert (4 in fams_used) == (name == "two-term"), (name, fams_used)
+    err = max(float((a - b).abs().max()) for a, b in zip(outs["three-term"], outs["two-term"]))
+    assert err <= 2e-5, err
+
+
 def test_cloned_reuse_features_keep_their_layout(hip_backend):
     """The carried encoder features are pair-interleaved [8,H,W,2] tensors (ops.head_fused(planar=False)); a caller that
     clones the `reuse` tuple loses the tag on them, and a planar [1,16,H,W] tensor (the reference's layout, e.g. an oracle's
