@@ -90,6 +90,9 @@ SIGNATURES = {
     "drba_head_fused_packed_floats": (_z, []),
     "drba_head_fused_pack": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "drba_head_fused": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "drba_head_fused16_packed_floats": (_z, []),
+    "drba_head_fused16_pack": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "drba_head_fused16": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "drba_ifblock_input_lazy_batch": (_i, [_p, _i, _p, _i, _i, _f, _i, _i, _i, _i, _f, _p]),
     "drba_warp_blend_lazy_batch": (_i, [_p, _i, _p, _i, _i, _f, _i, _i, _p]),
     "drba_ifblock_update_batch": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),

@@ -55,7 +55,15 @@ struct SplitCfg {
 #ifndef DRBA_SPLIT_BDEPTH_BIG
 #define DRBA_SPLIT_BDEPTH_BIG 2
 #endif
-  static constexpr int BDEPTH = (RW * MW >= 4) ? DRBA_SPLIT_BDEPTH_BIG : 4;  // weight fetch distance in steps (>= ~700 cycles of MFMAs)
+#ifndef DRBA_SPLIT_BDEPTH2_BIG
+#define DRBA_SPLIT_BDEPTH2_BIG 2
+#endif
+#ifndef DRBA_SPLIT_BDEPTH2_SMALL
+#define DRBA_SPLIT_BDEPTH2_SMALL 4
+#endif
+  // weight fetch distance in steps (>= ~700 cycles of MFMAs); the two-term form's steps are half as long
+  static constexpr int BDEPTH = PL == 3 ? ((RW * MW >= 4) ? DRBA_SPLIT_BDEPTH_BIG : 4)
+                                        : ((RW * MW >= 4) ? DRBA_SPLIT_BDEPTH2_BIG : DRBA_SPLIT_BDEPTH2_SMALL);
 #ifndef DRBA_SPLIT_MINB3
 #define DRBA_SPLIT_MINB3 1
 #endif

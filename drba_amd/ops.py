@@ -597,6 +597,7 @@ class ConvChain:
 PAIR_FEATURES = True  # warped stages read the encoder features from a pair-interleaved copy (half the gather instructions)
 
 
+HEAD_TWO_TERM = None  # None: follow CONV_FAMILIES (family 4 allowed -> head_fused16.hip); True / False force it (tests, A/B)
 HEAD_FUSED = True  # IFNet's encoder as one kernel (drba_head_fused) instead of four layers + the pair-interleave copy (tools/ab_bench.py --no-head-fused: A/B)
 
 
@@ -612,22 +613,27 @@ def head_fused(img, layers, holder, planar=True):
     if n != 1 or c != 3 or H % 2 or W % 4:
         return None
     lib = _lib.load()
-    pk = getattr(holder, "_fused_pack", None)
+    # the two-term fp16 form of the kernel (head_fused16.hip) when the conv tuner may use kernel family 4, else fp32 MFMA
+    two = HEAD_TWO_TERM if HEAD_TWO_TERM is not None else (4 in CONV_FAMILIES)
+    attr, sfx = ("_fused_pack16", "16") if two else ("_fused_pack", "")
+    launch = getattr(lib, "drba_head_fused" + sfx)
+    pk = getattr(holder, attr, None)
     if pk is None:
         c0, c1, c2, c3 = layers
-        buf = torch.empty(lib.drba_head_fused_packed_floats(), dtype=torch.float32)
+        buf = torch.empty(getattr(lib, f"drba_head_fused{sfx}_packed_floats")(), dtype=torch.float32)
         hb = [l.bias.detach().float().cpu().contiguous() for l in layers]
-        _lib.check(lib.drba_head_fused_pack(*(C.c_void_p(t.data_ptr()) for t in (c0.w_host, hb[0], c1.w_host, hb[1], c2.w_host, hb[2],
-                                                                                  c3.w_host, hb[3])), C.c_void_p(buf.data_ptr())),
-                   "drba_head_fused_pack")
-        pk = holder._fused_pack = buf.to(img.device)
+        _lib.check(getattr(lib, f"drba_head_fused{sfx}_pack")(*(C.c_void_p(t.data_ptr()) for t in (c0.w_host, hb[0], c1.w_host, hb[1],
+                                                                                                    c2.w_host, hb[2], c3.w_host, hb[3])),
+                                                              C.c_void_p(buf.data_ptr())), f"drba_head_fused{sfx}_pack")
+        pk = buf.to(img.device)
+        setattr(holder, attr, pk)
     f = torch.empty((1, 16, H, W), dtype=torch.float32, device=img.device) if planar else None
     fp = torch.empty((8, H, W, 2), dtype=torch.float32, device=img.device)
     # algorithmic bytes: the frame read, the features written in both layouts; 9.5 GFLOP of fp32 MFMA work per 1080p frame
     # ride along (61 us at the fp32 MFMA peak against 50 us of HBM time: the matrix cores are the binding roofline)
     flop = 2.0 * (16 * 27 + 2 * 16 * 144) * (H // 2) * (W // 2) + 2.0 * 16 * 16 * 16 * (H // 2) * (W // 2)
-    _lib.check(_timed("head_fused", (H, W), flop, "flop", lambda: lib.drba_head_fused(_p(img), _p(pk), _p(f), _p(fp), 1, H, W, _stream())),
-               "drba_head_fused")
+    _lib.check(_timed("head_fused" + sfx, (H, W), flop, "flop", lambda: launch(_p(img), _p(pk), _p(f), _p(fp), 1, H, W, _stream())),
+               "drba_head_fused" + sfx)
     if not planar:
         fp._drba_is_pair = True
         return fp

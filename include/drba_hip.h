@@ -34,7 +34,7 @@ extern "C" {
 
 /* ABI version.  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
  * drba_deconv4x4s2, so no earlier id changes meaning), drba_deconv4x4_cfg_family, and a `terms` argument (3 or 2) on the
- * drba_linear_split_* entry points.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
+ * drba_linear_split_* entry points; drba_head_fused16_*.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
  * NULL (nothing but f_pair_out is written), and every stage-input entry point accepts items with f0 == f1 == NULL when
  * f0_pair / f1_pair are set (the first, unwarped stage reads the pair layout too).  3: drba_stage_item_t grew by term[DRBA_MAX_FLOW_TERMS]; drba_flow_terms_t and the entry points that take the
  * running flow as terms (drba_ifblock_input_lazy_batch, drba_warp_blend_lazy_batch); drba_stage_conv0_*.
@@ -255,6 +255,12 @@ size_t drba_head_fused_packed_floats(void);
 int drba_head_fused_pack(const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
                          const float *w3, const float *b3, float *packed);
 int drba_head_fused(const float *img, const float *packed_w, float *f_out, float *f_pair_out, int N, int H, int W, void *stream);
+/* the same fusion in the two-term fp16 form (kernel family 4 of drba_conv3x3_cfg_family; head_fused16.hip): same arguments,
+ * same outputs to the tolerance of the family, its own packing */
+size_t drba_head_fused16_packed_floats(void);
+int drba_head_fused16_pack(const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
+                           const float *w3, const float *b3, float *packed);
+int drba_head_fused16(const float *img, const float *packed_w, float *f_out, float *f_pair_out, int N, int H, int W, void *stream);
 /* drba_ifblock_input_lds_batch with the flow given as terms (any scale of the pyramid; nothing but `out` is written). */
 int drba_ifblock_input_lazy_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int hp, int wp,
                                   float prev_scale, int H, int W, int h, int w, float scale, void *stream);

@@ -219,24 +219,26 @@ def check_conv_layers(dev):
             y = F.leaky_relu(F.conv2d(y, d["encode.cnn1.weight"], d["encode.cnn1.bias"], padding=1), 0.2)
             y = F.leaky_relu(F.conv2d(y, d["encode.cnn2.weight"], d["encode.cnn2.bias"], padding=1), 0.2)
             ref = F.conv_transpose2d(y, d["encode.cnn3.weight"], d["encode.cnn3.bias"], stride=2, padding=1).float()
-            ops.HEAD_FUSED = True
-            f = head(x.to(dev))
-            fp = getattr(f, "_drba_pair", None)
+            tol = 2e-5 * max(1.0, float(ref.abs().max()))
+            want_pair = ref[0].reshape(8, 2, h, w).permute(0, 2, 3, 1).contiguous()
             ops.HEAD_FUSED = False
             f_layers = head(x.to(dev))
             ops.HEAD_FUSED = True
-            tol = 2e-5 * max(1.0, float(ref.abs().max()))
-            rows.append((f"head_fused {h}x{w} vs fp64 reference layers", _diff(f, ref), tol, ""))
-            rows.append((f"head_fused {h}x{w} vs layer-by-layer HIP path", _diff(f, f_layers.cpu()), tol, ""))
-            want_pair = ref[0].reshape(8, 2, h, w).permute(0, 2, 3, 1).contiguous()
-            rows.append((f"head_fused {h}x{w} pair-interleaved copy", float("inf") if fp is None else _diff(fp, want_pair), tol, ""))
-            f2 = head(x.to(dev), planar=False)  # the hot path's form: the pair layout only
-            rows.append((f"head_fused {h}x{w} pair layout only", _diff(f2, want_pair) if ops.is_pair(f2) else float("inf"), tol, ""))
-            rows.append((f"head_fused {h}x{w} pair layout only -> features_planar", _diff(ops.features_planar(f2), ref), tol, ""))
+            for two in (False, True):  # head_fused.hip (fp32 MFMA) / head_fused16.hip (two fp16 terms per operand): the same bound
+                ops.HEAD_TWO_TERM = two
+                tag = f"head_fused{'16' if two else ''} {h}x{w}"
+                f = head(x.to(dev))
+                fp = getattr(f, "_drba_pair", None)
+                rows.append((f"{tag} vs fp64 reference layers", _diff(f, ref), tol, ""))
+                rows.append((f"{tag} vs layer-by-layer HIP path", _diff(f, f_layers.cpu()), tol, ""))
+                rows.append((f"{tag} pair-interleaved copy", float("inf") if fp is None else _diff(fp, want_pair), tol, ""))
+                f2 = head(x.to(dev), planar=False)  # the hot path's form: the pair layout only
+                rows.append((f"{tag} pair layout only", _diff(f2, want_pair) if ops.is_pair(f2) else float("inf"), tol, ""))
+                rows.append((f"{tag} pair layout only -> features_planar", _diff(ops.features_planar(f2), ref), tol, ""))
     except Exception as e:  # noqa: BLE001
         rows.append(("head_fused", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     finally:
-        ops.HEAD_FUSED = True
+        ops.HEAD_FUSED, ops.HEAD_TWO_TERM = True, None
     return rows
 
 
