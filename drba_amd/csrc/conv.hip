@@ -548,8 +548,11 @@ static int first_ks_cfg() { return first_dma_cfg() + (split_enabled() ? conv_dma
 static int first_f16_cfg() { return first_ks_cfg() + (split_enabled() ? conv_ks_num_cfgs() : 0); }
 static int first_f16_dma_cfg() { return first_f16_cfg() + (split_enabled() ? conv_split_num_cfgs() : 0); }
 static int first_f16_ks_cfg() { return first_f16_dma_cfg() + (split_enabled() ? conv_dma_num_cfgs() : 0); }
-int drba_conv3x3_num_cfgs(void) { return first_f16_ks_cfg() + (split_enabled() ? conv_ks_num_cfgs() : 0); }
+// ... and its stride-2 tiles (family 4, stride 2: conv_split.hip MODE 2)
+static int first_f16_s2_cfg() { return first_f16_ks_cfg() + (split_enabled() ? conv_ks_num_cfgs() : 0); }
+int drba_conv3x3_num_cfgs(void) { return first_f16_s2_cfg() + (split_enabled() ? conv_split_s2_num_cfgs() : 0); }
 int drba_conv3x3_cfg_stride(int cfg) {
+  if (cfg >= first_f16_s2_cfg() && cfg < drba_conv3x3_num_cfgs()) return 2;
   if (cfg >= kNumConvCfg && cfg < drba_conv3x3_num_cfgs()) return 1;
   return (cfg < 0 || cfg >= kNumConvCfg) ? DRBA_EINVAL : kConv[cfg].S;
 }
@@ -573,8 +576,9 @@ int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride) {
 }
 
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
-  if (cfg >= first_f16_ks_cfg())
-    return cfg < drba_conv3x3_num_cfgs() ? conv_ks_packed_floats(Cin, Cout, cfg - first_f16_ks_cfg() + conv_ks_f16_first()) : 0;
+  if (cfg >= first_f16_s2_cfg())
+    return cfg < drba_conv3x3_num_cfgs() ? conv_split_packed_floats(Cin, Cout, cfg - first_f16_s2_cfg() + conv_split_s2_first()) : 0;
+  if (cfg >= first_f16_ks_cfg()) return conv_ks_packed_floats(Cin, Cout, cfg - first_f16_ks_cfg() + conv_ks_f16_first());
   if (cfg >= first_f16_dma_cfg()) return conv_dma_packed_floats(Cin, Cout, cfg - first_f16_dma_cfg() + conv_dma_f16_first());
   if (cfg >= first_f16_cfg()) return conv_split_packed_floats(Cin, Cout, cfg - first_f16_cfg() + conv_split_f16_first());
   if (cfg >= first_ks_cfg()) return conv_ks_packed_floats(Cin, Cout, cfg - first_ks_cfg());
@@ -587,7 +591,9 @@ size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
 // fragment order: packed[(((cz*nchunks + q)*9 + tap)*CG + cg)*NT + nt][lane] =
 //   w[cz*NTC + nt*16 + (lane&15)][q*CK + cg*4 + (lane>>4)][tap], zero outside Cout/Cin
 int drba_conv3x3_pack(const float *w, float *packed, int Cin, int Cout, int cfg) {
-  if (cfg >= first_f16_ks_cfg() && cfg < drba_conv3x3_num_cfgs())
+  if (cfg >= first_f16_s2_cfg() && cfg < drba_conv3x3_num_cfgs())
+    return conv_split_pack(w, packed, Cin, Cout, cfg - first_f16_s2_cfg() + conv_split_s2_first());
+  if (cfg >= first_f16_ks_cfg() && cfg < first_f16_s2_cfg())
     return conv_ks_pack(w, packed, Cin, Cout, cfg - first_f16_ks_cfg() + conv_ks_f16_first());
   if (cfg >= first_f16_dma_cfg() && cfg < first_f16_ks_cfg())
     return conv_dma_pack(w, packed, Cin, Cout, cfg - first_f16_dma_cfg() + conv_dma_f16_first());
@@ -621,7 +627,12 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
   if (beta && !residual) return DRBA_EINVAL;
   if (residual2 && !residual) return DRBA_EINVAL;
   if (act < 0 || act > 4) return DRBA_EINVAL;
-  if (cfg >= first_f16_ks_cfg() && cfg < drba_conv3x3_num_cfgs()) {
+  if (cfg >= first_f16_s2_cfg() && cfg < drba_conv3x3_num_cfgs()) {
+    if (stride != 2) return DRBA_EINVAL;
+    return conv_split_launch(cfg - first_f16_s2_cfg() + conv_split_s2_first(), in, packed_w, bias, beta, residual, residual2, out, N,
+                             Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream);
+  }
+  if (cfg >= first_f16_ks_cfg() && cfg < first_f16_s2_cfg()) {
     if (stride != 1) return DRBA_EINVAL;
     return conv_ks_launch(cfg - first_f16_ks_cfg() + conv_ks_f16_first(), in, packed_w, bias, beta, residual, residual2, out, N, Cin,
                           H, W, Cout, act, post_slope, pre_act, pre_slope, stream);

@@ -36,15 +36,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 32;  // channels per chunk = the K of one bf16 MFMA
 
+// MODE 2 (two-term form only): conv3x3 stride 2, pad 1 -- the tile is TH x TW OUTPUT pixels, its window the (2 TH + 1) x
+// (2 TW + 1) input pixels under it (each split once, every tap of every output reads the planes at 2 * pixel + tap);
+// Cin need not be a multiple of 32: the last chunk's missing channels read as zero through the buffer range check and
+// their weights are packed as zero.
 // MODE 0: conv3x3 stride 1.  MODE 1: one row phase py (both column phases px) of ConvTranspose2d(k=4, s=2, p=1), a
 // 2x2-tap convolution over the same haloed window (tap offsets and phase algebra as in conv.hip).
 // PL = 3: the three-term bf16 split above.  PL = 2: the two-term fp16 split (header comment "Two-term form").
 template <int MODE_, int RW_, int MW_, int NT_, int PL_ = 3>
 struct SplitCfg {
   static constexpr int MODE = MODE_, RW = RW_, MW = MW_, NT = NT_, PL = PL_;
-  static constexpr int NTAP = MODE == 0 ? 9 : 4, NPX = MODE == 0 ? 1 : 2;
+  static constexpr int NTAP = MODE != 1 ? 9 : 4, NPX = MODE != 1 ? 1 : 2;
   static constexpr int TH = 4 * RW, TW = 16 * MW, NTC = 16 * NT;
-  static constexpr int TR = TH + 2, TC = TW + 2, NPIX = TR * TC;
+  static constexpr int TR = MODE == 2 ? 2 * TH + 1 : TH + 2, TC = MODE == 2 ? 2 * TW + 1 : TW + 2, NPIX = TR * TC;
   // LDS: [plane PL][group 4][NPIXP][8 x 16 bit]; NPIXP*16 bytes == 64 (mod 256) spreads the four channel groups of a wave
   // read over distinct banks
   static constexpr int NPIXP = ((NPIX + 15) / 16) * 16 + 4;
@@ -140,7 +144,8 @@ __global__ void __launch_bounds__(256, Cfg::MINB)  // at least two workgroups pe
 conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                 const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
                 float *__restrict__ out, int Cin, int H, int W, int Cout, int act, float post_slope, float pre_slope,
-                int n_ctiles, int nbx, int nby, int total, int pixel_shuffle) {
+                int n_ctiles, int nbx, int nby, int total, int pixel_shuffle, int Hi, int Wi) {
+  // H, W: the map the tiles are laid over (MODE 0 / 1: the input = Hi x Wi; MODE 2: the OUTPUT, the input being Hi x Wi)
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MODE = Cfg::MODE, NTAP = Cfg::NTAP, NPX = Cfg::NPX;
   constexpr int RW = Cfg::RW, MW = Cfg::MW, NT = Cfg::NT, TH = Cfg::TH, TW = Cfg::TW, TC = Cfg::TC;
@@ -151,8 +156,8 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kq = lane >> 4;
-  const size_t HW = (size_t)H * W;
-  const int nchunks = Cin / CK;
+  const size_t HW = (size_t)H * W, HWi = (size_t)Hi * Wi;
+  const int nchunks = (Cin + CK - 1) / CK;
   const int row0 = wave * RW;
 
   // Persistent workgroups: work item i of workgroup b is tile xcd_band(b + i * gridDim.x) -- gridDim.x is a multiple
@@ -179,22 +184,22 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   // Global reads go through buffer descriptors: the address is (scalar base) + (per-lane 32-bit offset), no 64-bit
   // vector address arithmetic, and a lane whose pixel is outside the image reads offset >= num_records -> 0 (the
   // zero padding) without a branch.
-  const unsigned img_bytes = (unsigned)((size_t)Cin * HW * 4);
+  const unsigned img_bytes = (unsigned)((size_t)Cin * HWi * 4);
   const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, n_ctiles * (MODE == 0 ? 1 : 4) * nchunks * Cfg::FRAG_U4 * 16, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, n_ctiles * (MODE != 1 ? 1 : 4) * nchunks * Cfg::FRAG_U4 * 16, 0x00020000);
   float pre[LIT][8];
   auto fetch = [&](const TileCtx &c, int q) {
     const __amdgpu_buffer_rsrc_t irsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)c.n * Cin * HW), 0, img_bytes, 0x00020000);
-    const int plane = (int)HW * 4;
+        __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)c.n * Cin * HWi), 0, img_bytes, 0x00020000);
+    const int plane = (int)HWi * 4;
 #pragma unroll
     for (int it = 0; it < LIT; ++it) {
       const int item = tid + 256 * it;
       const int g = item / NPIX, p = item - g * NPIX;  // group-major
       const int r = p / TC, cc = p - r * TC;
-      const int y = c.y0 + r - 1, x = c.x0 + cc - 1;
-      const bool ok = item < Cfg::ITEMS && y >= 0 && y < H && x >= 0 && x < W;
-      const unsigned voff = ok ? (unsigned)(g * 8 * plane + (y * W + x) * 4) : 0xffffffffu;
+      const int y = (MODE == 2 ? 2 * c.y0 : c.y0) + r - 1, x = (MODE == 2 ? 2 * c.x0 : c.x0) + cc - 1;
+      const bool ok = item < Cfg::ITEMS && y >= 0 && y < Hi && x >= 0 && x < Wi;
+      const unsigned voff = ok ? (unsigned)(g * 8 * plane + (y * Wi + x) * 4) : 0xffffffffu;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         pre[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irsrc, voff, (q * CK + i) * plane, 0));
@@ -225,7 +230,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     }
   };
 
-  const bool vec = (W & 3) == 0;
+  const bool vec = (W & 3) == 0 && (MW & 1) == 0;  // (the regrouped stores pair column blocks 2j, 2j + 1)
 
   int work = blockIdx.x;
   if (work >= total) return;
@@ -261,7 +266,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     if (next < total) nctx = decode(next);
     // per-channel epilogue constants: fetched here so that their latency sits under the tile's MFMAs
     // (MODE 0 with W % 4 == 0 stores in the regrouped layout of the epilogue: lane -> couts (lane >> 3) and + 8 of a tile)
-    const bool regroup = MODE == 0 && vec;
+    const bool regroup = MODE != 1 && vec;
     float bs[NT], bt[NT], bs2[NT], bt2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -284,7 +289,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       // A "tap slot" ts is a (column phase, tap) pair: 9 for the convolution, 2 x 4 for the transposed one.
       constexpr int NTS = NPX * NTAP, STEPS = NTS * NT, D = Cfg::BDEPTH;
       // byte offset of this (cout tile[, row phase], chunk); the px = 1 block of a transposed conv follows nchunks later
-      const int wq = ((MODE == 0 ? ctx.cz : ctx.cz * 4 + 2 * ctx.py) * nchunks + q) * (Cfg::FRAG_U4 * 16);
+      const int wq = ((MODE != 1 ? ctx.cz : ctx.cz * 4 + 2 * ctx.py) * nchunks + q) * (Cfg::FRAG_U4 * 16);
       const int px_bytes = nchunks * (Cfg::FRAG_U4 * 16);
       auto wload = [&](int step, int pl) -> u32x4 {
         const int p = step / (NTAP * NT), r = step - p * (NTAP * NT);  // r = tap * NT + nt
@@ -318,9 +323,10 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       u32x4 af[RW][MW][PL];
       auto load_piece = [&](int ts, int rw, int mw) {
         const int p = ts / NTAP, tap = ts - p * NTAP;
-        const int ro = MODE == 0 ? tap / 3 : ((tap >> 1) ? 0 : 1) + ctx.py;
-        const int co = MODE == 0 ? tap % 3 : ((tap & 1) ? 0 : 1) + p;
-        const int slot = kq * NPIXP + (row0 + rw + ro) * TC + mw * 16 + m + co;
+        const int ro = MODE != 1 ? tap / 3 : ((tap >> 1) ? 0 : 1) + ctx.py;
+        const int co = MODE != 1 ? tap % 3 : ((tap & 1) ? 0 : 1) + p;
+        const int slot = MODE == 2 ? kq * NPIXP + (2 * (row0 + rw) + ro) * TC + 2 * (mw * 16 + m) + co
+                                   : kq * NPIXP + (row0 + rw + ro) * TC + mw * 16 + m + co;
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) af[rw][mw][pl] = tile[4 * pl * NPIXP + slot];
       };
@@ -396,7 +402,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     // the post activation: act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10.  The activation is
     // selected ONCE around the tile loops: selected per element, the inlined copies of the switch (each with a tanhf
     // expansion to jump over) made the epilogue 10k instructions and as slow as the tile's MFMAs.
-    if constexpr (MODE == 0) {
+    if constexpr (MODE != 1) {
       const size_t img = (size_t)ctx.n * Cout * HW;
       if (vec) {
         // Whole-line stores and residual reads.  The accumulator leaves lane (m, kq) with 4 consecutive x of ONE cout:
@@ -648,6 +654,12 @@ using F3 = SplitCfg<0, 1, 4, 2, 2>;
 using F4 = SplitCfg<0, 2, 2, 2, 2>;
 using G0 = SplitCfg<1, 1, 2, 2, 2>;
 using G1 = SplitCfg<1, 1, 2, 4, 2>;
+// stride 2 (two-term form only): ids 2 * kNum .. 2 * kNum + kNumX - 1 of this file
+using X0 = SplitCfg<2, 1, 2, 2, 2>;  // 4x32 output px x 32 cout (window 9 x 65)
+using X1 = SplitCfg<2, 1, 2, 4, 2>;  // 4x32 x 64
+using X2 = SplitCfg<2, 1, 1, 2, 2>;  // 4x16 x 32 (window 9 x 33)
+using X3 = SplitCfg<2, 1, 1, 4, 2>;  // 4x16 x 64
+constexpr int kNumX = 4;
 struct Info {
   int NT, NTC, frag_u4, PL;
 };
@@ -655,8 +667,9 @@ template <class C>
 constexpr Info info() {
   return {C::NT, C::NTC, C::FRAG_U4, C::PL};
 }
-const Info kInfo[2 * kNum] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>(),
-                              info<F0>(), info<F1>(), info<F2>(), info<F3>(), info<F4>()};
+const Info kInfo[2 * kNum + kNumX] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>(),
+                                      info<F0>(), info<F1>(), info<F2>(), info<F3>(), info<F4>(),
+                                      info<X0>(), info<X1>(), info<X2>(), info<X3>()};
 const Info kInfoT[2 * kNumT] = {info<T0>(), info<T1>(), info<G0>(), info<G1>()};
 
 template <class Cfg, bool PRE, bool RL = false>
@@ -670,8 +683,10 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
            float *out, int N, int Cin, int H, int W, int Cout, int act, float post_slope, int pre_act, float pre_slope,
            int pixel_shuffle, hipStream_t s) {
   const int n_ct = (Cout + Cfg::NTC - 1) / Cfg::NTC;
+  const int Hi = H, Wi = W;  // the input map; the tiles are laid over the OUTPUT of a stride-2 layer
+  if (Cfg::MODE == 2) H = (Hi - 1) / 2 + 1, W = (Wi - 1) / 2 + 1;
   const int nbx = (W + Cfg::TW - 1) / Cfg::TW, nby = (H + Cfg::TH - 1) / Cfg::TH;
-  const long long total = (long long)nbx * nby * N * n_ct * (Cfg::MODE == 0 ? 1 : 2);  // x2: row phases
+  const long long total = (long long)nbx * nby * N * n_ct * (Cfg::MODE != 1 ? 1 : 2);  // x2: row phases
   if (total >= (1ll << 31)) return DRBA_EUNSUPPORTED;
   // persistent grid: what the 256 CUs can hold (LDS-limited workgroups per CU, at most 3 by registers), a multiple of 8
   int per_cu = 160 * 1024 / Cfg::LDS_BYTES;
@@ -683,7 +698,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     DRBA_LAUNCH(kernel, g, dim3(256), Cfg::LDS_BYTES, s, in, wf, bias, beta, res, res2, out, Cin, H, W, Cout, act,
-                      post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle);
+                      post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle, Hi, Wi);
     return DRBA_OK;
   };
   int rc;
@@ -704,18 +719,22 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
 
 namespace drba {
 
-// ids 0 .. kNum-1: three-term bf16; kNum .. 2*kNum-1: the same tiles in the two-term fp16 form
+// ids 0 .. kNum-1: three-term bf16; kNum .. 2*kNum-1: the same tiles in the two-term fp16 form; then the stride-2 tiles
+// (two-term form, any Cin)
 int conv_split_num_cfgs() { return drba_conv_split::kNum; }
 int conv_split_f16_first() { return drba_conv_split::kNum; }
+int conv_split_s2_first() { return 2 * drba_conv_split::kNum; }
+int conv_split_s2_num_cfgs() { return drba_conv_split::kNumX; }
 
 bool conv_split_supports(int Cin, int Cout, int id) {
-  return id >= 0 && id < 2 * drba_conv_split::kNum && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
+  if (id >= 2 * drba_conv_split::kNum) return id < 2 * drba_conv_split::kNum + drba_conv_split::kNumX && Cin > 0 && Cout > 0;
+  return id >= 0 && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
 }
 
 size_t conv_split_packed_floats(int Cin, int Cout, int id) {
   if (!conv_split_supports(Cin, Cout, id)) return 0;
   const drba_conv_split::Info &c = drba_conv_split::kInfo[id];
-  const size_t n_ct = (Cout + c.NTC - 1) / c.NTC, nch = Cin / drba_conv_split::CK;
+  const size_t n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + drba_conv_split::CK - 1) / drba_conv_split::CK;
   return n_ct * nch * c.frag_u4 * 4;
 }
 
@@ -725,7 +744,7 @@ int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id) {
   using namespace drba_conv_split;
   if (!w || !packed || !conv_split_supports(Cin, Cout, id)) return DRBA_EINVAL;
   const Info &c = kInfo[id];
-  const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = Cin / CK;
+  const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + CK - 1) / CK;
   memset(packed, 0, sizeof(float) * conv_split_packed_floats(Cin, Cout, id));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   for (int cz = 0; cz < n_ct; ++cz)
@@ -737,6 +756,7 @@ int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id) {
             if (co >= Cout) continue;
             for (int i = 0; i < 8; ++i) {
               const int ci = q * CK + 8 * (lane >> 4) + i;
+              if (ci >= Cin) continue;  // (stride-2 ids: the last chunk of a ragged Cin)
               unsigned short term[3];
               split_weight_terms(w[((size_t)co * Cin + ci) * 9 + tap], c.PL, term);
               for (int pl = 0; pl < c.PL; ++pl) {
@@ -771,6 +791,10 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
     DRBA_CASE(7, F2)
     DRBA_CASE(8, F3)
     DRBA_CASE(9, F4)
+    DRBA_CASE(10, X0)
+    DRBA_CASE(11, X1)
+    DRBA_CASE(12, X2)
+    DRBA_CASE(13, X3)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;

@@ -35,6 +35,8 @@ static inline void split_weight_terms(float x, int PL, unsigned short *bits) {
 
 int conv_split_num_cfgs();   // ids 0 .. n-1: three-term bf16 split; ids n .. 2n-1: the same tiles, two-term fp16 split
 int conv_split_f16_first();  // = n
+int conv_split_s2_first();   // = 2n: then conv_split_s2_num_cfgs() stride-2 tiles in the two-term form (any Cin; H, W = the INPUT map)
+int conv_split_s2_num_cfgs();
 bool conv_split_supports(int Cin, int Cout, int id);  // stride 1, Cin a multiple of 32
 size_t conv_split_packed_floats(int Cin, int Cout, int id);
 int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id);

@@ -110,6 +110,8 @@ def check_conv_layers(dev):
     lib = ops._lib.load()
     n_fp32 = 14
     for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
+        if lib.drba_conv3x3_cfg_stride(cfg) != 1:
+            continue  # (the stride-2 tiles of the two-term form: below)
         # (the LDS-DMA family: 32 input channels, at most 32 output channels, widths that are multiples of 4 -- its windows
         # move in 16-byte units -- still ragged in tiles)
         # the K-split family: 2 / 3 / 4 / 6 chunks of 32 input channels, any width (dword windows when it is not a multiple of 4)
@@ -146,6 +148,28 @@ def check_conv_layers(dev):
                              5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
             except Exception as e:  # noqa: BLE001
                 rows.append((f"conv split cfg{cfg} {kind}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    # stride 2 in the two-term form (conv_split.hip MODE 2): ragged Cin (the last chunk padded), odd and even maps, widths that
+    # are and are not multiples of 4 on the output side, a batch, the PReLU pre-activation, Cout past one tile; against fp64
+    for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
+        if lib.drba_conv3x3_cfg_stride(cfg) != 2:
+            continue
+        for (nb, cin, cout, h, w, kind) in ((1, 52, 32, 22, 90, "conv"), (2, 39, 96, 17, 31, "conv"), (1, 16, 32, 40, 64, "conv"),
+                                            (2, 48, 96, 9, 72, "pre"), (1, 64, 128, 34, 60, "conv"), (1, 7, 16, 5, 70, "conv")):
+            try:
+                x = torch.randn(nb, cin, h, w, generator=g) * 3.0
+                wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+                b = torch.randn(cout, generator=g) * 0.1
+                if kind == "pre":
+                    ref = F.conv2d(F.prelu(x.double(), torch.tensor([0.25], dtype=torch.float64)), wt.double(), b.double(), stride=2, padding=1)
+                    got = ops.Conv3x3(wt, b, 2, None, None, device=dev, cfg=cfg, pre_slope=0.25)(x.to(dev))
+                else:
+                    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=1), 0.2)
+                    got = ops.Conv3x3(wt, b, 2, True, None, device=dev, cfg=cfg)(x.to(dev))
+                scale = float(ref.abs().max())
+                rows.append((f"conv split s2 cfg{cfg} {kind} [{nb}x{cin}->{cout} {h}x{w}]", _diff(got, ref.float()),
+                             5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+            except Exception as e:  # noqa: BLE001
+                rows.append((f"conv split s2 cfg{cfg} {kind}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     for cfg in range(6):
         for (cin, cout, h, w, ps) in ((20, 52, 11, 45, True), (9, 16, 6, 70, False)):
             try:

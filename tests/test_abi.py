@@ -117,6 +117,18 @@ def test_split_conv_weight_packing_reconstructs_fp32():
     for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
         fam = lib.drba_conv3x3_cfg_family(cfg)
         seen.add(fam)
+        if lib.drba_conv3x3_cfg_stride(cfg) == 2:  # the two-term form's stride-2 tiles take any Cin (last chunk padded with zeros)
+            assert fam == 4 and lib.drba_conv3x3_packed_floats(20, 32, cfg) > 0
+            cin, cout = 52, 40
+            n = lib.drba_conv3x3_packed_floats(cin, cout, cfg)
+            w = torch.randn(cout, cin, 3, 3, generator=g)
+            buf = torch.full((n,), float("nan"))
+            assert lib.drba_conv3x3_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr()), cin, cout, cfg) == 0
+            vals = buf.view(torch.float16).numpy().astype(np.float64).reshape(-1, 2, 64, 8)
+            total = (vals[:, 0] + vals[:, 1] / 2048.0).reshape(-1)
+            nz, ref = np.sort(total[total != 0]), np.sort(w.numpy().astype(np.float64).reshape(-1))
+            assert nz.size == ref.size and np.all(np.abs(nz - ref) <= 2.0 ** -21 * np.abs(ref) + 2.0 ** -35)
+            continue
         assert lib.drba_conv3x3_cfg_stride(cfg) == 1
         assert lib.drba_conv3x3_packed_floats(20, 32, cfg) == 0
         # (the LDS-DMA kernels, three- and two-term: 32 -> <= 32 channels)

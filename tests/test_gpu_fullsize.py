@@ -210,7 +210,7 @@ def test_split_conv_configs_on_many_tile_shapes(hip_backend):
         scale = float(ref.abs().max())
         xg = x.to(dev)
         for cfg in range(14, lib.drba_conv3x3_num_cfgs()):
-            if lib.drba_conv3x3_packed_floats(cin, cout, cfg) == 0:
+            if lib.drba_conv3x3_cfg_stride(cfg) != 1 or lib.drba_conv3x3_packed_floats(cin, cout, cfg) == 0:
                 continue
             if kind == "res":
                 got = ops.Conv3x3(wt, b, 1, True, beta, device=dev, cfg=cfg)(xg, residual=xg)
@@ -220,6 +220,23 @@ def test_split_conv_configs_on_many_tile_shapes(hip_backend):
                 got = ops.Conv3x3(wt, b, 1, True, None, device=dev, cfg=cfg)(xg)
             rows.append((f"conv split cfg{cfg} {kind} [{nb}x{cin}->{cout} {h}x{w}]", gpu_checks._diff(got, ref),
                          5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+    # the stride-2 tiles of the two-term form on the step's conv0 layers at N = 8 (ragged Cin 52 / 39 / 16)
+    for (nb, cin, cout, h, w) in ((8, 52, 32, 544, 960), (8, 52, 48, 272, 480), (8, 16, 32, 544, 960), (8, 39, 96, 68, 120)):
+        x = torch.randn(nb, cin, h, w, generator=g) * 2.0
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = F.leaky_relu(F.conv2d(x[:2].double(), wt.double(), b.double(), stride=2, padding=1), 0.2).float()  # (items 0, 1)
+        last = F.leaky_relu(F.conv2d(x[-1:].double(), wt.double(), b.double(), stride=2, padding=1), 0.2).float()
+        scale = float(ref.abs().max())
+        xg = x.to(dev)
+        for cfg in range(14, lib.drba_conv3x3_num_cfgs()):
+            if lib.drba_conv3x3_cfg_stride(cfg) != 2 or lib.drba_conv3x3_packed_floats(cin, cout, cfg) == 0:
+                continue
+            got = ops.Conv3x3(wt, b, 2, True, None, device=dev, cfg=cfg)(xg)
+            rows.append((f"conv split s2 cfg{cfg} [{nb}x{cin}->{cout} {h}x{w}] items 0-1", gpu_checks._diff(got[:2], ref),
+                         5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
+            rows.append((f"conv split s2 cfg{cfg} [{nb}x{cin}->{cout} {h}x{w}] item 7", gpu_checks._diff(got[-1:], last),
+                         5e-6 * max(1.0, scale), ""))
     for (nb, cin, cout, h, w, ps) in ((2, 32, 52, 272, 480, True), (2, 64, 52, 136, 240, True), (1, 96, 64, 192, 480, False),
                                       (8, 32, 20, 272, 480, True), (8, 64, 52, 136, 240, True)):
         x = torch.randn(nb, cin, h, w, generator=g) * 2.0
