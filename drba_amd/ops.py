@@ -372,6 +372,10 @@ def _tune(shape_key, candidates, run, reps=3):
     for cfg in candidates:
         if run(cfg) != 0:  # warm: packs weights, faults pages; a configuration that refuses the shape is not a candidate
             continue
+        # the candidates are timed on an otherwise idle device: the first call for a shape usually comes from inside the
+        # three-stream pipeline, and a candidate timed beside another stream's kernels loses to one that was not (round 4: a
+        # 590 us stride-2 tile picked over a 321 us one for the largest conv0 layer, -1.5 % on the step)
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):

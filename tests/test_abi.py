@@ -178,6 +178,8 @@ def test_autotune_skips_configurations_that_refuse_the_shape(monkeypatch):
             return other.at - self.at
 
     monkeypatch.setattr(ops.torch.cuda, "Event", _Ev)
+    syncs = []
+    monkeypatch.setattr(ops.torch.cuda, "synchronize", lambda *a: syncs.append(1))  # (candidates are timed on an idle device)
     monkeypatch.setattr(ops, "_tuned", {})
     cost = {3: 5.0, 4: 1.0, 5: 2.0}
 
@@ -188,6 +190,7 @@ def test_autotune_skips_configurations_that_refuse_the_shape(monkeypatch):
         return 0
 
     assert ops._tune(("shape",), [3, 4, 5], run) == 5
+    assert len(syncs) == 2  # one per candidate that accepted the shape
     with pytest.raises(_lib.DrbaHipError):
         ops._tune(("other",), [4], run)
 
