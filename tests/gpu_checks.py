@@ -148,6 +148,22 @@ def check_conv_layers(dev):
                              5e-6 * max(1.0, scale), f"|ref|max={scale:.2f}"))
             except Exception as e:  # noqa: BLE001
                 rows.append((f"conv split cfg{cfg} {kind}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
+    # the two-term form's range: activations far from 1 (the split pre-scales by 2^-4 and keeps l scaled by 2^11, so that the
+    # operand's magnitude does not matter between fp16's normal range and 65504 * 16; below |x| ~ 1e-3 the error is bounded
+    # absolutely instead, 2^-32) -- |x| ~ 1e5 and |x| ~ 1e-2, same relative bound
+    for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
+        if lib.drba_conv3x3_cfg_family(cfg) != 4 or lib.drba_conv3x3_cfg_stride(cfg) != 1 or lib.drba_conv3x3_packed_floats(64, 64, cfg) == 0:
+            continue
+        for mag in (3e4, 1e-2):
+            try:
+                x = torch.randn(1, 64, 12, 40, generator=g) * mag
+                wt = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+                ref = F.conv2d(x.double(), wt.double(), None, padding=1)
+                got = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=cfg)(x.to(dev))
+                scale = float(ref.abs().max())
+                rows.append((f"conv two-term cfg{cfg} |x| ~ {mag:g}", _diff(got, ref.float()), 5e-6 * scale, f"|ref|max={scale:.3g}"))
+            except Exception as e:  # noqa: BLE001
+                rows.append((f"conv two-term cfg{cfg} |x| ~ {mag:g}", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     # stride 2 in the two-term form (conv_split.hip MODE 2): ragged Cin (the last chunk padded), odd and even maps, widths that
     # are and are not multiples of 4 on the output side, a batch, the PReLU pre-activation, Cout past one tile; against fp64
     for cfg in range(n_fp32, lib.drba_conv3x3_num_cfgs()):
