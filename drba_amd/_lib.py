@@ -111,7 +111,7 @@ SIGNATURES = {
     "drba_channel_normalize3": (_i, [_p, _p, _i, _z, _p, _p, _p]),
     "drba_layernorm": (_i, [_p, _p, _p, _p, _p, _z, _i, _f, _p]),
     "drba_gelu": (_i, [_p, _p, _z, _p]),
-    "drba_window_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p, _p]),
+    "drba_window_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p, _i, _p]),
     "drba_window_attention_ws_floats": (_z, [_i, _i, _i, _i]),
     "drba_linear_split_packed_floats": (_z, [_i, _i, _i]),
     "drba_linear_split_pack": (_i, [_p, _p, _i, _i, _i]),

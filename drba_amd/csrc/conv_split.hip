@@ -238,7 +238,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 #ifdef DRBA_SPLIT_STAGGER  // experiment: put the co-resident workgroups of a CU out of phase
   {
     const int b = blockIdx.x;
-    const bool late = DRBA_SPLIT_STAGGER == 1 ? (b & 1) : DRBA_SPLIT_STAGGER == 2 ? (b >= (int)gridDim.x / 2) : ((b >> 3) & 1);
+    const bool late = DRBA_SPLIT_STAGGER == 1 ? (b & 1) : DRBA_SPLIT_STAGGER == 2 ? (b >= (int)gridDim.x / 2) : DRBA_SPLIT_STAGGER == 4 ? ((b >> 8) & 1) : ((b >> 3) & 1);
     if (late) {
       for (int i = 0; i < DRBA_SPLIT_STAGGER_N; ++i) __builtin_amdgcn_s_sleep(127);
     }

@@ -261,6 +261,244 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel in the two-term fp16 form (kernel family 4; conv_split.hip "Two-term form"): every fp32 operand of the two
+// GEMMs is taken as h + 2^-11 l with two fp16 terms and contracted with v_mfma_f32_16x16x32_f16 (three products per fragment
+// pair, the cross products in a second accumulator), 48 + 48 MFMAs of ~17 clocks per 64-key chunk and wave instead of
+// 128 + 128 fp32 ones of 32.  Scores, masks, the online softmax and the running rescale stay fp32 as above.
+//   * K of a chunk lives in LDS as two fp16 planes [key][128 ch] (row stride 272 bytes); a lane's A operand for the 32-channel
+//     step j of key tile t is one 16-byte read.  K is pre-scaled by 2^-4 (undone with the 1 / sqrt(C) factor), Q is split once
+//     into registers;
+//   * the MFMA's K index is free as long as both operands agree, and so is the key a score row stands for: a loader thread
+//     holds 8 CONSECUTIVE keys of 4 channels, which is exactly the 8 k-values a lane supplies to one PV MFMA -- V goes to LDS
+//     TRANSPOSED as [channel][key unit of 8][8 x fp16] with one 16-byte write per channel and plane, no 2-byte scatter --, and
+//     score row 4 g + i of tile t stands for key 32 (t >> 1) + 8 g + 4 (t & 1) + i, so that lane group g leaves the softmax
+//     holding the probabilities of keys 32 ss + 8 g .. + 7 in PV-operand order;
+//   * O^T tiles hold channels 16 dt + 4 g + i: 16-byte stores of consecutive channels.
+constexpr int kKU = 17;                    // 16-byte units per K row: 128 halves + 16 bytes (row r and r + 16 still share a slot: 2-way)
+constexpr int kVU = 9;                     // 16-byte units per V^T row: 64 keys + 16 bytes (9 m mod 16 distinct: conflict-free reads)
+constexpr int kLds16Bytes = (2 * kKeys * kKU + 2 * kC * kVU) * 16 + kKeys * 4;  // 34816 + 36864 + 256 = 71.9 KB: two workgroups per CU
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int SHIFT>  // (a, b) * 2^-SHIFT -> packed fp16 h and packed (remainder * 2^11)
+__device__ __forceinline__ void split2h(float a, float b, unsigned &h, unsigned &l) {
+  const f32x2 v = (f32x2){a, b} * (1.f / (float)(1 << SHIFT));
+  const f16x2 hh = __builtin_convertvector(v, f16x2);
+  const f32x2 r = (v - __builtin_convertvector(hh, f32x2)) * 2048.f;
+  const f16x2 ll = __builtin_convertvector(r, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+[[maybe_unused]] constexpr int kKShift = 4;
+
+__global__ void __launch_bounds__(256, 2)  // two waves per SIMD = two workgroups per CU: <= 256 registers
+window_attention16_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                          float *__restrict__ out, Geometry g, int nwin, int qtiles, float scale, int ldq, int ldk, int ldv, int ksplit,
+                          float *__restrict__ part) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
+  u32x4 *KsH = lds16, *KsL = lds16 + kKeys * kKU;           // [key][kKU]
+  u32x4 *VtH = lds16 + 2 * kKeys * kKU, *VtL = VtH + kC * kVU;  // [channel][kVU]
+  int *Kreg = reinterpret_cast<int *>(VtL + kC * kVU);
+  constexpr int TPW = 4, LIT = 8;
+
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7;
+  int slot = lin >> 3;
+  const int ks = slot % ksplit;
+  slot /= ksplit;
+  const int win = (slot / qtiles) * 8 + xcd, qt = slot - (slot / qtiles) * qtiles;
+  if (win >= nwin) return;
+  const Window wd = window_of(g, win);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, grp = lane >> 4;
+
+  // ---- this lane's query row: B operand of S^T = K Q^T, channels 32 j + 8 grp .. + 7 for step j, split once
+  const int qtok = qt * kRows + wave * 16 + n16;
+  const bool qlive = qtok < g.L;
+  int qreg;
+  const size_t qrow = token_row(g, wd, min(qtok, g.L - 1), qreg);
+  u32x4 qh[4], ql[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(q + qrow * ldq + 32 * j + 8 * grp);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(q + qrow * ldq + 32 * j + 8 * grp + 4);
+    unsigned h, l;
+    split2h<0>(a[0], a[1], h, l), qh[j][0] = h, ql[j][0] = l;
+    split2h<0>(a[2], a[3], h, l), qh[j][1] = h, ql[j][1] = l;
+    split2h<0>(b[0], b[1], h, l), qh[j][2] = h, ql[j][2] = l;
+    split2h<0>(b[2], b[3], h, l), qh[j][3] = h, ql[j][3] = l;
+  }
+
+  // ---- chunk loader: thread -> (keys 8 * (tid / 32) + it, it = 0..7; 4 channels at 4 * (tid % 32))
+  const int lkey = tid >> 5, lc4 = (tid & 31) * 4;
+  f32x4 pk[LIT], pv[LIT];
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < LIT; ++it) {
+      int unused;
+      const size_t row = token_row(g, wd, min(chunk * kKeys + 8 * lkey + it, g.L - 1), unused);
+      pk[it] = *reinterpret_cast<const f32x4 *>(k + row * ldk + lc4);
+      pv[it] = *reinterpret_cast<const f32x4 *>(v + row * ldv + lc4);
+    }
+  };
+  auto stage = [&](int chunk) {
+    // K: [key][channel] planes, 8 bytes (4 channels) per plane and key
+#pragma unroll
+    for (int it = 0; it < LIT; ++it) {
+      const int key = 8 * lkey + it;
+      u32x2 h, l;
+      unsigned a, b;
+      split2h<kKShift>(pk[it][0], pk[it][1], a, b), h[0] = a, l[0] = b;
+      split2h<kKShift>(pk[it][2], pk[it][3], a, b), h[1] = a, l[1] = b;
+      unsigned char *dst = reinterpret_cast<unsigned char *>(KsH + key * kKU) + lc4 * 2;
+      *reinterpret_cast<u32x2 *>(dst) = h;
+      *reinterpret_cast<u32x2 *>(dst + kKeys * kKU * 16) = l;
+    }
+    // V^T: this thread's 8 consecutive keys of channel lc4 + c are one 16-byte unit [channel][key unit lkey]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      u32x4 h, l;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        unsigned a, b;
+        split2h<0>(pv[2 * p][c], pv[2 * p + 1][c], a, b);
+        h[p] = a, l[p] = b;
+      }
+      VtH[(lc4 + c) * kVU + lkey] = h;
+      VtL[(lc4 + c) * kVU + lkey] = l;
+    }
+    if (g.shift && tid < kKeys) {
+      int region;
+      token_row(g, wd, min(chunk * kKeys + tid, g.L - 1), region);
+      Kreg[tid] = region;
+    }
+  };
+
+  f32x4 oh[8], ol[8];  // O^T tile dt: channels 16 dt + 4 grp + i of query n16; hi: h*h products, lo: the cross products (2^-11)
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) oh[dt] = ol[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int all_chunks = (g.L + kKeys - 1) / kKeys, per = (all_chunks + ksplit - 1) / ksplit;
+  const int ch0 = ks * per, chunks = min(all_chunks, ch0 + per);
+  const float s_scale = (float)(1 << kKShift) / scale;  // undoes K's pre-scale, applies 1 / sqrt(C)
+  // key a score row stands for: tile t, row 4 g + i  <->  key 32 (t >> 1) + 8 g + 4 (t & 1) + i
+  int krow[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) krow[t] = (32 * (t >> 1) + 8 * (n16 >> 2) + 4 * (t & 1) + (n16 & 3)) * kKU + grp;
+  if (ch0 < chunks) fetch(ch0);
+  for (int ch = ch0; ch < chunks; ++ch) {
+    __syncthreads();  // every wave is done reading the previous chunk
+    stage(ch);
+    __syncthreads();
+    if (ch + 1 < chunks) fetch(ch + 1);
+
+    // ---- S^T tiles: A = K rows (16 keys of tile t, channels 32 j + 8 kq ..), B = this lane's Q fragment of step j
+    f32x4 sh[TPW], sl[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) sh[t] = sl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f16x8 bh = __builtin_bit_cast(f16x8, qh[j]), bl = __builtin_bit_cast(f16x8, ql[j]);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, KsH[krow[t] + 4 * j]), al = __builtin_bit_cast(f16x8, KsL[krow[t] + 4 * j]);
+        sl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, sl[t], 0, 0, 0);
+        sl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, sl[t], 0, 0, 0);
+        sh[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, sh[t], 0, 0, 0);
+      }
+    }
+
+    // ---- scale, mask, online softmax (fp32)
+    float s[TPW][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int key0 = 32 * (t >> 1) + 8 * grp + 4 * (t & 1);  // this lane's 4 keys of tile t
+      int krs[4] = {0, 0, 0, 0};
+      if (g.shift) {
+        const int4 kr = *reinterpret_cast<const int4 *>(&Kreg[key0]);
+        krs[0] = kr.x, krs[1] = kr.y, krs[2] = kr.z, krs[3] = kr.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x = (sh[t][i] + sl[t][i] * (1.f / 2048.f)) * s_scale;  // scores / sqrt(C) (transformer.py:91)
+        if (g.shift && krs[i] != qreg) x += -100.f;
+        if (ch * kKeys + key0 + i >= g.L) x = -INFINITY;
+        s[t][i] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);       // finite: every chunk holds at least one real key
+    const float alpha = __expf(m_run - m_new);  // 0 on the first chunk
+    float ls = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[t][i] = __expf(s[t][i] - m_new);
+        ls += s[t][i];
+      }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) oh[dt] *= alpha, ol[dt] *= alpha;
+
+    // ---- O^T += V^T P^T: step ss contracts keys 32 ss + 8 kq + i; B = this lane's probabilities of tiles 2 ss, 2 ss + 1
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      u32x4 ph, pl;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        unsigned a, b;
+        split2h<0>(s[2 * ss + (p >> 1)][2 * (p & 1)], s[2 * ss + (p >> 1)][2 * (p & 1) + 1], a, b);
+        ph[p] = a, pl[p] = b;
+      }
+      const f16x8 bh = __builtin_bit_cast(f16x8, ph), bl = __builtin_bit_cast(f16x8, pl);
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const int u = (16 * dt + n16) * kVU + 4 * ss + grp;
+        const f16x8 ah = __builtin_bit_cast(f16x8, VtH[u]), al = __builtin_bit_cast(f16x8, VtL[u]);
+        ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, ol[dt], 0, 0, 0);
+        ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, ol[dt], 0, 0, 0);
+        oh[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, oh[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // lane (query n16, group grp) holds channels 16 dt + 4 grp + i of its row
+  if (ksplit > 1) {
+    if (qlive) {
+      float *prow = part + (((size_t)win * g.L + qtok) * ksplit + ks) * 132;
+      if (grp == 0) {
+        prow[0] = m_run;
+        prow[1] = l_run;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4 *>(prow + 4 + 16 * dt + 4 * grp) = oh[dt] + ol[dt] * (1.f / 2048.f);
+    }
+    return;
+  }
+  if (qlive) {
+    const float inv = 1.f / l_run;
+    float *orow = out + qrow * kC + 4 * grp;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4 *>(orow + 16 * dt) = (oh[dt] + ol[dt] * (1.f / 2048.f)) * inv;
+  }
+#endif
+}
+
 // out row = sum_ks exp(m_ks - m) O_ks / sum_ks exp(m_ks - m) l_ks, m = max_ks m_ks; one wave per query row, 2 channels per lane
 __global__ void __launch_bounds__(256)
 window_attention_merge(const float *__restrict__ part, float *__restrict__ out, Geometry g, int nwin, int ksplit) {
@@ -307,9 +545,10 @@ extern "C" size_t drba_window_attention_ws_floats(int B, int H, int W, int split
 }
 
 extern "C" int drba_window_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int W, int C,
-                                     int splits, int shift, float scale, int ldq, int ldk, int ldv, float *ws,
+                                     int splits, int shift, float scale, int ldq, int ldk, int ldv, float *ws, int terms,
                                      void *stream) {
   if (!q || !k || !v || !out || B <= 0 || H <= 0 || W <= 0 || splits <= 0 || !(scale > 0.f)) return DRBA_EINVAL;
+  if (terms != 2 && terms != 3) return DRBA_EINVAL;  // 3: fp32 MFMA (the name counts operand bits: 24); 2: two fp16 terms
   if (C != drba_attn::kC) return DRBA_EUNSUPPORTED;  // GMFlow's feature_channels
   if (ldq < C || ldk < C || ldv < C || ((ldq | ldk | ldv) & 3)) return DRBA_EINVAL;  // rows are read as 16-byte vectors
   if (H % splits || W % splits) return DRBA_EINVAL;  // the reference's window split needs whole windows
@@ -327,10 +566,17 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
   const int ksplit = ws ? attn_ksplit(nwin, g.L) : 1;  // without a workspace every workgroup walks all keys
   const dim3 grid((unsigned)(groups * 8 * qtiles * ksplit));
   // beyond the default 64 KB dynamic-LDS limit
-  if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention_kernel), drba_attn::kLdsBytes) != hipSuccess)
-    return DRBA_ELAUNCH;
-  DRBA_LAUNCH(drba_attn::window_attention_kernel, grid, dim3(kBlock), drba_attn::kLdsBytes, (hipStream_t)stream, q, k, v,
-                    out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws);
+  if (terms == 2) {
+    if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention16_kernel), drba_attn::kLds16Bytes) != hipSuccess)
+      return DRBA_ELAUNCH;
+    DRBA_LAUNCH(drba_attn::window_attention16_kernel, grid, dim3(kBlock), drba_attn::kLds16Bytes, (hipStream_t)stream, q, k, v,
+                      out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws);
+  } else {
+    if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention_kernel), drba_attn::kLdsBytes) != hipSuccess)
+      return DRBA_ELAUNCH;
+    DRBA_LAUNCH(drba_attn::window_attention_kernel, grid, dim3(kBlock), drba_attn::kLdsBytes, (hipStream_t)stream, q, k, v,
+                      out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws);
+  }
   if (ksplit > 1)
     DRBA_LAUNCH(drba_attn::window_attention_merge, dim3((unsigned)(((size_t)nwin * g.L + 3) / 4)), dim3(kBlock), 0,
                        (hipStream_t)stream, ws, out, g, nwin, ksplit);

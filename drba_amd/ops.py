@@ -1188,9 +1188,16 @@ class LinearSplit:
         return out.view(*lead, 128)
 
 
-def window_attention(q, k, v, h, w, splits, shift, scale):
+ATTN_TWO_TERM = None  # None: follow CONV_FAMILIES (family 4 allowed -> the two-term fp16 kernel); True / False force it (tests, A/B)
+
+
+def window_attention(q, k, v, h, w, splits, shift, scale, terms=None):
     """single_head_split_window_attention (transformer.py:46-113) fused: q, k, v [B, h*w, 128] -> [B, h*w, 128].
-    q, k, v may be last-dim slices of a wider tensor (a fused projection output): only the row stride is used."""
+    q, k, v may be last-dim slices of a wider tensor (a fused projection output): only the row stride is used.
+    terms: 3 = fp32 MFMA, 2 = the GEMM operands as two fp16 terms (default: 2 when kernel family 4 is allowed)."""
+    if terms is None:
+        two = ATTN_TWO_TERM if ATTN_TWO_TERM is not None else (4 in CONV_FAMILIES)
+        terms = 2 if two else 3
     b, n, c = q.shape
     assert n == h * w and k.shape == q.shape and v.shape == q.shape
 
@@ -1208,9 +1215,9 @@ def window_attention(q, k, v, h, w, splits, shift, scale):
     ws = _workspace(q.device, nws) if nws else None
     # QK^T and PV: 2 x 2 L^2 C FLOP per window of L = (h / splits)(w / splits) tokens, b * splits^2 windows
     L = (h // int(splits)) * (w // int(splits))
-    _lib.check(_timed("window_attention", (b, h, w, c, int(splits), int(bool(shift))), 4.0 * b * int(splits) ** 2 * L * L * c, "flop",
+    _lib.check(_timed("window_attention", (b, h, w, c, int(splits), int(bool(shift)), int(terms)), 4.0 * b * int(splits) ** 2 * L * L * c, "flop",
                       lambda: lib.drba_window_attention(_p(q), _p(k), _p(v), _p(out), b, h, w, c, int(splits), int(bool(shift)),
-                                                        float(scale), ldq, ldk, ldv, _p(ws), _stream())), "drba_window_attention")
+                                                        float(scale), ldq, ldk, ldv, _p(ws), int(terms), _stream())), "drba_window_attention")
     return out
 
 

@@ -34,7 +34,7 @@ extern "C" {
 
 /* ABI version.  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
  * drba_deconv4x4s2, so no earlier id changes meaning), drba_deconv4x4_cfg_family, and a `terms` argument (3 or 2) on the
- * drba_linear_split_* entry points; drba_head_fused16_*.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
+ * drba_linear_split_* entry points and on drba_window_attention; drba_head_fused16_*.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
  * NULL (nothing but f_pair_out is written), and every stage-input entry point accepts items with f0 == f1 == NULL when
  * f0_pair / f1_pair are set (the first, unwarped stage reads the pair layout too).  3: drba_stage_item_t grew by term[DRBA_MAX_FLOW_TERMS]; drba_flow_terms_t and the entry points that take the
  * running flow as terms (drba_ifblock_input_lazy_batch, drba_warp_blend_lazy_batch); drba_stage_conv0_*.
@@ -332,7 +332,9 @@ int drba_gelu(const float *x, float *out, size_t n, void *stream); /* nn.GELU(),
  * generate_shift_window_attn_mask (transformer.py:19-43), softmax(q k^T / scale) v and the inverse partition / roll
  * are applied through index maps; the score matrix is never stored.  splits = 1, shift = 0 is full attention. */
 int drba_window_attention(const float *q, const float *k, const float *v, float *out, int B, int H, int W, int C,
-                          int splits, int shift, float scale, int ldq, int ldk, int ldv, float *ws, void *stream);
+                          int splits, int shift, float scale, int ldq, int ldk, int ldv, float *ws, int terms, void *stream);
+/* terms: 3 = both GEMMs on the fp32 matrix cores; 2 = their operands as two fp16 terms (kernel family 4: 22 bits, fp32
+ * accumulation; scores, masks and the softmax stay fp32) */
 /* ws: drba_window_attention_ws_floats(B, H, W, splits) floats (may be 0 / NULL): shapes with few, long windows split each
  * window's keys over several workgroups and merge the partial softmax states through it */
 size_t drba_window_attention_ws_floats(int B, int H, int W, int splits);

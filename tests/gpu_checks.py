@@ -848,14 +848,15 @@ def check_window_attention(dev):
         wh, ww = h // splits, w // splits
         mask = ogm.shift_window_mask(h, w, wh, ww, wh // 2, ww // 2) if shift else None
         want = ogm.window_attention(q, k, v, splits, shift, h, w, mask)
-        got = ops.window_attention(q.to(dev), k.to(dev), v.to(dev), h, w, splits, shift, 128 ** 0.5)
-        rows.append((f"window_attention b{b} {h}x{w} splits{splits} shift{int(shift)} (L={wh * ww})", _diff(got, want), 2e-5,
-                     f"ref_absmax={float(want.abs().max()):.3g}"))
+        for terms in (3, 2):  # fp32 MFMA / the two-term fp16 kernel: the same bound
+            got = ops.window_attention(q.to(dev), k.to(dev), v.to(dev), h, w, splits, shift, 128 ** 0.5, terms=terms)
+            rows.append((f"window_attention terms={terms} b{b} {h}x{w} splits{splits} shift{int(shift)} (L={wh * ww})", _diff(got, want), 2e-5,
+                         f"ref_absmax={float(want.abs().max()):.3g}"))
         if h * w // (splits * splits) >= 2048:  # the key-split path (few long windows) must be what ran
             assert ops._lib.load().drba_window_attention_ws_floats(b, h, w, splits) > 0
         if idx == 0:  # q, k, v as column slices of one [tokens, 3C] tensor (the fused projection's output): same bits
             qkv = torch.cat((q, k, v), -1).to(dev)
-            got2 = ops.window_attention(qkv[..., :128], qkv[..., 128:256], qkv[..., 256:], h, w, splits, shift, 128 ** 0.5)
+            got2 = ops.window_attention(qkv[..., :128], qkv[..., 128:256], qkv[..., 256:], h, w, splits, shift, 128 ** 0.5, terms=2)
             rows.append(("window_attention on column slices of a fused qkv tensor", float((got2 - got).abs().max()), 0.0, ""))
     return rows
 

@@ -31,12 +31,11 @@ def main():
         L = (h // splits) * (w // splits)
         flops = 4.0 * b * splits * splits * L * L * 128
         for shift in (False, True):
-            f = timeit(lambda: ops.window_attention(q, k, v, h, w, splits, shift, 128 ** 0.5))
-            u = timeit(lambda: net._attention_unfused(q, k, v, h, w, splits, shift))
-            d = (ops.window_attention(q, k, v, h, w, splits, shift, 128 ** 0.5) - net._attention_unfused(q, k, v, h, w, splits, shift)).abs().max()
-            print(f"b{b} {h}x{w} splits{splits} shift{int(shift)} L={L}: fused {f * 1e3:.0f} us ({flops / f / 1e9:.1f} TFLOP/s)  "
-                  f"unfused {u * 1e3:.0f} us  max|diff| {float(d):.2e}", flush=True)
-
+            f = timeit(lambda: ops.window_attention(q, k, v, h, w, splits, shift, 128 ** 0.5, terms=3))
+            f2 = timeit(lambda: ops.window_attention(q, k, v, h, w, splits, shift, 128 ** 0.5, terms=2))
+            d2 = (ops.window_attention(q, k, v, h, w, splits, shift, 128 ** 0.5, terms=2) - ops.window_attention(q, k, v, h, w, splits, shift, 128 ** 0.5, terms=3)).abs().max()
+            print(f"b{b} {h}x{w} splits{splits} shift{int(shift)} L={L}: fp32 MFMA {f * 1e3:.0f} us ({flops / f / 1e9:.1f} TFLOP/s)  "
+                  f"two-term fp16 {f2 * 1e3:.0f} us ({flops / f2 / 1e9:.1f} TFLOP/s)  max|two-term - fp32| {float(d2):.2e}", flush=True)
 
 if __name__ == "__main__":
     main()
