@@ -285,9 +285,9 @@ def _arithmetic_note():
     from drba_amd import ops
     two = 4 in ops.CONV_FAMILIES
     return {"tensors": "fp32 in HBM, fp32 accumulation, fp32 outputs",
-            "mfma_operands": ("stride-1 / transposed convolutions and GMFlow linears: each fp32 operand as two fp16 terms h + 2^-11 l "
-                              "(22 significand bits, 3 MFMA products, kernel family 4); stride-2 convolutions, the encoder, stage_conv0, "
-                              "attention: fp32 MFMA" if two else
+            "mfma_operands": ("stride-1 / transposed / most stride-2 convolutions, the encoder, GMFlow's linears and window attention: each "
+                              "fp32 operand as two fp16 terms h + 2^-11 l (22 significand bits, 3 MFMA products, kernel family 4); "
+                              "stage_conv0, the largest stride-2 layers, global correlation: fp32 MFMA" if two else
                               "stride-1 / transposed convolutions and GMFlow linears: each fp32 operand as three bf16 terms (24 bits, 6 MFMA "
                               "products); the rest fp32 MFMA"),
             "conv_families": sorted(ops.CONV_FAMILIES)}
