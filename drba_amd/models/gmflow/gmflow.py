@@ -3,7 +3,7 @@ position}.py, same state-dict keys; configuration used by DRBA: 2 scales, swin a
 
 Division of labour: the 3x3 convolutions run on the MFMA implicit-GEMM kernels; the 7x7 / 1x1 convolutions, the norms,
 local-window correlation / propagation, convex upsampling and warps are hand-written HIP kernels
-(drba_amd/csrc/gmflow.hip); every linear layer is drba_linear_split (three-term bf16 MFMA, fp32-level error), the
+(drba_amd/csrc/gmflow.hip); every linear layer is drba_linear_split (fp32 operands as two fp16 or three bf16 terms on the matrix cores, fp32-level error), the
 window attention is one fused kernel (window_attn.hip) and the global correlation / propagation softmaxes are a
 flash-style kernel that never forms the L x L score matrix (global_corr.hip).  torch does views, cat and nothing else:
 no arithmetic and no vendor BLAS.
