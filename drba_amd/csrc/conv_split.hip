@@ -542,6 +542,13 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
                 const int xb = ctx.x0 + mw * 16 + kq * 4;
                 if (co >= Cout || y >= H || xb >= W) continue;
                 const size_t idx = img + ((size_t)co * H + y) * W + xb;
+                if ((W & 3) == 0 && !res && !res2) {  // (odd MW tiles on aligned maps, no residual: one 16-byte store per lane)
+                  f32x4 o;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) o[k] = post(v[k] + bs[nt]);
+                  *reinterpret_cast<f32x4 *>(out + idx) = o;
+                  continue;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                   if (xb + k >= W) continue;
