@@ -87,6 +87,10 @@ SIGNATURES = {
     "drba_stage_conv0_pack": (_i, [_p, _p]),
     "drba_stage_conv0_supported": (_i, [_i, _i, _f, _f, _i]),
     "drba_stage_conv0_batch": (_i, [_p, _i, _p, _i, _i, _f, _i, _i, _p, _p, _p]),
+    "drba_stage_conv16_packed_floats": (_z, [_i]),
+    "drba_stage_conv16_pack": (_i, [_p, _i, _p]),
+    "drba_stage_conv16_supported": (_i, [_i, _i, _f, _f, _i]),
+    "drba_stage_conv16_batch": (_i, [_p, _i, _p, _i, _i, _f, _i, _i, _f, _i, _p, _p, _p]),
     "drba_head_fused_packed_floats": (_z, []),
     "drba_head_fused_pack": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "drba_head_fused": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),

@@ -45,26 +45,40 @@ template <int CAP_R, int CAP_C, int NTHREADS>
 __device__ __forceinline__ void terms_stage(float *lds, const FlowTermsArg &T, const float *const *ptr, int Xa, int Ya, int Xb, int Yb,
                                             int tid, int (&rx0)[kMaxTerms], int (&ry0)[kMaxTerms]) {
   constexpr int CAP = CAP_R * CAP_C;
+  constexpr int PER = (CAP + NTHREADS - 1) / NTHREADS;  // footprint pixels per lane and term
+  // all loads of all terms are issued before the first LDS write: one memory round trip for the workgroup's prologue instead
+  // of one per term (round 5: the per-term "load, wait, write" loop was 4 dependent L2 / HBM latencies on the critical path of
+  // every gather workgroup, 2-8k clocks)
+  f32x4t v[kMaxTerms][PER];
+  bool on[kMaxTerms][PER];
 #pragma unroll
   for (int i = 0; i < kMaxTerms; ++i) {
     rx0[i] = ry0[i] = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) on[i][k] = false, v[i][k] = (f32x4t){0.f, 0.f, 0.f, 0.f};
     if (i < T.n) {
       rx0[i] = lerp_src(Xa, T.inv[i], T.w[i]).i0, ry0[i] = lerp_src(Ya, T.inv[i], T.h[i]).i0;
       const int rw = min(lerp_src(Xb, T.inv[i], T.w[i]).i1 - rx0[i] + 1, CAP_C);
       const int rh = min(lerp_src(Yb, T.inv[i], T.h[i]).i1 - ry0[i] + 1, CAP_R);
       const size_t plane = (size_t)T.h[i] * T.w[i];
-      for (int e = tid; e < CAP; e += NTHREADS) {
-        const int r = e / CAP_C, col = e - r * CAP_C;
-        if (r < rh && col < rw) {
-          const float *src = ptr[i] + (size_t)(ry0[i] + r) * T.w[i] + rx0[i] + col;
-          f32x4t v;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = src[(size_t)c * plane];
-          *reinterpret_cast<f32x4t *>(lds + (size_t)(i * CAP + e) * 4) = v;
+      for (int k = 0; k < PER; ++k) {
+        const int e = tid + k * NTHREADS;
+        const int r = e / CAP_C, col = e - r * CAP_C;
+        on[i][k] = e < CAP && r < rh && col < rw;
+        if (on[i][k]) {
+          const float *src = ptr[i] + (size_t)(ry0[i] + r) * T.w[i] + rx0[i] + col;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[i][k][c] = src[(size_t)c * plane];
         }
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < kMaxTerms; ++i)
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (on[i][k]) *reinterpret_cast<f32x4t *>(lds + (size_t)(i * CAP + tid + k * NTHREADS) * 4) = v[i][k];
 }
 
 // Sum of the terms at full-resolution pixel (X, Y); returns false (fl untouched) when there are none.

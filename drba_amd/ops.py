@@ -861,18 +861,28 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
 
 
 STAGE_CONV_FUSED = True  # the scale-1 stage input and the IFBlock's first convolution in one kernel (tools/ab_bench.py --no-stage-conv: A/B)
+STAGE_CONV_TWO_TERM = None  # None: follow CONV_FAMILIES (family 4 allowed -> stage_conv16.hip); True / False force it (tests, A/B)
+
+
+def _stage_conv_two_term(conv):
+    return bool(STAGE_CONV_TWO_TERM if STAGE_CONV_TWO_TERM is not None else (4 in CONV_FAMILIES))
 
 
 def stage_conv0_ok(conv, H, W, scale, prev_scale):
-    """Can drba_stage_conv0_batch replace stage_inputs(scale) + conv (the IFBlock's first convolution)?"""
-    return bool(STAGE_CONV_FUSED and PAIR_FEATURES and conv.cin == 52 and conv.stride == 2 and conv.act == 1 and conv.beta is None
-                and conv.pre_slope is None and conv.post_slope == 0.0
-                and _lib.load().drba_stage_conv0_supported(H, W, float(scale), float(prev_scale), conv.cout))
+    """Can drba_stage_conv{0,16}_batch replace stage_inputs(scale) + conv (the IFBlock's first convolution)?"""
+    if not (STAGE_CONV_FUSED and PAIR_FEATURES and conv.cin == 52 and conv.stride == 2 and conv.act == 1 and conv.beta is None
+            and conv.pre_slope is None and conv.post_slope == 0.0):
+        return False
+    lib = _lib.load()
+    if _stage_conv_two_term(conv):
+        return bool(lib.drba_stage_conv16_supported(H, W, float(scale), float(prev_scale), conv.cout))
+    return bool(lib.drba_stage_conv0_supported(H, W, float(scale), float(prev_scale), conv.cout))  # 16 output channels only
 
 
 def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None):
     """The scale-1 stage input of every item fused with `conv` (52 -> 16, stride 2, LeakyReLU): stage_inputs(..., scale=1)
-    followed by conv(xin) without the 52-channel tensor (drba_stage_conv0_batch).  Returns (y0 [B,16,Ho,Wo], folded flows
+    followed by conv(xin) without the 52-channel tensor (drba_stage_conv16_batch: two fp16 terms per operand, kernel family 4;
+    drba_stage_conv0_batch: exact fp32 products, when family 4 is not allowed).  Returns (y0 [B,16,Ho,Wo], folded flows
     or None).  terms: as in stage_inputs (instead of flows / fold)."""
     B = len(items)
     lazy = terms is not None
@@ -885,11 +895,18 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
     _, _, H, W = img0.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     dev = img0.device
-    if getattr(conv, "_stage_pack", None) is None:
+    two = _stage_conv_two_term(conv)
+    attr = "_stage_pack16" if two else "_stage_pack"
+    if getattr(conv, attr, None) is None:
         lib = _lib.load()
-        buf = torch.empty(lib.drba_stage_conv0_packed_floats(), dtype=torch.float32)
-        _lib.check(lib.drba_stage_conv0_pack(C.c_void_p(conv.w_host.data_ptr()), C.c_void_p(buf.data_ptr())), "drba_stage_conv0_pack")
-        conv._stage_pack = buf.to(dev)
+        if two:
+            buf = torch.empty(lib.drba_stage_conv16_packed_floats(conv.cout), dtype=torch.float32)
+            _lib.check(lib.drba_stage_conv16_pack(C.c_void_p(conv.w_host.data_ptr()), conv.cout, C.c_void_p(buf.data_ptr())), "drba_stage_conv16_pack")
+        else:
+            buf = torch.empty(lib.drba_stage_conv0_packed_floats(), dtype=torch.float32)
+            _lib.check(lib.drba_stage_conv0_pack(C.c_void_p(conv.w_host.data_ptr()), C.c_void_p(buf.data_ptr())), "drba_stage_conv0_pack")
+        setattr(conv, attr, buf.to(dev))
+    packed = getattr(conv, attr)
     tmp_prev = _f32(tmp_prev)
     hp, wp = tmp_prev.shape[2], tmp_prev.shape[3]
     out = torch.empty((B, conv.cout, Ho, Wo), dtype=torch.float32, device=dev)
@@ -914,10 +931,15 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
     # 53 us of HBM time: the byte roofline is the binding one)
     nbytes = B * 4.0 * ((39.0 if lazy else 43.0) * H * W + conv.cout * Ho * Wo + (4.0 * H * W if fold else 0.0))
     bias = None if conv.bias is None else conv.bias.data_ptr()
-    _lib.check(_timed("stage_conv0" + ("+fold" if fold else "+lazy" if lazy else ""), (52, conv.cout, H, W, B), nbytes, "byte",
-                      lambda: _lib.load().drba_stage_conv0_batch(C.cast(arr, C.c_void_p), B, (C.cast(C.pointer(ft), C.c_void_p) if lazy else None), hp, wp,
-                                                                 float(prev_scale), H, W, conv._stage_pack.data_ptr(), bias, _stream())),
-               "drba_stage_conv0_batch")
+    tptr = C.cast(C.pointer(ft), C.c_void_p) if lazy else None
+    name = ("stage_conv16" if two else "stage_conv0") + ("+fold" if fold else "+lazy" if lazy else "")
+    if two:
+        call = lambda: _lib.load().drba_stage_conv16_batch(C.cast(arr, C.c_void_p), B, tptr, hp, wp, float(prev_scale), H, W, 1.0,  # noqa: E731
+                                                           conv.cout, packed.data_ptr(), bias, _stream())
+    else:
+        call = lambda: _lib.load().drba_stage_conv0_batch(C.cast(arr, C.c_void_p), B, tptr, hp, wp, float(prev_scale), H, W,  # noqa: E731
+                                                          packed.data_ptr(), bias, _stream())
+    _lib.check(_timed(name, (52, conv.cout, H, W, B), nbytes, "byte", call), "drba_stage_conv16_batch" if two else "drba_stage_conv0_batch")
     return out, ([flow_out[k:k + 1] for k in range(B)] if fold else None)
 
 

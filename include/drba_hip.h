@@ -32,7 +32,7 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
+/* ABI version.  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form).  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
  * drba_deconv4x4s2, so no earlier id changes meaning), drba_deconv4x4_cfg_family, and a `terms` argument (3 or 2) on the
  * drba_linear_split_* entry points and on drba_window_attention; drba_head_fused16_*.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
  * NULL (nothing but f_pair_out is written), and every stage-input entry point accepts items with f0 == f1 == NULL when
@@ -42,7 +42,7 @@ extern "C" {
  * workspace that must be ZERO on entry (they leave it zero on return: self-cleaning accumulator) instead of clearing it
  * themselves; batched stage entry points added; drba_conv3x3_cfg_family added and configuration ids 19 (LDS-DMA, 32
  * channels) / 20 (K split across waves) behind drba_conv3x3; the allocation exception above.  1: the first release. */
-#define DRBA_ABI_VERSION 5  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
+#define DRBA_ABI_VERSION 6  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 
@@ -273,6 +273,16 @@ int drba_stage_conv0_pack(const float *w, float *packed);
 int drba_stage_conv0_supported(int H, int W, float scale, float prev_scale, int Cout);
 int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms /* NULL: flow / fold as above */,
                            int hp, int wp, float prev_scale, int H, int W, const float *packed_w, const float *bias, void *stream);
+/* ABI 6: the same fusion in the two-term fp16 form (kernel family 4 of drba_conv3x3_cfg_family; stage_conv16.hip): the gathered
+ * values are split into two fp16 terms on their way into LDS and the convolution runs on the 16-bit matrix pipe (3 products per
+ * multiply, fp32 accumulation), the channels in 4 groups of 16 instead of 13 of 4.  Same items / terms / hp / wp / prev_scale
+ * semantics, same flows (bit for bit), convolution output to the tolerance of the family; Cout = 16 or 32 (w [Cout,52,3,3]);
+ * `scale` is the stage's scale (1 is the one supported); packed_w 16-byte aligned.  drba_stage_conv16_pack is a HOST function. */
+size_t drba_stage_conv16_packed_floats(int Cout);
+int drba_stage_conv16_pack(const float *w, int Cout, float *packed);
+int drba_stage_conv16_supported(int H, int W, float scale, float prev_scale, int Cout);
+int drba_stage_conv16_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int hp, int wp, float prev_scale,
+                            int H, int W, float scale, int Cout, const float *packed_w, const float *bias, void *stream);
 /* drba_ifblock_update for several items (arrays of n_items device pointers; flow_in may be NULL or hold NULLs). */
 int drba_ifblock_update_batch(const float *const *tmp, const float *const *flow_in, float *const *flow_out, int n_items,
                               int h, int w, int H, int W, float scale, void *stream);
