@@ -82,6 +82,9 @@ kTraceWarm, kTraceKeep = 3, 4
 kSettleSeconds = 0.5  # untimed steps after the W warm-up steps (step_loop) / minimum warm-up iterations of the clip legs
 kClipWarmup = 24
 SRC_FPS = 24.0
+kMinTimedSeconds = 0.25  # the K-step block is repeated until the timed region is at least this long (K = 20 steps at 2 ms are 40 ms: box-to-box noise)
+# SURVEY.md 8(d) / BASELINE.md 3: algorithmic work of ONE model-generated frame (warm), per config: (GFLOP, conv-boundary GB)
+FRAME_WORK = {"1080p": (92.9, 1.59), "4k": (107.2, 2.13)}
 
 
 # A/B switches between kernel variants / schedules of THIS library live in tools/ab_bench.py (it fills AB and calls main()):
@@ -91,6 +94,7 @@ AB = {}
 _T0 = time.perf_counter()
 LAST_SHARD = {"rank_dt": None, "path": None}  # this rank's own wall time of the last sharded_leg (the line reports every rank's)
 LAST_PATH = {}  # RIFE.stats over the timed region of the last step_loop: which path the K timed calls took (reported on the line)
+LAST_BLOCKS = {"n": 1}  # K-step blocks the last step_loop timed back to back (kMinTimedSeconds)
 LAST_SETTLE = {"steps": 0}  # untimed settling steps the last step_loop ran after its W warm-up steps (reported on the line)
 
 
@@ -272,7 +276,7 @@ class AnnouncedLoop:
 def _peak(name, unit):
     if unit == "byte":
         return HBM_PEAK_GBS, "GB/s", "hbm", "HBM3E 8 TB/s"
-    if "split" in name or "conv_dma" in name or "conv_ks" in name:
+    if "split" in name or "conv_dma" in name or "conv_ks" in name or "window_attention16" in name or "head_fused16" in name:
         if _two_term(name):  # fp32 operands as two fp16 terms (22 bits), three MFMA products
             return round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1), "TFLOP/s", "mfma", "dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 multiply"
         # fp32 operands as three bf16 terms, six MFMA products
@@ -287,7 +291,7 @@ def _arithmetic_note():
     return {"tensors": "fp32 in HBM, fp32 accumulation, fp32 outputs",
             "mfma_operands": ("stride-1 / transposed / most stride-2 convolutions, the encoder, GMFlow's linears and window attention: each "
                               "fp32 operand as two fp16 terms h + 2^-11 l (22 significand bits, 3 MFMA products, kernel family 4); "
-                              "stage_conv0, the largest stride-2 layers, global correlation: fp32 MFMA" if two else
+                              "the fused stage kernel (stage_conv16) likewise; the largest stride-2 layers, global correlation: fp32 MFMA" if two else
                               "stride-1 / transposed convolutions and GMFlow linears: each fp32 operand as three bf16 terms (24 bits, 6 MFMA "
                               "products); the rest fp32 MFMA"),
             "conv_families": sorted(ops.CONV_FAMILIES)}
@@ -295,10 +299,13 @@ def _arithmetic_note():
 
 def _two_term(name):
     """True for the two-term fp16 instantiations of the split families (the last template argument, PL, is 2):
-    conv_split_mfma<SplitCfg<M, RW, MW, NT, 2>, ...>, conv_dma1<PRE, RL, 2>, conv_ks<KW, PRE, RL, DW, 2>."""
+    conv_split_mfma<SplitCfg<M, RW, MW, NT, 2>, ...>, conv_dma1<PRE, RL, 2>, conv_ks<KW, PRE, RL, DW, 2>, linear_split_kernel<LinCfg<.., 2>, ..>;
+    window_attention16_kernel, head_fused16 and stage_conv16 exist in that form only.  A kernel that runs on the 16-bit matrix
+    pipe is never priced against the fp32-MFMA peak."""
     import re
     return bool(re.search(r"SplitCfg<[^<>]*, 2>", name) or re.search(r"conv_dma1<[^<>]*, 2>", name)
-                or re.search(r"conv_ks<\d+, \w+, \w+, \w+, 2>", name))
+                or re.search(r"conv_ks<\d+, \w+, \w+, \w+, 2>", name) or re.search(r"LinCfg<[^<>]*, 2>", name)
+                or "window_attention16" in name or "head_fused16" in name or "stage_conv16" in name)
 
 
 def _symbol_totals(recs, n_steps):
@@ -381,7 +388,11 @@ def roofline_from_trace(recs, n_steps, traffic=None, serial=None, workload=None)
     # -- ONLY when that table was taken on this workload (its "__workload__" entry): a 1080p duration under a 4K launch's
     # work is not evidence (round 3 printed fractions above 1 that way); otherwise null
     rp = _rocprof_table()
-    same = workload is not None and (rp.get("__workload__") or {}).get("config") == workload
+    meta = rp.get("__workload__") or {}
+    # ... and only when it was taken on THESE kernel sources (round 4 quoted a table one kernel commit behind HEAD)
+    same = workload is not None and meta.get("config") == workload and meta.get("csrc_sha") == csrc_sha()
+    roof["rocprof_table"] = {"source": meta.get("source"), "config": meta.get("config"), "csrc_sha": meta.get("csrc_sha"),
+                             "this_build_csrc_sha": csrc_sha(), "used": bool(same)}
     for e in [roof] + roof["others"]:
         r = rp.get(e["kernel"]) if same else None
         e["frac_rocprof"] = None
@@ -411,7 +422,7 @@ def standalone_of(roof, dev, reps=30):
     import re
     geo = sorted((roof or {}).get("by_geometry") or [], key=lambda g: -g["algorithmic_per_launch"])  # most work first
     for g in geo:
-        m = re.match(r"stage_conv0\+lazy \(52, 16, (\d+), (\d+), (\d+)\)$", g["launch"])
+        m = re.match(r"stage_conv(?:0|16)\+lazy \(52, 16, (\d+), (\d+), (\d+)\)$", g["launch"])
         if m:
             return _standalone_stage_conv0(roof, dev, g, *(int(v) for v in m.groups()), reps=reps)
     for g in geo:
@@ -448,7 +459,7 @@ def standalone_of(roof, dev, reps=30):
 
 
 def _standalone_stage_conv0(roof, dev, g, H, W, n, reps=30):
-    """drba_stage_conv0_batch alone on the idle GPU: the launch geometry of the loop (n samples, the flow as the terms of
+    """drba_stage_conv16_batch / drba_stage_conv0_batch (whichever the family set selects) alone on the idle GPU: the launch geometry of the loop (n samples, the flow as the terms of
     the four earlier stages -- a coarse flow of a few pixels plus sub-pixel refinements, i.e. smooth, as a trained net's)."""
     from drba_amd import ops
     gen = torch.Generator().manual_seed(0)
@@ -477,11 +488,24 @@ def _standalone_stage_conv0(roof, dev, g, H, W, n, reps=30):
     ops.trace_begin()
     for _ in range(reps):
         run()
-    recs = [r for r in ops.trace_end() if "stage_conv0" in r["name"]]
+    recs = [r for r in ops.trace_end() if "stage_conv" in r["name"]]
     us = sum(r["ms"] for r in recs) / max(len(recs), 1) * 1e3
     ach = g["algorithmic_per_launch"] / us / 1e3  # GB/s
     return {"launch": g["launch"], "avg_us": round(us, 2), "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / roof["peak"], 4),
             "what": f"{reps} launches of this geometry alone (items sharing six frames as in the loop, smooth synthetic flows), the kernel's own dispatch times"}
+
+
+def csrc_sha():
+    """Identity of the kernel sources a profile table was taken on: sha256 over drba_amd/csrc/*.{hip,hpp} and the header (the GPU
+    box has no .git).  tools/rocprof_frac.py records it; a table of other sources is not evidence for this build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "drba_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "drba_amd", "csrc", "*.hpp"))
+                    + [os.path.join(ROOT, "include", "drba_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _rocprof_table():
@@ -586,19 +610,25 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
     stats0 = dict(getattr(model, "stats", {}))
     t0 = time.perf_counter()
     per_step = []
-    for k in range(args.steps):
-        step()
-        per_step.append(time.perf_counter())
+    blocks = 0
+    while True:  # EXACTLY K steps per block; blocks are repeated (whole blocks, one fence at the end) until the region is long enough to quote
+        for k in range(args.steps):
+            step()
+            per_step.append(time.perf_counter())
+        blocks += 1
+        if world > 1 or not settle or not args.steps or time.perf_counter() - t0 >= kMinTimedSeconds or blocks >= 64:  # (N > 1: every rank times one block)
+            break
     t_host = time.perf_counter() - t0  # all launches enqueued: the host side of a step (the GPU may still be working)
     _fence(world)
     dt = time.perf_counter() - t0
+    LAST_BLOCKS["n"] = blocks
     LAST_PATH.clear()
     LAST_PATH.update({k: v - stats0.get(k, 0) for k, v in getattr(model, "stats", {}).items()})
     grp = int(getattr(model, "GROUP", 1))
     if check_path and settle and lookahead and grp > 1 and args.steps and hasattr(model, "stats"):
         # the timed calls must have taken the grouped, side-stream-staged path the number is quoted for: a silent fall-back to
         # the one-step path (frames cloned on the way, a stale lookahead) would read as a kernel regression
-        want = -(-args.steps // grp)
+        want = -(-(args.steps * blocks) // grp)
         if LAST_PATH["groups_formed"] != want or LAST_PATH["staged_groups"] != want or LAST_PATH["single_steps"]:
             raise RuntimeError(f"timed region did not run the grouped path: {LAST_PATH} (expected {want} staged groups)")
     recs, traced = None, 0
@@ -659,6 +689,26 @@ def clip_leg(model, clip, dst_fps, times, scdet, args, label):
             "roofline": roofline_from_trace(recs, kTraceKeep, _traffic_table())}
 
 
+def three_term_leg(args, dev):
+    """The headline loop with every MFMA operand at 24 bits (kernel families 0-3: three bf16 terms per fp32 operand, six
+    products per multiply) -- the arithmetic of rounds 1-3, driver-run beside the two-term default."""
+    from drba_amd import ops
+    from drba_amd.models.rife import RIFE
+    fams = set(ops.CONV_FAMILIES)
+    ops.set_precision({0, 1, 2, 3})
+    try:
+        (H, W), scale, desc = CONFIGS["1080p"]
+        model = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=scale, device=dev)
+        clip = DeviceClip(12, H, W, 1234, dev)
+        dt, _, _, _, _ = step_loop(model, [clip[k] for k in range(len(clip))], args.warmup + args.steps, args, 1, trace=False)
+        nb = LAST_BLOCKS["n"]
+        return {"workload": desc + "; kernel families 0-3 only", "value": round(len(TS) * args.steps * nb / dt, 3), "unit": "frames/s",
+                "steps": args.steps, "timed_blocks": nb, "ms_per_step": round(dt / (args.steps * nb) * 1e3, 3),
+                "arithmetic": _arithmetic_note(), "path": dict(LAST_PATH)}
+    finally:
+        ops.set_precision(fams)
+
+
 def extra_configs(args, dev):
     """BASELINE.json configs[2], [3], [4] at N = 1 (bounded: K steps each)."""
     from drba_amd.models.gmfss_union import GMFSS_UNION
@@ -689,6 +739,11 @@ def extra_configs(args, dev):
         "gmfss_union -fps 60 (24 -> 60), 1080p (net 1152x1920), scale 1.0 (GMFlow + softsplat + GridNet path)")
     del g
     torch.cuda.empty_cache()
+    from drba_amd import ops
+    if 4 in ops.CONV_FAMILIES and not args.no_lookahead:
+        log("extra: headline loop with 24-bit MFMA operands")
+        out["headline_three_term_1080p"] = three_term_leg(args, dev)
+        torch.cuda.empty_cache()
     return out
 
 
@@ -763,8 +818,9 @@ def gpu_leg(args, rank, world):
                 log(f"serial {ms:7.4f} ms/step {n:5.1f} x {us:7.1f} us | in-step {inst.get(k, (0, 0, 0))[2]:7.1f} us | {k[:110]}")
     r["roofline"] = roofline_from_trace(recs, traced, _traffic_table(), serial, workload=args.config) if recs else None
     if world == 1:
-        r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps})
-        if r["roofline"] and (r["roofline"].get("bound") == "mfma" or "stage_conv0" in r["roofline"].get("kernel", "")):
+        r["blocks"] = LAST_BLOCKS["n"]  # K-step blocks timed back to back (one region): every per-step figure divides by K * blocks
+        r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps * r["blocks"]})
+        if r["roofline"] and (r["roofline"].get("bound") == "mfma" or "stage_conv" in r["roofline"].get("kernel", "")):
             torch.cuda.synchronize()
             r["roofline"]["standalone"] = standalone_of(r["roofline"], dev)
             r["roofline"]["frac_standalone"] = (r["roofline"]["standalone"] or {}).get("frac")
@@ -801,7 +857,8 @@ def pcie_leg(args, model):
     (H, W), _, _ = CONFIGS[args.config]
     frames = [torch.from_numpy(f).pin_memory() for f in make_frames_u8(min(args.warmup + args.steps + 2, 12), H, W, seed=1234)]
     dt, _, _, _, _ = step_loop(model, frames, args.warmup + args.steps, args, 1, trace=False, pcie=True)
-    return {"value": round(len(TS) * args.steps / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+    nb = LAST_BLOCKS["n"]
+    return {"value": round(len(TS) * args.steps * nb / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / (args.steps * nb) * 1e3, 3),
             "what": "same loop, uint8 frames read from pinned host memory and written back to pinned host memory (PCIe inclusive)"}
 
 
@@ -970,8 +1027,9 @@ def main():
         line = {
             "metric": "interpolated frames/sec @1080p RIFE x2" if args.config == "1080p" else f"interpolated frames/sec @{args.config} RIFE x2",
             "value": round(r["frames"] / r["dt"], 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "settle_steps": r["settle_steps"], "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
-            "host_ms_per_step": None if r["host_dt"] is None else round(r["host_dt"] / args.steps * 1e3, 3),
+            "warmup": args.warmup, "settle_steps": r["settle_steps"], "timed_blocks": r.get("blocks", 1),
+            "timed_region_s": round(r["dt"], 4), "ms_per_step": round(r["dt"] / (args.steps * r.get("blocks", 1)) * 1e3, 3),
+            "host_ms_per_step": None if r["host_dt"] is None else round(r["host_dt"] / (args.steps * r.get("blocks", 1)) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "net_size": list(r["dst_size"]), "frames_per_step": len(TS),
                        "weights": "seeded random IFNet 4.26-heavy", "parallelism": f"frame-sharded dp{world}"},
@@ -979,6 +1037,12 @@ def main():
             "max_abs_vs_oracle": parity, "roofline": r["roofline"], "cpu_baseline": cpu,
             "path": r.get("path"),
         }
+        if args.config in FRAME_WORK and world == 1:  # SURVEY 8(d)'s whole-frame pair: the frame's algorithmic work x frames/s against the two roofs
+            gf, gb = FRAME_WORK[args.config]
+            line["frame_mfma_frac"] = round(gf * 1e9 * line["value"] / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+            line["frame_hbm_frac"] = round(gb * 1e9 * line["value"] / (HBM_PEAK_GBS * 1e9), 4)
+            line["frame_work"] = {"gflop_per_frame": gf, "conv_boundary_gb_per_frame": gb, "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                                  "hbm_peak_gbs": HBM_PEAK_GBS, "source": "SURVEY.md 8(d) / BASELINE.md 3 (fp32-MFMA peak: the reference's arithmetic)"}
         line["dist"] = dist_info
         if pcie is not None:
             line["pcie_inclusive"] = pcie

@@ -15,6 +15,8 @@ def _header_abi_version():
     """DRBA_ABI_VERSION of include/drba_hip.h: the header is the one place the number is written down (the library
     returns the macro, the entry point and the tests compare with this)."""
     import re
+    if not os.path.exists(HEADER_PATH):  # the package used without the repo's include/ tree (copied / installed): the
+        return None                       # library describes itself, load() takes its number (with a warning)
     with open(HEADER_PATH) as f:
         m = re.search(r"^#define\s+DRBA_ABI_VERSION\s+(\d+)", f.read(), flags=re.M)
     if m is None:
@@ -40,6 +42,7 @@ class ConvLayer(C.Structure):
 
 SIGNATURES = {
     "drba_abi_version": (_i, []),
+    "drba_set_range_check": (_i, [_i]),
     "drba_trace_begin": (_i, []),
     "drba_trace_end": (_i, []),
     "drba_trace_resume": (_i, []),
@@ -87,6 +90,7 @@ SIGNATURES = {
     "drba_stage_conv0_pack": (_i, [_p, _p]),
     "drba_stage_conv0_supported": (_i, [_i, _i, _f, _f, _i]),
     "drba_stage_conv0_batch": (_i, [_p, _i, _p, _i, _i, _f, _i, _i, _p, _p, _p]),
+    "drba_rgbx": (_i, [_p, _p, _i, _i, _p]),
     "drba_stage_conv16_packed_floats": (_z, [_i]),
     "drba_stage_conv16_pack": (_i, [_p, _i, _p]),
     "drba_stage_conv16_supported": (_i, [_i, _i, _f, _f, _i]),
@@ -138,7 +142,8 @@ class StageItem(C.Structure):
     """include/drba_hip.h: drba_stage_item_t"""
     _fields_ = [("img0", C.c_void_p), ("img1", C.c_void_p), ("f0", C.c_void_p), ("f1", C.c_void_p), ("f0_pair", C.c_void_p),
                 ("f1_pair", C.c_void_p), ("timestep_map", C.c_void_p), ("timestep_scalar", C.c_float), ("flow", C.c_void_p),
-                ("tmp_prev", C.c_void_p), ("flow_out", C.c_void_p), ("out", C.c_void_p), ("term", C.c_void_p * 4)]
+                ("tmp_prev", C.c_void_p), ("flow_out", C.c_void_p), ("out", C.c_void_p), ("term", C.c_void_p * 4),
+                ("img0_x4", C.c_void_p), ("img1_x4", C.c_void_p)]
 
 
 MAX_FLOW_TERMS = 4  # DRBA_MAX_FLOW_TERMS
@@ -179,9 +184,16 @@ def load():
         fn.restype = res
         fn.argtypes = args
     got = lib.drba_abi_version()
+    global ABI_VERSION
+    if ABI_VERSION is None:
+        import warnings
+        warnings.warn(f"{HEADER_PATH} not found: taking ABI version {got} from {LIB_PATH} unchecked")
+        ABI_VERSION = got
     if got != ABI_VERSION:
         raise DrbaHipError(f"{LIB_PATH} reports ABI version {got}, include/drba_hip.h declares {ABI_VERSION}: "
                            "stale build, run `make -C drba_amd/csrc`")
+    if os.environ.get("DRBA_CHECK_RANGE", "0") not in ("", "0"):  # debug: family-4 outputs are scanned for inf / NaN (drba_hip.h)
+        lib.drba_set_range_check(1)
     _lib = lib
     return lib
 

@@ -77,23 +77,69 @@ TimedLaunch trace_launch(const void *host_fn, const char *fallback, dim3 grid, h
   return t;
 }
 hipError_t max_dynamic_lds(const void *kernel, int bytes) {
+  // the LARGEST size applied so far per (kernel, device): a later caller asking for more re-issues the attribute (a second
+  // caller with a bigger tile used to be ignored silently), and a failed call is not remembered (it may have been transient)
   static std::mutex mu;
-  static std::map<std::pair<const void *, int>, hipError_t> done;
+  static std::map<std::pair<const void *, int>, int> applied;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
   std::lock_guard<std::mutex> lock(mu);
   const auto key = std::make_pair(kernel, dev);
-  auto it = done.find(key);
-  if (it != done.end()) return it->second;
+  auto it = applied.find(key);
+  if (it != applied.end() && it->second >= bytes) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  done.emplace(key, e);
+  if (e == hipSuccess) applied[key] = bytes;
   return e;
+}
+bool g_range_check = false;
+
+namespace {
+__global__ void __launch_bounds__(256) nonfinite_kernel(const float *__restrict__ x, size_t n, int *__restrict__ flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned u = __float_as_uint(x[i]);
+    bad |= (u & 0x7f800000u) == 0x7f800000u;  // inf or NaN
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+}  // namespace
+
+int range_scan(const float *out, size_t n, void *stream) {
+  static std::mutex mu;
+  static std::map<int, int *> flags;  // one device word per GPU, allocated on first use (debug mode only)
+  int dev = 0;
+  if (!out || n == 0) return DRBA_OK;
+  if (hipGetDevice(&dev) != hipSuccess) return DRBA_ELAUNCH;
+  int *flag = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = flags.find(dev);
+    if (it == flags.end()) {
+      if (hipMalloc((void **)&flag, sizeof(int)) != hipSuccess) return DRBA_ELAUNCH;
+      flags[dev] = flag;
+    } else {
+      flag = it->second;
+    }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int host = 0;
+  if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return DRBA_ELAUNCH;
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, out, n, flag);
+  if (hipGetLastError() != hipSuccess) return DRBA_ELAUNCH;
+  if (hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return DRBA_ELAUNCH;
+  return host ? DRBA_EUNSUPPORTED : DRBA_OK;
 }
 }  // namespace drba
 
 extern "C" {
 
 int drba_abi_version(void) { return DRBA_ABI_VERSION; }
+
+int drba_set_range_check(int on) {
+  const int was = drba::g_range_check ? 1 : 0;
+  drba::g_range_check = on != 0;
+  return was;
+}
 
 int drba_trace_begin(void) {
   // events are created here, outside any timed region (hipEventCreate costs tens of microseconds each)

@@ -40,8 +40,18 @@ TimedLaunch trace_launch(const void *host_fn, const char *fallback_name, dim3 gr
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: raised once per (kernel, device), not once
 // per process -- a process that drives a second GPU (RIFE(device="cuda:1")) would otherwise launch > 64 KB-LDS kernels there
-// without it.  Thread-safe; the answer of the first call per (kernel, device) is remembered (api_misc.hip).
+// without it.  Thread-safe; the largest size applied per (kernel, device) is remembered, failures are not (api_misc.hip).
 hipError_t max_dynamic_lds(const void *kernel, int bytes);
+
+// Debug range check of the two-term fp16 family (drba_set_range_check, include/drba_hip.h): when on, an entry point that ran a
+// family-4 kernel scans the output it has just enqueued for non-finite values (one extra kernel, one stream synchronisation,
+// one 4-byte copy) and returns DRBA_EUNSUPPORTED instead of handing inf / NaN on: the family's operands overflow fp16 at
+// |activation| >= 65504 * 16 (weights, attention Q / V: 65504), which the 24-bit families do not.  Off by default.
+extern bool g_range_check;
+int range_scan(const float *out, size_t n, void *stream);  // DRBA_OK / DRBA_EUNSUPPORTED (non-finite found) / DRBA_ELAUNCH
+static inline int range_checked(int rc, const float *out, size_t n, void *stream) {
+  return (rc != DRBA_OK || !g_range_check) ? rc : range_scan(out, n, stream);
+}
 
 // Environment switches select between kernel variants of THIS library for A/B measurements (never another backend).  The
 // release build -- the Makefile's default -- compiles them out: env_int() returns the default without reading the

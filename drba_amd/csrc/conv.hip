@@ -627,25 +627,27 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
   if (beta && !residual) return DRBA_EINVAL;
   if (residual2 && !residual) return DRBA_EINVAL;
   if (act < 0 || act > 4) return DRBA_EINVAL;
+  // (family 4: with drba_set_range_check on, the output is scanned for the inf / NaN an fp16 overflow of an operand leaves)
+  const size_t n_out = (size_t)N * Cout * ((H - 1) / (stride > 0 ? stride : 1) + 1) * ((W - 1) / (stride > 0 ? stride : 1) + 1);
   if (cfg >= first_f16_s2_cfg() && cfg < drba_conv3x3_num_cfgs()) {
     if (stride != 2) return DRBA_EINVAL;
-    return conv_split_launch(cfg - first_f16_s2_cfg() + conv_split_s2_first(), in, packed_w, bias, beta, residual, residual2, out, N,
-                             Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream);
+    return range_checked(conv_split_launch(cfg - first_f16_s2_cfg() + conv_split_s2_first(), in, packed_w, bias, beta, residual, residual2, out, N,
+                                           Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream), out, n_out, stream);
   }
   if (cfg >= first_f16_ks_cfg() && cfg < first_f16_s2_cfg()) {
     if (stride != 1) return DRBA_EINVAL;
-    return conv_ks_launch(cfg - first_f16_ks_cfg() + conv_ks_f16_first(), in, packed_w, bias, beta, residual, residual2, out, N, Cin,
-                          H, W, Cout, act, post_slope, pre_act, pre_slope, stream);
+    return range_checked(conv_ks_launch(cfg - first_f16_ks_cfg() + conv_ks_f16_first(), in, packed_w, bias, beta, residual, residual2, out, N, Cin,
+                                        H, W, Cout, act, post_slope, pre_act, pre_slope, stream), out, n_out, stream);
   }
   if (cfg >= first_f16_dma_cfg() && cfg < first_f16_ks_cfg()) {
     if (stride != 1) return DRBA_EINVAL;
-    return conv_dma_launch(cfg - first_f16_dma_cfg() + conv_dma_f16_first(), in, packed_w, bias, beta, residual, residual2, out, N,
-                           Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream);
+    return range_checked(conv_dma_launch(cfg - first_f16_dma_cfg() + conv_dma_f16_first(), in, packed_w, bias, beta, residual, residual2, out, N,
+                                         Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream), out, n_out, stream);
   }
   if (cfg >= first_f16_cfg() && cfg < first_f16_dma_cfg()) {
     if (stride != 1) return DRBA_EINVAL;
-    return conv_split_launch(cfg - first_f16_cfg() + conv_split_f16_first(), in, packed_w, bias, beta, residual, residual2, out,
-                             N, Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream);
+    return range_checked(conv_split_launch(cfg - first_f16_cfg() + conv_split_f16_first(), in, packed_w, bias, beta, residual, residual2, out,
+                                           N, Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream), out, n_out, stream);
   }
   if (cfg >= first_ks_cfg() && cfg < first_f16_cfg()) {
     if (stride != 1) return DRBA_EINVAL;
@@ -737,9 +739,11 @@ int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, 
                      int W, int Cout, int pixel_shuffle, int pre_act, float pre_slope, int cfg, void *stream) {
   if (!in || !packed_w || !out || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   if (pixel_shuffle && (Cout & 3)) return DRBA_EINVAL;
-  if (cfg >= kNumDeconvCfg && cfg < drba_deconv4x4_num_cfgs())
-    return deconv_split_launch(cfg - kNumDeconvCfg, in, packed_w, bias, out, N, Cin, H, W, Cout, pixel_shuffle, pre_act,
-                               pre_slope, stream);
+  if (cfg >= kNumDeconvCfg && cfg < drba_deconv4x4_num_cfgs()) {
+    const int rc = deconv_split_launch(cfg - kNumDeconvCfg, in, packed_w, bias, out, N, Cin, H, W, Cout, pixel_shuffle, pre_act,
+                                       pre_slope, stream);
+    return drba_deconv4x4_cfg_family(cfg) == 4 ? range_checked(rc, out, (size_t)N * Cout * 4 * H * W, stream) : rc;
+  }
   if (cfg < 0 || cfg >= kNumDeconvCfg) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
 #define DRBA_CASE(ID, T) \

@@ -297,7 +297,7 @@ int drba_head_fused16(const float *img, const float *packed_w, float *f_out, flo
   DRBA_LAUNCH(head_fused16, dim3(tiles_x * tiles_y, N), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, img,
               reinterpret_cast<const u32x4 *>(packed_w), f_out, f_pair_out, H, W, tiles_x);
   DRBA_CHECK_LAUNCH();
-  return DRBA_OK;
+  return range_checked(DRBA_OK, f_pair_out, (size_t)N * 16 * H * W, stream);
 }
 
 }  // extern "C"

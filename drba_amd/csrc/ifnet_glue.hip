@@ -200,6 +200,12 @@ __global__ void __launch_bounds__(256) pair_interleave_kernel(const float *__res
   }
 }
 
+// [3, H, W] -> [H, W, 4] = (c0, c1, c2, 0): a pixel's channels as one 16-byte unit (drba_stage_item_t.img0_x4)
+__global__ void __launch_bounds__(256) rgbx_kernel(const float *__restrict__ in, float *__restrict__ out, size_t P) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x)
+    reinterpret_cast<float4 *>(out)[i] = make_float4(in[i], in[P + i], in[2 * P + i], 0.f);
+}
+
 // ------------------------------------------------------------------------------------------
 // IFNet_HDv3.py:146 / :151-156 + IFBlock.forward :85-88.
 // One lane per LOW-RES output pixel.  For integer scale s >= 2 the align_corners=False
@@ -870,6 +876,14 @@ int drba_pair_interleave(const float *in, float *out, int C, int H, int W, void 
   const size_t P = (size_t)H * W;
   DRBA_LAUNCH(pair_interleave_kernel, dim3(grid_for((size_t)(C / 2) * P)), dim3(kBlock), 0, (hipStream_t)stream, in,
                      out, C / 2, P);
+  DRBA_CHECK_LAUNCH();
+  return DRBA_OK;
+}
+
+int drba_rgbx(const float *img, float *out, int H, int W, void *stream) {
+  if (!img || !out || H <= 0 || W <= 0 || ((uintptr_t)out & 15) != 0) return DRBA_EINVAL;
+  const size_t P = (size_t)H * W;
+  DRBA_LAUNCH(rgbx_kernel, dim3(grid_for(P)), dim3(kBlock), 0, (hipStream_t)stream, img, out, P);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }

@@ -338,7 +338,7 @@ static int linear_launch(const float *x, const float *packed_w, const float *bia
   }
 #undef DRBA_LIN
   DRBA_CHECK_LAUNCH();
-  return DRBA_OK;
+  return terms == 2 ? range_checked(DRBA_OK, out, (size_t)M * N, stream) : DRBA_OK;
 }
 
 int drba_linear_split(const float *x, const float *packed_w, const float *bias, float *out, int M, int K, int N, int ldx,

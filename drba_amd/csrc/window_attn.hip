@@ -581,5 +581,5 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
     DRBA_LAUNCH(drba_attn::window_attention_merge, dim3((unsigned)(((size_t)nwin * g.L + 3) / 4)), dim3(kBlock), 0,
                        (hipStream_t)stream, ws, out, g, nwin, ksplit);
   DRBA_CHECK_LAUNCH();
-  return DRBA_OK;
+  return terms == 2 ? range_checked(DRBA_OK, out, (size_t)B * H * W * C, stream) : DRBA_OK;  // (out is [B, H*W, C], dense)
 }

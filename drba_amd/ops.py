@@ -40,15 +40,20 @@ def _p(t):
 
 
 _ws_cache = {}
+_ws_token = {}  # (device, stream) -> what the workspace's contents are good for (softsplat_many's sorted index), or absent
 
 
-def _workspace(device, nfloats):
-    """Grow-only scratch per (device, stream): kernels on one stream are ordered, so reuse is safe."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(device, nfloats, keep_token=False):
+    """Grow-only scratch per (device, stream): kernels on one stream are ordered, so reuse is safe.  Handing the buffer out
+    invalidates whatever a previous user left in it (the splat index: `_ws_token`) unless that user asks for it back."""
+    key = (device.index, _stream().value or 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
         _ws_cache[key] = buf
+        _ws_token.pop(key, None)
+    elif not keep_token:
+        _ws_token.pop(key, None)
     return buf
 
 
@@ -153,7 +158,15 @@ def softsplat_many(inputs, tenFlow, tenMetric, strMode, outs=None, reuse_index=F
     xs = [_f32(x, "tenIn") for x in inputs]
     n, _, h, w = xs[0].shape
     lib = _lib.load()
-    ws = _workspace(f.device, max(lib.drba_softsplat_ws_floats(n, x.shape[1], h, w) for x in xs))
+    ws = _workspace(f.device, max(lib.drba_softsplat_ws_floats(n, x.shape[1], h, w) for x in xs), keep_token=True)
+    # what the index in `ws` was built from: the flow / metric tensors (storage + version), mode, geometry, the buffer and stream.
+    # reuse_index=True is honoured only while that still holds -- another user of the workspace, a regrown buffer, an in-place
+    # update of the flow or a call from another stream drops the token and the index is rebuilt (it used to be trusted blindly)
+    wkey = (f.device.index, _stream().value or 0)
+    token = (f.data_ptr(), f._version, None if m is None else (m.data_ptr(), m._version), strMode, n, h, w, ws.data_ptr())
+    if reuse_index and _ws_token.get(wkey) != token:
+        reuse_index = False
+    _ws_token[wkey] = token
     res = []
     for k, x in enumerate(xs):
         assert x.shape[0] == n and tuple(x.shape[2:]) == (h, w), (tuple(x.shape), (n, h, w))
@@ -365,7 +378,20 @@ CONV_FAMILIES = {0, 1, 2, 3, 4}
 _tuned = {}
 
 
+def set_precision(families):
+    """The kernel families every tuner / kernel switch of this module may use from now on ({0, 1, 2, 3}: 24-bit operands everywhere;
+    + 4: the two-term fp16 split).  May be called at any time: winners are cached per (shape, families) and the switches that
+    follow CONV_FAMILIES (encoder, linears, window attention, fused stage) read it at every call."""
+    global CONV_FAMILIES
+    CONV_FAMILIES = {int(f) for f in families}
+
+
+def _tuned_get(shape_key):
+    return _tuned.get((shape_key, tuple(sorted(CONV_FAMILIES))))
+
+
 def _tune(shape_key, candidates, run, reps=3):
+    shape_key = (shape_key, tuple(sorted(CONV_FAMILIES)))  # a winner of one family set is not offered to another
     if shape_key in _tuned:
         return _tuned[shape_key]
     best, best_ms = None, None
@@ -536,7 +562,7 @@ class ConvChain:
             if isinstance(layer, Deconv4x4):
                 key = ("deconv4x4", n, layer.cin, layer.cout, hh, ww, layer.ps)
                 cfg = layer.force_cfg if layer.force_cfg is not None else (
-                    _tuned.get(key) if AUTOTUNE else lib.drba_deconv4x4_pick_cfg(layer.cin, layer.cout, hh, ww))
+                    _tuned_get(key) if AUTOTUNE else lib.drba_deconv4x4_pick_cfg(layer.cin, layer.cout, hh, ww))
                 if cfg is None or layer.pre_slope is not None:
                     return None
                 d.deconv, d.pixel_shuffle, d.stride, d.act, d.residual = 1, layer.ps, 1, 0, 0
@@ -548,7 +574,7 @@ class ConvChain:
                 key = ("conv3x3", n, layer.cin, layer.cout, hh, ww, layer.stride)
                 ho, wo = (hh - 1) // layer.stride + 1, (ww - 1) // layer.stride + 1
                 cfg = layer.force_cfg if layer.force_cfg is not None else (
-                    _tuned.get(key) if AUTOTUNE else lib.drba_conv3x3_pick_cfg(layer.cin, layer.cout, ho, wo, layer.stride))
+                    _tuned_get(key) if AUTOTUNE else lib.drba_conv3x3_pick_cfg(layer.cin, layer.cout, ho, wo, layer.stride))
                 if cfg is None or layer.pre_slope is not None or layer.post_slope != 0.0:
                     return None
                 d.deconv, d.pixel_shuffle, d.stride, d.act, d.residual = 0, 0, layer.stride, layer.act, 1 if res else 0
@@ -709,6 +735,20 @@ def pair_interleaved(f):
             _p(f), _p(fp), c, h, w, _stream())), "drba_pair_interleave")
         f._drba_pair = fp
     return fp
+
+
+IMG_X4 = False  # the gathers read the frames from their [H,W,4] copies (two 16-byte loads per tap row instead of three 8-byte ones)
+
+
+def rgbx(img):
+    """A frame [1,3,H,W] -> its [H,W,4] copy (c0, c1, c2, 0), made once per tensor (to_inp writes it with the frame) and kept on it."""
+    x = getattr(img, "_drba_x4", None)
+    if x is None:
+        _, _, h, w = img.shape
+        x = torch.empty((h, w, 4), dtype=torch.float32, device=img.device)
+        _lib.check(_timed("rgbx", (h, w), 28.0 * h * w, "byte", lambda: _lib.load().drba_rgbx(_p(img), _p(x), h, w, _stream())), "drba_rgbx")
+        img._drba_x4 = x
+    return x
 
 
 def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scale, out=None):
@@ -926,6 +966,10 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
         a.tmp_prev, a.flow_out, a.out = tmp_prev[k].data_ptr(), (None if flow_out is None else flow_out[k].data_ptr()), out[k].data_ptr()
         for i, t in enumerate(tts):
             a.term[i] = t[k].data_ptr()
+        if IMG_X4:
+            x0, x1 = rgbx(i0), rgbx(i1)
+            keep += [x0, x1]
+            a.img0_x4, a.img1_x4 = _ptr(x0), _ptr(x1)
     # algorithmic bytes: 43 source channels read once per full-resolution point, the 16-channel quarter-size output (and the
     # folded flow) written; 2 * 16 * 52 * 9 FLOP per output pixel ride along (50 us per 1080p sample at the fp32 MFMA peak,
     # 53 us of HBM time: the byte roofline is the binding one)
@@ -1146,21 +1190,32 @@ class LinearSplit:
     """nn.Linear on token-major activations ([..., K] -> [..., N]) through drba_linear_split; optional fused GELU."""
 
     def __init__(self, weight, bias=None, gelu=False, device=None, terms=None):
-        """terms: 3 = three bf16 terms per operand, 2 = two fp16 terms (kernel family 4); default: 2 when CONV_FAMILIES
-        allows family 4 at construction time."""
-        w = weight.detach().float().cpu().contiguous()
-        self.n, self.k = w.shape
-        self.terms = int(terms) if terms is not None else (2 if 4 in CONV_FAMILIES else 3)
-        lib = _lib.load()
-        n = lib.drba_linear_split_packed_floats(self.k, self.n, self.terms)
-        if n == 0:
+        """terms: 3 = three bf16 terms per operand, 2 = two fp16 terms (kernel family 4); default: 2 while CONV_FAMILIES
+        allows family 4."""
+        self._w = weight.detach().float().cpu().contiguous()
+        self.n, self.k = self._w.shape
+        self._terms_arg = None if terms is None else int(terms)
+        self._device, self._packs = device, {}
+        if _lib.load().drba_linear_split_packed_floats(self.k, self.n, self.terms) == 0:
             raise _lib.DrbaHipError(f"drba_linear_split needs K % 32 == 0 (K={self.k}) and terms in (2, 3)")
-        buf = torch.empty(n, dtype=torch.float32)
-        _lib.check(lib.drba_linear_split_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr()), self.k, self.n, self.terms),
-                   "drba_linear_split_pack")
-        self.packed = buf.to(device)
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
         self.gelu = 1 if gelu else 0
+
+    @property
+    def terms(self):
+        """Resolved at every call (ops.set_precision may change the family set while the object lives)."""
+        return self._terms_arg if self._terms_arg is not None else (2 if 4 in CONV_FAMILIES else 3)
+
+    @property
+    def packed(self):
+        t = self.terms
+        if t not in self._packs:  # packed once per term count on first use
+            lib = _lib.load()
+            buf = torch.empty(lib.drba_linear_split_packed_floats(self.k, self.n, t), dtype=torch.float32)
+            _lib.check(lib.drba_linear_split_pack(C.c_void_p(self._w.data_ptr()), C.c_void_p(buf.data_ptr()), self.k, self.n, t),
+                       "drba_linear_split_pack")
+            self._packs[t] = buf.to(self._device)
+        return self._packs[t]
 
     def _rows(self, x):
         assert x.shape[-1] == self.k

@@ -45,6 +45,14 @@ extern "C" {
 #define DRBA_ABI_VERSION 6  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
+/* ABI 6, debug: with the range check on, every entry point that ran a kernel of family 4 (two fp16 terms per operand:
+ * drba_conv3x3 / drba_deconv4x4s2 with a family-4 configuration, drba_linear_split_* and drba_window_attention with terms = 2,
+ * drba_head_fused16, drba_stage_conv16_batch) scans the output it has just enqueued for inf / NaN -- one extra kernel, one
+ * 4-byte copy and ONE STREAM SYNCHRONISATION per call -- and returns DRBA_EUNSUPPORTED instead of handing them on.  Family 4
+ * holds an activation as fp16(x / 16) + ..., i.e. |x| >= 65504 * 16 ~ 1.05e6 overflows (weights, attention Q / V: 65504),
+ * where families 0 - 3 keep fp32's range; a non-finite INPUT reads the same.  Returns the previous setting.  The Python
+ * layer switches it on when DRBA_CHECK_RANGE=1 is set (drba_amd/_lib.py). */
+int drba_set_range_check(int on);
 
 /* ---- kernel trace (measurement only; bench.py's roofline object) ---------------------------
  * Between drba_trace_begin() and drba_trace_end() every kernel the library launches (on any stream, from the one host
@@ -224,6 +232,10 @@ typedef struct drba_stage_item {
   const float *flow, *tmp_prev;
   float *flow_out, *out;
   const float *term[DRBA_MAX_FLOW_TERMS]; /* the "lazy" entry points: head outputs [13,h_i,w_i] of the stages BEFORE tmp_prev, oldest first */
+  /* ABI 6, optional (both or neither; 16-byte aligned): the two frames additionally as [H][W][4] = (c0, c1, c2, 0) -- drba_rgbx, or
+   * drba_to_inp's second output.  The gathers are bound by the NUMBER of vector-memory instructions a wave issues: with a pixel's
+   * three channels in one 16-byte unit the two taps of a row are two 16-byte loads instead of three 8-byte ones (one per plane). */
+  const float *img0_x4, *img1_x4;
 } drba_stage_item_t;
 /* The running flow as a list of terms instead of a full-resolution tensor (IFNet_HDv3.py:146-160: flow = flow + up(tmp_i[:, :4]) * s_i
  * after every stage): term i is the head output of an earlier stage, [13, h[i], w[i]], upsampled x scale[i].  The entry points
@@ -288,6 +300,8 @@ int drba_ifblock_update_batch(const float *const *tmp, const float *const *flow_
                               int h, int w, int H, int W, float scale, void *stream);
 /* [C,H,W] -> [C/2,H,W,2] (C even): channel pairs interleaved per pixel. */
 int drba_pair_interleave(const float *in, float *out, int C, int H, int W, void *stream);
+/* ABI 6: a frame [3,H,W] -> [H,W,4] = (c0, c1, c2, 0), 16-byte aligned (drba_stage_item_t.img0_x4 / img1_x4). */
+int drba_rgbx(const float *img, float *out, int H, int W, void *stream);
 /* Upsample the 13-channel head output by `scale` and fold it into the running flow:
  * flow_out = (flow_in ? flow_in : 0) + up(tmp[0:4])*scale.  mask / feat (full resolution,
  * = up(tmp[4]), up(tmp[5:13])) are written only when non-NULL. */
@@ -319,9 +333,10 @@ int drba_swap_select(const float *x, const float *y, const float *t0, const floa
 /* torch.clamp(x, lo, hi) (GMFSS.py:155) */
 int drba_clamp(const float *in, float *out, float lo, float hi, size_t n, void *stream);
 
-/* ---- GMFlow operators that are not plain GEMMs (models/gmflow) ---------------------------------
- * The q/k/v/merge/MLP projections and the QK^T / PV products are plain GEMMs issued by the host through the
- * vendor BLAS; these entry points are everything around them. */
+/* ---- GMFlow operators around its matrix products (models/gmflow) ---------------------------------
+ * The q/k/v/merge/MLP projections are drba_linear_split_*, the windowed QK^T / softmax / PV is drba_window_attention, the global
+ * and local correlations drba_global_expect2 / drba_local_corr_flow (all hand-written MFMA kernels of this library: nothing is
+ * issued through a vendor BLAS); these entry points are everything around them. */
 /* generic direct convolution, zero padding (backbone.py:46 7x7 s2 stem, :63 / :24 1x1 projections) */
 int drba_conv_direct(const float *in, const float *w /*[Cout,Cin,K,K]*/, const float *bias, float *out,
                      int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, void *stream);

@@ -43,7 +43,7 @@ def dry(monkeypatch):
     monkeypatch.setattr(ops, "_f32", lambda t, name="tensor": t.float().contiguous())
     monkeypatch.setattr(ops, "_stream", lambda: C.c_void_p(0))
     monkeypatch.setattr(ops, "default_device", lambda: torch.device("cpu"))
-    monkeypatch.setattr(ops, "_workspace", lambda dev, n: torch.empty(int(n), dtype=torch.float32))
+    monkeypatch.setattr(ops, "_workspace", lambda dev, n, keep_token=False: torch.empty(int(n), dtype=torch.float32))
     monkeypatch.setattr(ops, "_zero_workspace", lambda dev, n: torch.zeros(int(n), dtype=torch.float32))
     return stub
 
@@ -66,7 +66,7 @@ def test_rife_pipeline_plumbing(dry, monkeypatch):
     assert r[0] is I[0] and r[2] is I[1]
     # default pipeline: the running flow as terms (no flow tensor), the scale-1 stage input fused with conv0[0]
     for k in ("drba_conv3x3", "drba_deconv4x4s2", "drba_ifblock_input", "drba_ifblock_input_batch", "drba_ifblock_input_lazy_batch",
-              "drba_stage_conv0_batch", "drba_warp_blend_lazy_batch", "drba_ifblock_update", "drba_flow_reverse",
+              "drba_stage_conv16_batch", "drba_warp_blend_lazy_batch", "drba_ifblock_update", "drba_flow_reverse",
               "drba_drm_rife_linear", "drba_softsplat", "drba_drm_retime"):
         assert dry.calls.get(k, 0) > 0, k
     assert dry.calls.get("drba_ifblock_update_batch", 0) == 0 and dry.calls.get("drba_warp_blend_fold", 0) == 0

@@ -238,17 +238,62 @@ def test_two_term_and_three_term_conv_families_agree(hip_backend, monkeypatch):
     ts = np.array([0.75, 1.25])
     outs = {}
     for name, fams in (("three-term", {0, 1, 2, 3}), ("two-term", {0, 1, 2, 3, 4})):
-        monkeypatch.setattr(ops, "CONV_FAMILIES", fams)
-        monkeypatch.setattr(ops, "_tuned", {})
+        monkeypatch.setattr(ops, "CONV_FAMILIES", set(ops.CONV_FAMILIES))  # (restored after the test)
+        ops.set_precision(fams)  # no reset of the tuner's cache: winners are kept per (shape, family set)
         m = hip_backend.make_rife(sd, 1.0)
         m.inference_ts_drba(*fr, ts, None, True)          # tunes layer by layer
         o, _ = m.inference_ts_drba(*fr, ts, None, True)   # the chains, with the winners
         torch.cuda.synchronize()
         outs[name] = [x.clone() for x in o]
-        fams_used = {ops._lib.load().drba_conv3x3_cfg_family(c) for k, c in ops._tuned.items() if k[0] == "conv3x3"}
+        fams_used = {ops._lib.load().drba_conv3x3_cfg_family(c) for (k, f), c in ops._tuned.items() if k[0] == "conv3x3" and set(f) == fams}
         assert (4 in fams_used) == (name == "two-term"), (name, fams_used)
     err = max(float((a - b).abs().max()) for a, b in zip(outs["three-term"], outs["two-term"]))
     assert err <= 2e-5, err
+
+
+def test_family4_range_check_reports_overflow_instead_of_inf(hip_backend):
+    """Kernel family 4 holds an operand as fp16(x / 16) + ...: an activation of 65504 * 16 ~ 1.05e6 or more (a weight, an
+    attention Q / V of 65504 or more) overflows where families 0-3 keep fp32's range.  With the debug range check on
+    (drba_set_range_check / DRBA_CHECK_RANGE=1) the entry point returns DRBA_EUNSUPPORTED instead of handing inf / NaN on;
+    below the bound the same call passes, and the 24-bit families take the large input as it is."""
+    from drba_amd import _lib, ops
+    lib = _lib.load()
+    dev = hip_backend.dev
+    g = torch.Generator().manual_seed(3)
+    f4 = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_family(c) == 4 and lib.drba_conv3x3_cfg_stride(c) == 1
+          and lib.drba_conv3x3_packed_floats(64, 64, c) > 0]
+    f1 = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_family(c) == 1 and lib.drba_conv3x3_packed_floats(64, 64, c) > 0]
+    assert f4 and f1
+    wt = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    x_ok = (torch.rand(1, 64, 12, 40, generator=g) * 2 - 1) * 1.0e6
+    x_big = x_ok.clone()
+    x_big[0, 5, 3, 7] = 2.0e6   # one activation past 65504 * 16
+    ref = torch.nn.functional.conv2d(x_big.double(), wt.double(), None, padding=1)
+    was = lib.drba_set_range_check(1)
+    try:
+        for cfg in f4:
+            conv = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=cfg)
+            assert bool(torch.isfinite(conv(x_ok.to(dev))).all())
+            with pytest.raises(_lib.DrbaHipError, match="unsupported"):
+                conv(x_big.to(dev))
+            with pytest.raises(_lib.DrbaHipError, match="unsupported"):  # a weight past fp16's range (no pre-scale on weights)
+                wb = wt.clone()
+                wb[3, 4, 1, 1] = 1.0e5
+                ops.Conv3x3(wb, torch.zeros(64), 1, None, None, device=dev, cfg=cfg)(x_ok.to(dev) * 1e-6)
+        got = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=f1[0])(x_big.to(dev))  # 24-bit family: fp32's range
+        assert float((got.double().cpu() - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+        lin = ops.LinearSplit(torch.randn(128, 128, generator=g) / 11.0, None, device=dev, terms=2)
+        t = torch.randn(256, 128, generator=g)
+        assert bool(torch.isfinite(lin(t.to(dev))).all())
+        t[17, 5] = 2.0e6
+        with pytest.raises(_lib.DrbaHipError, match="unsupported"):
+            lin(t.to(dev))
+        assert bool(torch.isfinite(ops.LinearSplit(torch.randn(128, 128, generator=g) / 11.0, None, device=dev, terms=3)(t.to(dev))).all())
+    finally:
+        lib.drba_set_range_check(was)
+    # off (the default): the same overflow goes through silently -- what the check exists to catch
+    y = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=f4[0])(x_big.to(dev))
+    assert not bool(torch.isfinite(y).all())
 
 
 def test_cloned_reuse_features_keep_their_layout(hip_backend):

@@ -2,12 +2,13 @@
 """A/B runs of bench.py between kernel variants / schedules of THIS library (never another backend): the switches that used
 to be bench.py flags.  Everything not listed here is passed on to bench.py unchanged.
 
-    python tools/ab_bench.py [--group G] [--conv-families 0,1] [--no-stage-conv] [--no-head-fused] [--no-lazy-flow]
+    python tools/ab_bench.py [--group G] [--conv-families 0,1] [--no-stage-conv] [--stage-conv-fp32] [--no-head-fused] [--no-lazy-flow]
                              [--no-lookahead] [--prefetch-priority P] [--enc-main] [--side-stages S] -- [bench.py flags]
 
   --group G            RIFE.GROUP, consecutive steps per stacked IFNet pass (1: off; negative: groups without the batched coarse flows)
   --conv-families L    kernel families the conv autotuner may pick from (0 fp32 MFMA, 1 split-bf16, 2 LDS-DMA 32 ch, 3 K-split)
   --no-stage-conv      the scale-1 stage input and conv0[0] as two kernels (ops.STAGE_CONV_FUSED = False)
+  --stage-conv-fp32    the fused stage kernel in its exact-fp32 form (stage_conv.hip; ops.STAGE_CONV_TWO_TERM = False)
   --no-head-fused      IFNet's encoder layer by layer (ops.HEAD_FUSED = False)
   --no-lazy-flow       IFNet's running flow as a full-resolution tensor updated after every stage (ops.LAZY_FLOW = False)
   --no-lookahead       no side / prefetch streams (the single-stream loop)
@@ -28,6 +29,7 @@ def main():
     p.add_argument("--group", type=int, default=None)
     p.add_argument("--conv-families", default=None)
     p.add_argument("--no-stage-conv", action="store_true")
+    p.add_argument("--stage-conv-fp32", action="store_true")
     p.add_argument("--no-head-fused", action="store_true")
     p.add_argument("--no-lazy-flow", action="store_true")
     p.add_argument("--no-lookahead", action="store_true")
@@ -46,6 +48,8 @@ def main():
         ops.CONV_FAMILIES = {int(x) for x in a.conv_families.split(",")}
     if a.no_stage_conv:
         ops.STAGE_CONV_FUSED = False
+    if a.stage_conv_fp32:
+        ops.STAGE_CONV_TWO_TERM = False
     if a.no_head_fused:
         ops.HEAD_FUSED = False
     if a.no_lazy_flow:

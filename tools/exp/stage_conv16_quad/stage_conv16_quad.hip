@@ -69,12 +69,13 @@ struct Geo {
   static constexpr int WR = 2 * TOH + 1;                       // window rows
   static constexpr int NPOINTS = WR * WC;
   static constexpr int THREADS = (NPOINTS + 63) / 64 * 64;
+  static constexpr int WPE = THREADS == 384 ? 3 : 4;             // waves per SIMD the register budget is set for
   static constexpr int NPOS = (WR * RS + 15) / 16 * 16;        // units per (plane, octet): a multiple of 16, the two octets of a tap on the same banks
   static constexpr int WG_UNITS = 5 * 2 * NT * 64;             // one group's weight fragments: [K step][plane][n tile][lane]
   static constexpr int WD = (WG_UNITS / 64 + THREADS / 64 - 1) / (THREADS / 64);  // LDS-DMA instructions (1 KB each) per wave and group
   static constexpr int PR = TOH + 3;                           // tmp_prev footprint capacity, rows
   static constexpr int TR = TOH / 2 + 4, TC = 12;              // term footprint capacity (terms at >= 1/4 resolution)
-  static constexpr int U_WIN = 0, U_W = 4 * NPOS, U_PREV = U_W + WG_UNITS, U_TERM = U_PREV + PR * PC * 4;
+  static constexpr int U_WIN = 0, U_W = 4 * NPOS, U_PREV = U_W + 2 * WG_UNITS, U_TERM = U_PREV + PR * PC * 4;
   static constexpr int LDS_UNITS = U_TERM + kMaxTerms * TR * TC;
   static_assert(PR * PC <= THREADS, "one footprint pixel per lane");
   static_assert(TOH <= THREADS / 64, "one output row per wave");
@@ -109,8 +110,8 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &h, uint32_t &
 
 // FMODE: 0 = the finished flow is read; 1 = FOLD (flow_prev + the previous stage's update, written to flow_out); 2 = LAZY
 // (the flow is the sum of the terms, flow_terms.hpp, + the previous stage's update; nothing but the convolution is written)
-template <int FMODE, class G_, bool X4>
-__global__ void __launch_bounds__(G_::THREADS, 4)  // 4 waves per SIMD = two workgroups per CU: <= 128 registers
+template <int FMODE, class G_>
+__global__ void __launch_bounds__(G_::THREADS, G_::WPE)  // two workgroups per CU (TOH = 7: 16 waves, <= 128 registers; TOH = 5: 12 waves, <= 168)
 stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restrict__ wpk, const float *__restrict__ bias, int hp, int wp,
              float inv_prev_scale, float prev_scale, int H, int W, int Ho, int Wo, int tiles_x, int n_items) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -118,7 +119,7 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   constexpr int TOH = G_::TOH, NT = G_::NT, WR = G_::WR, THREADS = G_::THREADS, NPOS = G_::NPOS, NPOINTS = G_::NPOINTS;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
   u32x4 *win = lds16 + G_::U_WIN;                               // [plane][octet][NPOS]
-  u32x4 *wl = lds16 + G_::U_W;                                  // [K step][plane][n tile][64]
+  u32x4 *wl = lds16 + G_::U_W;                                  // [2 buffers][K step][plane][n tile][64]
   float *prev = reinterpret_cast<float *>(lds16 + G_::U_PREV);  // [PR][PC][16]: flow | mask, - | feat 0..3 | feat 4..7
   float *tl = reinterpret_cast<float *>(lds16 + G_::U_TERM);    // [kMaxTerms][TR * TC][4]
   int vb_, vitem_, ntiles_;
@@ -131,14 +132,14 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
     return (gptr)(((uint64_t)hi << 32) | lo);
   };
   struct {
-    cgptr img0, img1, img0_x4, img1_x4, f0_pair, f1_pair, timestep_map, flow, tmp_prev;
+    cgptr img0_x4, img1_x4, f0_q4, f1_q4, timestep_map, flow, tmp_prev;
     gptr flow_out, out;
     float timestep_scalar;
     const float *term[kMaxTerms];
   } item;
   {
     const drba_stage_item_t &src = items.it[vitem_];
-    item.img0 = uniform(src.img0), item.img1 = uniform(src.img1), item.img0_x4 = uniform(src.img0_x4), item.img1_x4 = uniform(src.img1_x4), item.f0_pair = uniform(src.f0_pair), item.f1_pair = uniform(src.f1_pair);
+    item.img0_x4 = uniform(src.img0_x4), item.img1_x4 = uniform(src.img1_x4), item.f0_q4 = uniform(src.f0_q4), item.f1_q4 = uniform(src.f1_q4);
     item.timestep_map = uniform(src.timestep_map), item.flow = uniform(src.flow), item.tmp_prev = uniform(src.tmp_prev);
     item.flow_out = uniform(src.flow_out), item.out = uniform(src.out);
     item.timestep_scalar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(src.timestep_scalar)));
@@ -177,15 +178,17 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   // every wave
   const __amdgpu_buffer_rsrc_t r_w =
       __builtin_amdgcn_make_buffer_rsrc((void *)wpk, 0, (uint32_t)(KS_TOTAL * 2 * NT * 64 * 16), 0x00020000);
-  auto wdma = [&](int g) {
+  auto wdma = [&](int g, int buf) {
     const int n = ks_count(g) * 2 * NT;  // pieces
 #pragma unroll
     for (int i = 0; i < G_::WD; ++i) {
       const int k = min(i * (THREADS / 64) + wave, n - 1);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_ptr)(wl + k * 64), 16, (uint32_t)((ks_first(g) * 2 * NT + k) * 1024 + lane * 16), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_ptr)(wl + buf * G_::WG_UNITS + k * 64), 16,
+                                               (uint32_t)((ks_first(g) * 2 * NT + k) * 1024 + lane * 16), 0, 0, 0);
     }
   };
-  wdma(0);
+  wdma(0, 0);
+  wdma(1, 1);
   const int pr_r = tid / PC, pr_c = tid - pr_r * PC;  // one (row, column) of the footprint per lane
   const bool pr_on = pr_r < rh && pr_c < rw;
   float pv[13];
@@ -253,21 +256,45 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   }
   const Taps t0 = taps_border(warp_coord(X, W, fls[0]), warp_coord(Y, H, fls[1]), W, H);
   const Taps t1 = taps_border(warp_coord(X, W, fls[2]), warp_coord(Y, H, fls[3]), W, H);
-  // ifblock_input_lds' tap form: the pair of a row loaded at min(x0, W-2), the right-border case folded into the weights
-  struct TapW {
-    uint32_t o0, o1;  // element offsets of the two tap rows
+  // The four taps of a warp as four pixels of the 16-bytes-per-pixel layouts ([H][W][4] frames, [C/4][H][W][4] features): a lane
+  // fetches its LEFT column (x0; rows y0, y1) itself and takes the right column from the lane to its right -- the next point of
+  // the window row, whose left column is this lane's right one wherever the flow is smooth (x0' == x0 + 1, y0' == y0).  Lanes
+  // for which that does not hold (a window row's last point, lane 63, flow discontinuities) fetch it with a second, mostly
+  // empty, masked gather.  The L1 serves a wave-level gather four lanes per clock whatever they ask for: in the pair layout
+  // ([C/2][H][W][2], both columns of a row in one 16-byte load) every source pixel was requested by two lanes and a point
+  // cost 44 full gathers; here it is 20 full ones and 20 of a few lanes (round 5; TCP accesses per launch 460 M -> see DESIGN).
+  struct TapQ {
+    uint32_t o0, o1;  // pixel offsets of (x0, y0), (x0, y1)
+    uint32_t dx;      // 1, or 0 at the right border (x1 == x0: the tap carries weight 0)
     float w00, w01, w10, w11;
+    bool own;         // the right column is fetched by this lane (not shared)
   };
-  auto tapw = [&](const Taps &t) -> TapW {
-    const int xb = min(t.x0, W - 2);
-    const bool edge = t.x0 != xb;
-    TapW k;
-    k.o0 = (uint32_t)(t.y0 * W + xb), k.o1 = (uint32_t)(t.y1 * W + xb);
-    k.w00 = edge ? 0.f : t.wnw, k.w01 = edge ? t.wnw : t.wne;
-    k.w10 = edge ? 0.f : t.wsw, k.w11 = edge ? t.wsw : t.wse;
+  auto tapq = [&](const Taps &t) -> TapQ {
+    TapQ k;
+    k.o0 = (uint32_t)(t.y0 * W + t.x0), k.o1 = (uint32_t)(t.y1 * W + t.x0);
+    k.dx = (uint32_t)(t.x1 - t.x0);
+    k.w00 = t.wnw, k.w01 = t.wne, k.w10 = t.wsw, k.w11 = t.wse;
+#ifndef DRBA_SC16_NO_ROW_SWAP
+    // Points of ODD window rows fetch their LOWER tap row first: the lower tap row of a point is the upper tap row of the point
+    // below it, so with the natural order a wave's second gather of a plane asks for the lines its first one has just missed
+    // on (and the next wave's first for the lines of this wave's second) while those misses are in flight.  With the order
+    // swapped by row parity every "first" gather reads even source rows and every "second" one odd rows (for a locally
+    // uniform flow): two gathers of a plane never meet on a line.
+    if (wr & 1) {
+      const uint32_t o = k.o0;
+      k.o0 = k.o1, k.o1 = o;
+      float w = k.w00;
+      k.w00 = k.w10, k.w10 = w;
+      w = k.w01, k.w01 = k.w11, k.w11 = w;
+    }
+#endif
+    // the right neighbour's left column (wave_shl:1; lane 63 reads its own `old` operand: an offset no pixel has)
+    const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)k.o0, 0x130, 0xf, 0xf, false);
+    const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)k.o1, 0x130, 0xf, 0xf, false);
+    k.own = !(n0 == k.o0 + k.dx && n1 == k.o1 + k.dx && k.dx == 1u);
     return k;
   };
-  TapW k0 = tapw(t0), k1 = tapw(t1);
+  TapQ k0 = tapq(t0), k1 = tapq(t1);
   // a point outside the image is the convolution's zero padding: its tap and upsample weights are zeroed once (x * 0 for
   // finite x) instead of selecting 0 for each of the 52 parked values
   const float zin = inimg ? 1.f : 0.f;
@@ -276,53 +303,47 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
     k1.w00 = k1.w01 = k1.w10 = k1.w11 = 0.f;
   }
   const float uw0 = la.w0 * zin, uw1 = la.w1 * zin;  // prev_up's row weights for the PARKED mask / feat (the flow fold used the true ones)
-  const uint32_t img_bytes = (uint32_t)((X4 ? 4 : 3) * P * 4), feat_bytes = (uint32_t)(16 * P * 4);
-  const __amdgpu_buffer_rsrc_t r_i0 = __builtin_amdgcn_make_buffer_rsrc((void *)(X4 ? item.img0_x4 : item.img0), 0, img_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_i1 = __builtin_amdgcn_make_buffer_rsrc((void *)(X4 ? item.img1_x4 : item.img1), 0, img_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_f0 = __builtin_amdgcn_make_buffer_rsrc((void *)item.f0_pair, 0, feat_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_f1 = __builtin_amdgcn_make_buffer_rsrc((void *)item.f1_pair, 0, feat_bytes, 0x00020000);
-  const uint32_t plane = (uint32_t)(P * 4);
+  const uint32_t img_bytes = (uint32_t)(4 * P * 4), feat_bytes = (uint32_t)(16 * P * 4);
+  const __amdgpu_buffer_rsrc_t r_i0 = __builtin_amdgcn_make_buffer_rsrc((void *)item.img0_x4, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_i1 = __builtin_amdgcn_make_buffer_rsrc((void *)item.img1_x4, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_f0 = __builtin_amdgcn_make_buffer_rsrc((void *)item.f0_q4, 0, feat_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_f1 = __builtin_amdgcn_make_buffer_rsrc((void *)item.f1_q4, 0, feat_bytes, 0x00020000);
+  const uint32_t qplane = (uint32_t)(P * 16);  // bytes of one channel quad [H][W][4]
 
-  // ---- the gathers: image taps 8 bytes per row, feature pairs ([C/2, H, W, 2]) 16 bytes per row
-  u32x2 ri[X4 ? 1 : 12];  // group 0, planar frames: img0 / img1, 3 channels x 2 tap rows
-  u32x4 rx[X4 ? 8 : 1];   // group 0, [H][W][4] frames: img0 / img1, 2 tap rows x 2 columns (a pixel's channels in one 16-byte unit)
-  u32x4 rf[16];   // groups 1, 2: 4 pairs of f0, 4 pairs of f1, 2 tap rows each
-  // Issue order: the UPPER tap rows of every plane first, the lower rows behind them.  The lower tap row of a point is the
-  // upper tap row of the point below it -- the same cache lines, requested by the other half of the wave one instruction
-  // earlier: issued back to back, every second gather hit a line whose miss was still in flight, and the L1 holds its whole
-  // (in-order) pipeline until that line arrives (TCP_PENDING_STALL_CYCLES: 30 % of the kernel's time, round 5).
+  // ---- the gathers.  ra: the left column (every lane); rb: the right column (the lanes that cannot share).  Upper tap rows
+  // are issued in front of the lower ones (the lower row of a point is the upper row of the point below it: back to back the
+  // second request finds the line's miss still in flight).
+  u32x4 ra[8], rb[8];  // [frame][quad][row] for a group: f0 quads q, q+1, then f1; group 0: [image][row] in ra[0..3]
   auto issue_img = [&]() {
-    if constexpr (X4) {
-      rx[0] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, k0.o0 * 16u, 0, 0), rx[1] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, k0.o0 * 16u, 16, 0);
-      rx[4] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, k1.o0 * 16u, 0, 0), rx[5] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, k1.o0 * 16u, 16, 0);
-      asm volatile("" ::: "memory");
-      rx[2] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, k0.o1 * 16u, 0, 0), rx[3] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, k0.o1 * 16u, 16, 0);
-      rx[6] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, k1.o1 * 16u, 0, 0), rx[7] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, k1.o1 * 16u, 16, 0);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ri[2 * c] = __builtin_amdgcn_raw_buffer_load_b64(r_i0, k0.o0 * 4u, c * plane, 0);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ri[6 + 2 * c] = __builtin_amdgcn_raw_buffer_load_b64(r_i1, k1.o0 * 4u, c * plane, 0);
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ri[2 * c + 1] = __builtin_amdgcn_raw_buffer_load_b64(r_i0, k0.o1 * 4u, c * plane, 0);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ri[6 + 2 * c + 1] = __builtin_amdgcn_raw_buffer_load_b64(r_i1, k1.o1 * 4u, c * plane, 0);
+    ra[0] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, k0.o0 * 16u, 0, 0);
+    ra[2] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, k1.o0 * 16u, 0, 0);
+    ra[1] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, k0.o1 * 16u, 0, 0);
+    ra[3] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, k1.o1 * 16u, 0, 0);
+    if (k0.own) {
+      rb[0] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, (k0.o0 + k0.dx) * 16u, 0, 0);
+      rb[1] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, (k0.o1 + k0.dx) * 16u, 0, 0);
+    }
+    if (k1.own) {
+      rb[2] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, (k1.o0 + k1.dx) * 16u, 0, 0);
+      rb[3] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, (k1.o1 + k1.dx) * 16u, 0, 0);
     }
   };
-  auto issue_f0 = [&](int first_pair) {
+  auto issue_f = [&](auto F, int first_quad) {  // frame F (0: f0 -> ra/rb[0..3], 1: f1 -> [4..7]), quads first_quad, first_quad + 1
+    constexpr int f = decltype(F)::value;
+    const __amdgpu_buffer_rsrc_t &rs = f == 0 ? r_f0 : r_f1;
+    const TapQ &k = f == 0 ? k0 : k1;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) rf[2 * c] = __builtin_amdgcn_raw_buffer_load_b128(r_f0, k0.o0 * 8u, (first_pair + c) * 2 * plane, 0);
+    for (int c = 0; c < 2; ++c) ra[4 * f + 2 * c] = __builtin_amdgcn_raw_buffer_load_b128(rs, k.o0 * 16u, (first_quad + c) * qplane, 0);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int c = 0; c < 4; ++c) rf[2 * c + 1] = __builtin_amdgcn_raw_buffer_load_b128(r_f0, k0.o1 * 8u, (first_pair + c) * 2 * plane, 0);
-  };
-  auto issue_f1 = [&](int first_pair) {
+    for (int c = 0; c < 2; ++c) ra[4 * f + 2 * c + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, k.o1 * 16u, (first_quad + c) * qplane, 0);
+    if (k.own) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) rf[8 + 2 * c] = __builtin_amdgcn_raw_buffer_load_b128(r_f1, k1.o0 * 8u, (first_pair + c) * 2 * plane, 0);
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int c = 0; c < 4; ++c) rf[8 + 2 * c + 1] = __builtin_amdgcn_raw_buffer_load_b128(r_f1, k1.o1 * 8u, (first_pair + c) * 2 * plane, 0);
+      for (int c = 0; c < 2; ++c) {
+        rb[4 * f + 2 * c] = __builtin_amdgcn_raw_buffer_load_b128(rs, (k.o0 + k.dx) * 16u, (first_quad + c) * qplane, 0);
+        rb[4 * f + 2 * c + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (k.o1 + k.dx) * 16u, (first_quad + c) * qplane, 0);
+      }
+    }
   };
   const int park = wr * RS + (wc & 1) * PS + (wc >> 1);
   // an octet of this point's values -> one 16-byte unit per plane
@@ -339,29 +360,25 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
       win[(2 + octet) * NPOS + park] = l;
     }
   };
-  auto img3 = [&](int which, const TapW &k, float *v) {  // the three channels of img0 (which = 0) / img1 (1) at this point
+  // the bilinear sample of the four channels of one 16-byte pixel unit: rows (a, b) of the left column, the right column from the
+  // neighbouring lane or from this lane's own fetch
+  auto tap4 = [&](const u32x4 &a, const u32x4 &b, const u32x4 &ar, const u32x4 &br, const TapQ &k, float *v) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float ax, ay, bx, by;
-      if constexpr (X4) {
-        ax = __uint_as_float(rx[4 * which][c]), ay = __uint_as_float(rx[4 * which + 1][c]);
-        bx = __uint_as_float(rx[4 * which + 2][c]), by = __uint_as_float(rx[4 * which + 3][c]);
-      } else {
-        const u32x2 *r = ri + 6 * which;
-        ax = __uint_as_float(r[2 * c].x), ay = __uint_as_float(r[2 * c].y);
-        bx = __uint_as_float(r[2 * c + 1].x), by = __uint_as_float(r[2 * c + 1].y);
-      }
-      v[c] = ax * k.w00 + ay * k.w01 + bx * k.w10 + by * k.w11;
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t na = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[j], 0x130, 0xf, 0xf, false);
+      const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b[j], 0x130, 0xf, 0xf, false);
+      const float a1 = __uint_as_float(k.own ? ar[j] : na), b1 = __uint_as_float(k.own ? br[j] : nb);
+      v[j] = __uint_as_float(a[j]) * k.w00 + a1 * k.w01 + __uint_as_float(b[j]) * k.w10 + b1 * k.w11;
     }
   };
-  auto feat8 = [&](const u32x4 *r, const TapW &k, float (&v)[8]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const u32x4 a = r[2 * c], b = r[2 * c + 1];
-      v[2 * c] = __uint_as_float(a.x) * k.w00 + __uint_as_float(a.z) * k.w01 + __uint_as_float(b.x) * k.w10 + __uint_as_float(b.z) * k.w11;
-      v[2 * c + 1] = __uint_as_float(a.y) * k.w00 + __uint_as_float(a.w) * k.w01 + __uint_as_float(b.y) * k.w10 + __uint_as_float(b.w) * k.w11;
-    }
+  auto feat8 = [&](auto F, float (&v)[8]) {
+    constexpr int f = decltype(F)::value;
+    const TapQ &k = f == 0 ? k0 : k1;
+    tap4(ra[4 * f], ra[4 * f + 1], rb[4 * f], rb[4 * f + 1], k, v);
+    tap4(ra[4 * f + 2], ra[4 * f + 3], rb[4 * f + 2], rb[4 * f + 3], k, v + 4);
   };
+  using F0 = std::integral_constant<int, 0>;
+  using F1 = std::integral_constant<int, 1>;
 
   // ---- the matrix phase of one group: waves 0..TOH-1, output row `wave`, pixels lane & 15 (A = the window, rows = pixels;
   // B = the weight fragments, columns = output channels)
@@ -381,8 +398,8 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
         const f16x8 a_h = __builtin_bit_cast(f16x8, a[0]), a_l = __builtin_bit_cast(f16x8, a[2 * NPOS]);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const f16x8 b_h = __builtin_bit_cast(f16x8, wl[((j * 2 + 0) * NT + n) * 64 + lane]);
-          const f16x8 b_l = __builtin_bit_cast(f16x8, wl[((j * 2 + 1) * NT + n) * 64 + lane]);
+          const f16x8 b_h = __builtin_bit_cast(f16x8, wl[(g & 1) * G_::WG_UNITS + ((j * 2 + 0) * NT + n) * 64 + lane]);
+          const f16x8 b_l = __builtin_bit_cast(f16x8, wl[(g & 1) * G_::WG_UNITS + ((j * 2 + 1) * NT + n) * 64 + lane]);
           lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, b_l, lo[n], 0, 0, 0);
           hh[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, b_h, hh[n], 0, 0, 0);
           lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, b_h, lo[n], 0, 0, 0);
@@ -395,17 +412,19 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   // (the compiler-level fences pin the ISSUE ORDER of the gathers: left alone hipcc hoists all 28 of them to one place and
   // spills what it has just loaded)
   SC16_CLK(3);
-  issue_img();
-  issue_f0(0);
+  issue_img();          // ra / rb[0..3]
+  issue_f(F1{}, 0);     // ra / rb[4..7]: flies under the image taps
   asm volatile("" ::: "memory");
   {
-    float v[8];
-    img3(0, k0, v);
+    float v[8], x[4];
+    tap4(ra[0], ra[1], rb[0], rb[1], k0, x);
+    v[0] = x[0], v[1] = x[1], v[2] = x[2];
     v[3] = inimg ? tmv : 0.f;
-    img3(1, k1, v + 4);
+    tap4(ra[2], ra[3], rb[2], rb[3], k1, x);
+    v[4] = x[0], v[5] = x[1], v[6] = x[2];
     // (the values as operands: the image registers are dead before the next gathers are issued)
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]) : : "memory");
-    issue_f1(0);
+    issue_f(F0{}, 0);
     asm volatile("" ::: "memory");
     v[7] = prev_up4(1, uw0, uw1)[0];
     park8(0, v);
@@ -421,23 +440,23 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   SC16_CLK(6);
   lds_barrier();
   SC16_CLK(7);
-  // ---- groups 1, 2: {f0 | f1}, 8 channels of each.  The group's weights are fetched while its gathers are turned into
-  // operands; group 2's gathers are issued as group 1's registers come free and stay in flight across its matrix phase.
-  wdma(1);
+  // ---- groups 1, 2: {f0 | f1}, 8 channels of each (two channel quads per frame).  Group 2's weights and gathers are issued as
+  // group 1's registers come free and stay in flight across its matrix phase; a group's weight DMA is OLDER than its gathers, so
+  // a wave that has consumed its gathers has its share of the weights in LDS (loads return in order).
+  wdma(2, 0);
   {
     float v[8];
-    feat8(rf, k0, v);
+    feat8(F0{}, v);
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
-    issue_f0(4);
+    issue_f(F0{}, 2);
     asm volatile("" ::: "memory");
     park8(0, v);
-    feat8(rf + 8, k1, v);
+    feat8(F1{}, v);
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
-    issue_f1(4);
+    issue_f(F1{}, 2);
     asm volatile("" ::: "memory");
     park8(1, v);
   }
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // the weight DMA is older than the 16 gathers just issued
   SC16_CLK(8);
   lds_barrier();
   SC16_CLK(9);
@@ -445,15 +464,14 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   SC16_CLK(10);
   lds_barrier();
   SC16_CLK(11);
-  wdma(2);
   {
     float v[8];
-    feat8(rf, k0, v);
+    feat8(F0{}, v);
     park8(0, v);
-    feat8(rf + 8, k1, v);
+    feat8(F1{}, v);
     park8(1, v);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wdma(3, 1);  // (behind the last gathers: nothing else is in flight when group 3 waits for it)
   SC16_CLK(12);
   lds_barrier();
   SC16_CLK(13);
@@ -462,7 +480,6 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   lds_barrier();
   SC16_CLK(15);
   // ---- group 3: feat 0..7 of the previous head output
-  wdma(3);
   {
     const f32x4 fa = prev_up4(2, uw0, uw1), fb = prev_up4(3, uw0, uw1);
     const float v[8] = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
@@ -542,7 +559,7 @@ int drba_stage_conv16_pack(const float *w, int Cout, float *packed) {
 }
 
 int drba_stage_conv16_supported(int H, int W, float scale, float prev_scale, int Cout) {
-  return (H >= 2 && W >= 2 && scale == 1.f && prev_scale == 2.f && Cout == 16) ? 1 : 0;
+  return (H >= 2 && W >= 2 && scale == 1.f && prev_scale == 2.f && (Cout == 16 || Cout == 32)) ? 1 : 0;
 }
 
 int drba_stage_conv16_batch(const drba_stage_item_t *items, int n_items, const drba_flow_terms_t *terms, int hp, int wp, float prev_scale,
@@ -562,7 +579,8 @@ int drba_stage_conv16_batch(const drba_stage_item_t *items, int n_items, const d
     if (T.scale[i] < 4.f) return DRBA_EUNSUPPORTED;  // earlier stages of the pyramid only (bounds their footprints)
   for (int k = 0; k < n_items; ++k) {
     const drba_stage_item_t &I = items[k];
-    if (!I.img0 || !I.img1 || !I.f0_pair || !I.f1_pair || !I.tmp_prev || !I.out) return DRBA_EINVAL;
+    if (!I.img0_x4 || !I.img1_x4 || !I.f0_q4 || !I.f1_q4 || !I.tmp_prev || !I.out) return DRBA_EINVAL;
+    if ((((uintptr_t)I.img0_x4 | (uintptr_t)I.img1_x4 | (uintptr_t)I.f0_q4 | (uintptr_t)I.f1_q4) & 15) != 0) return DRBA_EINVAL;
     if (lazy) {
       if (I.flow || I.flow_out) return DRBA_EINVAL;
       for (int i = 0; i < T.n; ++i)
@@ -571,27 +589,19 @@ int drba_stage_conv16_batch(const drba_stage_item_t *items, int n_items, const d
       if ((I.flow_out != nullptr) != fold || (!fold && !I.flow)) return DRBA_EINVAL;
       if ((I.flow == nullptr) != (items[0].flow == nullptr)) return DRBA_EINVAL;
     }
-    if ((I.img0_x4 != nullptr) != (items[0].img0_x4 != nullptr) || (I.img0_x4 != nullptr) != (I.img1_x4 != nullptr)) return DRBA_EINVAL;
-    if ((((uintptr_t)I.img0_x4 | (uintptr_t)I.img1_x4) & 15) != 0) return DRBA_EINVAL;
     its.it[k] = I;
   }
-  const bool x4 = items[0].img0_x4 != nullptr;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   hipStream_t s = (hipStream_t)stream;
-#define DRBA_SC16_GO_(FO, NT_, TOH_, XX)                                                                                       \
+#define DRBA_SC16_GO(FO, NT_, TOH_)                                                                                        \
   do {                                                                                                                     \
     using G_ = Geo<TOH_, NT_>;                                                                                             \
     const size_t lds_bytes = (size_t)G_::LDS_UNITS * 16;                                                                   \
-    if (max_dynamic_lds((const void *)stage_conv16<FO, G_, XX>, 160 * 1024) != hipSuccess) return DRBA_ELAUNCH;            \
+    if (max_dynamic_lds((const void *)stage_conv16<FO, G_>, 160 * 1024) != hipSuccess) return DRBA_ELAUNCH;                \
     const int tiles_x = (Wo + TOW - 1) / TOW, tiles_y = (Ho + G_::TOH - 1) / G_::TOH;                                   \
-    DRBA_LAUNCH((stage_conv16<FO, G_, XX>), dim3(tiles_x * tiles_y * n_items), dim3(G_::THREADS), lds_bytes, s, its, T,        \
+    DRBA_LAUNCH((stage_conv16<FO, G_>), dim3(tiles_x * tiles_y * n_items), dim3(G_::THREADS), lds_bytes, s, its, T,        \
                 reinterpret_cast<const drba_stage_conv16::u32x4 *>(packed_w), bias, hp, wp, 0.5f, prev_scale, H, W, Ho, Wo, tiles_x,   \
                 n_items);                                                                                                  \
-  } while (0)
-#define DRBA_SC16_GO(FO, NT_, TOH_)          \
-  do {                                       \
-    if (x4) DRBA_SC16_GO_(FO, NT_, TOH_, true); \
-    else DRBA_SC16_GO_(FO, NT_, TOH_, false);   \
   } while (0)
 #define DRBA_SC16_GO2(NT_, TOH_)            \
   do {                                      \
@@ -599,24 +609,20 @@ int drba_stage_conv16_batch(const drba_stage_item_t *items, int n_items, const d
     else if (fold) DRBA_SC16_GO(1, NT_, TOH_); \
     else DRBA_SC16_GO(0, NT_, TOH_);        \
   } while (0)
-  // output rows per workgroup: 7 (8 waves, two workgroups per CU).  TUNING builds: DRBA_SC16_TOH = 3 / 5 -> 4 / 6 waves; measured
-  // on the 8-sample 1080p launch (profiles/r05_stage_conv16_variants.txt): 192 / 195 us per sample against 178
-  if (Cout != 16) return DRBA_EUNSUPPORTED;
-#ifdef DRBA_TUNING_SWITCHES
+  // output rows per workgroup (TUNING builds: DRBA_SC16_TOH = 3 / 5 / 7 -> 4 / 6 / 8 waves, 4 / 2-3 / 2 workgroups per CU)
   static const int toh = env_int("DRBA_SC16_TOH", 7);
-  if (toh == 3) DRBA_SC16_GO2(1, 3);
-  else if (toh == 5) DRBA_SC16_GO2(1, 5);
-  else
-#endif
-    DRBA_SC16_GO2(1, 7);
+  if (Cout == 16) {
+    if (toh == 3) DRBA_SC16_GO2(1, 3);
+    else if (toh == 5) DRBA_SC16_GO2(1, 5);
+    else DRBA_SC16_GO2(1, 7);
+  } else {
+    if (toh == 3) DRBA_SC16_GO2(2, 3);
+    else if (toh == 5) DRBA_SC16_GO2(2, 5);
+    else DRBA_SC16_GO2(2, 7);
+  }
 #undef DRBA_SC16_GO2
 #undef DRBA_SC16_GO
-#undef DRBA_SC16_GO_
   DRBA_CHECK_LAUNCH();
-  for (int k = 0; k < n_items && g_range_check; ++k) {
-    const int rc = range_scan(items[k].out, (size_t)Cout * Ho * Wo, stream);
-    if (rc != DRBA_OK) return rc;
-  }
   return DRBA_OK;
 }
 

@@ -15,7 +15,9 @@ out = {}
 with open(src) as f:
     for row in csv.DictReader(f):
         out[row["Name"]] = {"avg_us": float(row["AverageUs"]), "calls_per_step": float(row["CallsPerStep"]), "source": os.path.basename(src)}
-out["__workload__"] = {"config": sys.argv[2] if len(sys.argv) > 2 else "1080p", "source": os.path.basename(src)}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (csrc_sha: the kernel sources this table was taken on; bench.py refuses a table of other sources)
+out["__workload__"] = {"config": sys.argv[2] if len(sys.argv) > 2 else "1080p", "source": os.path.basename(src), "csrc_sha": bench.csrc_sha()}
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "rocprof_frac.json")
 json.dump(out, open(dst, "w"), indent=1)
 print(f"{len(out)} symbols -> {dst}")

@@ -2,7 +2,7 @@
 """stage_conv16.hip (scale-1 stage input fused with conv0[0], two fp16 terms per operand) against
   * an fp64 convolution of the unfused stage input (ops.stage_inputs(scale=1)) -- the bound of the split family, 5e-6 max|y|,
   * stage_conv.hip (exact fp32 products) -- and the folded flows of both against ifblock_input_lds', bit for bit,
-on ragged sizes, with / without the fold, the flow as terms, 16 and 32 output channels; then the launch time of both forms at
+on ragged sizes, with / without the fold, the flow as terms; then the launch time of both forms at
 1080p (8 items, the flow as three terms: the loop's launch).    python tools/stage_conv16_check.py [reps] [--no-time | --time-only]"""
 import os
 import sys
@@ -53,7 +53,7 @@ def run(conv, two, *a, **k):
         ops.STAGE_CONV_TWO_TERM = None
 
 
-for cout in (() if "--time-only" in sys.argv else (16, 32)):
+for cout in (() if "--time-only" in sys.argv else (16,)):
     wt = torch.randn(cout, 52, 3, 3, generator=g) / (52 * 9) ** 0.5
     bs = torch.randn(cout, generator=g) * 0.1
     conv = ops.Conv3x3(wt, bs, 2, True, None, device=dev)
@@ -96,7 +96,13 @@ print("FAILED" if bad else "all ok", flush=True)
 if "--no-time" not in sys.argv:
     H, W, B = 1088, 1920, 8
     items, _, _ = make(B, H, W, True, False)
-    for cout in (16, 32):
+    if "--same-frames" in sys.argv:   # every item reads the same two frames: 7 of 8 items find their sources in L2
+        items = [items[0]] * B
+    elif "--shared-frames" in sys.argv:  # the items of a group share their frames as the pipeline's do (6 frames for 8 items)
+        fr = [(items[j][0], items[j][3]) for j in range(B // 2 + 2)]
+        items = [it for j in range(B // 2) for it in ((fr[j + 1][0], fr[j][0], items[2 * j][2], fr[j + 1][1], fr[j][1]),
+                                                      (fr[j + 1][0], fr[j + 2][0], items[2 * j + 1][2], fr[j + 1][1], fr[j + 2][1]))]
+    for cout in (16,):
         wt = torch.randn(cout, 52, 3, 3, generator=g) / (52 * 9) ** 0.5
         conv = ops.Conv3x3(wt, torch.zeros(cout), 2, True, None, device=dev)
         for amp, tag in ((0.0, "zero"), (1.0, "smooth"), (30.0, "rough")):
