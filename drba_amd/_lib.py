@@ -57,6 +57,7 @@ SIGNATURES = {
     "drba_flow_distance": (_i, [_p, _p, _i, _i, _i, _p]),
     "drba_flow_reverse": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "drba_drm_rife_linear": (_i, [_p, _p, _f, _p, _f, _p, _p, _i, _i, _i, _p]),
+    "drba_drm_rife_linear_batch": (_i, [_p, _i, _f, _p, _i, _i, _p]),
     "drba_drm_ratio": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _p]),
     "drba_affine": (_i, [_p, _f, _f, _p, _z, _p]),
     "drba_mul_map": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     "drba_u8hwc_to_f32nchw": (_i, [_p, _p, _i, _i, _p]),
     "drba_f32nchw_to_u8hwc": (_i, [_p, _p, _i, _i, _p]),
     "drba_to_inp": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _p]),
+    "drba_to_inp_x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _f, _p]),
     "drba_to_out": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _i, _p]),
     "drba_ssim3d_32": (_i, [_p, _p, _p, _p]),
     "drba_conv3x3_pick_cfg": (_i, [_i, _i, _i, _i, _i]),
@@ -144,6 +146,11 @@ class StageItem(C.Structure):
                 ("f1_pair", C.c_void_p), ("timestep_map", C.c_void_p), ("timestep_scalar", C.c_float), ("flow", C.c_void_p),
                 ("tmp_prev", C.c_void_p), ("flow_out", C.c_void_p), ("out", C.c_void_p), ("term", C.c_void_p * 4),
                 ("img0_x4", C.c_void_p), ("img1_x4", C.c_void_p)]
+
+
+class DrmJob(C.Structure):
+    """include/drba_hip.h: drba_drm_job_t"""
+    _fields_ = [("flow_self", C.c_void_p), ("flow_other", C.c_void_p), ("t", C.c_float), ("out", C.c_void_p)]
 
 
 MAX_FLOW_TERMS = 4  # DRBA_MAX_FLOW_TERMS

@@ -235,6 +235,21 @@ __device__ __forceinline__ void sample_pair(const float *__restrict__ pp, int W,
   v1 = a01 * t.wnw + a.w * t.wne + b01 * t.wsw + b.w * t.wse;
 }
 
+// The three channels of a frame kept as [H][W][4] (c0, c1, c2, 0) at the four taps: two 16-byte loads per tap row.  Same
+// products in the same order as sample() per channel (the right-border case: x1 == x0 carries weight 0).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sample_x4(const float *__restrict__ px, int W, const Taps &t, float (&v)[3]) {
+  const int xb = min(t.x0, W - 2);
+  const bool edge = t.x0 != xb;
+  const f32x4v a0 = *reinterpret_cast<const f32x4v *>(px + ((size_t)t.y0 * W + xb) * 4), a1 = *reinterpret_cast<const f32x4v *>(px + ((size_t)t.y0 * W + xb + 1) * 4);
+  const f32x4v b0 = *reinterpret_cast<const f32x4v *>(px + ((size_t)t.y1 * W + xb) * 4), b1 = *reinterpret_cast<const f32x4v *>(px + ((size_t)t.y1 * W + xb + 1) * 4);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float al = edge ? a1[c] : a0[c], bl = edge ? b1[c] : b0[c];
+    v[c] = al * t.wnw + a1[c] * t.wne + bl * t.wsw + b1[c] * t.wse;
+  }
+}
+
 // Source taps of F.interpolate(bilinear, align_corners=False) along one axis.
 struct Lerp {
   int i0, i1;

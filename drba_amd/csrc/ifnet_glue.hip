@@ -54,8 +54,8 @@ __global__ void __launch_bounds__(256) resize_bilinear_kernel(const float *__res
 
 // to_inp = resize(to_tensor(img), dst_size) in ONE pass: uint8 HWC -> /255. -> bilinear -> fp32 [1,3,Hout,Wout].
 // (the reference materialises the full-size fp32 frame in between, tools.py:33-34,59-60)
-__global__ void __launch_bounds__(256) to_inp_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int Hin, int Win,
-                                                     int Hout, int Wout, float sy, float sx) {
+__global__ void __launch_bounds__(256) to_inp_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, float *__restrict__ out_x4,
+                                                     int Hin, int Win, int Hout, int Wout, float sy, float sx) {
   const Tile2D p = tile_pixel(Wout, Hout);
   if (!p.valid) return;
   const Lerp ly = lerp_src_aten(p.y, sy, Hin), lx = lerp_src_aten(p.x, sx, Win);
@@ -65,8 +65,11 @@ __global__ void __launch_bounds__(256) to_inp_kernel(const uint8_t *__restrict__
   for (int c = 0; c < 3; ++c) {
     const float a = (float)r0[lx.i0 * 3 + c] / 255.f, b = (float)r0[lx.i1 * 3 + c] / 255.f;
     const float cc = (float)r1[lx.i0 * 3 + c] / 255.f, d = (float)r1[lx.i1 * 3 + c] / 255.f;
-    out[c * P + o] = lerp2_aten(ly, lx, a, b, cc, d);
+    const float v = lerp2_aten(ly, lx, a, b, cc, d);
+    out[c * P + o] = v;
+    if (out_x4) out_x4[4 * o + c] = v;
   }
+  if (out_x4) out_x4[4 * o + 3] = 0.f;
 }
 
 // to_out = to_cv2(resize(x, src_size)) in ONE pass: fp32 [1,3,Hin,Win] -> bilinear -> *255. truncated -> uint8 HWC,
@@ -92,8 +95,8 @@ __global__ void __launch_bounds__(256) to_out_kernel(const float *__restrict__ i
 // one pixel with 12 scalar loads and 3 byte (or 3 dword) stores: same values bit for bit, a third of the time (round 4: the
 // one-pixel kernels were 46 + 2 x 34 us of a 2.43 ms 1080p step at 0.9 TB/s).
 typedef float f32x4g __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) to_inp_rows_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int Hin, int W, int Hout,
-                                                          float sy) {
+__global__ void __launch_bounds__(256) to_inp_rows_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, float *__restrict__ out_x4,
+                                                          int Hin, int W, int Hout, float sy) {
   const int W4 = W >> 2;
   const size_t total = (size_t)W4 * Hout, P = (size_t)Hout * W;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -114,6 +117,11 @@ __global__ void __launch_bounds__(256) to_inp_rows_kernel(const uint8_t *__restr
       }
 #pragma unroll
     for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4g *>(out + (size_t)c * P + (size_t)y * W + x) = o[c];
+    if (out_x4) {  // the same values pixel-major, (c0, c1, c2, 0): 64 contiguous bytes per lane
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+        *reinterpret_cast<f32x4g *>(out_x4 + ((size_t)y * W + x + px) * 4) = (f32x4g){o[0][px], o[1][px], o[2][px], 0.f};
+    }
   }
 }
 __global__ void __launch_bounds__(256) to_out_rows_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, int Hin, int W, int Hout,
@@ -522,11 +530,28 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   const int Xb = SINGLE ? ox_b : lerp_src(ox_b, scale, W).i1, Yb = SINGLE ? oy_b : lerp_src(oy_b, scale, H).i1;
   const int rx0 = lerp_src(Xa, inv_prev_scale, wp).i0, ry0 = lerp_src(Ya, inv_prev_scale, hp).i0;
   const int rw = lerp_src(Xb, inv_prev_scale, wp).i1 - rx0 + 1, rh = lerp_src(Yb, inv_prev_scale, hp).i1 - ry0 + 1;
-  for (int i = threadIdx.x; i < (13 - C0) * rh * rw; i += 256) {
-    const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
-    prev[r][col][C0 + c] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
+  {
+    // the footprint's loads are all issued before the first LDS write (at most 6 x 20 pixels x 13 channels = 7 per lane): the
+    // "load, write, next" loop was up to 6 dependent memory round trips at the head of every workgroup (round 5)
+    constexpr int NL = (13 * kPrevRH * kPrevRW + 255) / 256;
+    float v[NL];
+    const int npx = rh * rw, ntot = (13 - C0) * npx;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = min((int)threadIdx.x + k * 256, ntot - 1);
+      const int c = i / npx, r = (i - c * npx) / rw, col = i - c * npx - r * rw;
+      v[k] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
+    }
+    if (LAZY) terms_stage<kTermR, kTermC, 256>(tl, T, item_.term, Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = (int)threadIdx.x + k * 256;
+      if (i < ntot) {
+        const int c = i / npx, r = (i - c * npx) / rw, col = i - c * npx - r * rw;
+        prev[r][col][C0 + c] = v[k];
+      }
+    }
   }
-  if (LAZY) terms_stage<kTermR, kTermC, 256>(tl, T, item_.term, Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -647,14 +672,31 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
     v1 = a.y * k.w00 + a.w * k.w01 + b.y * k.w10 + b.w * k.w11;
   };
   const float tmv = comb(tmap ? tmap[q] : tscalar);
+  // the three channels of a frame at this point: from its [H][W][4] copy when the item has one (two 16-byte loads per tap row
+  // instead of three 8-byte ones: 8 gathers per point instead of 12), else from the planes
+  const float *__restrict__ img0x = item_.img0_x4, *__restrict__ img1x = item_.img1_x4;
+  auto sample3 = [&](const float *__restrict__ planar, const float *__restrict__ x4, const TapW &k, float (&v)[3]) {
+    if (x4) {
+      const f32x4a a0 = *reinterpret_cast<const f32x4a *>(x4 + 4 * (size_t)k.o0), a1 = *reinterpret_cast<const f32x4a *>(x4 + 4 * (size_t)k.o0 + 4);
+      const f32x4a b0 = *reinterpret_cast<const f32x4a *>(x4 + 4 * (size_t)k.o1), b1 = *reinterpret_cast<const f32x4a *>(x4 + 4 * (size_t)k.o1 + 4);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = a0[c] * k.w00 + a1[c] * k.w01 + b0[c] * k.w10 + b1[c] * k.w11;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = sample(planar + (size_t)c * P, W, k);
+    }
+  };
+  float i0v[3], i1v[3];
+  sample3(img0, img0x, k0, i0v);
+  sample3(img1, img1x, k1, i1v);
   if (VS && SINGLE) {
     // batches of four channels: {img0 0..2, timestep}, {img1 0..2, mask}, 8 x {f0 pair, f1 pair}, feat 0..3, feat 4..7, flow
 #pragma unroll
-    for (int c = 0; c < 3; ++c) park(c, comb(sample(img0 + (size_t)c * P, W, k0)));
+    for (int c = 0; c < 3; ++c) park(c, comb(i0v[c]));
     park(3, tmv);
     flush_out(g4 < 3 ? g4 : 38);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) park(c, comb(sample(img1 + (size_t)c * P, W, k1)));
+    for (int c = 0; c < 3; ++c) park(c, comb(i1v[c]));
     park(3, comb(prev_up4(1)[0]));  // mask = channel 4
     flush_out(g4 < 3 ? 3 + g4 : 39);
 #pragma unroll 1
@@ -687,7 +729,7 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float v0 = comb(sample(img0 + (size_t)c * P, W, k0)), v1 = comb(sample(img1 + (size_t)c * P, W, k1));
+    const float v0 = comb(i0v[c]), v1 = comb(i1v[c]);
     emit(c, v0);
     emit(3 + c, v1);
   }
@@ -740,6 +782,7 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
 constexpr int kWbTermR = 6, kWbTermC = 18;  // term footprint capacity under a 32 x 8 tile (terms at >= 2 x the last scale >= 2)
 struct BlendItems {
   const float *img0[kMaxItems], *img1[kMaxItems], *flow[kMaxItems], *tmp[kMaxItems];
+  const float *img0x[kMaxItems], *img1x[kMaxItems];  // the frames as [H][W][4] (drba_stage_item_t.img0_x4), or NULL
   float *out[kMaxItems];
   const float *term[kMaxItems][kMaxTerms];
 };
@@ -750,6 +793,7 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   tile_item_block(n_items, vb_, vitem_, ntiles_);  // one grid dimension: the items of a tile back to back on one XCD
   const float *__restrict__ img0 = items.img0[vitem_], *__restrict__ img1 = items.img1[vitem_];
   const float *__restrict__ flow = items.flow[vitem_], *__restrict__ tmp = items.tmp[vitem_];
+  const float *__restrict__ img0x = items.img0x[vitem_], *__restrict__ img1x = items.img1x[vitem_];
   float *__restrict__ out = items.out[vitem_];
   __shared__ __attribute__((aligned(16))) float prev[10][36][8];  // [row][column][flow 0..3 | mask, 3 x padding]: 16-byte LDS words
   __shared__ __attribute__((aligned(16))) float tl[LAZY ? kMaxTerms * 4 * kWbTermR * kWbTermC : 4];
@@ -761,11 +805,28 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   const int Xa = tx * kTileW, Ya = ty * kTileH, Xb = min(Xa + kTileW - 1, W - 1), Yb = min(Ya + kTileH - 1, H - 1);
   const int rx0 = lerp_src(Xa, inv_scale, w).i0, ry0 = lerp_src(Ya, inv_scale, h).i0;
   const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
-  for (int i = threadIdx.x; i < 5 * rh * rw; i += 256) {
-    const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
-    prev[r][col][c] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
+  {
+    // the footprint's loads are all issued before the first LDS write (at most 10 x 36 pixels x 5 channels = 8 per lane): the
+    // "load, write, next" loop was up to 7 dependent memory round trips at the head of every workgroup (round 5)
+    constexpr int NL = (5 * 10 * 36 + 255) / 256;
+    float v[NL];
+    const int npx = rh * rw, ntot = 5 * npx;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = min((int)threadIdx.x + k * 256, ntot - 1);
+      const int c = i / npx, r = (i - c * npx) / rw, col = i - c * npx - r * rw;
+      v[k] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
+    }
+    if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[vitem_], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = (int)threadIdx.x + k * 256;
+      if (i < ntot) {
+        const int c = i / npx, r = (i - c * npx) / rw, col = i - c * npx - r * rw;
+        prev[r][col][c] = v[k];
+      }
+    }
   }
-  if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[vitem_], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
   const int x = Xa + (threadIdx.x & (kTileW - 1)), y = Ya + (threadIdx.x >> 5);
   if (x >= W || y >= H) return;
@@ -791,6 +852,14 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   const Taps t1 = taps_border(warp_coord(x, W, fl[2]), warp_coord(y, H, fl[3]), W, H);
   const float mk = up(4);
   const float m = 1.f / (1.f + expf(-mk));
+  if (img0x) {  // [H][W][4] frames: the two taps of a row are two 16-byte loads (4 + 4 gathers instead of 6 + 6 of 8 bytes)
+    float a[3], b[3];
+    sample_x4(img0x, W, t0, a);
+    sample_x4(img1x, W, t1, b);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(size_t)c * P + p] = a[c] * m + b[c] * (1.f - m);
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float a = sample(img0 + (size_t)c * P, W, t0), b = sample(img1 + (size_t)c * P, W, t1);
@@ -902,19 +971,24 @@ int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *str
   return DRBA_OK;
 }
 
-int drba_to_inp(const uint8_t *img_hwc, float *out, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
-                void *stream) {
-  if (!img_hwc || !out || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DRBA_EINVAL;
+int drba_to_inp_x4(const uint8_t *img_hwc, float *out, float *out_x4, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
+                   void *stream) {
+  if (!img_hwc || !out || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || ((uintptr_t)out_x4 & 15) != 0) return DRBA_EINVAL;
   if (Win == Wout && scale_x == 1.f && (Wout & 3) == 0 && (((uintptr_t)img_hwc & 3) | ((uintptr_t)out & 15)) == 0) {
-    DRBA_LAUNCH(to_inp_rows_kernel, dim3(grid_for((size_t)(Wout >> 2) * Hout)), dim3(kBlock), 0, (hipStream_t)stream, img_hwc, out, Hin,
-                Wout, Hout, scale_y);
+    DRBA_LAUNCH(to_inp_rows_kernel, dim3(grid_for((size_t)(Wout >> 2) * Hout)), dim3(kBlock), 0, (hipStream_t)stream, img_hwc, out, out_x4,
+                Hin, Wout, Hout, scale_y);
     DRBA_CHECK_LAUNCH();
     return DRBA_OK;
   }
-  DRBA_LAUNCH(to_inp_kernel, dim3(tiles_for(Wout, Hout)), dim3(kBlock), 0, (hipStream_t)stream, img_hwc, out, Hin, Win, Hout,
+  DRBA_LAUNCH(to_inp_kernel, dim3(tiles_for(Wout, Hout)), dim3(kBlock), 0, (hipStream_t)stream, img_hwc, out, out_x4, Hin, Win, Hout,
               Wout, scale_y, scale_x);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
+}
+
+int drba_to_inp(const uint8_t *img_hwc, float *out, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
+                void *stream) {
+  return drba_to_inp_x4(img_hwc, out, nullptr, Hin, Win, Hout, Wout, scale_y, scale_x, stream);
 }
 
 int drba_to_out(const float *in, uint8_t *out_hwc, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
@@ -939,6 +1013,7 @@ static int stage_items_ok(const drba_stage_item_t *items, int n, bool lds) {
     if (!I.img0 || !I.img1 || !I.out) return DRBA_EINVAL;
     if ((I.f0_pair == nullptr) != (I.f1_pair == nullptr) || (I.f0 == nullptr) != (I.f1 == nullptr)) return DRBA_EINVAL;
     if (!I.f0 && !I.f0_pair) return DRBA_EINVAL;  // the features in one layout at least: planar [16,H,W] or pair-interleaved [8,H,W,2]
+    if ((I.img0_x4 != nullptr) != (I.img1_x4 != nullptr) || (((uintptr_t)I.img0_x4 | (uintptr_t)I.img1_x4) & 15) != 0) return DRBA_EINVAL;
     // one kernel instantiation serves the batch: the items agree on what is optional
     if ((I.flow == nullptr) != (items[0].flow == nullptr) || (I.flow_out == nullptr) != (items[0].flow_out == nullptr) ||
         (I.f0_pair == nullptr) != (items[0].f0_pair == nullptr) || (I.f0 == nullptr) != (items[0].f0 == nullptr) ||
@@ -1112,7 +1187,9 @@ int drba_warp_blend_lazy_batch(const drba_stage_item_t *items, int n_items, cons
   for (int k = 0; k < n_items; ++k) {
     const drba_stage_item_t &I = items[k];
     if (!I.img0 || !I.img1 || !I.tmp_prev || !I.out) return DRBA_EINVAL;
+    if ((I.img0_x4 != nullptr) != (I.img1_x4 != nullptr) || (((uintptr_t)I.img0_x4 | (uintptr_t)I.img1_x4) & 15) != 0) return DRBA_EINVAL;
     its.img0[k] = I.img0, its.img1[k] = I.img1, its.tmp[k] = I.tmp_prev, its.out[k] = I.out;
+    its.img0x[k] = I.img0_x4, its.img1x[k] = I.img1_x4;
     for (int i = 0; i < T.n; ++i) {
       if (!I.term[i]) return DRBA_EINVAL;
       its.term[k][i] = I.term[i];

@@ -220,10 +220,21 @@ class RIFE:
     ENC_ON_MAIN = False  # A/B runs: the frames' encoders in the caller's stream (right behind to_inp) instead of the prefetch stream
     SIDE_STAGES = 3  # IFNet stages of the NEXT step run by the lookahead on the side stream (class attribute: A/B runs set it)
 
-    def _items(self, I0, I1, I2, ts, linear, flow10, flow12, f0, f1, f2):
+    def _items(self, I0, I1, I2, ts, linear, flow10, flow12, f0, f1, f2, defer=None):
         """DRM maps and the (img0, img1, timestep, f0, f1) work items of one step; output holds pass-through frames
-        and, for the frames to synthesise, their index into items."""
+        and, for the frames to synthesise, their index into items.  defer (a list, linear DRM only): the maps are not computed here --
+        (flow_self, flow_other, t) is appended and the item carries its index into `defer` as the timestep; the caller computes
+        the maps of all its steps in one launch (_ops.drm_rife_linear_many) and calls _fill_drm."""
         output, items = [], []
+
+        def drm_of(fs, fo, t, key):
+            if not linear:
+                return calc_drm_rife(t, flow10, flow12, False)[key]
+            if defer is None:
+                return _ops.drm_rife_linear(fs, fo, t, 1e-4)
+            defer.append((fs, fo, t))
+            return len(defer) - 1
+
         for t in ts:
             if t == 0:
                 output.append(I0)
@@ -234,14 +245,12 @@ class RIFE:
             elif 0 < t < 1:
                 t = 1 - t
                 # only the map this frame consumes is computed (the reference builds both, drm.py:89-96)
-                drm = (_ops.drm_rife_linear(flow10, flow12, t, 1e-4) if linear
-                       else calc_drm_rife(t, flow10, flow12, False)["drm_t1_t01"])
+                drm = drm_of(flow10, flow12, t, "drm_t1_t01")
                 output.append(len(items))
                 items.append((I1, I0, drm, f1, f0))
             elif 1 < t < 2:
                 t = t - 1
-                drm = (_ops.drm_rife_linear(flow12, flow10, t, 1e-4) if linear
-                       else calc_drm_rife(t, flow10, flow12, False)["drm_t1_t12"])
+                drm = drm_of(flow12, flow10, t, "drm_t1_t12")
                 output.append(len(items))
                 items.append((I1, I2, drm, f1, f2))
         return output, items
@@ -276,14 +285,16 @@ class RIFE:
         """Work items of the steps (F[j], F[j+1], F[j+2]; ts_list[j]), j = 0 .. len(ts_list) - 1: P[j] = calc_flow(F[j+1], F[j+2]),
         reuse0 what the step before the first one handed on.  -> (per-step outputs with placeholders, per-step item counts,
         all items, per-step reuse: reuses[j] enters step j, reuses[j + 1] leaves it)."""
-        outs, counts, items, reuses = [], [], [], [reuse0]
+        outs, counts, items, reuses, jobs = [], [], [], [reuse0], []
         for j, ts in enumerate(ts_list):
             r, p = reuses[j], P[j]
-            o, it = self._items(F[j], F[j + 1], F[j + 2], ts, True, r[0], p[0], r[3], r[2], p[3])
+            o, it = self._items(F[j], F[j + 1], F[j + 2], ts, True, r[0], p[0], r[3], r[2], p[3], defer=jobs)
             outs.append(o)
             counts.append(len(it))
             items += it
             reuses.append((p[1], p[0], p[3], p[2]))  # (flow21, flow12, f2, f1), reference rife.py:109
+        maps = _ops.drm_rife_linear_many(jobs, 1e-4)  # the group's DRM maps: one launch pair (they were 2 launches per map)
+        items = [(a, b, maps[t], fa, fb) for (a, b, t, fa, fb) in items]
         return outs, counts, items, reuses
 
     def _stage_group(self, F, ts_list, reuse0):

@@ -227,6 +227,33 @@ def drm_rife_linear(flow_self, flow_other, t, eps=1e-4, t_dev=None):
     return out
 
 
+def drm_rife_linear_many(jobs, eps=1e-4):
+    """drm_rife_linear(flow_self, flow_other, t, eps) for every (flow_self, flow_other, t) of `jobs` ([1,2,H,W] flows of one
+    size) in ONE launch pair (drba_drm_rife_linear_batch; chunks of MAX_STAGE_ITEMS) -> list of [1,1,H,W] maps."""
+    if not jobs:
+        return []
+    flows = [(_f32(a, "flow_self"), _f32(b, "flow_other"), float(t)) for a, b, t in jobs]
+    _, _, h, w = flows[0][0].shape
+    dev = flows[0][0].device
+    res = []
+    for c0 in range(0, len(flows), _lib.MAX_STAGE_ITEMS):
+        chunk = flows[c0:c0 + _lib.MAX_STAGE_ITEMS]
+        n = len(chunk)
+        out = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
+        arr = (_lib.DrmJob * n)()
+        for k, (a, b, t) in enumerate(chunk):
+            if tuple(a.shape) != (1, 2, h, w) or tuple(b.shape) != (1, 2, h, w):
+                raise _lib.DrbaHipError("drm_rife_linear_many: every flow must be [1,2,H,W] of one size")
+            arr[k].flow_self, arr[k].flow_other, arr[k].t, arr[k].out = a.data_ptr(), b.data_ptr(), t, out[k].data_ptr()
+        ws = _zero_workspace(dev, n * h * w * 2)
+        first = _trace_pos()
+        _lib.check(_lib.load().drba_drm_rife_linear_batch(C.cast(arr, C.c_void_p), n, float(eps), _p(ws), h, w, _stream()),
+                   "drba_drm_rife_linear_batch")
+        _tag(first, [None, (20.0 * n * h * w, "byte", f"drm_rife_linear {(n, h, w)}")])
+        res += [out[k:k + 1] for k in range(n)]
+    return res
+
+
 def drm_ratio(flow10, flow12, eps):
     a, b = _f32(flow10), _f32(flow12)
     n, _, h, w = a.shape
@@ -321,9 +348,13 @@ def to_inp(img_u8, dst_size):
     h, w = img_u8.shape[:2]
     ho, wo = int(dst_size[0]), int(dst_size[1])
     out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=img_u8.device)
+    # ... and the same frame pixel-major, [H,W,4]: what the gathers read their image taps from (IMG_X4), written in the same pass
+    x4 = torch.empty((ho, wo, 4), dtype=torch.float32, device=img_u8.device) if IMG_X4 else None
     sy, sx = float(np.float32(h) / np.float32(ho)), float(np.float32(w) / np.float32(wo))  # ATen: static_cast<float>(in) / out
-    _lib.check(_timed("to_inp", (h, w, ho, wo), 3.0 * min(h * w, 4 * ho * wo) + 12.0 * ho * wo, "byte", lambda: _lib.load().drba_to_inp(
-        _p(img_u8), _p(out), h, w, ho, wo, sy, sx, _stream())), "drba_to_inp")
+    _lib.check(_timed("to_inp", (h, w, ho, wo), 3.0 * min(h * w, 4 * ho * wo) + (28.0 if IMG_X4 else 12.0) * ho * wo, "byte",
+                      lambda: _lib.load().drba_to_inp_x4(_p(img_u8), _p(out), _p(x4), h, w, ho, wo, sy, sx, _stream())), "drba_to_inp_x4")
+    if x4 is not None:
+        out._drba_x4 = (x4, out._version)
     return out
 
 
@@ -737,18 +768,26 @@ def pair_interleaved(f):
     return fp
 
 
-IMG_X4 = False  # the gathers read the frames from their [H,W,4] copies (two 16-byte loads per tap row instead of three 8-byte ones)
+IMG_X4 = True  # the gathers read the frames from their [H,W,4] copies (two 16-byte loads per tap row instead of three 8-byte ones)
+
+
+def _x4_of(img):
+    """The [H,W,4] copy a frame carries (ops.to_inp writes it with the frame; rgbx() makes it on demand), or None: then the
+    kernels read the planes.  A frame that did not come from to_inp (tests, a caller's own tensors) is NOT converted behind the
+    caller's back per call -- rgbx(frame) once is the caller's choice."""
+    x = getattr(img, "_drba_x4", None) if IMG_X4 else None
+    return x[0] if x is not None and x[1] == img._version else None  # (a frame written in place since: the copy is stale)
 
 
 def rgbx(img):
     """A frame [1,3,H,W] -> its [H,W,4] copy (c0, c1, c2, 0), made once per tensor (to_inp writes it with the frame) and kept on it."""
     x = getattr(img, "_drba_x4", None)
-    if x is None:
+    if x is None or x[1] != img._version:
         _, _, h, w = img.shape
-        x = torch.empty((h, w, 4), dtype=torch.float32, device=img.device)
-        _lib.check(_timed("rgbx", (h, w), 28.0 * h * w, "byte", lambda: _lib.load().drba_rgbx(_p(img), _p(x), h, w, _stream())), "drba_rgbx")
-        img._drba_x4 = x
-    return x
+        x4 = torch.empty((h, w, 4), dtype=torch.float32, device=img.device)
+        _lib.check(_timed("rgbx", (h, w), 28.0 * h * w, "byte", lambda: _lib.load().drba_rgbx(_p(img), _p(x4), h, w, _stream())), "drba_rgbx")
+        x = img._drba_x4 = (x4, img._version)
+    return x[0]
 
 
 def ifblock_input(img0, img1, f0, f1, timestep, flow, tmp_prev, prev_scale, scale, out=None):
@@ -877,6 +916,11 @@ def stage_inputs(items, flows, tmp_prev, prev_scale, scale, out, fold=False, lds
         a.tmp_prev = None if tmp_prev is None else tmp_prev[k].data_ptr()
         a.flow_out = None if flow_out is None else flow_out[k].data_ptr()
         a.out = out[k].data_ptr()
+        if lds:  # (the LDS-staged gathers read the [H,W,4] copies of the frames where both carry one)
+            x0, x1 = _x4_of(i0), _x4_of(i1)
+            if x0 is not None and x1 is not None:
+                keep += [x0, x1]
+                a.img0_x4, a.img1_x4 = _ptr(x0), _ptr(x1)
         for i, t in enumerate(tts):
             a.term[i] = t[k].data_ptr()
     pts = H * W if scale <= 2 else 4 * h * w
@@ -954,6 +998,7 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
     arr = (_lib.StageItem * B)()
     keep = []
     feats = _feat_batch(items)
+    x4_all = all(_x4_of(_f32(it[0])) is not None and _x4_of(_f32(it[1])) is not None for it in items)  # (the items of a launch agree)
     for k, (i0, i1, t, _f0, _f1) in enumerate(items):
         i0, i1 = _f32(i0), _f32(i1)
         (f0, f0p), (f1, f1p) = feats[k]
@@ -966,10 +1011,9 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
         a.tmp_prev, a.flow_out, a.out = tmp_prev[k].data_ptr(), (None if flow_out is None else flow_out[k].data_ptr()), out[k].data_ptr()
         for i, t in enumerate(tts):
             a.term[i] = t[k].data_ptr()
-        if IMG_X4:
-            x0, x1 = rgbx(i0), rgbx(i1)
-            keep += [x0, x1]
-            a.img0_x4, a.img1_x4 = _ptr(x0), _ptr(x1)
+        x0, x1 = (_x4_of(i0), _x4_of(i1)) if x4_all else (None, None)
+        keep += [x0, x1]
+        a.img0_x4, a.img1_x4 = _ptr(x0), _ptr(x1)
     # algorithmic bytes: 43 source channels read once per full-resolution point, the 16-channel quarter-size output (and the
     # folded flow) written; 2 * 16 * 52 * 9 FLOP per output pixel ride along (50 us per 1080p sample at the fp32 MFMA peak,
     # 53 us of HBM time: the byte roofline is the binding one)
@@ -1037,6 +1081,10 @@ def warp_blend_lazy(items, terms, tmp_last, scale):
         keep += [i0, i1]
         a = arr[k]
         a.img0, a.img1, a.tmp_prev, a.out = _ptr(i0), _ptr(i1), tmp_last[k].data_ptr(), out[k].data_ptr()
+        x0, x1 = _x4_of(i0), _x4_of(i1)
+        if x0 is not None and x1 is not None:
+            keep += [x0, x1]
+            a.img0_x4, a.img1_x4 = _ptr(x0), _ptr(x1)
         for i, t in enumerate(tts):
             a.term[i] = t[k].data_ptr()
     nbytes = B * 4.0 * ((6 + 3) * H * W + 5 * h * w)

@@ -64,7 +64,7 @@ def ifnet_state_dict(seed=0):
         if key.endswith("beta"):
             t = torch.rand(shape, generator=g) * 0.5 + 0.25
         elif key.endswith("bias"):
-            t = torch.randn(shape, generator=g) * 0.02
+            t = torch.randn(shape, generator=g) * (0.002 if key == "backbone.conv2.bias" and damp_transformer else 0.02)
         else:
             if "lastconv" in key or "cnn3" in key:  # ConvTranspose2d: each output gets 2x2 taps
                 fan_in = shape[0] * 4
@@ -196,7 +196,7 @@ def seeded_state_dict(shapes, seed=0, tag="", damp_transformer=True):
         if len(shape) == 1 and shape[0] == 1:  # nn.PReLU() slope
             t = torch.rand(shape, generator=g) * 0.3 + 0.1
         elif key.endswith("bias"):
-            t = torch.randn(shape, generator=g) * 0.02
+            t = torch.randn(shape, generator=g) * (0.002 if key == "backbone.conv2.bias" and damp_transformer else 0.02)
         elif len(shape) == 1:  # LayerNorm weight
             t = 1.0 + torch.randn(shape, generator=g) * 0.05
             if key.startswith("transformer.") and damp_transformer:
@@ -212,6 +212,14 @@ def seeded_state_dict(shapes, seed=0, tag="", damp_transformer=True):
             else:
                 fan_in = shape[1]
             gain = 0.7 if ("residual_model" in key or "metric_net" in key) else 1.0
+            if key == "backbone.conv2.weight" and damp_transformer:
+                # GMFlow's matching features = CNN features + a weight-free sinusoidal position embedding.  Random CNN features
+                # of low-texture synthetic frames match globally at random (flows of hundreds of pixels whose arg-max flips under
+                # a 1-ulp input change: the oracle's own 1152x1920 frame moved by 4.5e-2, rounds 1-4); scaled down, the position
+                # term dominates, matches stay near the identity as a trained network's do on small motion (flows <= 20 px) and the
+                # oracle's self-sensitivity at 1152x1920 is 6e-5 on frames, 1.3e-4 on flows (tools/exp/union_floor_probe.py) --
+                # the end-to-end 1e-3 bar is falsifiable at every size
+                gain = 0.1
             t = torch.randn(shape, generator=g) * (gain / fan_in ** 0.5)
         sd[key] = t.contiguous()
     return sd

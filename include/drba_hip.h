@@ -107,6 +107,15 @@ int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, in
  * is read from that device float instead of `t` (so a captured HIP graph can be replayed for any t). */
 int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float t, const float *t_dev,
                          float eps, float *out, float *ws, int N, int H, int W, void *stream);
+/* ABI 6: n_jobs (<= DRBA_MAX_STAGE_ITEMS) maps of one geometry in one launch pair: job k = drba_drm_rife_linear(flow_self,
+ * flow_other, t, NULL, eps, out, ., 1, H, W) on tensors of its own (the maps of a group of DRBA steps: 2 launches instead of
+ * 2 per map).  ws: n_jobs*H*W*2 floats, zero on entry and on return. */
+typedef struct drba_drm_job {
+  const float *flow_self, *flow_other; /* [2,H,W] each */
+  float t;
+  float *out; /* [1,H,W] */
+} drba_drm_job_t;
+int drba_drm_rife_linear_batch(const drba_drm_job_t *jobs, int n_jobs, float eps, float *ws, int H, int W, void *stream);
 
 /* ---- DRM building blocks for the non-fused variants (drm.py:110-195, :10-62) */
 /* ratio maps: a = d10/(d10+d12), b = d12/(d10+d12), d = |flow| + eps; either output may be NULL */
@@ -135,6 +144,10 @@ int drba_f32nchw_to_u8hwc(const float *in, uint8_t *out, int H, int W, void *str
  * Arithmetic pinned to ATen's CPU kernel (fma(scale, dst+0.5, -0.5); fma(w0, a, w1*b) per axis): bit-exact. */
 int drba_to_inp(const uint8_t *img_hwc, float *out, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
                 void *stream);
+/* ABI 6: drba_to_inp that also writes the frame pixel-major, [Hout][Wout][4] = (c0, c1, c2, 0) (out_x4, 16-byte aligned, may be
+ * NULL): the copy the gathers read their image taps from (drba_stage_item_t.img0_x4), at no extra pass over the frame. */
+int drba_to_inp_x4(const uint8_t *img_hwc, float *out, float *out_x4, int Hin, int Win, int Hout, int Wout, float scale_y,
+                   float scale_x, void *stream);
 int drba_to_out(const float *in, uint8_t *out_hwc, int Hin, int Win, int Hout, int Wout, float scale_y, float scale_x,
                 int reverse_channels, void *stream);
 

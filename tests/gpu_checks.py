@@ -557,7 +557,7 @@ def check_glue_n8_fullsize(dev, H=1088, W=1920, B=8, ref_items=(0, 3, 7)):
 def check_gmfss_union_teacher_forced(dev, frames, rel=1e-4):
     """BASELINE.json configs[3] AT ITS SIZE (frames: three fp32 [1,3,1152,1920] network inputs), stage by stage, every HIP stage
     fed the ORACLE's intermediate tensors, so that nothing upstream amplifies a rounding difference (end to end at this size the
-    seeded GMFlow moves the oracle's own frame by 4.5e-2 under a 1-ulp input change: that run cannot fail at 1e-3; these can):
+    rounds 1-4's seeded GMFlow moved the oracle's own frame by 4.5e-2 under a 1-ulp input change and that run could not fail at 1e-3; since round 5 both can):
       FeatureNet (FeatureNet.py:29-33) | GMFlow CNN encoder (backbone.py:39-117) | coarse transformer (transformer.py:236-302)
       | global correlation + propagation (matching.py:7-38, transformer.py:355-372) | fine-scale refinement: warp, transformer,
       local correlation r=4, local propagation, convex upsampling (gmflow.py:140-185) | MetricNet (MetricNet.py:45-65) | the
@@ -773,16 +773,14 @@ def check_gmfss_parts(dev, size=(128, 256)):
 
 
 def check_gmfss_union(hip, ora, golden, scale, size, tol=1e-3):
-    """Bar: 1e-3 max-abs.  Two properties of this path are measured rather than assumed:
-    * GMFlow's correlation softmax amplifies rounding (a +-1e-7 change of the input frames moves the oracle's own
-      flows by a few 1e-4 here), so an output whose fp32 conditioning floor (oracle vs oracle on 1-ulp-perturbed
-      frames) exceeds 2.5e-4 is allowed 4x that floor instead;
-    * the soft splat with exp(10*tanh) weights, the ones-splat hole tests and the >25x swap masks are discontinuous
-      decisions: in occlusion patches a 1-ulp input change moves the ORACLE's own frame by 3e-3 .. 3e-2 over 40-550
-      pixels (measured with several perturbation seeds; which patch flips depends on the seed), so up to 0.1 % of
-      an output's elements may exceed the tolerance as long as they stay below 5e-2.
-    Rows: (name, max error of the in-tolerance part, tolerance, details); a violation of the outlier budget is
-    reported as the full max error."""
+    """Bar: 1e-3 max-abs, FLAT, against the oracle run here and against the reference's fixture.  (Rounds 1-4 allowed 4 x the
+    oracle's own movement under a 1-ulp input change: the seeded GMFlow of those rounds matched low-texture frames at random and
+    that movement reached 5e-4 at these sizes, 4.5e-2 at 1152x1920.  The synthetic weights are well conditioned since round 5
+    -- drba_amd/utils/synth.py -- so the allowance is gone; the floor is still measured and reported.)
+    The soft splat with exp(10*tanh) weights, the ones-splat hole tests and the > 25x swap masks are discontinuous decisions: up
+    to 0.02 % of an output's elements may exceed the tolerance as long as they stay below 5e-2, and are counted.
+    Rows: (name, max error of the in-tolerance part, tolerance, details); a violation of the outlier budget is reported as the
+    full max error."""
     sds = synth.gmfss_union_state_dicts(seed=0)
     H, W = size
     rows = []
@@ -793,10 +791,10 @@ def check_gmfss_union(hip, ora, golden, scale, size, tol=1e-3):
     for k in o:
         d = _diff(g[k], o[k])
         floor = _diff(o2[k], o[k])
-        tk = max(tol, 4.0 * floor)
+        tk = tol
         n_out, n = _outliers(g[k], o[k], tk)
         fx, fx_out, fx_n = cases.compare_to_fixture(golden, k, g[k], count_above=tk)
-        budget_ok = n_out <= n // 1000 and d <= 5e-2 and fx_out <= max(1, fx_n // 1000) and fx <= 5e-2
+        budget_ok = n_out <= n // 5000 and d <= 5e-2 and fx_out <= max(1, fx_n // 5000) and fx <= 5e-2
         shown = min(d, tk) if budget_ok else max(d, fx)
         rows.append((k, shown, tk, f"max={d:.2e} outliers>{tk:.2g}: {n_out}/{n} fp32_floor={floor:.2e} "
                                    f"vs_fixture={fx:.2e} ({fx_out}/{fx_n} above)"))

@@ -142,8 +142,9 @@ def test_to_inp_to_out_fullsize_bit_exact(hip_backend):
 def test_gmfss_union_1080p_warm_step_parity(hip_backend, oracle_backend):
     """BASELINE.json configs[3] at 1152x1920 (pad 128), scale 1.0: the reuse entering the step is rebuilt with
     warm_reuse (what the previous DRBA step would have returned), then one warm inference_ts_drba, ts = [0.75, 1.25].
-    Bar as in gpu_checks.check_gmfss_union: 1e-3, or 4x the fp32 conditioning floor where that is larger (oracle vs
-    oracle on 1-ulp-perturbed frames); at most 0.1 % of a frame's elements above it, none above 5e-2."""
+    Bar: 1e-3 max-abs, flat (the synthetic GMFlow weights are well conditioned since round 5: the oracle's own frame moves by
+    6e-5 under a 1-ulp input change at this size, tools/exp/union_floor_probe.py); at most 0.02 % of a tensor's elements above
+    it (splat / mask decisions), none above 5e-2.  Flows are compared in pixels: up to 20 px here."""
     sds = synth.gmfss_union_state_dicts(seed=0)
     frames = _net_frames(3, 1080, 1920, (1152, 1920), seed=4321)
 
@@ -158,23 +159,19 @@ def test_gmfss_union_1080p_warm_step_parity(hip_backend, oracle_backend):
     with torch.no_grad():
         g = run(hip_backend, frames)
         o = run(oracle_backend, frames)
-        o2 = None
-        if any(gpu_checks._diff(g[k], o[k]) > 1e-3 for k in o):  # the conditioning floor costs a second oracle run
-            gen = torch.Generator().manual_seed(99)
-            o2 = run(oracle_backend, [f + (torch.rand(f.shape, generator=gen) - 0.5) * 2e-7 for f in frames])
     rows = []
     for k in o:
-        d, floor = gpu_checks._diff(g[k], o[k]), (gpu_checks._diff(o2[k], o[k]) if o2 is not None else 0.0)
-        tk = max(1e-3, 4.0 * floor)
+        d = gpu_checks._diff(g[k], o[k])
+        tk = 1e-3
         n_out, n = gpu_checks._outliers(g[k], o[k], tk)
-        ok = n_out <= n // 1000 and d <= 5e-2
-        rows.append((k, min(d, tk) if ok else d, tk, f"max={d:.2e} outliers>{tk:.2g}: {n_out}/{n} fp32_floor={floor:.2e}"))
+        ok = n_out <= n // 5000 and d <= 5e-2
+        rows.append((k, min(d, tk) if ok else d, tk, f"max={d:.2e} outliers>{tk:.2g}: {n_out}/{n} |ref|max={float(o[k].abs().max()):.3g}"))
     _assert_rows(rows)
 
 
 def test_gmfss_union_1080p_teacher_forced_stages(hip_backend):
     """BASELINE.json configs[3] at 1152x1920, stage by stage on the oracle's intermediate tensors: a check that CAN fail at
-    1e-4 * max|ref| (the end-to-end row above sits on a 4.5e-2 conditioning floor at this size)."""
+    1e-4 * max|ref| (a tighter, per-stage bar beside the end-to-end 1e-3 row above)."""
     frames = _net_frames(3, 1080, 1920, (1152, 1920), seed=4321)
     _assert_rows(gpu_checks.check_gmfss_union_teacher_forced(hip_backend.dev, frames))
 
