@@ -465,6 +465,8 @@ def _standalone_stage_conv0(roof, dev, g, H, W, n, reps=30):
     gen = torch.Generator().manual_seed(0)
     # the items of a group share their frames as the pipeline's do: step j = (I[j+1], I[j]) and (I[j+1], I[j+2])
     fr = [(torch.rand(1, 3, H, W, generator=gen).to(dev), torch.randn(1, 16, H, W, generator=gen).to(dev)) for _ in range(n // 2 + 2)]
+    for im, _ in fr:
+        ops.rgbx(im)  # the [H,W,4] copy a pipeline frame carries (ops.to_inp writes it with the frame)
     items = []
     for j in range(n // 2):
         (a, fa), (b, fb), (c, fc) = fr[j], fr[j + 1], fr[j + 2]

@@ -297,8 +297,9 @@ def test_family4_range_check_reports_overflow_instead_of_inf(hip_backend):
 
 def test_drm_maps_of_a_group_in_one_launch_equal_the_single_calls(hip_backend):
     """drba_drm_rife_linear_batch (the DRM maps of a group of steps: one launch pair) against drba_drm_rife_linear per map:
-    the same kernels on the same inputs -- bit-identical, for smooth, long (beyond the tile halo) and non-finite flows, a
-    ragged size, more jobs than one launch takes."""
+    the same kernels on the same inputs, for smooth, long (beyond the tile halo) and non-finite flows, a ragged size, more jobs
+    than one launch takes.  Equal to summation order: a tile ranks the sources of an output pixel by an LDS atomic, long flows
+    go through global atomics -- two runs of ONE call differ in the last bits as well (2e-6 on maps of magnitude <= 1)."""
     from drba_amd import ops
     dev = hip_backend.dev
     g = torch.Generator().manual_seed(17)
@@ -312,7 +313,9 @@ def test_drm_maps_of_a_group_in_one_launch_equal_the_single_calls(hip_backend):
         many = ops.drm_rife_linear_many(jobs, 1e-4)
         for (a, b, t), m in zip(jobs, many):
             one = ops.drm_rife_linear(a, b, t, 1e-4)
-            assert torch.equal(torch.nan_to_num(one, nan=-7.0), torch.nan_to_num(m, nan=-7.0)), (h, w, amp, t)
+            assert torch.equal(torch.isnan(one), torch.isnan(m)), (h, w, amp, t)
+            d = float((torch.nan_to_num(one, nan=0.0) - torch.nan_to_num(m, nan=0.0)).abs().max())
+            assert d <= 2e-6 * max(1.0, float(torch.nan_to_num(one, nan=0.0).abs().max())), (h, w, amp, t, d)
 
 
 def test_splat_index_reuse_is_validated(hip_backend):
@@ -324,17 +327,20 @@ def test_splat_index_reuse_is_validated(hip_backend):
     g = torch.Generator().manual_seed(23)
     x, y = torch.rand(1, 3, 48, 80, generator=g).to(dev), torch.rand(1, 5, 48, 80, generator=g).to(dev)
     f1, f2 = (torch.randn(1, 2, 48, 80, generator=g) * 3).to(dev), (torch.randn(1, 2, 48, 80, generator=g) * 3).to(dev)
+    def same(a, b):  # (the sort ranks a pixel's sources by an atomic: two runs of one call agree to summation order)
+        return float((a - b).abs().max()) <= 2e-6
+
     ref_y1 = ops.softsplat(y, f1, None, "avg")
     ref_y2 = ops.softsplat(y, f2, None, "avg")
     ops.softsplat(x, f1, None, "avg")
-    assert torch.equal(ops.softsplat_many([y], f1, None, "avg", reuse_index=True)[0], ref_y1)      # the honest reuse
-    assert torch.equal(ops.softsplat_many([y], f2, None, "avg", reuse_index=True)[0], ref_y2)      # another flow: rebuilt
+    assert same(ops.softsplat_many([y], f1, None, "avg", reuse_index=True)[0], ref_y1)      # the honest reuse
+    assert same(ops.softsplat_many([y], f2, None, "avg", reuse_index=True)[0], ref_y2)      # another flow: rebuilt
     ops.softsplat(x, f1, None, "avg")
     ops.instance_norm(torch.rand(1, 4, 48, 80, generator=g).to(dev))                                # another workspace user
-    assert torch.equal(ops.softsplat_many([y], f1, None, "avg", reuse_index=True)[0], ref_y1)
+    assert same(ops.softsplat_many([y], f1, None, "avg", reuse_index=True)[0], ref_y1)
     ops.softsplat(x, f1, None, "avg")
     f1.add_(0.25)                                                                                   # the flow changed in place
-    assert torch.equal(ops.softsplat_many([y], f1, None, "avg", reuse_index=True)[0], ops.softsplat(y, f1, None, "avg"))
+    assert same(ops.softsplat_many([y], f1, None, "avg", reuse_index=True)[0], ops.softsplat(y, f1, None, "avg"))
 
 
 def test_cloned_reuse_features_keep_their_layout(hip_backend):

@@ -51,6 +51,8 @@ ops.pair_interleaved(f0), ops.pair_interleaved(f1)  # made once, as in the pipel
 img2 = torch.rand(1, 3, H, W, generator=g).to(dev)
 f2 = torch.randn(1, 16, H, W, generator=g).to(dev)
 ops.pair_interleaved(f2)
+for _im in (img0, img1, img2):
+    ops.rgbx(_im)  # the [H,W,4] copies the pipeline's frames carry (ops.to_inp writes them): the gathers read their image taps from those
 items2 = [(img1, img0, tmap, f1, f0), (img1, img2, tmap, f1, f2)]
 flows2 = [flow, (flow * 0.9).contiguous()]
 # N = 2: the samples of one `-t 2` step (what a step-by-step driver launches); N = 8: a group of 4 steps (RIFE.GROUP, what
@@ -61,6 +63,7 @@ frames6 = [(img0, f0), (img1, f1), (img2, f2)]
 for _ in range(3):
     im, ft = torch.rand(1, 3, H, W, generator=g).to(dev), torch.randn(1, 16, H, W, generator=g).to(dev)
     ops.pair_interleaved(ft)
+    ops.rgbx(im)
     frames6.append((im, ft))
 items8 = []
 for j in range(4):

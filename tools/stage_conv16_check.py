@@ -96,6 +96,9 @@ print("FAILED" if bad else "all ok", flush=True)
 if "--no-time" not in sys.argv:
     H, W, B = 1088, 1920, 8
     items, _, _ = make(B, H, W, True, False)
+    if "--planar-frames" not in sys.argv:  # the pipeline's frames carry their [H,W,4] copies (ops.to_inp): the launch the loop makes
+        for it in items:
+            ops.rgbx(it[0]), ops.rgbx(it[1])
     if "--same-frames" in sys.argv:   # every item reads the same two frames: 7 of 8 items find their sources in L2
         items = [items[0]] * B
     elif "--shared-frames" in sys.argv:  # the items of a group share their frames as the pipeline's do (6 frames for 8 items)
