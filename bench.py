@@ -349,7 +349,13 @@ def roofline_from_trace(recs, n_steps, traffic=None, serial=None, workload=None)
     # (Round 3's first passes ranked by the single-stream block's time; since the loop launches 8 samples per kernel and the
     # single-stream block 2, the two run different configurations of the layers and only the in-loop ranking describes the
     # timed region.  The single-stream figures stay on every entry as serial_*.)
-    ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+    # ... capped by the symbol's single-stream time where that is known: a side-stream kernel (the encoder on the low-priority
+    # prefetch stream, the coarse stages) spends most of its in-step "duration" waiting for CUs the main stream's kernels hold
+    # (round 5: head_fused16 read 526 us in the step, 83 us alone, and outranked every main-stream kernel)
+    def rank_ms(kv):
+        ms = kv[1]["ms"] / n_steps
+        return min(ms, serial[kv[0]][0]) if serial and kv[0] in serial else ms
+    ranked = sorted(agg.items(), key=lambda kv: -rank_ms(kv))
 
     def entry(name, a, with_geo):
         e = {"kernel": name, "launches_per_step": round(a["n"] / n_steps, 2), "avg_us": round(a["ms"] / a["n"] * 1e3, 2),
@@ -410,7 +416,7 @@ def roofline_from_trace(recs, n_steps, traffic=None, serial=None, workload=None)
             roof["avg_concurrency"] = round(total_ms / span, 2)
     roof["kernels_per_step"] = round(len(recs) / n_steps, 1)
     roof["instrumented_steps"] = n_steps
-    roof["ranked_by"] = "in-step kernel time per step"
+    roof["ranked_by"] = "kernel time per step: in-step, capped by the same symbol's single-stream time"
     if serial:
         roof["serial_step_kernels_ms"] = round(sum(v[0] for v in serial.values()), 3)
     return roof
@@ -804,6 +810,7 @@ def gpu_leg(args, rank, world):
     clip = DeviceClip(min(n_total + 2, 12), H, W, 1234 + rank, dev)
     frames = [clip[k] for k in range(len(clip))]
     dt, t_host, recs, traced, dst = step_loop(model, frames, n_total, args, world, trace=not args.no_roofline)
+    r["blocks"] = LAST_BLOCKS["n"]  # K-step blocks timed back to back (one region): every per-step figure divides by K * blocks
     r["dst_size"] = dst
     r["settle_steps"] = LAST_SETTLE["steps"]
     r["path"] = dict(LAST_PATH, group=int(getattr(model, "GROUP", 1)), what="RIFE.stats over the K timed calls of this rank")
@@ -820,7 +827,6 @@ def gpu_leg(args, rank, world):
                 log(f"serial {ms:7.4f} ms/step {n:5.1f} x {us:7.1f} us | in-step {inst.get(k, (0, 0, 0))[2]:7.1f} us | {k[:110]}")
     r["roofline"] = roofline_from_trace(recs, traced, _traffic_table(), serial, workload=args.config) if recs else None
     if world == 1:
-        r["blocks"] = LAST_BLOCKS["n"]  # K-step blocks timed back to back (one region): every per-step figure divides by K * blocks
         r.update({"dt": dt, "host_dt": t_host, "frames": len(TS) * args.steps * r["blocks"]})
         if r["roofline"] and (r["roofline"].get("bound") == "mfma" or "stage_conv" in r["roofline"].get("kernel", "")):
             torch.cuda.synchronize()

@@ -508,6 +508,320 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
 #endif
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// The SCALE-2 stage fused the same way (IFNet_HDv3.py:85-88 at scale 2 -> conv0[0]): the stage input lives at half resolution,
+// each of its pixels the mean of the 2 x 2 full-resolution sample points under it (bilinear, align_corners=False, factor 0.5),
+// every sample point warped by its own flow.  Unfused, `ifblock_input_lds` writes the 52-channel half-resolution tensor (108 MB
+// per 1080p sample, 435 MB per 4K sample) for the stride-2 convolution to read it back: at 4K scale 0.5 -- where this is the LAST
+// stage -- the pair is 29 % of a step.  Here a lane owns one window position = FOUR sample points: their flows (terms + the
+// previous head output's update, term by term as everywhere), taps and the channels that come from LDS (mask, feat, flow,
+// timestep) are formed once, up front, the taps kept compact (two row offsets, the right column's x weight, the lower row's y
+// weight per frame: 32 registers for the four points); per channel group the points' gathers are issued and consumed one
+// (point, frame) at a time -- 8 x 16 bytes in flight -- and averaged into the group's 16 values, which are then split and
+// parked exactly as at scale 1.  The flow is given as terms (the lazy form) and the frames as [H][W][4]; anything else takes
+// the unfused pair.  NT = Cout / 16 output tiles per wave (1080p: block 3, 32 channels; 4K scale 0.5: block 4, 16).
+template <class G_>
+__global__ void __launch_bounds__(G_::THREADS, 4)
+stage_conv16_s2(const StageItems items, const FlowTermsArg T, const u32x4 *__restrict__ wpk, const float *__restrict__ bias, int hp, int wp,
+                float inv_prev_scale, float prev_scale, int H, int W, int h, int w, int Ho, int Wo, int tiles_x, int n_items) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TOH = G_::TOH, NT = G_::NT, WR = G_::WR, THREADS = G_::THREADS, NPOS = G_::NPOS, NPOINTS = G_::NPOINTS;
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
+  u32x4 *win = lds16 + G_::U_WIN;
+  u32x4 *wl = lds16 + G_::U_W;
+  float *prev = reinterpret_cast<float *>(lds16 + G_::U_PREV);
+  float *tl = reinterpret_cast<float *>(lds16 + G_::U_TERM);
+  int vb_, vitem_, ntiles_;
+  tile_item_block(n_items, vb_, vitem_, ntiles_);
+  typedef __attribute__((address_space(1))) float *gptr;
+  typedef __attribute__((address_space(1))) const float *cgptr;
+  auto uniform = [](const float *p) -> gptr {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gptr)(((uint64_t)hi << 32) | lo);
+  };
+  struct {
+    cgptr img0_x4, img1_x4, f0_pair, f1_pair, timestep_map, tmp_prev;
+    gptr out;
+    float timestep_scalar;
+    const float *term[kMaxTerms];
+  } item;
+  {
+    const drba_stage_item_t &src = items.it[vitem_];
+    item.img0_x4 = uniform(src.img0_x4), item.img1_x4 = uniform(src.img1_x4), item.f0_pair = uniform(src.f0_pair), item.f1_pair = uniform(src.f1_pair);
+    item.timestep_map = uniform(src.timestep_map), item.tmp_prev = uniform(src.tmp_prev), item.out = uniform(src.out);
+    item.timestep_scalar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(src.timestep_scalar)));
+#pragma unroll
+    for (int i = 0; i < kMaxTerms; ++i) item.term[i] = (const float *)uniform(src.term[i]);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t P = (size_t)H * W, p_prev = (size_t)hp * wp;
+  int tx, ty;
+  xcd_strip_tile(vb_, ntiles_, tiles_x, tx, ty);
+  const int ox0 = tx * TOW, oy0 = ty * TOH;
+  const int xs0 = 2 * ox0 - 1, ys0 = 2 * oy0 - 1;  // stage (half-resolution) coordinates of window (row 0, column 0)
+
+  // ---- this lane's window position and its 2 x 2 sample points (2 xs + i, 2 ys + j)
+  const bool active = tid < NPOINTS;
+  const int pt = min(tid, NPOINTS - 1);
+  const int wr = pt / WC, wc = pt - wr * WC;
+  const int xr = xs0 + wc, yr = ys0 + wr;
+  const bool inimg = xr >= 0 && xr < w && yr >= 0 && yr < h;  // outside: the convolution's zero padding
+  const int xs = min(max(xr, 0), w - 1), ys = min(max(yr, 0), h - 1);
+
+  // ---- prologue loads: group 0's weight fragments, tmp_prev's and the terms' footprints under the window's sample points
+  const int Xa = 2 * max(xs0, 0), Ya = 2 * max(ys0, 0), Xb = min(2 * min(xs0 + WC - 1, w - 1) + 1, W - 1), Yb = min(2 * min(ys0 + WR - 1, h - 1) + 1, H - 1);
+  const int rx0 = lerp_src(Xa, inv_prev_scale, wp).i0, ry0 = lerp_src(Ya, inv_prev_scale, hp).i0;
+  const int rw = min(lerp_src(Xb, inv_prev_scale, wp).i1 - rx0 + 1, PC), rh = min(lerp_src(Yb, inv_prev_scale, hp).i1 - ry0 + 1, G_::PR);
+  const __amdgpu_buffer_rsrc_t r_w =
+      __builtin_amdgcn_make_buffer_rsrc((void *)wpk, 0, (uint32_t)(KS_TOTAL * 2 * NT * 64 * 16), 0x00020000);
+  auto wdma = [&](int g) {
+    const int n = ks_count(g) * 2 * NT;  // pieces
+#pragma unroll
+    for (int i = 0; i < G_::WD; ++i) {
+      const int k = min(i * (THREADS / 64) + wave, n - 1);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_ptr)(wl + k * 64), 16, (uint32_t)((ks_first(g) * 2 * NT + k) * 1024 + lane * 16), 0, 0, 0);
+    }
+  };
+  wdma(3);  // the groups run in the order 3, 0, 1, 2 here: the one that needs no gather first (its eight values die early)
+  const int pr_r = tid / PC, pr_c = tid - pr_r * PC;
+  const bool pr_on = pr_r < rh && pr_c < rw;
+  float pv[13];
+  {
+    const cgptr tp = item.tmp_prev + (size_t)(ry0 + min(pr_r, rh - 1)) * wp + rx0 + min(pr_c, rw - 1);
+#pragma unroll
+    for (int c = 0; c < 13; ++c) pv[c] = tp[(size_t)c * p_prev];
+  }
+  float bs[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) bs[n] = bias ? bias[16 * n + (lane & 15)] : 0.f;
+  // the timestep at the four sample points (two adjacent pixels per row)
+  float tmv[4];
+  if (item.timestep_map) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x2 t2 = *reinterpret_cast<const __attribute__((address_space(1))) f32x2 *>(item.timestep_map + (size_t)(2 * ys + j) * W + 2 * xs);
+      tmv[2 * j] = t2.x, tmv[2 * j + 1] = t2.y;
+    }
+  } else {
+    tmv[0] = tmv[1] = tmv[2] = tmv[3] = item.timestep_scalar;
+  }
+  if (pr_on) {
+    float *d = prev + (pr_r * PC + pr_c) * 16;
+    *reinterpret_cast<f32x4 *>(d) = (f32x4){pv[0], pv[1], pv[2], pv[3]};
+    d[4] = pv[4];
+    *reinterpret_cast<f32x4 *>(d + 8) = (f32x4){pv[5], pv[6], pv[7], pv[8]};
+    *reinterpret_cast<f32x4 *>(d + 12) = (f32x4){pv[9], pv[10], pv[11], pv[12]};
+  }
+  int trx0[kMaxTerms], try0[kMaxTerms];
+  terms_stage<G_::TR, G_::TC, THREADS>(tl, T, item.term, Xa, Ya, Xb, Yb, tid, trx0, try0);
+  __syncthreads();
+
+  // ---- the four sample points: flow, compact taps, and the channels that come from LDS (averaged: 0.25 each, the factor-0.5
+  // bilinear downsample of a 2 x 2 block)
+  uint32_t to0[4][2], to1[4][2];  // [point][frame]: element offsets of the two tap rows (pair of a row loaded at min(x0, W - 2))
+  float twx[4][2], twy[4][2];     // weight of the RIGHT loaded pixel (the right-border case folded in), weight of the LOWER row
+  float a_ts = 0.f, a_mask = 0.f, a_flow[4] = {0.f, 0.f, 0.f, 0.f}, a_feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sp = 0; sp < 4; ++sp) {
+    const int X = 2 * xs + (sp & 1), Y = 2 * ys + (sp >> 1);
+    const Lerp la = lerp_src(Y, inv_prev_scale, hp), lb = lerp_src(X, inv_prev_scale, wp);
+    const int pr0 = min(la.i0 - ry0, G_::PR - 1) * PC, pr1 = min(la.i1 - ry0, G_::PR - 1) * PC, pc0 = min(lb.i0 - rx0, PC - 1), pc1 = min(lb.i1 - rx0, PC - 1);
+    auto prev_up4 = [&](int k) -> f32x4 {
+      const f32x4 q00 = *reinterpret_cast<const f32x4 *>(prev + (pr0 + pc0) * 16 + 4 * k), q01 = *reinterpret_cast<const f32x4 *>(prev + (pr0 + pc1) * 16 + 4 * k);
+      const f32x4 q10 = *reinterpret_cast<const f32x4 *>(prev + (pr1 + pc0) * 16 + 4 * k), q11 = *reinterpret_cast<const f32x4 *>(prev + (pr1 + pc1) * 16 + 4 * k);
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = lerp2_fma(la.w0, la.w1, lb.w0, lb.w1, q00[j], q01[j], q10[j], q11[j]);
+      return v;
+    };
+    const f32x4 pu0 = prev_up4(0);
+    float fls[4];
+    const bool have_terms = terms_flow<G_::TR, G_::TC>(tl, T, trx0, try0, X, Y, fls);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float fd = __fmul_rn(pu0[c], prev_scale);
+      fls[c] = have_terms ? __fadd_rn(fls[c], fd) : fd;
+      a_flow[c] += 0.25f * fls[c];
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      // taps_border's arithmetic, keeping the fractions instead of the four products: clip to [0, size - 1], floor, x1 / y1 clamped
+      float x = warp_coord(X, W, fls[2 * f]), y = warp_coord(Y, H, fls[2 * f + 1]);
+      x = fminf(fmaxf(x, 0.f), (float)(W - 1)), y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+      const float fx = floorf(x), fy = floorf(y);
+      const float wx1 = x - fx, wy1 = y - fy;
+      const int x0 = min(max((int)fx, 0), W - 1), y0 = min(max((int)fy, 0), H - 1), y1 = min(y0 + 1, H - 1);
+      const int xb = min(x0, W - 2);  // the pair of a row is loaded at min(x0, W - 2); at the right border (wx1 == 0) its RIGHT pixel is x0
+      to0[sp][f] = (uint32_t)(y0 * W + xb), to1[sp][f] = (uint32_t)(y1 * W + xb);
+      twx[sp][f] = x0 != xb ? 1.f - wx1 : wx1;
+      twy[sp][f] = wy1;
+    }
+    const f32x4 p1 = prev_up4(1), p2 = prev_up4(2), p3 = prev_up4(3);
+    a_mask += 0.25f * p1[0];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_feat[c] += 0.25f * p2[c], a_feat[4 + c] += 0.25f * p3[c];
+    a_ts += 0.25f * tmv[sp];
+    // (one sample point at a time: the four are independent and hipcc would otherwise interleave them -- 4 x the live registers)
+    asm volatile("" : "+v"(a_ts), "+v"(a_mask), "+v"(a_flow[0]), "+v"(a_flow[1]), "+v"(a_flow[2]), "+v"(a_flow[3]), "+v"(a_feat[0]), "+v"(a_feat[1]),
+                 "+v"(a_feat[2]), "+v"(a_feat[3]), "+v"(a_feat[4]), "+v"(a_feat[5]), "+v"(a_feat[6]), "+v"(a_feat[7]), "+v"(to0[sp][0]), "+v"(to0[sp][1]),
+                 "+v"(to1[sp][0]), "+v"(to1[sp][1]), "+v"(twx[sp][0]), "+v"(twx[sp][1]), "+v"(twy[sp][0]), "+v"(twy[sp][1]) : : "memory");
+  }
+  const uint32_t img_bytes = (uint32_t)(4 * P * 4), feat_bytes = (uint32_t)(16 * P * 4);
+  const __amdgpu_buffer_rsrc_t r_i0 = __builtin_amdgcn_make_buffer_rsrc((void *)item.img0_x4, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_i1 = __builtin_amdgcn_make_buffer_rsrc((void *)item.img1_x4, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_f0 = __builtin_amdgcn_make_buffer_rsrc((void *)item.f0_pair, 0, feat_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_f1 = __builtin_amdgcn_make_buffer_rsrc((void *)item.f1_pair, 0, feat_bytes, 0x00020000);
+  const uint32_t plane = (uint32_t)(P * 4);
+
+  const int park = wr * RS + (wc & 1) * PS + (wc >> 1);
+  auto park8 = [&](int octet, const float (&v)[8]) {
+    u32x4 hh_, ll_;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t a, b;
+      split2(inimg ? v[2 * i] : 0.f, inimg ? v[2 * i + 1] : 0.f, a, b);
+      hh_[i] = a, ll_[i] = b;
+    }
+    if (active) {
+      win[octet * NPOS + park] = hh_;
+      win[(2 + octet) * NPOS + park] = ll_;
+    }
+  };
+  // (the tap weights of (point, frame) are formed at the gathers from the two fractions: wxl = 1 - wxr, wy0 = 1 - wy1, the four
+  // products as taps_border forms them, times the 1 / 4 of the downsample)
+
+  // ---- the matrix phase of one group (as at scale 1)
+  const int m = lane & 15, kq = lane >> 4;
+  auto tap_off = [](int t) -> int { return (t / 3) * RS + ((t % 3) & 1) * PS + ((t % 3) >> 1); };
+  const int a_row = 2 * wave * RS + m;
+  f32x4 hh[NT], lo[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) hh[n] = lo[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mma_group = [&](auto G) {
+    constexpr int g = decltype(G)::value;
+    if (wave < TOH) {
+#pragma unroll
+      for (int j = 0; j < ks_count(g); ++j) {
+        const int tap = min(g < 3 ? 2 * j + (kq >> 1) : 4 * j + kq, 8);
+        const u32x4 *a = win + (g < 3 ? (kq & 1) * NPOS : 0) + a_row + tap_off(tap);
+        const f16x8 a_h = __builtin_bit_cast(f16x8, a[0]), a_l = __builtin_bit_cast(f16x8, a[2 * NPOS]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const f16x8 b_h = __builtin_bit_cast(f16x8, wl[((j * 2 + 0) * NT + n) * 64 + lane]);
+          const f16x8 b_l = __builtin_bit_cast(f16x8, wl[((j * 2 + 1) * NT + n) * 64 + lane]);
+          lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, b_l, lo[n], 0, 0, 0);
+          hh[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, b_h, hh[n], 0, 0, 0);
+          lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, b_h, lo[n], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto group_barriers = [&](auto G, bool last) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the group's weight DMA has landed (every gather is consumed)
+    lds_barrier();
+    mma_group(G);
+    if (!last) lds_barrier();
+  };
+  // ---- group 3 first: feat 0..7 of the previous head output (no gathers)
+  park8(0, a_feat);
+  group_barriers(std::integral_constant<int, 3>{}, false);
+  wdma(0);
+
+  // ---- group 0: {img0 x3, timestep, img1 x3, mask | flow x4, 0 x4}.  The gathers go in HALF STEPS -- one tap row of one frame
+  // at one sample point: two pixels of 16 bytes -- double-buffered: half step k + 1 is issued before half step k is consumed
+  // (16 half steps: frame, point, row)
+  {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    u32x4 rb[2][2];
+    auto issue = [&](int hs, u32x4 (&r)[2]) {
+      const int f = hs >> 3, sp = (hs >> 1) & 3, row = hs & 1;
+      const __amdgpu_buffer_rsrc_t &rs = f == 0 ? r_i0 : r_i1;
+      const uint32_t o = (row ? to1[sp][f] : to0[sp][f]) * 16u;
+      r[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0), r[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 16, 0);
+    };
+    issue(0, rb[0]);
+#pragma unroll
+    for (int hs = 0; hs < 16; ++hs) {
+      if (hs + 1 < 16) issue(hs + 1, rb[(hs + 1) & 1]);
+      const int f = hs >> 3, sp = (hs >> 1) & 3, row = hs & 1;
+      const float wxr = twx[sp][f], wxl = 1.f - wxr, wy = row ? twy[sp][f] : 1.f - twy[sp][f];
+      const float wl_ = 0.25f * (wxl * wy), wr_ = 0.25f * (wxr * wy);
+      const u32x4 (&r)[2] = rb[hs & 1];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[4 * f + c] += __uint_as_float(r[0][c]) * wl_ + __uint_as_float(r[1][c]) * wr_;
+      // (the sums as operands: a half step's registers are free before the one after the next is issued)
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]) : : "memory");
+    }
+    v[3] = a_ts, v[7] = a_mask;
+    park8(0, v);
+    // interpolate(flow, 1 / scale) * 1. / scale (IFNet_HDv3.py:87): the mean of the four sample points' flows, over the scale
+    const float fl[8] = {(a_flow[0] * 1.f) / 2.f, (a_flow[1] * 1.f) / 2.f, (a_flow[2] * 1.f) / 2.f, (a_flow[3] * 1.f) / 2.f, 0.f, 0.f, 0.f, 0.f};
+    park8(1, fl);
+  }
+  group_barriers(std::integral_constant<int, 0>{}, false);
+  // ---- groups 1, 2: {f0 | f1}, 8 channels (4 pairs) of each; half step = the four pairs of one tap row of one frame at one point
+#pragma unroll
+  for (int g = 1; g <= 2; ++g) {
+    wdma(g);
+    u32x4 rb[2][4];
+    auto issue = [&](int hs, u32x4 (&r)[4]) {
+      const int f = hs >> 3, sp = (hs >> 1) & 3, row = hs & 1;
+      const __amdgpu_buffer_rsrc_t &rs = f == 0 ? r_f0 : r_f1;
+      const uint32_t o = (row ? to1[sp][f] : to0[sp][f]) * 8u;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) r[c] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, (4 * (g - 1) + c) * 2 * plane, 0);
+    };
+    issue(0, rb[0]);
+    float v[8];
+#pragma unroll
+    for (int hs = 0; hs < 16; ++hs) {
+      if (hs + 1 < 16) issue(hs + 1, rb[(hs + 1) & 1]);
+      const int f = hs >> 3, sp = (hs >> 1) & 3, row = hs & 1;
+      if ((hs & 7) == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = 0.f;
+      }
+      const float wxr = twx[sp][f], wxl = 1.f - wxr, wy = row ? twy[sp][f] : 1.f - twy[sp][f];
+      const float wl_ = 0.25f * (wxl * wy), wr_ = 0.25f * (wxr * wy);
+      const u32x4 (&r)[4] = rb[hs & 1];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v[2 * c] += __uint_as_float(r[c].x) * wl_ + __uint_as_float(r[c].z) * wr_;
+        v[2 * c + 1] += __uint_as_float(r[c].y) * wl_ + __uint_as_float(r[c].w) * wr_;
+      }
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+      if ((hs & 7) == 7) park8(f, v);
+    }
+    if (g == 1) group_barriers(std::integral_constant<int, 1>{}, false);
+    else group_barriers(std::integral_constant<int, 2>{}, true);
+  }
+
+  // ---- epilogue
+  if (wave < TOH) {
+    const int oy = oy0 + wave, ox = ox0 + 4 * kq;
+    if (oy < Ho && ox < Wo) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int co = 16 * n + m;
+        const gptr dst = item.out + ((size_t)co * Ho + oy) * Wo + ox;
+        f32x4 y = (hh[n] + lo[n] * (1.f / 2048.f)) * kUnscale;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = lrelu02(y[k] + bs[n]);
+        if ((Wo & 3) == 0) {
+          *(__attribute__((address_space(1))) f32x4 *)dst = y;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (ox + k < Wo) dst[k] = y[k];
+        }
+      }
+    }
+  }
+#endif
+}
+
 }  // namespace drba_stage_conv16
 
 extern "C" {
@@ -542,6 +856,7 @@ int drba_stage_conv16_pack(const float *w, int Cout, float *packed) {
 }
 
 int drba_stage_conv16_supported(int H, int W, float scale, float prev_scale, int Cout) {
+  if (scale == 2.f) return (H >= 4 && W >= 4 && prev_scale == 4.f && (Cout == 16 || Cout == 32)) ? 1 : 0;  // (lazy flow + [H][W][4] frames only)
   return (H >= 2 && W >= 2 && scale == 1.f && prev_scale == 2.f && Cout == 16) ? 1 : 0;
 }
 
@@ -576,8 +891,33 @@ int drba_stage_conv16_batch(const drba_stage_item_t *items, int n_items, const d
     its.it[k] = I;
   }
   const bool x4 = items[0].img0_x4 != nullptr;
-  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   hipStream_t s = (hipStream_t)stream;
+  if (scale == 2.f) {
+    // the scale-2 stage: sample points at full resolution, the stage input at half, the convolution's output at a quarter
+    if (!lazy || !x4) return DRBA_EUNSUPPORTED;
+    for (int i = 0; i < T.n; ++i)
+      if (T.scale[i] < 8.f) return DRBA_EUNSUPPORTED;
+    const int h = H / 2, w = W / 2, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    const int tiles_x = (Wo + TOW - 1) / TOW, tiles_y = (Ho + 7 - 1) / 7;
+#define DRBA_SC16_S2(NT_)                                                                                                       \
+    do {                                                                                                                          \
+      using G_ = Geo<7, NT_>;                                                                                                     \
+      if (max_dynamic_lds((const void *)stage_conv16_s2<G_>, 160 * 1024) != hipSuccess) return DRBA_ELAUNCH;                       \
+      DRBA_LAUNCH((stage_conv16_s2<G_>), dim3(tiles_x * tiles_y * n_items), dim3(G_::THREADS), (size_t)G_::LDS_UNITS * 16, s, its, T, \
+                  reinterpret_cast<const drba_stage_conv16::u32x4 *>(packed_w), bias, hp, wp, 0.25f, prev_scale, H, W, h, w, Ho, Wo, \
+                  tiles_x, n_items);                                                                                              \
+    } while (0)
+    if (Cout == 16) DRBA_SC16_S2(1);
+    else DRBA_SC16_S2(2);
+#undef DRBA_SC16_S2
+    DRBA_CHECK_LAUNCH();
+    for (int k = 0; k < n_items && g_range_check; ++k) {
+      const int rc = range_scan(items[k].out, (size_t)Cout * Ho * Wo, stream);
+      if (rc != DRBA_OK) return rc;
+    }
+    return DRBA_OK;
+  }
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
 #define DRBA_SC16_GO_(FO, NT_, TOH_, XX)                                                                                       \
   do {                                                                                                                     \
     using G_ = Geo<TOH_, NT_>;                                                                                             \

@@ -244,8 +244,9 @@ class IFNet:
                 tmp_new = self.block[i].core(xin)
             else:
                 final = i == 4  # the last stage: only flow and mask of its head output are read (IFBlock.lastconv5)
-                if s == 1 and _ops.stage_conv0_ok(self.block[i].conv0_0, H, W, s, s_prev):
-                    y0, _ = _ops.stage_conv0(items, None, tmp, s_prev, self.block[i].conv0_0, terms=terms)
+                if s in (1, 2) and _ops.stage_conv0_ok(self.block[i].conv0_0, H, W, s, s_prev, items=items):
+                    # scale 1, and scale 2 where the two-term kernel takes it (the flow as terms, frames with their [H,W,4] copies)
+                    y0, _ = _ops.stage_conv0(items, None, tmp, s_prev, self.block[i].conv0_0, terms=terms, scale=s)
                     tmp_new = (self.block[i].chain_tail5 if final else self.block[i].chain_tail)(y0)
                 else:
                     xin = torch.empty((B, 52, h, w), dtype=torch.float32, device=dev)

@@ -952,18 +952,26 @@ def _stage_conv_two_term(conv):
     return bool(STAGE_CONV_TWO_TERM if STAGE_CONV_TWO_TERM is not None else (4 in CONV_FAMILIES))
 
 
-def stage_conv0_ok(conv, H, W, scale, prev_scale):
-    """Can drba_stage_conv{0,16}_batch replace stage_inputs(scale) + conv (the IFBlock's first convolution)?"""
+STAGE_CONV_S2 = True  # the scale-2 stage fused the same way (stage_conv16_s2; A/B: tools/ab_bench.py --no-stage-conv-s2)
+
+
+def stage_conv0_ok(conv, H, W, scale, prev_scale, items=None):
+    """Can drba_stage_conv{0,16}_batch replace stage_inputs(scale) + conv (the IFBlock's first convolution)?  Scale 2 is taken by
+    the two-term kernel only, for the lazy flow, when every frame of `items` carries its [H,W,4] copy (ops.to_inp / ops.rgbx)."""
     if not (STAGE_CONV_FUSED and PAIR_FEATURES and conv.cin == 52 and conv.stride == 2 and conv.act == 1 and conv.beta is None
             and conv.pre_slope is None and conv.post_slope == 0.0):
         return False
     lib = _lib.load()
+    if float(scale) == 2.0:
+        if not (STAGE_CONV_S2 and _stage_conv_two_term(conv) and items is not None
+                and all(_x4_of(_f32(it[0])) is not None and _x4_of(_f32(it[1])) is not None for it in items)):
+            return False
     if _stage_conv_two_term(conv):
         return bool(lib.drba_stage_conv16_supported(H, W, float(scale), float(prev_scale), conv.cout))
     return bool(lib.drba_stage_conv0_supported(H, W, float(scale), float(prev_scale), conv.cout))  # 16 output channels only
 
 
-def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None):
+def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None, scale=1):
     """The scale-1 stage input of every item fused with `conv` (52 -> 16, stride 2, LeakyReLU): stage_inputs(..., scale=1)
     followed by conv(xin) without the 52-channel tensor (drba_stage_conv16_batch: two fp16 terms per operand, kernel family 4;
     drba_stage_conv0_batch: exact fp32 products, when family 4 is not allowed).  Returns (y0 [B,16,Ho,Wo], folded flows
@@ -977,7 +985,11 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
         raise _lib.DrbaHipError(f"stage_conv0: at most {_lib.MAX_STAGE_ITEMS} items per launch")
     img0 = _f32(items[0][0])
     _, _, H, W = img0.shape
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    sc = int(scale)
+    if sc not in (1, 2) or (sc == 2 and not (lazy and _stage_conv_two_term(conv))):
+        raise _lib.DrbaHipError("stage_conv0: scale 1, or scale 2 with the flow as terms in the two-term form")
+    hs, ws_ = H // sc, W // sc                              # the stage's resolution
+    Ho, Wo = (hs - 1) // 2 + 1, (ws_ - 1) // 2 + 1          # the convolution's output
     dev = img0.device
     two = _stage_conv_two_term(conv)
     attr = "_stage_pack16" if two else "_stage_pack"
@@ -1020,9 +1032,9 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
     nbytes = B * 4.0 * ((39.0 if lazy else 43.0) * H * W + conv.cout * Ho * Wo + (4.0 * H * W if fold else 0.0))
     bias = None if conv.bias is None else conv.bias.data_ptr()
     tptr = C.cast(C.pointer(ft), C.c_void_p) if lazy else None
-    name = ("stage_conv16" if two else "stage_conv0") + ("+fold" if fold else "+lazy" if lazy else "")
+    name = ("stage_conv16" if two else "stage_conv0") + ("_s2" if sc == 2 else "") + ("+fold" if fold else "+lazy" if lazy else "")
     if two:
-        call = lambda: _lib.load().drba_stage_conv16_batch(C.cast(arr, C.c_void_p), B, tptr, hp, wp, float(prev_scale), H, W, 1.0,  # noqa: E731
+        call = lambda: _lib.load().drba_stage_conv16_batch(C.cast(arr, C.c_void_p), B, tptr, hp, wp, float(prev_scale), H, W, float(sc),  # noqa: E731
                                                            conv.cout, packed.data_ptr(), bias, _stream())
     else:
         call = lambda: _lib.load().drba_stage_conv0_batch(C.cast(arr, C.c_void_p), B, tptr, hp, wp, float(prev_scale), H, W,  # noqa: E731

@@ -295,6 +295,18 @@ def test_family4_range_check_reports_overflow_instead_of_inf(hip_backend):
     assert not bool(torch.isfinite(y).all())
 
 
+def test_fused_stage_kernels_against_fp64(hip_backend):
+    """stage_conv16 (scale 1) and stage_conv16_s2 (scale 2): the stage input fused with conv0[0] in the two-term fp16 form, against
+    an fp64 convolution of the unfused stage input (ops.stage_inputs) at 5e-6 max|y| -- ragged sizes, tiles cut by the border, the
+    fold / the finished flow / the flow as terms, 16 and 32 output channels, smooth and rough flows, 1088x1920 -- and the folded
+    flows bit-identical to ifblock_input_lds' (tools/stage_conv16_check.py holds the cases; it exits non-zero on any failure)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stage_conv16_check.py"), "--no-time"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count("all ok") == 2, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_drm_maps_of_a_group_in_one_launch_equal_the_single_calls(hip_backend):
     """drba_drm_rife_linear_batch (the DRM maps of a group of steps: one launch pair) against drba_drm_rife_linear per map:
     the same kernels on the same inputs, for smooth, long (beyond the tile halo) and non-finite flows, a ragged size, more jobs

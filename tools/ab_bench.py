@@ -9,6 +9,7 @@ to be bench.py flags.  Everything not listed here is passed on to bench.py uncha
   --conv-families L    kernel families the conv autotuner may pick from (0 fp32 MFMA, 1 split-bf16, 2 LDS-DMA 32 ch, 3 K-split)
   --no-stage-conv      the scale-1 stage input and conv0[0] as two kernels (ops.STAGE_CONV_FUSED = False)
   --stage-conv-fp32    the fused stage kernel in its exact-fp32 form (stage_conv.hip; ops.STAGE_CONV_TWO_TERM = False)
+  --no-stage-conv-s2   the scale-2 stage as two kernels (gather + conv0[0]; ops.STAGE_CONV_S2 = False)
   --no-head-fused      IFNet's encoder layer by layer (ops.HEAD_FUSED = False)
   --no-lazy-flow       IFNet's running flow as a full-resolution tensor updated after every stage (ops.LAZY_FLOW = False)
   --no-lookahead       no side / prefetch streams (the single-stream loop)
@@ -30,6 +31,7 @@ def main():
     p.add_argument("--conv-families", default=None)
     p.add_argument("--no-stage-conv", action="store_true")
     p.add_argument("--stage-conv-fp32", action="store_true")
+    p.add_argument("--no-stage-conv-s2", action="store_true")
     p.add_argument("--no-head-fused", action="store_true")
     p.add_argument("--no-lazy-flow", action="store_true")
     p.add_argument("--no-lookahead", action="store_true")
@@ -50,6 +52,8 @@ def main():
         ops.STAGE_CONV_FUSED = False
     if a.stage_conv_fp32:
         ops.STAGE_CONV_TWO_TERM = False
+    if a.no_stage_conv_s2:
+        ops.STAGE_CONV_S2 = False
     if a.no_head_fused:
         ops.HEAD_FUSED = False
     if a.no_lazy_flow:

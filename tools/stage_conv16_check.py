@@ -91,9 +91,73 @@ for cout in (() if "--time-only" in sys.argv else (16,)):
             ok = err <= 5e-6 * max(1.0, mag) and bool(torch.isfinite(y).all())
             bad += not ok
             print(f"cout {cout} lazy B{B} {H}x{W} {tag}: {err:.2e} vs fp64 (|y| <= {mag:.2f}) {'ok' if ok else 'FAIL'}", flush=True)
+# ---- scale 2 (stage_conv16_s2): the stage input at half resolution (the mean of 2 x 2 warped sample points) fused with conv0[0];
+# reference = the unfused gather (ops.stage_inputs at scale 2, flow as terms) + an fp64 convolution; 16 and 32 output channels
+def heads2(B, H, W, amp=1.0):
+    def head(st, a):
+        t = torch.randn(B, 13, max(H // st, 1), max(W // st, 1), generator=g)
+        lo = torch.randn(B, 4, max(H // st // 8, 2), max(W // st // 8, 2), generator=g) * a
+        t[:, :4] = torch.nn.functional.interpolate(lo, size=t.shape[2:], mode="bicubic", align_corners=False)
+        return t.to(dev)
+    return [(head(16, amp), 16.0), (head(8, 0.4), 8.0)], head(4, 0.3)
+
+
+for cout in (() if "--time-only" in sys.argv else (16, 32)):
+    wt = torch.randn(cout, 52, 3, 3, generator=g) / (52 * 9) ** 0.5
+    bs = torch.randn(cout, generator=g) * 0.1
+    conv = ops.Conv3x3(wt, bs, 2, True, None, device=dev)
+    for (B, H, W) in ((2, 128, 256), (3, 96, 160), (1, 72, 104), (1, 64, 64), (2, 1088, 1920)):
+        items, _, _ = make(B, H, W, True, False)
+        for it in items:
+            ops.rgbx(it[0]), ops.rgbx(it[1])
+        for amp, tag in ((1.0, "smooth flows"), (20.0, "rough flows")):
+            terms, tprev = heads2(B, H, W, amp)
+            xin = torch.empty(B, 52, H // 2, W // 2, device=dev)
+            ops.stage_inputs(items, None, tprev, 4.0, 2.0, xin, terms=terms)
+            ref = conv64(xin, wt, bs)
+            assert ops.stage_conv0_ok(conv, H, W, 2.0, 4.0, items=items)
+            y, _ = run(conv, True, items, None, tprev, 4.0, conv, terms=terms, scale=2)
+            torch.cuda.synchronize()
+            mag = float(ref.abs().max())
+            err = float((y.double() - ref).abs().max())
+            ok = err <= 5e-6 * max(1.0, mag) and bool(torch.isfinite(y).all()) and tuple(y.shape) == tuple(ref.shape)
+            bad += not ok
+            print(f"scale 2 cout {cout} B{B} {H}x{W} {tag}: {err:.2e} vs fp64 (|y| <= {mag:.2f}) {'ok' if ok else 'FAIL'}", flush=True)
 print("FAILED" if bad else "all ok", flush=True)
 
-if "--no-time" not in sys.argv:
+if "--no-time" not in sys.argv and "--scale1-only" not in sys.argv:
+    for (H, W, cout, tag) in ((1088, 1920, 32, "1080p block 3"), (2176, 3840, 16, "4K scale 0.5 block 4")):
+        B = 8
+        items, _, _ = make(B, H, W, True, False)
+        fr = [(items[j][0], items[j][3]) for j in range(B // 2 + 2)]   # six frames for eight items, as the pipeline's groups
+        items = [it for j in range(B // 2) for it in ((fr[j + 1][0], fr[j][0], items[2 * j][2], fr[j + 1][1], fr[j][1]),
+                                                      (fr[j + 1][0], fr[j + 2][0], items[2 * j + 1][2], fr[j + 1][1], fr[j + 2][1]))]
+        for im, _ in fr:
+            ops.rgbx(im)
+        wt = torch.randn(cout, 52, 3, 3, generator=g) / (52 * 9) ** 0.5
+        conv = ops.Conv3x3(wt, torch.zeros(cout), 2, True, None, device=dev)
+        terms, tprev = heads2(B, H, W, 1.0)
+        xin = torch.empty(B, 52, H // 2, W // 2, device=dev)
+
+        def unfused():
+            ops.stage_inputs(items, None, tprev, 4.0, 2.0, xin, terms=terms)
+            return conv(xin)
+
+        def fused():
+            return run(conv, True, items, None, tprev, 4.0, conv, terms=terms, scale=2)
+
+        for name, fn in (("gather + conv0[0]", unfused), ("fused (stage_conv16_s2)", fused)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ops.trace_begin()
+            for _ in range(reps):
+                fn()
+            recs = ops.trace_end()
+            us = sum(r["ms"] for r in recs) / reps * 1e3
+            print(f"scale 2, {tag} ({H}x{W}, cout {cout}, B{B}, shared frames): {name}: {us:8.1f} us per call ({', '.join(sorted({r['name'].split('<')[0].split('::')[-1] for r in recs}))})", flush=True)
+
+if "--no-time" not in sys.argv and "--scale2-only" not in sys.argv:
     H, W, B = 1088, 1920, 8
     items, _, _ = make(B, H, W, True, False)
     if "--planar-frames" not in sys.argv:  # the pipeline's frames carry their [H,W,4] copies (ops.to_inp): the launch the loop makes
