@@ -32,7 +32,8 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form).  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
+/* ABI version.  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form, scale 1 and 2), drba_stage_item_t grew by
+ * img0_x4 / img1_x4 ([H][W][4] frames), drba_to_inp_x4, drba_rgbx, drba_drm_rife_linear_batch, drba_set_range_check (debug).  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
  * drba_deconv4x4s2, so no earlier id changes meaning), drba_deconv4x4_cfg_family, and a `terms` argument (3 or 2) on the
  * drba_linear_split_* entry points and on drba_window_attention; drba_head_fused16_*.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
  * NULL (nothing but f_pair_out is written), and every stage-input entry point accepts items with f0 == f1 == NULL when
@@ -301,8 +302,11 @@ int drba_stage_conv0_batch(const drba_stage_item_t *items, int n_items, const dr
 /* ABI 6: the same fusion in the two-term fp16 form (kernel family 4 of drba_conv3x3_cfg_family; stage_conv16.hip): the gathered
  * values are split into two fp16 terms on their way into LDS and the convolution runs on the 16-bit matrix pipe (3 products per
  * multiply, fp32 accumulation), the channels in 4 groups of 16 instead of 13 of 4.  Same items / terms / hp / wp / prev_scale
- * semantics, same flows (bit for bit), convolution output to the tolerance of the family; Cout = 16 or 32 (w [Cout,52,3,3]);
- * `scale` is the stage's scale (1 is the one supported); packed_w 16-byte aligned.  drba_stage_conv16_pack is a HOST function. */
+ * semantics, same flows (bit for bit), convolution output to the tolerance of the family; w [Cout,52,3,3].
+ * `scale` = 1: Cout = 16, prev_scale = 2, any of the three flow forms.  `scale` = 2 (stage_conv16_s2): the stage input at half
+ * resolution (each pixel the mean of its 2 x 2 warped sample points), out [Cout, ((H/2)-1)/2+1, ((W/2)-1)/2+1], Cout = 16 or 32,
+ * prev_scale = 4, the flow as `terms` (scales >= 8) and items with img0_x4 / img1_x4 only -- DRBA_EUNSUPPORTED otherwise (the
+ * caller takes drba_ifblock_input_lazy_batch + drba_conv3x3).  packed_w 16-byte aligned.  drba_stage_conv16_pack is a HOST function. */
 size_t drba_stage_conv16_packed_floats(int Cout);
 int drba_stage_conv16_pack(const float *w, int Cout, float *packed);
 int drba_stage_conv16_supported(int H, int W, float scale, float prev_scale, int Cout);
