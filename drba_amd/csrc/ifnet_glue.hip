@@ -530,28 +530,11 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   const int Xb = SINGLE ? ox_b : lerp_src(ox_b, scale, W).i1, Yb = SINGLE ? oy_b : lerp_src(oy_b, scale, H).i1;
   const int rx0 = lerp_src(Xa, inv_prev_scale, wp).i0, ry0 = lerp_src(Ya, inv_prev_scale, hp).i0;
   const int rw = lerp_src(Xb, inv_prev_scale, wp).i1 - rx0 + 1, rh = lerp_src(Yb, inv_prev_scale, hp).i1 - ry0 + 1;
-  {
-    // the footprint's loads are all issued before the first LDS write (at most 6 x 20 pixels x 13 channels = 7 per lane): the
-    // "load, write, next" loop was up to 6 dependent memory round trips at the head of every workgroup (round 5)
-    constexpr int NL = (13 * kPrevRH * kPrevRW + 255) / 256;
-    float v[NL];
-    const int npx = rh * rw, ntot = (13 - C0) * npx;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const int i = min((int)threadIdx.x + k * 256, ntot - 1);
-      const int c = i / npx, r = (i - c * npx) / rw, col = i - c * npx - r * rw;
-      v[k] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
-    }
-    if (LAZY) terms_stage<kTermR, kTermC, 256>(tl, T, item_.term, Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const int i = (int)threadIdx.x + k * 256;
-      if (i < ntot) {
-        const int c = i / npx, r = (i - c * npx) / rw, col = i - c * npx - r * rw;
-        prev[r][col][C0 + c] = v[k];
-      }
-    }
+  for (int i = threadIdx.x; i < (13 - C0) * rh * rw; i += 256) {
+    const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
+    prev[r][col][C0 + c] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
   }
+  if (LAZY) terms_stage<kTermR, kTermC, 256>(tl, T, item_.term, Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -805,28 +788,11 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   const int Xa = tx * kTileW, Ya = ty * kTileH, Xb = min(Xa + kTileW - 1, W - 1), Yb = min(Ya + kTileH - 1, H - 1);
   const int rx0 = lerp_src(Xa, inv_scale, w).i0, ry0 = lerp_src(Ya, inv_scale, h).i0;
   const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
-  {
-    // the footprint's loads are all issued before the first LDS write (at most 10 x 36 pixels x 5 channels = 8 per lane): the
-    // "load, write, next" loop was up to 7 dependent memory round trips at the head of every workgroup (round 5)
-    constexpr int NL = (5 * 10 * 36 + 255) / 256;
-    float v[NL];
-    const int npx = rh * rw, ntot = 5 * npx;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const int i = min((int)threadIdx.x + k * 256, ntot - 1);
-      const int c = i / npx, r = (i - c * npx) / rw, col = i - c * npx - r * rw;
-      v[k] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
-    }
-    if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[vitem_], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const int i = (int)threadIdx.x + k * 256;
-      if (i < ntot) {
-        const int c = i / npx, r = (i - c * npx) / rw, col = i - c * npx - r * rw;
-        prev[r][col][c] = v[k];
-      }
-    }
+  for (int i = threadIdx.x; i < 5 * rh * rw; i += 256) {
+    const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
+    prev[r][col][c] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
   }
+  if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[vitem_], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
   const int x = Xa + (threadIdx.x & (kTileW - 1)), y = Ya + (threadIdx.x >> 5);
   if (x >= W || y >= H) return;

@@ -172,25 +172,26 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   const int Xa = max(X0, 0), Ya = max(Y0, 0), Xb = min(X0 + WC - 1, W - 1), Yb = min(Y0 + WR - 1, H - 1);
   const int rx0 = lerp_src(Xa, inv_prev_scale, wp).i0, ry0 = lerp_src(Ya, inv_prev_scale, hp).i0;
   const int rw = lerp_src(Xb, inv_prev_scale, wp).i1 - rx0 + 1, rh = lerp_src(Yb, inv_prev_scale, hp).i1 - ry0 + 1;
-  // a group's weight fragments go global -> LDS by LDS-DMA (no registers): every wave issues WD 1-KB pieces (the surplus ones
-  // repeat the last piece: the same bytes to the same place), so that "the DMA is older than my last N loads" is the same N on
-  // every wave
+  // a group's weight fragments go global -> LDS by LDS-DMA (no registers), 1-KB pieces dealt round robin to the waves.  A wave's
+  // pieces are OLDER than the 16 gathers it issues next, so `s_waitcnt vmcnt(16)` -- at most the 16 youngest loads outstanding --
+  // covers them however many pieces the wave had
   const __amdgpu_buffer_rsrc_t r_w =
       __builtin_amdgcn_make_buffer_rsrc((void *)wpk, 0, (uint32_t)(KS_TOTAL * 2 * NT * 64 * 16), 0x00020000);
   auto wdma = [&](int g) {
     const int n = ks_count(g) * 2 * NT;  // pieces
 #pragma unroll
     for (int i = 0; i < G_::WD; ++i) {
-      const int k = min(i * (THREADS / 64) + wave, n - 1);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_ptr)(wl + k * 64), 16, (uint32_t)((ks_first(g) * 2 * NT + k) * 1024 + lane * 16), 0, 0, 0);
+      const int k = i * (THREADS / 64) + wave;
+      if (k < n)  // (wave-uniform: a wave without a piece issues nothing)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_ptr)(wl + k * 64), 16, (uint32_t)((ks_first(g) * 2 * NT + k) * 1024 + lane * 16), 0, 0, 0);
     }
   };
   wdma(0);
   const int pr_r = tid / PC, pr_c = tid - pr_r * PC;  // one (row, column) of the footprint per lane
   const bool pr_on = pr_r < rh && pr_c < rw;
   float pv[13];
-  {
-    const cgptr tp = item.tmp_prev + (size_t)(ry0 + min(pr_r, rh - 1)) * wp + rx0 + min(pr_c, rw - 1);
+  if (pr_on) {  // (only the lanes that own a footprint pixel: a wave without one issues no load -- the L1 charges a gather per instruction)
+    const cgptr tp = item.tmp_prev + (size_t)(ry0 + pr_r) * wp + rx0 + pr_c;
 #pragma unroll
     for (int c = C0; c < 13; ++c) pv[c] = tp[(size_t)c * p_prev];
   }
@@ -580,16 +581,17 @@ stage_conv16_s2(const StageItems items, const FlowTermsArg T, const u32x4 *__res
     const int n = ks_count(g) * 2 * NT;  // pieces
 #pragma unroll
     for (int i = 0; i < G_::WD; ++i) {
-      const int k = min(i * (THREADS / 64) + wave, n - 1);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_ptr)(wl + k * 64), 16, (uint32_t)((ks_first(g) * 2 * NT + k) * 1024 + lane * 16), 0, 0, 0);
+      const int k = i * (THREADS / 64) + wave;
+      if (k < n)  // (wave-uniform: a wave without a piece issues nothing)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_ptr)(wl + k * 64), 16, (uint32_t)((ks_first(g) * 2 * NT + k) * 1024 + lane * 16), 0, 0, 0);
     }
   };
   wdma(3);  // the groups run in the order 3, 0, 1, 2 here: the one that needs no gather first (its eight values die early)
   const int pr_r = tid / PC, pr_c = tid - pr_r * PC;
   const bool pr_on = pr_r < rh && pr_c < rw;
   float pv[13];
-  {
-    const cgptr tp = item.tmp_prev + (size_t)(ry0 + min(pr_r, rh - 1)) * wp + rx0 + min(pr_c, rw - 1);
+  if (pr_on) {
+    const cgptr tp = item.tmp_prev + (size_t)(ry0 + pr_r) * wp + rx0 + pr_c;
 #pragma unroll
     for (int c = 0; c < 13; ++c) pv[c] = tp[(size_t)c * p_prev];
   }

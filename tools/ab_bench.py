@@ -10,6 +10,7 @@ to be bench.py flags.  Everything not listed here is passed on to bench.py uncha
   --no-stage-conv      the scale-1 stage input and conv0[0] as two kernels (ops.STAGE_CONV_FUSED = False)
   --stage-conv-fp32    the fused stage kernel in its exact-fp32 form (stage_conv.hip; ops.STAGE_CONV_TWO_TERM = False)
   --no-stage-conv-s2   the scale-2 stage as two kernels (gather + conv0[0]; ops.STAGE_CONV_S2 = False)
+  --no-img-x4          the gathers read the planar frames, to_inp writes no [H,W,4] copy (ops.IMG_X4 = False; the scale-2 fusion needs the copies)
   --no-head-fused      IFNet's encoder layer by layer (ops.HEAD_FUSED = False)
   --no-lazy-flow       IFNet's running flow as a full-resolution tensor updated after every stage (ops.LAZY_FLOW = False)
   --no-lookahead       no side / prefetch streams (the single-stream loop)
@@ -32,6 +33,7 @@ def main():
     p.add_argument("--no-stage-conv", action="store_true")
     p.add_argument("--stage-conv-fp32", action="store_true")
     p.add_argument("--no-stage-conv-s2", action="store_true")
+    p.add_argument("--no-img-x4", action="store_true")
     p.add_argument("--no-head-fused", action="store_true")
     p.add_argument("--no-lazy-flow", action="store_true")
     p.add_argument("--no-lookahead", action="store_true")
@@ -54,6 +56,8 @@ def main():
         ops.STAGE_CONV_TWO_TERM = False
     if a.no_stage_conv_s2:
         ops.STAGE_CONV_S2 = False
+    if a.no_img_x4:
+        ops.IMG_X4 = False
     if a.no_head_fused:
         ops.HEAD_FUSED = False
     if a.no_lazy_flow:

@@ -22,7 +22,11 @@ ap.add_argument("--config", default="1080p")
 ap.add_argument("--brief", action="store_true")
 ap.add_argument("--one-stream", action="store_true", help="side / prefetch work on the main stream: every duration is the kernel's own")
 ap.add_argument("--table", action="store_true", help="per (symbol, launch label) totals instead of the timeline")
+ap.add_argument("--no-img-x4", action="store_true", help="A/B: the gathers read the planar frames (ops.IMG_X4 = False)")
 a = ap.parse_args()
+if a.no_img_x4:
+    from drba_amd import ops as _ops
+    _ops.IMG_X4 = False
 if a.one_stream:
     from drba_amd.models import lookahead as _la
     _la.ONE_STREAM = True
