@@ -345,8 +345,8 @@ conv_mfma(const float *__restrict__ in, const float *__restrict__ wfrag, const f
         for (int k = 0; k < 4; ++k) {
           v[k] += bs;
           v1[k] += bs;
-          o0[k] = __shfl_xor(v[k], 1, 64);
-          o1[k] = __shfl_xor(v1[k], 1, 64);
+          o0[k] = quad_xor1(v[k]);
+          o1[k] = quad_xor1(v1[k]);
         }
         if (co >= Cout || y >= H || xb >= W) return;
         float *dst = out + ((size_t)c13 * (2 * Hd) + (2 * oy + si)) * (size_t)(2 * Wd) + 4 * xb;

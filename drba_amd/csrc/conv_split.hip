@@ -467,7 +467,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
                 f32x4 a, b;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                  const float got = __shfl_xor(hi ? v0[k] : v1[k], 8, 64);
+                  const float got = dpp_f32<0x128>(hi ? v0[k] : v1[k]);  // row_ror:8 = lane ^ 8 inside a row of 16: a VALU move, not an LDS-crossbar trip
                   a[k] = __shfl(hi ? got : v0[k], src, 64);
                   b[k] = __shfl(hi ? v1[k] : got, src, 64);
                 }
@@ -612,8 +612,8 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
               for (int k = 0; k < 4; ++k) {
                 v[k] += b0;
                 v1[k] += b0;
-                o0[k] = __shfl_xor(v[k], 1, 64);
-                o1[k] = __shfl_xor(v1[k], 1, 64);
+                o0[k] = quad_xor1(v[k]);
+                o1[k] = quad_xor1(v1[k]);
               }
               if (co >= Cout || y >= H || xb >= W) continue;
               float *dst = out + (size_t)ctx.n * (Cout / 4) * (2 * Hd) * (size_t)(2 * Wd) +
