@@ -218,7 +218,8 @@ class RIFE:
         return (flow_ba, flow_ab, fb, fa)
 
     ENC_ON_MAIN = False  # A/B runs: the frames' encoders in the caller's stream (right behind to_inp) instead of the prefetch stream
-    SIDE_STAGES = 3  # IFNet stages of the NEXT step run by the lookahead on the side stream (class attribute: A/B runs set it)
+    SIDE_STAGES = 2  # IFNet stages of the NEXT step / group run on the side stream (class attribute: A/B runs set it).  Round 5, same box, the
+    #                  stage at scale 2 being one fused kernel now: 2 -> 1075-1080 frames/s at 1080p, 3 -> 1053, 1 -> 1056-1060, 0 -> 1050-1053; 4K 535-537 against 531
 
     def _items(self, I0, I1, I2, ts, linear, flow10, flow12, f0, f1, f2, defer=None):
         """DRM maps and the (img0, img1, timestep, f0, f1) work items of one step; output holds pass-through frames

@@ -26,7 +26,24 @@ int main(int argc, char **argv) {
   hipMemcpy(p, hp.data(), pf * 4, hipMemcpyHostToDevice);
   hipMemcpy(b, hb.data(), C * 4, hipMemcpyHostToDevice);
   hipMemcpy(beta, hbeta.data(), C * 4, hipMemcpyHostToDevice);
-  auto run = [&]() { return drba::conv_split_launch(cfg, x, p, b, beta, x, nullptr, y, N, C, H, W, C, 1, 0.f, 0, 0.f, nullptr); };
+  // argv[6] = output channels of a TRANSPOSED convolution 4x4 s2 + PixelShuffle (deconv_split ids: cfg counts from the first two-term id)
+  const int dcout = argc > 6 ? atoi(argv[6]) : 0;
+  float *dp = nullptr, *dy = nullptr;
+  int dcfg = 0;
+  if (dcout) {
+    dcfg = drba::deconv_split_f16_first() + cfg;
+    const size_t dpf = drba::deconv_split_packed_floats(C, dcout, dcfg);
+    if (!dpf) return 3;
+    std::vector<float> dw((size_t)C * dcout * 16), dpk(dpf);
+    for (auto &v : dw) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+    if (drba::deconv_split_pack(dw.data(), dpk.data(), C, dcout, dcfg) != DRBA_OK) return 4;
+    hipMalloc(&dp, dpf * 4), hipMalloc(&dy, (size_t)N * dcout * 4 * H * W * 4);
+    hipMemcpy(dp, dpk.data(), dpf * 4, hipMemcpyHostToDevice);
+  }
+  auto run = [&]() {
+    if (dcout) return drba::deconv_split_launch(dcfg, x, dp, b, dy, N, C, H, W, dcout, 1, 0, 0.f, nullptr);
+    return drba::conv_split_launch(cfg, x, p, b, beta, x, nullptr, y, N, C, H, W, C, 1, 0.f, 0, 0.f, nullptr);
+  };
   for (int i = 0; i < 3; ++i)
     if (run() != DRBA_OK) return 2;
   hipDeviceSynchronize();
