@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 int main(int argc, char **argv) {
@@ -66,5 +67,24 @@ int main(int argc, char **argv) {
   printf("cfg %d N%d C%d %dx%d: %.1f us/launch (with counters), %.0f tiles/launch\n", cfg, N, C, H, W, ms / reps * 1e3, tiles / reps);
   printf("  per tile per wave: stage(+wait) %.0f clk, mfma phase %.0f clk, epilogue %.0f clk\n", ph[0] / (double)ph[3],
          ph[1] / (double)ph[3], ph[2] / (double)ph[3]);
+  // per workgroup (its four waves averaged): how the phases are distributed over the co-resident workgroups of a CU
+  if (getenv("DRBA_PHASE_DIST")) {
+    std::vector<double> m;
+    for (int b = 0; b < 1024; ++b) {
+      long long t = 0, mf = 0;
+      for (int w = 0; w < 4; ++w) t += buf[(b * 4 + w) * 4 + 3], mf += buf[(b * 4 + w) * 4 + 1];
+      if (t) m.push_back((double)mf / t);
+    }
+    std::vector<double> srt = m;
+    std::sort(srt.begin(), srt.end());
+    const size_t n_ = srt.size();
+    if (n_) printf("  mfma phase per tile over %zu workgroups: min %.0f  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f\n", n_, srt[0], srt[n_ / 10],
+                   srt[n_ / 2], srt[n_ * 9 / 10], srt[n_ - 1]);
+    printf("  first 16 workgroups and workgroups 256..271:");
+    for (size_t b = 0; b < 16 && b < n_; ++b) printf(" %.0f", m[b]);
+    printf(" |");
+    for (size_t b = 256; b < 272 && b < n_; ++b) printf(" %.0f", m[b]);
+    printf("\n");
+  }
   return 0;
 }
