@@ -695,17 +695,24 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   const int nbx = (W + Cfg::TW - 1) / Cfg::TW, nby = (H + Cfg::TH - 1) / Cfg::TH;
   const long long total = (long long)nbx * nby * N * n_ct * (Cfg::MODE != 1 ? 1 : 2);  // x2: row phases
   if (total >= (1ll << 31)) return DRBA_EUNSUPPORTED;
-  // persistent grid: what the 256 CUs can hold (LDS-limited workgroups per CU, at most 3 by registers), a multiple of 8
-  int per_cu = 160 * 1024 / Cfg::LDS_BYTES;
-  per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
-  long long grid = 256ll * per_cu;
-  if (grid > total) grid = (total + 7) / 8 * 8;
-  dim3 g((unsigned)grid);
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(wpk);
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
-    DRBA_LAUNCH(kernel, g, dim3(256), Cfg::LDS_BYTES, s, in, wf, bias, beta, res, res2, out, Cin, H, W, Cout, act,
-                      post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle, Hi, Wi);
+    // persistent grid: the workgroups the 256 CUs hold AT ONCE (registers and LDS of this instantiation, asked once), a
+    // multiple of 8.  A grid above the residency runs its surplus workgroups as a second round on half-empty CUs: the
+    // 227-register 4 x 32 x 64 tile was launched 3 per CU by its LDS size alone while 2 fit (64 ch 136x240 N8: 95 -> 86 us,
+    // tools/exp/split_per_cu.sh).
+    static int resident = 0;
+    if (!resident) {
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, Cfg::LDS_BYTES) != hipSuccess || occ < 1) occ = 1;
+      resident = occ > 3 ? 3 : occ;
+    }
+    const int per_cu = env_int("DRBA_SPLIT_PER_CU", resident);
+    long long grid = 256ll * per_cu;
+    if (grid > total) grid = (total + 7) / 8 * 8;
+    DRBA_LAUNCH(kernel, dim3((unsigned)grid), dim3(256), Cfg::LDS_BYTES, s, in, wf, bias, beta, res, res2, out, Cin, H, W, Cout,
+                act, post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle, Hi, Wi);
     return DRBA_OK;
   };
   int rc;

@@ -48,6 +48,19 @@ for name, n, c, h, w in layers:
         layer = ops.Conv3x3(wt, b, 1, True, beta, device=dev, cfg=cfg)
         res.append((timeit(lambda: layer(x, residual=x, out=out)), cfg))
     print(f"{name:18s} " + "  ".join(f"cfg{cfg} {us:6.1f}" for us, cfg in res), flush=True)
+# stride 2 (IFBlock conv0), two-term tiles only
+for name, n, cin, cout, h, w in [("conv0 52->48 s2 N8", 8, 52, 48, 272, 480), ("conv0 48->96 s2 N8", 8, 48, 96, 136, 240),
+                                 ("conv0 32->64 s2 N8", 8, 32, 64, 272, 480), ("conv0 52->64 s2 N8", 8, 52, 64, 136, 240)]:
+    x = torch.randn(n, cin, h, w, generator=g).to(dev)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    res = []
+    for cfg in range(lib.drba_conv3x3_num_cfgs()):
+        if lib.drba_conv3x3_cfg_stride(cfg) != 2 or lib.drba_conv3x3_cfg_family(cfg) != 4 or lib.drba_conv3x3_packed_floats(cin, cout, cfg) == 0:
+            continue
+        layer = ops.Conv3x3(wt, b, 2, True, None, device=dev, cfg=cfg)
+        res.append((timeit(lambda: layer(x)), cfg))
+    print(f"{name:22s} " + "  ".join(f"cfg{cfg} {us:6.1f}" for us, cfg in res), flush=True)
 # the transposed form (IFBlock lastconv): 32 -> 20 at 272x480 and 64 -> 52 at 136x240, N8
 for name, n, cin, cout, h, w in [("lastconv b4 32->20 N8", 8, 32, 20, 272, 480), ("lastconv b3 64->52 N8", 8, 64, 52, 136, 240),
                                  ("lastconv b2 96->52 N8", 8, 96, 52, 68, 120)]:
