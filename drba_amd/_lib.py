@@ -42,6 +42,7 @@ class ConvLayer(C.Structure):
 
 SIGNATURES = {
     "drba_abi_version": (_i, []),
+    "drba_rife_splat_ws_floats": (_z, [_i, _i, _i, _i]),
     "drba_set_range_check": (_i, [_i]),
     "drba_trace_begin": (_i, []),
     "drba_trace_end": (_i, []),

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) distance_kernel(const float *__restrict__
 // [v0*w, (v1*w,) w] at (x+fx, y+fy).  NV = number of value channels (1 or 2).
 template <int NV>
 __device__ __forceinline__ void scatter_avg(float *__restrict__ acc, int x, int y, float fx_, float fy_,
-                                            const float (&v)[NV], int H, int W) {
+                                            const float (&v)[NV], int H, int W, int *__restrict__ dirty = nullptr,
+                                            int tiles_x = 0) {
   const float X = (float)x + fx_, Y = (float)y + fy_;
   if (!(isfinite(X) && isfinite(Y))) return;
   const float fx = floorf(X), fy = floorf(Y);
@@ -83,6 +84,8 @@ __device__ __forceinline__ void scatter_avg(float *__restrict__ acc, int x, int 
 #pragma unroll
     for (int c = 0; c < NV; ++c) atomic_add_f32(d + c, v[c] * wgt[k]);
     atomic_add_f32(d + NV, wgt[k]);
+    // the 32 x 16 output tile this corner lies in has something to collect from the accumulator (kSX, kSY below)
+    if (dirty) atomicOr(dirty + ((y0 + (k >> 1)) >> 4) * tiles_x + ((x0 + (k & 1)) >> 5), 1);
   }
 }
 
@@ -97,7 +100,10 @@ __device__ __forceinline__ void scatter_avg(float *__restrict__ acc, int x, int 
 // no global atomics for "short" flows (all four corners within R of the source).  The rare
 // "long" pixels are scattered by a pre-pass with global atomics into `gacc` (zeroed), which the
 // finish step adds in.  Each (source, corner) pair is accumulated exactly once either way.
-constexpr int kR = 16;  // tile halo: sources with longer flows take the global-atomic pre-pass
+#ifndef DRBA_SPLAT_R
+#define DRBA_SPLAT_R 16
+#endif
+constexpr int kR = DRBA_SPLAT_R;  // tile halo: sources with longer flows take the global-atomic pre-pass
 
 template <int MODE>
 struct SplatSrc {
@@ -168,6 +174,8 @@ __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restric
     fs += (size_t)n * 2 * P;
     if (fo) fo += (size_t)n * 2 * P;
   }
+  const int tiles_x = (W + 31) >> 5, tiles = tiles_x * ((H + 15) >> 4);
+  int *dirty = reinterpret_cast<int *>(gacc + (size_t)gridDim.y * P * (NV + 1)) + (size_t)n * tiles;
   gacc += (size_t)n * P * (NV + 1);
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
     const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
@@ -175,10 +183,10 @@ __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restric
     if (!s.finite || s.is_short) continue;
     if (MODE == 0) {
       const float v[2] = {s.v[0], s.v[1]};
-      scatter_avg<2>(gacc, x, y, s.fx, s.fy, v, H, W);
+      scatter_avg<2>(gacc, x, y, s.fx, s.fy, v, H, W, dirty, tiles_x);
     } else {
       const float v[1] = {s.v[0]};
-      scatter_avg<1>(gacc, x, y, s.fx, s.fy, v, H, W);
+      scatter_avg<1>(gacc, x, y, s.fx, s.fy, v, H, W, dirty, tiles_x);
     }
   }
 }
@@ -205,8 +213,14 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
   __shared__ int cnt[kNKEY + 1];   // per key: count, then (after the scan) segment start; [kNKEY] = total
   __shared__ int wsum[4];
   __shared__ float4 rec[kCAP];     // (v0, v1, X - tx0, Y - ty0) of a source, grouped by key
+  __shared__ int spilled;          // this tile put records beyond kCAP into the global accumulator
   const int n = blockIdx.z;
   const size_t P = (size_t)H * W;
+  static_assert(kSX == 32 && kSY == 16, "scatter_avg marks 32 x 16 tiles");
+  // dirty[tile] != 0: the long-flow pre-pass scattered into this tile.  Only then (or after a spill of its own) does the
+  // tile read its accumulator entries -- 8-12 bytes per output pixel that are zero in all but a few tiles of a frame.
+  int *dirty = reinterpret_cast<int *>(gacc + (size_t)gridDim.z * P * (NV + 1)) + ((size_t)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int was_dirty = __builtin_nontemporal_load(dirty);
   if (jobs.n) {
     fs = jobs.fs[n], fo = jobs.fo[n], t = jobs.t[n], out = jobs.out[n];
   } else {
@@ -218,6 +232,7 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
   const int tx0 = blockIdx.x * kSX, ty0 = blockIdx.y * kSY;
   const int tid = threadIdx.x;
   for (int i = tid; i <= kNKEY; i += 256) cnt[i] = 0;
+  if (tid == 0) spilled = 0;
   __syncthreads();
 
   // pass 1: all of this thread's window sources are loaded first (independent loads, issued back to back), then
@@ -299,6 +314,7 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
       const float X = val[i].z + (float)tx0, Y = val[i].w + (float)ty0;
       const float fl_x = floorf(X), fl_y = floorf(Y);
       const int x0 = (int)fl_x, y0 = (int)fl_y;
+      spilled = 1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
@@ -316,6 +332,11 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __syncthreads();
 
+#ifndef DRBA_SPLAT_ALWAYS_COLLECT  // A/B builds: every tile reads its accumulator entries, as before ABI 7
+#define DRBA_SPLAT_ALWAYS_COLLECT 0
+#endif
+  const bool collect = DRBA_SPLAT_ALWAYS_COLLECT || was_dirty != 0 || spilled != 0;  // uniform over the workgroup
+  if (was_dirty && tid == 0) *dirty = 0;                // self-cleaning, like the accumulator itself
   // gather: output pixel (lx, ly) takes, for dy in {0,1}, the segments of keys (lx, ly-dy+1) [dx = 1] and (lx+1, ly-dy+1) [dx = 0]
   const float fill = (float)max(H, W);
   for (int i = tid; i < kSX * kSY; i += 256) {
@@ -341,12 +362,15 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
       }
     }
     const size_t p = (size_t)y * W + x;
-    float *g = gacc + p * (NV + 1);
-    const float g0 = g[0], g1 = NV == 2 ? g[1] : 0.f, gw = g[NV];
-    if (g0 != 0.f || g1 != 0.f || gw != 0.f) {  // self-cleaning accumulator: zero on entry, zero again on return
-      g[0] = 0.f;                               // (no memset launch per call; nothing is written in the usual case)
-      if (NV == 2) g[1] = 0.f;
-      g[NV] = 0.f;
+    float g0 = 0.f, g1 = 0.f, gw = 0.f;
+    if (collect) {
+      float *g = gacc + p * (NV + 1);
+      g0 = g[0], g1 = NV == 2 ? g[1] : 0.f, gw = g[NV];
+      if (g0 != 0.f || g1 != 0.f || gw != 0.f) {  // self-cleaning accumulator: zero on entry, zero again on return
+        g[0] = 0.f;                               // (no memset launch per call; nothing is written in the usual case)
+        if (NV == 2) g[1] = 0.f;
+        g[NV] = 0.f;
+      }
     }
     sw += gw;
     const float nrm = sw + 0.0000001f;
@@ -358,8 +382,9 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
       out[P + p] = (gap ? fill : -1.f * (a1 / nrm)) * 2.f;
     } else {
       a0 += g0;
-      const SplatSrc<MODE> sp = splat_source<MODE>(fs, fo, P, p, x, y, t, eps);  // the unaligned value for holes
-      out[p] = gap ? sp.v[0] : a0 / nrm;
+      float o = a0 / nrm;
+      if (gap) o = splat_source<MODE>(fs, fo, P, p, x, y, t, eps).v[0];  // the unaligned value for holes (rare: not loaded otherwise)
+      out[p] = o;
     }
   }
 }
@@ -748,6 +773,12 @@ int drba_flow_distance(const float *flow, float *out, int N, int H, int W, void 
   DRBA_LAUNCH(distance_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, flow, out, H, W);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
+}
+
+size_t drba_rife_splat_ws_floats(int N, int H, int W, int values) {
+  if (N <= 0 || H <= 0 || W <= 0 || values < 1 || values > 2) return 0;
+  // accumulators [N][H*W][values + 1], then one flag per (item, 32 x 16 output tile)
+  return (size_t)N * H * W * (values + 1) + (size_t)N * ((W + kSX - 1) / kSX) * ((H + kSY - 1) / kSY);
 }
 
 int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, int W, void *stream) {

@@ -207,7 +207,7 @@ def flow_reverse(flow):
     flow = _f32(flow, "flow")
     n, _, h, w = flow.shape
     out = torch.empty_like(flow)
-    ws = _zero_workspace(flow.device, n * h * w * 3)
+    ws = _zero_workspace(flow.device, _lib.load().drba_rife_splat_ws_floats(n, h, w, 2))
     first = _trace_pos()
     _lib.check(_lib.load().drba_flow_reverse(_p(flow), _p(out), _p(ws), n, h, w, _stream()), "drba_flow_reverse")
     _tag(first, [None, (16.0 * n * h * w, "byte", f"flow_reverse {(n, h, w)}")])  # long-flow prepass, then the tiled splat
@@ -219,7 +219,7 @@ def drm_rife_linear(flow_self, flow_other, t, eps=1e-4, t_dev=None):
     a, b = _f32(flow_self, "flow_self"), _f32(flow_other, "flow_other")
     n, _, h, w = a.shape
     out = torch.empty((n, 1, h, w), dtype=torch.float32, device=a.device)
-    ws = _zero_workspace(a.device, n * h * w * 2)
+    ws = _zero_workspace(a.device, _lib.load().drba_rife_splat_ws_floats(n, h, w, 1))
     first = _trace_pos()
     _lib.check(_lib.load().drba_drm_rife_linear(_p(a), _p(b), float(t), _p(t_dev), float(eps), _p(out), _p(ws), n, h,
                                                 w, _stream()), "drba_drm_rife_linear")
@@ -245,7 +245,7 @@ def drm_rife_linear_many(jobs, eps=1e-4):
             if tuple(a.shape) != (1, 2, h, w) or tuple(b.shape) != (1, 2, h, w):
                 raise _lib.DrbaHipError("drm_rife_linear_many: every flow must be [1,2,H,W] of one size")
             arr[k].flow_self, arr[k].flow_other, arr[k].t, arr[k].out = a.data_ptr(), b.data_ptr(), t, out[k].data_ptr()
-        ws = _zero_workspace(dev, n * h * w * 2)
+        ws = _zero_workspace(dev, _lib.load().drba_rife_splat_ws_floats(n, h, w, 1))
         first = _trace_pos()
         _lib.check(_lib.load().drba_drm_rife_linear_batch(C.cast(arr, C.c_void_p), n, float(eps), _p(ws), h, w, _stream()),
                    "drba_drm_rife_linear_batch")

@@ -32,7 +32,8 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form, scale 1 and 2), drba_stage_item_t grew by
+/* ABI version.  7: drba_rife_splat_ws_floats -- the workspace of drba_flow_reverse / drba_drm_rife_linear(_batch) grew by one flag per
+ * 32 x 16 output tile (same zero-on-entry, zero-on-return contract).  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form, scale 1 and 2), drba_stage_item_t grew by
  * img0_x4 / img1_x4 ([H][W][4] frames), drba_to_inp_x4, drba_rgbx, drba_drm_rife_linear_batch, drba_set_range_check (debug).  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
  * drba_deconv4x4s2, so no earlier id changes meaning), drba_deconv4x4_cfg_family, and a `terms` argument (3 or 2) on the
  * drba_linear_split_* entry points and on drba_window_attention; drba_head_fused16_*.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
@@ -43,7 +44,7 @@ extern "C" {
  * workspace that must be ZERO on entry (they leave it zero on return: self-cleaning accumulator) instead of clearing it
  * themselves; batched stage entry points added; drba_conv3x3_cfg_family added and configuration ids 19 (LDS-DMA, 32
  * channels) / 20 (K split across waves) behind drba_conv3x3; the allocation exception above.  1: the first release. */
-#define DRBA_ABI_VERSION 6  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
+#define DRBA_ABI_VERSION 7  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 /* ABI 6, debug: with the range check on, every entry point that ran a kernel of family 4 (two fp16 terms per operand:
@@ -95,22 +96,24 @@ int drba_backwarp(const float *in, const float *flow, float *out, int N, int C, 
 int drba_flow_distance(const float *flow, float *out, int N, int H, int W, void *stream);
 
 /* ---- fused flow reversal: models/rife.py:59-73 (calc_flow tail)
- * out = 2 * where(splat_avg(1, f) < 0.999, max(H,W), -splat_avg(f, f)).  ws: N*H*W*3 floats that are ZERO on entry
- * (the accumulator of the rare long / converging sources); the kernel reads every entry once and writes the non-zero
- * ones back to zero, so the buffer is zero again on return: allocate it zeroed once and keep it for these two entry
- * points (no memset per call). */
+ * out = 2 * where(splat_avg(1, f) < 0.999, max(H,W), -splat_avg(f, f)).  ws: drba_rife_splat_ws_floats(N, H, W, 2) floats
+ * that are ZERO on entry: the accumulator of the rare long / converging sources (N*H*W*3 floats) and, ABI 7, one flag per
+ * 32 x 16 output tile behind it (set where the long-flow pre-pass scattered into the tile: only those tiles read their
+ * accumulator entries).  The kernels write every entry they found non-zero back to zero, so the buffer is zero again on
+ * return: allocate it zeroed once and keep it for these entry points (no memset per call). */
+size_t drba_rife_splat_ws_floats(int N, int H, int W, int values); /* values: 2 = flow reversal, 1 = linear DRM */
 int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, int W, void *stream);
 
 /* ---- fused linear DRM, one direction: models/drm.py:65-107 with linear=True
  * u = d_other/(d_self+d_other) * t * 2 with d = |flow| + eps; out = splat_avg(u, self*u) with
  * uncovered pixels (ones-splat < 0.999) keeping u.  drm_t1_t01 = (self=flow10, other=flow12),
- * drm_t1_t12 = (self=flow12, other=flow10).  ws: N*H*W*2 floats, zero on entry and on return (as above).  If t_dev != NULL the timestep
+ * drm_t1_t12 = (self=flow12, other=flow10).  ws: drba_rife_splat_ws_floats(N, H, W, 1) floats, zero on entry and on return (as above).  If t_dev != NULL the timestep
  * is read from that device float instead of `t` (so a captured HIP graph can be replayed for any t). */
 int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float t, const float *t_dev,
                          float eps, float *out, float *ws, int N, int H, int W, void *stream);
 /* ABI 6: n_jobs (<= DRBA_MAX_STAGE_ITEMS) maps of one geometry in one launch pair: job k = drba_drm_rife_linear(flow_self,
  * flow_other, t, NULL, eps, out, ., 1, H, W) on tensors of its own (the maps of a group of DRBA steps: 2 launches instead of
- * 2 per map).  ws: n_jobs*H*W*2 floats, zero on entry and on return. */
+ * 2 per map).  ws: drba_rife_splat_ws_floats(n_jobs, H, W, 1) floats, zero on entry and on return. */
 typedef struct drba_drm_job {
   const float *flow_self, *flow_other; /* [2,H,W] each */
   float t;
