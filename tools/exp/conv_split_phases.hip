@@ -50,6 +50,9 @@ int main(int argc, char **argv) {
   hipDeviceSynchronize();
   static long long buf[1024 * 4 * 4];
   hipMemcpyToSymbol(HIP_SYMBOL(drba_conv_split::g_phase), buf, sizeof(buf));
+#ifdef DRBA_HAVE_LOADER_CLOCKS  // (tools/exp/conv_split_loader: the loader-wave variants keep a second table)
+  hipMemcpyToSymbol(HIP_SYMBOL(drba_conv_split::g_loader), buf, sizeof(long long) * 1024 * 4);
+#endif
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
   const int reps = 10;
@@ -67,6 +70,17 @@ int main(int argc, char **argv) {
   printf("cfg %d N%d C%d %dx%d: %.1f us/launch (with counters), %.0f tiles/launch\n", cfg, N, C, H, W, ms / reps * 1e3, tiles / reps);
   printf("  per tile per wave: stage(+wait) %.0f clk, mfma phase %.0f clk, epilogue %.0f clk\n", ph[0] / (double)ph[3],
          ph[1] / (double)ph[3], ph[2] / (double)ph[3]);
+#ifdef DRBA_HAVE_LOADER_CLOCKS
+  {
+    static long long lb[1024 * 4];
+    hipMemcpyFromSymbol(lb, HIP_SYMBOL(drba_conv_split::g_loader), sizeof(lb));
+    long long l[3] = {0, 0, 0};
+    for (int i = 0; i < 1024; ++i)
+      for (int k = 0; k < 3; ++k) l[k] += lb[i * 4 + k];
+    if (l[0] + l[1] + l[2])
+      printf("  loader wave per tile: fetch issue %.0f clk, wait + split + stage %.0f clk, barrier wait %.0f clk\n", l[0] / tiles, l[1] / tiles, l[2] / tiles);
+  }
+#endif
   // per workgroup (its four waves averaged): how the phases are distributed over the co-resident workgroups of a CU
   if (getenv("DRBA_PHASE_DIST")) {
     std::vector<double> m;
