@@ -24,6 +24,7 @@
 #include "conv_split.hpp"
 
 #include <string.h>
+#include <type_traits>
 
 using namespace drba;
 
@@ -453,12 +454,18 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
               rb[nt & 1][rw][j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ob, 0, 0);
             }
         };
-        if (!RL && res) load_res(0);
-        auto epilogue = [&](auto post) {
+        if (!RL && (res || res2)) load_res(0);
+        // KIND: which operands the layer has -- 0 none, 1 one residual, 2 two residuals (GridNet's lateral sums), 3 the ResConv
+        // form y * beta + x.  Like the activation it is selected ONCE around the tile's loops: tested per piece (three uniform
+        // branches on `beta`, `res`, `res2`, their masks spilled to VGPR lanes and read back) the epilogue of the 4 x 32 x 64
+        // tile took 7.9k clocks instead of 5.3k (tools/exp/conv_split_phases.hip).
+        auto epilogue = [&](auto kind_, auto post) {
+          constexpr int KIND = decltype(kind_)::value;
+          constexpr bool kBeta = KIND == 3, kRes = !RL && KIND >= 1, kRes2 = !RL && KIND == 2;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const float bsA = bs[nt], bsB = bs2[nt], btA = bt[nt], btB = bt2[nt];
-            if (!RL && res && nt + 1 < NT) load_res(nt + 1);
+            if (kRes && nt + 1 < NT) load_res(nt + 1);
 #pragma unroll
             for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
@@ -474,11 +481,11 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
                 unsigned oa, ob;
                 offs(nt, rw, j, oa, ob);
                 f32x4 xa = (f32x4){0.f, 0.f, 0.f, 0.f}, xb_ = xa, xa2 = xa, xb2 = xa;
-                if (!RL && res) {
+                if (kRes) {
                   xa = __builtin_bit_cast(f32x4, ra[nt & 1][rw][j]);
                   xb_ = __builtin_bit_cast(f32x4, rb[nt & 1][rw][j]);
                 }
-                if (!RL && res2) {
+                if (kRes2) {
                   xa2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2rsrc, oa, 0, 0));
                   xb2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2rsrc, ob, 0, 0));
                 }
@@ -502,12 +509,12 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                   float ua = a[k] + bsA, ub = b[k] + bsB;
-                  if (beta) {
+                  if (kBeta) {
                     ua = ua * btA + xa[k];
                     ub = ub * btB + xb_[k];
                   } else {
-                    if (RL || res) ua = ua + xa[k], ub = ub + xb_[k];
-                    if (!RL && res2) ua = ua + xa2[k], ub = ub + xb2[k];
+                    if (RL || kRes) ua = ua + xa[k], ub = ub + xb_[k];
+                    if (kRes2) ua = ua + xa2[k], ub = ub + xb2[k];
                   }
                   a[k] = post(ua);
                   b[k] = post(ub);
@@ -520,13 +527,17 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
               }
           }
         };
-        switch (act) {
-          case 1: epilogue([](float v) { return lrelu02(v); }); break;
-          case 2: epilogue([post_slope](float v) { return v > 0.f ? v : post_slope * v; }); break;
-          case 3: epilogue([](float v) { return fmaxf(v, 0.f); }); break;
-          case 4: epilogue([](float v) { return tanhf(v) * 10.f; }); break;
-          default: epilogue([](float v) { return v; }); break;
-        }
+        // activations 0-3 are one form, v > 0 ? v : slope * v with slope 1 / 0.2 / post_slope / 0 (exact: v * 1 == v; ReLU
+        // keeps a NaN as torch.relu does); tanh is its own instantiation
+        const float slope = act == 1 ? 0.2f : act == 2 ? post_slope : act == 3 ? 0.f : 1.f;
+        auto with_act = [&](auto kind_) {
+          if (act == 4) epilogue(kind_, [](float v) { return tanhf(v) * 10.f; });
+          else epilogue(kind_, [slope](float v) { return v > 0.f ? v : slope * v; });
+        };
+        if (beta) with_act(std::integral_constant<int, 3>{});
+        else if (!RL && res2) with_act(std::integral_constant<int, 2>{});  // (a missing first residual reads as zero: rrsrc has no records)
+        else if (RL || res) with_act(std::integral_constant<int, 1>{});
+        else with_act(std::integral_constant<int, 0>{});
       } else {
         // W not a multiple of 4: element-wise stores from the accumulator layout (lane = cout m, pixels 4*kq..+3)
         auto epilogue = [&](auto post) {

@@ -43,6 +43,7 @@ int main(int argc, char **argv) {
   }
   auto run = [&]() {
     if (dcout) return drba::deconv_split_launch(dcfg, x, dp, b, dy, N, C, H, W, dcout, 1, 0, 0.f, nullptr);
+    if (getenv("DRBA_PHASE_NORES")) return drba::conv_split_launch(cfg, x, p, b, nullptr, nullptr, nullptr, y, N, C, H, W, C, 1, 0.f, 0, 0.f, nullptr);
     return drba::conv_split_launch(cfg, x, p, b, beta, x, nullptr, y, N, C, H, W, C, 1, 0.f, 0, 0.f, nullptr);
   };
   for (int i = 0; i < 3; ++i)
