@@ -586,58 +586,73 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       // xb..xb+3 for px = 0 (v) and px = 1 (v1), i.e. the 8 consecutive output columns 2*xb .. 2*xb+7 of row 2y+py
       // (conv.hip MODE 1; bias only)
       const int Hd = 2 * H, Wd = 2 * W;
-      float *oimg = out + (size_t)ctx.n * Cout * Hd * Wd;
+      // Stores through a buffer descriptor over this image's output (32-bit byte offsets; the launcher refuses outputs of
+      // 4 GB per image): a lane outside the map or past Cout gets an offset beyond num_records and its store is dropped, so the
+      // loop is straight-line code -- with `continue`s around plain stores every merge point carried an s_waitcnt vmcnt(0)
+      // and the 64-bit address arithmetic of every piece (the epilogue was 4.3k of the 32 -> 20 tile's 12.2k clocks).  The
+      // PixelShuffle form is selected once around the loops.
+      const unsigned obytes = (unsigned)((size_t)Cout * Hd * Wd * 4);
+      const __amdgpu_buffer_rsrc_t orsrc =
+          __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)ctx.n * Cout * Hd * Wd), 0, obytes, 0x00020000);
+      const bool whole = (W & 3) == 0;  // every lane's 4 input columns are inside the map or none is
+      auto epilogue_t = [&](auto ps_) {
+        constexpr bool PS = decltype(ps_)::value;
 #pragma unroll
-      for (int rw = 0; rw < RW; ++rw)
+        for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-        for (int mw = 0; mw < MW; ++mw)
+          for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            f32x4 v = acc[0][rw][mw][nt], v1 = acc[NPX - 1][rw][mw][nt];
-            const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
-            const int y = ctx.y0 + row0 + rw;
-            const int xb = ctx.x0 + mw * 16 + kq * 4;
-            const int oy = 2 * y + ctx.py;
-            const float b0 = bs[nt];
-            if (!pixel_shuffle) {
-              if (co >= Cout || y >= H || xb >= W) continue;
-              float *dst = oimg + ((size_t)co * Hd + oy) * Wd + 2 * xb;
-              if (xb + 3 < W && (Wd & 3) == 0) {
-                *reinterpret_cast<f32x4 *>(dst) = (f32x4){v[0] + b0, v1[0] + b0, v[1] + b0, v1[1] + b0};
-                *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){v[2] + b0, v1[2] + b0, v[3] + b0, v1[3] + b0};
-              } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                  if (xb + k < W) {
-                    dst[2 * k] = v[k] + b0;
-                    dst[2 * k + 1] = v1[k] + b0;
-                  }
-              }
-            } else {
-              // + PixelShuffle(2): cout = 4*c13 + 2*si + sj lands at row 2*oy+si, column 4i + 2px + sj of plane c13.
-              // Lanes m and m^1 (sj = 0 / 1, same c13 and si) exchange their values, after which each holds the 4
-              // consecutive columns 4i..4i+3 for every i; the even lane stores i = xb, xb+1, the odd lane xb+2, xb+3.
-              const int c13 = co >> 2, si = (co >> 1) & 1, sj = co & 1;
-              f32x4 o0, o1;
+            for (int nt = 0; nt < NT; ++nt) {
+              f32x4 v = acc[0][rw][mw][nt], v1 = acc[NPX - 1][rw][mw][nt];
+              const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
+              const int y = ctx.y0 + row0 + rw;
+              const int xb = ctx.x0 + mw * 16 + kq * 4;
+              const int oy = 2 * y + ctx.py;
+              const float b0 = bs[nt];
+              const bool inside = co < Cout && y < H && xb < W;
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
                 v[k] += b0;
                 v1[k] += b0;
-                o0[k] = quad_xor1(v[k]);
-                o1[k] = quad_xor1(v1[k]);
               }
-              if (co >= Cout || y >= H || xb >= W) continue;
-              float *dst = out + (size_t)ctx.n * (Cout / 4) * (2 * Hd) * (size_t)(2 * Wd) +
-                    ((size_t)c13 * (2 * Hd) + (2 * oy + si)) * (size_t)(2 * Wd) + 4 * xb;
+              if constexpr (!PS) {
+                const unsigned base = (unsigned)(((co * Hd + oy) * Wd + 2 * xb) * 4);
+                if (whole) {
+                  const unsigned o = inside ? base : 0xffffffffu;
+                  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v1[0], v[1], v1[1]}), orsrc, o, 0, 0);
+                  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[2], v1[2], v[3], v1[3]}), orsrc, o, 16, 0);
+                } else {
 #pragma unroll
-              for (int kk = 0; kk < 2; ++kk) {
-                const int k = sj * 2 + kk;  // even lane: input columns xb, xb+1; odd lane: xb+2, xb+3
-                if (xb + k >= W) continue;
-                const f32x4 qv = sj ? (f32x4){o0[k], v[k], o1[k], v1[k]} : (f32x4){v[k], o0[k], v1[k], o1[k]};
-                *reinterpret_cast<f32x4 *>(dst + 4 * k) = qv;
+                  for (int k = 0; k < 4; ++k) {
+                    const unsigned o = (inside && xb + k < W) ? base + 8u * k : 0xffffffffu;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[k]), orsrc, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1[k]), orsrc, o, 4, 0);
+                  }
+                }
+              } else {
+                // + PixelShuffle(2): cout = 4*c13 + 2*si + sj lands at row 2*oy+si, column 4i + 2px + sj of plane c13.
+                // Lanes m and m^1 (sj = 0 / 1, same c13 and si) exchange their values, after which each holds the 4
+                // consecutive columns 4i..4i+3 for every i; the even lane stores i = xb, xb+1, the odd lane xb+2, xb+3.
+                const int c13 = co >> 2, si = (co >> 1) & 1, sj = co & 1;
+                f32x4 o0, o1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  o0[k] = quad_xor1(v[k]);
+                  o1[k] = quad_xor1(v1[k]);
+                }
+                const unsigned base = (unsigned)(((c13 * (2 * Hd) + (2 * oy + si)) * (2 * Wd) + 4 * xb) * 4);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                  const int k = sj * 2 + kk;  // even lane: input columns xb, xb+1; odd lane: xb+2, xb+3
+                  const f32x4 qv = sj ? (f32x4){o0[k], v[k], o1[k], v1[k]} : (f32x4){v[k], o0[k], v1[k], o1[k]};
+                  const unsigned o = (inside && xb + k < W) ? base + 16u * k : 0xffffffffu;
+                  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qv), orsrc, o, 0, 0);
+                }
               }
             }
-          }
+      };
+      if (pixel_shuffle) epilogue_t(std::true_type{});
+      else epilogue_t(std::false_type{});
     }
     DRBA_CLK(c_e1);
     DRBA_CLK_ADD(2, c_e0, c_e1);
@@ -882,6 +897,7 @@ int deconv_split_launch(int id, const float *in, const float *packed_w, const fl
   using namespace drba_conv_split;
   if (!deconv_split_supports(Cin, Cout, id)) return DRBA_EUNSUPPORTED;
   if ((size_t)Cin * H * W * 4 >= (1ull << 31)) return DRBA_EUNSUPPORTED;  // 32-bit byte offsets inside an image
+  if ((size_t)Cout * 4 * H * W * 4 >= (1ull << 32) - 64) return DRBA_EUNSUPPORTED;  // ... and inside an output image (buffer stores)
   hipStream_t s = (hipStream_t)stream;
 #define DRBA_CASE(ID, T) \
   case ID:               \
