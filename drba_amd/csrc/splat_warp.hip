@@ -103,7 +103,7 @@ __device__ __forceinline__ void scatter_avg(float *__restrict__ acc, int x, int 
 #ifndef DRBA_SPLAT_R
 #define DRBA_SPLAT_R 16
 #endif
-constexpr int kR = DRBA_SPLAT_R;  // tile halo: sources with longer flows take the global-atomic pre-pass
+constexpr int kRMax = DRBA_SPLAT_R;  // largest tile halo: sources with longer flows take the global-atomic pre-pass
 
 template <int MODE>
 struct SplatSrc {
@@ -132,8 +132,8 @@ __device__ __forceinline__ SplatSrc<MODE> splat_source_from(float su, float sv, 
   }
   const float X = (float)x + s.fx, Y = (float)y + s.fy;
   s.finite = isfinite(X) && isfinite(Y);
-  // all four corners within kR of the source <=> floor(f) >= -kR and floor(f)+1 <= kR
-  s.is_short = s.fx >= -(float)kR && s.fx < (float)(kR - 1) && s.fy >= -(float)kR && s.fy < (float)(kR - 1);
+  // all four corners within kRMax of the source <=> floor(f) >= -kRMax and floor(f)+1 <= kRMax
+  s.is_short = s.fx >= -(float)kRMax && s.fx < (float)(kRMax - 1) && s.fy >= -(float)kRMax && s.fy < (float)(kRMax - 1);
   return s;
 }
 
@@ -159,14 +159,23 @@ struct SplatJobs {
   float *out[DRBA_MAX_STAGE_ITEMS];
 };
 
-// pre-pass: long (but finite) pixels -> global atomics into gacc [P][NV+1]
+// Workspace of the two fused splats (drba_rife_splat_ws_floats): [kReachWords ints: the reach map, scratch -- any content on entry
+// and on return][accumulators [N][P][NV + 1], zero on entry and on return][one dirty flag per (item, tile), zero on entry and on return].
+// The reach map has a FIXED place in front so that no other geometry's accumulators ever lie over it: the entry points share one
+// zeroed buffer (ops._zero_workspace) and the map is not zeroed after use.
+constexpr int kReachWords = 1 << 18;  // 1 MB: 8 items of a 4K map are 130 560 tiles; larger launches run without the map
+
+// pre-pass, one workgroup per 32 x 16 tile of SOURCES: long (but finite) pixels -> global atomics into gacc [P][NV+1]; the
+// short ones -> the tile's reach, the smallest halo R with all four corners of each within R of its source (what
+// splat_source_from's is_short tests against kR): an output tile whose 3 x 3 neighbourhood of source tiles has reach <= R
+// receives nothing from beyond R pixels and scans a (32 + 2R) x (16 + 2R) window instead of 64 x 48.
 template <int MODE>
 __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restrict__ fs, const float *__restrict__ fo,
                                                           float t, const float *__restrict__ t_dev, float eps,
-                                                          float *__restrict__ gacc, int H, int W, const SplatJobs jobs) {
+                                                          float *__restrict__ ws, int H, int W, const SplatJobs jobs) {
   constexpr int NV = MODE == 0 ? 2 : 1;
   if (t_dev) t = *t_dev;  // timestep from device memory: lets one captured HIP graph serve every t
-  const int n = blockIdx.y;
+  const int n = blockIdx.z;
   const size_t P = (size_t)H * W;
   if (jobs.n) {
     fs = jobs.fs[n], fo = jobs.fo[n], t = jobs.t[n];
@@ -174,13 +183,27 @@ __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restric
     fs += (size_t)n * 2 * P;
     if (fo) fo += (size_t)n * 2 * P;
   }
-  const int tiles_x = (W + 31) >> 5, tiles = tiles_x * ((H + 15) >> 4);
-  int *dirty = reinterpret_cast<int *>(gacc + (size_t)gridDim.y * P * (NV + 1)) + (size_t)n * tiles;
+  const int tiles_x = gridDim.x, tiles = tiles_x * gridDim.y;
+  int *reach = reinterpret_cast<int *>(ws);
+  float *gacc = ws + kReachWords;
+  int *dirty = reinterpret_cast<int *>(gacc + (size_t)gridDim.z * P * (NV + 1)) + (size_t)n * tiles;
   gacc += (size_t)n * P * (NV + 1);
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
-    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+  const int tid = threadIdx.x;
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int x = blockIdx.x * 32 + (tid & 31), y = blockIdx.y * 16 + (tid >> 5) + 8 * i;
+    if (x >= W || y >= H) continue;
+    const size_t p = (size_t)y * W + x;
     const SplatSrc<MODE> s = splat_source<MODE>(fs, fo, P, p, x, y, t, eps);
-    if (!s.finite || s.is_short) continue;
+    if (!s.finite) continue;
+    if (s.is_short) {
+      // fx in [-R, R - 1)  <=>  R >= -fx and R > fx + 1
+      const int rx = s.fx < 0.f ? (int)ceilf(-s.fx) : (int)floorf(s.fx) + 2;
+      const int ry = s.fy < 0.f ? (int)ceilf(-s.fy) : (int)floorf(s.fy) + 2;
+      r = max(r, max(rx, ry));
+      continue;
+    }
     if (MODE == 0) {
       const float v[2] = {s.v[0], s.v[1]};
       scatter_avg<2>(gacc, x, y, s.fx, s.fy, v, H, W, dirty, tiles_x);
@@ -189,6 +212,13 @@ __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restric
       scatter_avg<1>(gacc, x, y, s.fx, s.fy, v, H, W, dirty, tiles_x);
     }
   }
+  if ((size_t)gridDim.z * tiles > (size_t)kReachWords) return;  // (no room for the map: the tiles scan the full halo)
+  __shared__ int wr[4];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) r = max(r, __shfl_xor(r, d, 64));
+  if ((tid & 63) == 0) wr[tid >> 6] = r;
+  __syncthreads();
+  if (tid == 0) reach[(size_t)n * tiles + blockIdx.y * tiles_x + blockIdx.x] = max(max(wr[0], wr[1]), max(wr[2], wr[3]));
 }
 
 // Tile kernel.  On gfx950 ds_add_f32 retires ~0.33 lane-adds per clock per CU while integer LDS atomics retire ~13
@@ -200,35 +230,20 @@ __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restric
 constexpr int kSX = 32, kSY = 16;                       // output tile of the sorted kernel
 constexpr int kKX = kSX + 1, kKY = kSY + 1;             // key grid: footprint origins (-1..kSX-1) x (-1..kSY-1)
 constexpr int kNKEY = kKX * kKY;
-constexpr int kSWX = kSX + 2 * kR, kSWY = kSY + 2 * kR; // source window
-constexpr int kSPT = (kSWX * kSWY + 255) / 256;         // window sources per thread
 constexpr int kCAP = 1536;                              // records held in LDS (3 per output pixel)
 
-template <int MODE>
-__global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs, const float *__restrict__ fo, float t,
-                                                   const float *__restrict__ t_dev, float eps, float *gacc,
-                                                   float *__restrict__ out, int H, int W, const SplatJobs jobs) {
+// R: the halo this tile scans (kR, or less where the reach map allows it)
+template <int MODE, int R>
+__device__ __forceinline__ void splat_tile_body(const float *__restrict__ fs, const float *__restrict__ fo, float t, float eps,
+                                                float *gacc, int *dirty, float *__restrict__ out, int H, int W, int *cnt,
+                                                int *wsum, float4 *rec, int *spilled_) {
   constexpr int NV = MODE == 0 ? 2 : 1;
-  if (t_dev) t = *t_dev;
-  __shared__ int cnt[kNKEY + 1];   // per key: count, then (after the scan) segment start; [kNKEY] = total
-  __shared__ int wsum[4];
-  __shared__ float4 rec[kCAP];     // (v0, v1, X - tx0, Y - ty0) of a source, grouped by key
-  __shared__ int spilled;          // this tile put records beyond kCAP into the global accumulator
-  const int n = blockIdx.z;
+  constexpr int kSWX = kSX + 2 * R, kSWY = kSY + 2 * R;  // source window
+  constexpr int kSPT = (kSWX * kSWY + 255) / 256;        // window sources per thread
+  constexpr int kR = R;                                  // (the window arithmetic below)
+  volatile int &spilled = *spilled_;
   const size_t P = (size_t)H * W;
-  static_assert(kSX == 32 && kSY == 16, "scatter_avg marks 32 x 16 tiles");
-  // dirty[tile] != 0: the long-flow pre-pass scattered into this tile.  Only then (or after a spill of its own) does the
-  // tile read its accumulator entries -- 8-12 bytes per output pixel that are zero in all but a few tiles of a frame.
-  int *dirty = reinterpret_cast<int *>(gacc + (size_t)gridDim.z * P * (NV + 1)) + ((size_t)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   const int was_dirty = __builtin_nontemporal_load(dirty);
-  if (jobs.n) {
-    fs = jobs.fs[n], fo = jobs.fo[n], t = jobs.t[n], out = jobs.out[n];
-  } else {
-    fs += (size_t)n * 2 * P;
-    if (fo) fo += (size_t)n * 2 * P;
-    out += (size_t)n * (MODE == 0 ? 2 : 1) * P;
-  }
-  gacc += (size_t)n * P * (NV + 1);
   const int tx0 = blockIdx.x * kSX, ty0 = blockIdx.y * kSY;
   const int tid = threadIdx.x;
   for (int i = tid; i <= kNKEY; i += 256) cnt[i] = 0;
@@ -387,6 +402,52 @@ __global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs,
       out[p] = o;
     }
   }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) splat_tiled(const float *__restrict__ fs, const float *__restrict__ fo, float t,
+                                                   const float *__restrict__ t_dev, float eps, float *ws,
+                                                   float *__restrict__ out, int H, int W, const SplatJobs jobs) {
+  constexpr int NV = MODE == 0 ? 2 : 1;
+  if (t_dev) t = *t_dev;
+  __shared__ int cnt[kNKEY + 1];   // per key: count, then (after the scan) segment start; [kNKEY] = total
+  __shared__ int wsum[4];
+  __shared__ float4 rec[kCAP];     // (v0, v1, X - tx0, Y - ty0) of a source, grouped by key
+  __shared__ int spilled;          // this tile put records beyond kCAP into the global accumulator
+  static_assert(kSX == 32 && kSY == 16, "scatter_avg and the pre-pass work on 32 x 16 tiles");
+  const int n = blockIdx.z;
+  const size_t P = (size_t)H * W;
+  if (jobs.n) {
+    fs = jobs.fs[n], fo = jobs.fo[n], t = jobs.t[n], out = jobs.out[n];
+  } else {
+    fs += (size_t)n * 2 * P;
+    if (fo) fo += (size_t)n * 2 * P;
+    out += (size_t)n * (MODE == 0 ? 2 : 1) * P;
+  }
+  const int tiles_x = gridDim.x, tiles_y = gridDim.y, tiles = tiles_x * tiles_y;
+  const int *reach = reinterpret_cast<const int *>(ws) + (size_t)n * tiles;
+  float *gacc = ws + kReachWords;
+  // dirty[tile] != 0: the long-flow pre-pass scattered into this tile.  Only then (or after a spill of its own) does the
+  // tile read its accumulator entries -- 8-12 bytes per output pixel that are zero in all but a few tiles of a frame.
+  int *dirty = reinterpret_cast<int *>(gacc + (size_t)gridDim.z * P * (NV + 1)) + ((size_t)n * tiles_y + blockIdx.y) * tiles_x + blockIdx.x;
+  gacc += (size_t)n * P * (NV + 1);
+  // the halo: what the source tiles around this one reach (all of them lie within kRMax = 16 <= a tile's smaller side)
+  int r = kRMax;
+  if ((size_t)gridDim.z * tiles <= (size_t)kReachWords) {
+    r = 0;
+    const int bx = blockIdx.x, by = blockIdx.y;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = by + dy, xx = bx + dx;
+        if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x) r = max(r, __builtin_nontemporal_load(reach + yy * tiles_x + xx));
+      }
+    r = __builtin_amdgcn_readfirstlane(r);
+  }
+  if (r <= 4) splat_tile_body<MODE, 4>(fs, fo, t, eps, gacc, dirty, out, H, W, cnt, wsum, rec, &spilled);
+  else if (r <= 8) splat_tile_body<MODE, 8>(fs, fo, t, eps, gacc, dirty, out, H, W, cnt, wsum, rec, &spilled);
+  else splat_tile_body<MODE, kRMax>(fs, fo, t, eps, gacc, dirty, out, H, W, cnt, wsum, rec, &spilled);
 }
 
 
@@ -777,19 +838,18 @@ int drba_flow_distance(const float *flow, float *out, int N, int H, int W, void 
 
 size_t drba_rife_splat_ws_floats(int N, int H, int W, int values) {
   if (N <= 0 || H <= 0 || W <= 0 || values < 1 || values > 2) return 0;
-  // accumulators [N][H*W][values + 1], then one flag per (item, 32 x 16 output tile)
-  return (size_t)N * H * W * (values + 1) + (size_t)N * ((W + kSX - 1) / kSX) * ((H + kSY - 1) / kSY);
+  // the reach map (fixed size, scratch), accumulators [N][H*W][values + 1], then one flag per (item, 32 x 16 output tile)
+  return (size_t)kReachWords + (size_t)N * H * W * (values + 1) + (size_t)N * ((W + kSX - 1) / kSX) * ((H + kSY - 1) / kSY);
 }
 
 int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, int W, void *stream) {
   if (!flow || !out || !ws || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const size_t P = (size_t)H * W;
   SplatJobs none;
   none.n = 0;
-  DRBA_LAUNCH(splat_long_prepass<0>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f,
+  dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);  // source tiles of the pre-pass = output tiles of the splat
+  DRBA_LAUNCH(splat_long_prepass<0>, g, dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f,
                      (const float *)nullptr, 0.f, ws, H, W, none);
-  dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);
   DRBA_LAUNCH(splat_tiled<0>, g, dim3(kBlock), 0, s, flow, (const float *)nullptr, 0.f, (const float *)nullptr,
                      0.f, ws, out, H, W, none);
   DRBA_CHECK_LAUNCH();
@@ -800,12 +860,11 @@ int drba_drm_rife_linear(const float *flow_self, const float *flow_other, float 
                          float *out, float *ws, int N, int H, int W, void *stream) {
   if (!flow_self || !flow_other || !out || !ws || N <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const size_t P = (size_t)H * W;
   SplatJobs none;
   none.n = 0;
-  DRBA_LAUNCH(splat_long_prepass<1>, dim3(grid_for(P), N), dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev,
-                     eps, ws, H, W, none);
   dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, N);
+  DRBA_LAUNCH(splat_long_prepass<1>, g, dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev,
+                     eps, ws, H, W, none);
   DRBA_LAUNCH(splat_tiled<1>, g, dim3(kBlock), 0, s, flow_self, flow_other, t, t_dev, eps, ws, out, H, W, none);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
@@ -821,10 +880,9 @@ int drba_drm_rife_linear_batch(const drba_drm_job_t *jobs, int n_jobs, float eps
     J.fs[k] = jobs[k].flow_self, J.fo[k] = jobs[k].flow_other, J.t[k] = jobs[k].t, J.out[k] = jobs[k].out;
   }
   hipStream_t s = (hipStream_t)stream;
-  const size_t P = (size_t)H * W;
-  DRBA_LAUNCH(splat_long_prepass<1>, dim3(grid_for(P), n_jobs), dim3(kBlock), 0, s, J.fs[0], J.fo[0], 0.f, (const float *)nullptr, eps, ws,
-              H, W, J);
   dim3 g((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, n_jobs);
+  DRBA_LAUNCH(splat_long_prepass<1>, g, dim3(kBlock), 0, s, J.fs[0], J.fo[0], 0.f, (const float *)nullptr, eps, ws,
+              H, W, J);
   DRBA_LAUNCH(splat_tiled<1>, g, dim3(kBlock), 0, s, J.fs[0], J.fo[0], 0.f, (const float *)nullptr, eps, ws, J.out[0], H, W, J);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;

@@ -32,8 +32,8 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  7: drba_rife_splat_ws_floats -- the workspace of drba_flow_reverse / drba_drm_rife_linear(_batch) grew by one flag per
- * 32 x 16 output tile (same zero-on-entry, zero-on-return contract).  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form, scale 1 and 2), drba_stage_item_t grew by
+/* ABI version.  7: drba_rife_splat_ws_floats -- the workspace of drba_flow_reverse / drba_drm_rife_linear(_batch) grew by a reach map in
+ * front (scratch) and one flag per 32 x 16 output tile behind (same zero-on-entry, zero-on-return contract for everything but the map).  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form, scale 1 and 2), drba_stage_item_t grew by
  * img0_x4 / img1_x4 ([H][W][4] frames), drba_to_inp_x4, drba_rgbx, drba_drm_rife_linear_batch, drba_set_range_check (debug).  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
  * drba_deconv4x4s2, so no earlier id changes meaning), drba_deconv4x4_cfg_family, and a `terms` argument (3 or 2) on the
  * drba_linear_split_* entry points and on drba_window_attention; drba_head_fused16_*.  4: drba_softsplat_again; the encoder features may be given in the pair-interleaved layout ONLY: drba_head_fused accepts f_out ==
@@ -96,11 +96,13 @@ int drba_backwarp(const float *in, const float *flow, float *out, int N, int C, 
 int drba_flow_distance(const float *flow, float *out, int N, int H, int W, void *stream);
 
 /* ---- fused flow reversal: models/rife.py:59-73 (calc_flow tail)
- * out = 2 * where(splat_avg(1, f) < 0.999, max(H,W), -splat_avg(f, f)).  ws: drba_rife_splat_ws_floats(N, H, W, 2) floats
- * that are ZERO on entry: the accumulator of the rare long / converging sources (N*H*W*3 floats) and, ABI 7, one flag per
- * 32 x 16 output tile behind it (set where the long-flow pre-pass scattered into the tile: only those tiles read their
- * accumulator entries).  The kernels write every entry they found non-zero back to zero, so the buffer is zero again on
- * return: allocate it zeroed once and keep it for these entry points (no memset per call). */
+ * out = 2 * where(splat_avg(1, f) < 0.999, max(H,W), -splat_avg(f, f)).  ws: drba_rife_splat_ws_floats(N, H, W, 2) floats.
+ * ABI 7 layout: [1 MB of scratch: the reach map -- per 32 x 16 tile of sources the halo their splat flows need, written by the
+ * pre-pass, so that an output tile scans a 4- or 8-pixel halo where nothing reaches it from further; any content on entry and
+ * on return] [the accumulator of the rare long / converging sources, N*H*W*3 floats] [one flag per tile, set where the pre-pass
+ * scattered into it: only those tiles read their accumulator entries].  Everything behind the first MB must be ZERO on entry; the
+ * kernels write every entry they found non-zero back to zero, so it is zero again on return: allocate the buffer zeroed once
+ * and keep it for these entry points (no memset per call). */
 size_t drba_rife_splat_ws_floats(int N, int H, int W, int values); /* values: 2 = flow reversal, 1 = linear DRM */
 int drba_flow_reverse(const float *flow, float *out, float *ws, int N, int H, int W, void *stream);
 

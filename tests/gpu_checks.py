@@ -415,7 +415,9 @@ def check_glue(dev):
     other = F.interpolate(torch.randn(1, 2, 5, 9, generator=g) * 4, size=(Hs, Ws), mode="bilinear")
     # all sources within the halo of the tile at x 64..95, y 32..47 pulled into it: ~2300 records for a capacity of 1536
     pinch = torch.stack([-0.45 * (xs - 79.5), -0.6 * (ys - 39.5)]).unsqueeze(0)
-    for fname, fl in (("smooth", smooth), ("long", longf), ("nan", nanf), ("converge", conv), ("pinch", pinch)):
+    # tiny / mid: every tile's neighbourhood reaches <= 4 / <= 8 pixels -- the tiles scan the smaller source windows the reach map allows
+    tiny, mid = smooth * 0.15, smooth * 0.45
+    for fname, fl in (("smooth", smooth), ("tiny", tiny), ("mid", mid), ("long", longf), ("nan", nanf), ("converge", conv), ("pinch", pinch)):
         ones = torch.ones(1, 1, Hs, Ws)
         ref = -1 * oracle.ops.softsplat(fl, fl, None, "avg")
         gap = oracle.ops.softsplat(ones, fl, None, "avg") < 0.999
@@ -440,7 +442,8 @@ def check_glue(dev):
     one = torch.cat((ops.flow_reverse(D(longf.contiguous())), ops.flow_reverse(D(pinch.contiguous()))), 0)
     rows.append(("flow_reverse N=2 vs two N=1 calls, atomics path", _diff(got2, one.cpu()), 2e-4, ""))
     zws = ops._zero_workspace(dev, 1)
-    rows.append(("fused splats leave their accumulator zeroed", float(zws.abs().max()), 0.0, ""))
+    head = ops._lib.load().drba_rife_splat_ws_floats(1, 1, 1, 1) - 3  # the reach map in front is scratch (include/drba_hip.h)
+    rows.append(("fused splats leave their accumulator zeroed", float(zws[head:].abs().max()), 0.0, ""))
     for sl in (1.0, 2.0):
         tl = torch.randn(1, 13, int(H / sl), int(W / sl), generator=g)
         m = torch.sigmoid(F.interpolate(tl, scale_factor=sl, mode="bilinear", align_corners=False)[:, 4:5])
