@@ -101,6 +101,10 @@ for n in (2, 8):
            lambda: ops.stage_inputs(items, None, pyr[4.0], 4.0, 2.0, xl2, terms=[(pyr[16.0], 16.0), (pyr[8.0], 8.0)]))
     target(f"stage input s=4, flow as 1 term, {n} samples",
            lambda: ops.stage_inputs(items, None, pyr[8.0], 8.0, 4.0, xin4, terms=[(pyr[16.0], 16.0)]))
+    # the scale-2 stage fused with block 3's conv0[0] (52 -> 32, stride 2), what the pipeline launches since round 5
+    conv0s2 = ops.Conv3x3(torch.randn(32, 52, 3, 3, generator=g) * 0.05, torch.zeros(32), 2, True, None, device=dev)
+    target(f"stage input s=2 + conv0[0] fused, flow as 2 terms, {n} samples",
+           lambda: ops.stage_conv0(items, None, pyr[4.0], 4.0, conv0s2, terms=[(pyr[16.0], 16.0), (pyr[8.0], 8.0)], scale=2))
     del xl2, pyr
     for (c, h, w) in ((64, 136, 240), (32, 272, 480), (96, 68, 120), (128, 34, 60), (192, 17, 30)) + (((32, 544, 960),) if n == 2 else ()):
         x = torch.randn(n, c, h, w, generator=g).to(dev)
