@@ -62,7 +62,8 @@ _zero_ws_cache = {}
 
 def _zero_workspace(device, nfloats):
     """Zero-initialised scratch per (device, stream) for the fused splats (drba_flow_reverse / drba_drm_rife_linear):
-    their kernels return the accumulator zeroed, so it is cleared once at allocation and never again."""
+    their kernels return the accumulator (and the per-tile flags behind it) zeroed, so it is cleared once at allocation and never
+    again.  The first MB is the kernels' reach map: plain scratch, written before it is read by every call (include/drba_hip.h)."""
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     buf = _zero_ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
