@@ -44,6 +44,8 @@ SIGNATURES = {
     "drba_abi_version": (_i, []),
     "drba_rife_splat_ws_floats": (_z, [_i, _i, _i, _i]),
     "drba_set_range_check": (_i, [_i]),
+    "drba_status_word": (_i, [C.POINTER(C.c_void_p)]),
+    "drba_status_clear": (_i, []),
     "drba_trace_begin": (_i, []),
     "drba_trace_end": (_i, []),
     "drba_trace_resume": (_i, []),

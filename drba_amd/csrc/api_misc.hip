@@ -3,6 +3,7 @@
 
 #include <cxxabi.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -93,6 +94,20 @@ hipError_t max_dynamic_lds(const void *kernel, int bytes) {
 }
 bool g_range_check = false;
 
+// Status words (drba_status_word): one 8-byte host-mapped allocation per device, made on request, never freed.  The table is
+// read on every family-4 launch (an atomic pointer load indexed by the current device) and written once per device.
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<unsigned long long *> g_status_host[kMaxDevices];
+std::atomic<unsigned char *> g_status_dev[kMaxDevices];
+std::mutex g_status_mu;
+}  // namespace
+unsigned char *status_bytes() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  return g_status_dev[dev].load(std::memory_order_acquire);
+}
+
 namespace {
 __global__ void __launch_bounds__(256) nonfinite_kernel(const float *__restrict__ x, size_t n, int *__restrict__ flag) {
   bool bad = false;
@@ -139,6 +154,37 @@ int drba_set_range_check(int on) {
   const int was = drba::g_range_check ? 1 : 0;
   drba::g_range_check = on != 0;
   return was;
+}
+
+int drba_status_word(volatile unsigned long long **host_word) {
+  if (!host_word) return DRBA_EINVAL;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= drba::kMaxDevices) return DRBA_EINVAL;
+  std::lock_guard<std::mutex> lock(drba::g_status_mu);
+  unsigned long long *h = drba::g_status_host[dev].load(std::memory_order_acquire);
+  if (!h) {
+    void *hp = nullptr, *dp = nullptr;
+    // coherent (fine-grained) host memory: a kernel's store is visible to the host once the kernel has finished
+    if (hipHostMalloc(&hp, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return DRBA_ELAUNCH;
+    *static_cast<unsigned long long *>(hp) = 0;
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+      (void)hipHostFree(hp);
+      return DRBA_ELAUNCH;
+    }
+    h = static_cast<unsigned long long *>(hp);
+    drba::g_status_host[dev].store(h, std::memory_order_release);
+    drba::g_status_dev[dev].store(static_cast<unsigned char *>(dp), std::memory_order_release);
+  }
+  *host_word = h;
+  return DRBA_OK;
+}
+
+int drba_status_clear(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= drba::kMaxDevices) return DRBA_EINVAL;
+  unsigned long long *h = drba::g_status_host[dev].load(std::memory_order_acquire);
+  if (h) *reinterpret_cast<volatile unsigned long long *>(h) = 0;
+  return DRBA_OK;
 }
 
 int drba_trace_begin(void) {

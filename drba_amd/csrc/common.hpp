@@ -53,6 +53,25 @@ static inline int range_checked(int rc, const float *out, size_t n, void *stream
   return (rc != DRBA_OK || !g_range_check) ? rc : range_scan(out, n, stream);
 }
 
+// Always-on overflow report of the same family (drba_status_word, include/drba_hip.h; ABI 8): every family-4 kernel takes the
+// device address of the current device's status bytes (null until the caller asked for the word: then nothing is reported),
+// folds each value it stores into a NaN accumulator (v * 0 + nf: NaN as soon as one v is inf / NaN, one VALU operation per stored
+// value, no branch, no compare-to-SGPR) and writes 1 into its byte at the end of the workgroup if that came out NaN.  The word is
+// host-mapped: the host reads it without touching the stream.
+unsigned char *status_bytes();  // device address for the current device, or nullptr
+__device__ __forceinline__ float nf_fold(float nf, float v) { return __builtin_fmaf(v, 0.f, nf); }
+__device__ __forceinline__ void nf_report(unsigned char *status, int which, float nf) {
+  if (status && nf != nf) status[which] = 1;
+}
+// ... and the weights of the family at pack time: the two-term form holds a weight as fp16(w) + 2^-11 fp16(...) with no
+// pre-scale, so |w| >= 65504 (or a non-finite one) cannot be packed: the *_pack entry points return DRBA_EUNSUPPORTED and the
+// host falls to a 24-bit family for that layer.
+static inline bool two_term_weights_ok(const float *w, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!(w[i] > -65504.f && w[i] < 65504.f)) return false;  // (NaN fails both comparisons)
+  return true;
+}
+
 // Environment switches select between kernel variants of THIS library for A/B measurements (never another backend).  The
 // release build -- the Makefile's default -- compiles them out: env_int() returns the default without reading the
 // environment; `make TUNING=1` (-DDRBA_TUNING_SWITCHES) builds the measuring library the tools/ scripts may use.

@@ -91,8 +91,9 @@ __global__ void __launch_bounds__(NTHREADS, 1)
 conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
           const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
           float *__restrict__ out, int H, int W, int Cout, int act, float post_slope, float pre_slope, int nbx, int nby,
-          int total, int *__restrict__ counters, int *__restrict__ counters_next) {
+          int total, int *__restrict__ counters, int *__restrict__ counters_next, unsigned char *status) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  float nf = 0.f;  // PL = 2: NaN once a sum of this lane came out non-finite (nf_fold / nf_report, common.hpp)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // the ONLY LDS object of the kernel
   constexpr int W_BYTES = w_bytes(PL), W_INSTR = W_BYTES / 1024, OFF_IDX = off_idx(PL);
   constexpr int NM = (PL == 3 ? 6 : 3) * NT;  // MFMAs of a group = slots of the block program
@@ -525,7 +526,11 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
             const int co = nt * 16 + m, y = cur.y0 + 2 * rp + o;
             const unsigned off = (y < H && xb < W && co < Cout) ? (unsigned)(((co * H + y) * W + xb) * 4) : 0xffffffffu;
             f32x4 v = acc[o][nt], x1 = (f32x4){0.f, 0.f, 0.f, 0.f}, x2 = x1;
-            if constexpr (PL == 2) v = (v + acl[o][nt] * (1.f / 2048.f)) * (float)(1 << kSplitActShift);  // exact powers of two
+            if constexpr (PL == 2) {
+              v = (v + acl[o][nt] * (1.f / 2048.f)) * (float)(1 << kSplitActShift);  // exact powers of two
+#pragma unroll
+              for (int k = 0; k < 4; ++k) nf = nf_fold(nf, v[k]);  // the family's overflow report
+            }
             if (RL) {  // the layer's input IS the residual: channel co of the window, row 2 rp + o + 1, columns 4 + 16 mw + 4 kq ..
               x1 = *reinterpret_cast<const f32x4 *>(ldsf + ab * (A_BYTES / 4) + co * CS + (2 * rp + o + 1) * WC + 4 + 16 * mw + 4 * kq);
             } else if (res) {
@@ -568,6 +573,7 @@ conv_dma1(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const f
     DRBA_CLK_ADD(4, 0, 1);
     ab ^= 1;
   }
+  if constexpr (PL == 2) nf_report(status, DRBA_STATUS_CONV_DMA, nf);
 #ifdef DRBA_EXP_CLOCKS
   if ((blockIdx.x == 131 || blockIdx.x == 7) && lane == 0 && clk_acc[4] && (wave == 0 || wave == 5))
     printf("wg %d wave %d: items %lld  barrier %lld  head %lld  blocks %lld  epilogue %lld (clocks per item)  first barrier %lld  total %lld\n",
@@ -640,7 +646,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     DRBA_LAUNCH(kernel, g, dim3(NTHREADS), lds_bytes(PL), s, in, wf, bias, beta, res, res2, out, H, W, Cout, act, post_slope,
-                pre_slope, nbx, nby, (int)total, counters, counters_next);
+                pre_slope, nbx, nby, (int)total, counters, counters_next, PL == 2 ? status_bytes() : nullptr);
     if (hipPeekAtLastError() != hipSuccess) return DRBA_ELAUNCH;  // not issued: the sets keep their roles
     counters_commit(slot);
     return DRBA_OK;
@@ -676,6 +682,7 @@ int conv_dma_pack(const float *w, float *packed, int Cin, int Cout, int id) {
   using namespace drba_conv_dma;
   if (!w || !packed || !conv_dma_supports(Cin, Cout, id)) return DRBA_EINVAL;
   const int PL = planes_of(id);
+  if (PL == 2 && !two_term_weights_ok(w, (size_t)Cout * Cin * 9)) return DRBA_EUNSUPPORTED;
   memset(packed, 0, w_bytes(PL));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   for (int tap = 0; tap < 9; ++tap)

@@ -68,7 +68,8 @@ template <int KW, bool PRE, bool RL, bool DW, int PL = 3>
 __global__ void __launch_bounds__(KW * 64)
 conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
         const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2, float *__restrict__ out,
-        int H, int W, int Cout, int act, float post_slope, float pre_slope, int n_ctiles, int ncb, int nrp, int total) {
+        int H, int W, int Cout, int act, float post_slope, float pre_slope, int n_ctiles, int ncb, int nrp, int total,
+        unsigned char *status) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = Geo<DW>;
   constexpr int CS = G::CS, WCOL = G::WCOL;
@@ -258,13 +259,19 @@ conv_ks(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const flo
 
   // ---- the KW partial sums meet in LDS: red[(wave * 4 + o * 2 + nt) * 64 + lane] (16 bytes per lane, behind the windows)
   f32x4 *red = reinterpret_cast<f32x4 *>(lds + KW * G::A_DW * 4);
+  float nf = 0.f;
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      if constexpr (PL == 2) acc[o][nt] = (acc[o][nt] + acl[o][nt] * (1.f / 2048.f)) * (float)(1 << kSplitActShift);  // exact powers of two
+      if constexpr (PL == 2) {
+        acc[o][nt] = (acc[o][nt] + acl[o][nt] * (1.f / 2048.f)) * (float)(1 << kSplitActShift);  // exact powers of two
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nf = nf_fold(nf, acc[o][nt][k]);  // the family's overflow report (common.hpp)
+      }
       red[(wave * 4 + o * 2 + nt) * 64 + lane] = acc[o][nt];
     }
+  if constexpr (PL == 2) nf_report(status, DRBA_STATUS_CONV_KS, nf);
   __syncthreads();
 
   // ---- epilogue, shared by the waves: accumulator (o, nt) = c is finished by wave c % KW.  y = sum + bias; ResConv:
@@ -354,7 +361,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     DRBA_LAUNCH(kernel, dim3((unsigned)total), dim3(KW * 64), lds_bytes, s, in, wf, bias, beta, res, res2, out, H, W, Cout, act,
-                post_slope, pre_slope, n_ct, ncb, nrp, (int)total);
+                post_slope, pre_slope, n_ct, ncb, nrp, (int)total, PL == 2 ? status_bytes() : nullptr);
     return DRBA_OK;
   };
   const bool rl = res && res == in && !res2 && !pre_act && Cout == KW * CK;
@@ -393,6 +400,7 @@ int conv_ks_pack(const float *w, float *packed, int Cin, int Cout, int id) {
   using namespace drba_conv_ks;
   if (!w || !packed || !conv_ks_supports(Cin, Cout, id)) return DRBA_EINVAL;
   const int n_ct = (Cout + NTC - 1) / NTC, nch = Cin / CK, PL = ks_planes(id);
+  if (PL == 2 && !two_term_weights_ok(w, (size_t)Cout * Cin * 9)) return DRBA_EUNSUPPORTED;
   memset(packed, 0, sizeof(float) * conv_ks_packed_floats(Cin, Cout, id));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   for (int cz = 0; cz < n_ct; ++cz)

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256, Cfg::MINB)  // at least two workgroups pe
 conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                 const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
                 float *__restrict__ out, int Cin, int H, int W, int Cout, int act, float post_slope, float pre_slope,
-                int n_ctiles, int nbx, int nby, int total, int pixel_shuffle, int Hi, int Wi) {
+                int n_ctiles, int nbx, int nby, int total, int pixel_shuffle, int Hi, int Wi, unsigned char *status) {
   // H, W: the map the tiles are laid over (MODE 0 / 1: the input = Hi x Wi; MODE 2: the OUTPUT, the input being Hi x Wi)
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MODE = Cfg::MODE, NTAP = Cfg::NTAP, NPX = Cfg::NPX;
@@ -236,6 +236,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   int work = blockIdx.x;
   if (work >= total) return;
   DRBA_CLK_INIT;
+  float nf = 0.f;  // PL = 2: NaN once a sum of this lane came out non-finite (nf_fold / nf_report, common.hpp)
 #ifdef DRBA_SPLIT_STAGGER  // experiment: put the co-resident workgroups of a CU out of phase
   {
     const int b = blockIdx.x;
@@ -396,7 +397,12 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
           for (int b = 0; b < MW; ++b)
 #pragma unroll
             for (int c = 0; c < NT; ++c)
+            {
               acc[p][a][b][c] = (acc[p][a][b][c] + acl[p][a][b][c] * (1.f / 2048.f)) * (float)(1 << kActShift);
+              // the family's overflow report (common.hpp): an operand past fp16's range has made its sums inf / NaN
+#pragma unroll
+              for (int k = 0; k < 4; ++k) nf = nf_fold(nf, acc[p][a][b][c][k]);
+            }
     }
 
     // ---- epilogue (conv.hip MODE 0): y = acc + bias; ResConv: y = y*beta + res; otherwise y += res (+ res2); then
@@ -664,6 +670,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     work = next;
     ctx = nctx;
   }
+  if constexpr (PL == 2) nf_report(status, DRBA_STATUS_CONV_SPLIT, nf);
 #endif
 }
 
@@ -722,6 +729,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   const long long total = (long long)nbx * nby * N * n_ct * (Cfg::MODE != 1 ? 1 : 2);  // x2: row phases
   if (total >= (1ll << 31)) return DRBA_EUNSUPPORTED;
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(wpk);
+  unsigned char *status = Cfg::PL == 2 ? status_bytes() : nullptr;
   auto go = [&](auto kernel, hipError_t lds_ok) -> int {
     if (lds_ok != hipSuccess) return DRBA_ELAUNCH;
     // persistent grid: the workgroups the 256 CUs hold AT ONCE (registers and LDS of this instantiation, asked once), a
@@ -738,7 +746,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
     long long grid = 256ll * per_cu;
     if (grid > total) grid = (total + 7) / 8 * 8;
     DRBA_LAUNCH(kernel, dim3((unsigned)grid), dim3(256), Cfg::LDS_BYTES, s, in, wf, bias, beta, res, res2, out, Cin, H, W, Cout,
-                act, post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle, Hi, Wi);
+                act, post_slope, pre_slope, n_ct, nbx, nby, (int)total, pixel_shuffle, Hi, Wi, status);
     return DRBA_OK;
   };
   int rc;
@@ -784,6 +792,7 @@ int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id) {
   using namespace drba_conv_split;
   if (!w || !packed || !conv_split_supports(Cin, Cout, id)) return DRBA_EINVAL;
   const Info &c = kInfo[id];
+  if (c.PL == 2 && !two_term_weights_ok(w, (size_t)Cout * Cin * 9)) return DRBA_EUNSUPPORTED;
   const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = (Cin + CK - 1) / CK;
   memset(packed, 0, sizeof(float) * conv_split_packed_floats(Cin, Cout, id));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
@@ -862,6 +871,7 @@ int deconv_split_pack(const float *w, float *packed, int Cin, int Cout, int id) 
   using namespace drba_conv_split;
   if (!w || !packed || !deconv_split_supports(Cin, Cout, id)) return DRBA_EINVAL;
   const Info &c = kInfoT[id];
+  if (c.PL == 2 && !two_term_weights_ok(w, (size_t)Cin * Cout * 16)) return DRBA_EUNSUPPORTED;
   const int n_ct = (Cout + c.NTC - 1) / c.NTC, nch = Cin / CK;
   memset(packed, 0, sizeof(float) * deconv_split_packed_floats(Cin, Cout, id));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);

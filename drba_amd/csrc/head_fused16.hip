@@ -78,7 +78,7 @@ __device__ __forceinline__ f32x4 join(const Acc2 &c) { return (c.hi + c.lo * (1.
 
 __global__ void __launch_bounds__(THREADS, 4)  // 4 waves per SIMD = two workgroups per CU: <= 128 registers
 head_fused16(const float *__restrict__ img, const u32x4 *__restrict__ wpk, float *__restrict__ f_out, float *__restrict__ fp_out, int H,
-             int W, int tiles_x) {
+             int W, int tiles_x, unsigned char *status) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
   u32x4 *bufA = lds16 + GP;                       // IN (fp32), then X1
@@ -198,6 +198,7 @@ head_fused16(const float *__restrict__ img, const u32x4 *__restrict__ wpk, float
   // K step s of a phase holds taps 2 s + (kq >> 1)
   {
     const f32x4 bias = *reinterpret_cast<const f32x4 *>(biases + 48 + 4 * kq);
+    float nf = 0.f;  // the family's overflow report (common.hpp): an overflow of any layer's fp16 planes reaches these values
     for (int u = wave; u < H2 * 2; u += 8) {      // (region row, 16-position half) units
       const int r = 3 + (u >> 1), c0 = 3 + (u & 1) * 16;
       const int M = rm + r, N = rn + c0 + m;       // this lane: position (M, N), output channels 4 kq .. + 3
@@ -220,6 +221,8 @@ head_fused16(const float *__restrict__ img, const u32x4 *__restrict__ wpk, float
         }
         const f32x4 v0 = join(acc[0]) + bias, v1 = join(acc[1]) + bias;  // columns 2N, 2N + 1 of row 2M + py
         if (inside) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) nf = nf_fold(nf_fold(nf, v0[e]), v1[e]);
           const int y = 2 * M + py, x = 2 * N;
           // pair layout [C/2][H][W][2]: channel pairs 2 kq, 2 kq + 1; (x, x + 1) x (even, odd channel) = 16 contiguous bytes
 #pragma unroll
@@ -235,6 +238,7 @@ head_fused16(const float *__restrict__ img, const u32x4 *__restrict__ wpk, float
         }
       }
     }
+    nf_report(status, DRBA_STATUS_HEAD, nf);
   }
 #endif
 }
@@ -250,6 +254,9 @@ int drba_head_fused16_pack(const float *w0, const float *b0, const float *w1, co
                            const float *w3, const float *b3, float *packed) {
   using namespace drba_head16;
   if (!w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !packed) return DRBA_EINVAL;
+  if (!two_term_weights_ok(w0, 16 * 27) || !two_term_weights_ok(w1, 16 * 144) || !two_term_weights_ok(w2, 16 * 144) ||
+      !two_term_weights_ok(w3, 16 * 256))
+    return DRBA_EUNSUPPORTED;
   memset(packed, 0, sizeof(float) * W_FLOATS);
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   auto put = [&](int unit_h, int lane, int i, float w) {  // unit_h: the h fragment's 64-lane block; the l fragment follows it
@@ -295,7 +302,7 @@ int drba_head_fused16(const float *img, const float *packed_w, float *f_out, flo
   const int tiles_x = (W / 2 + W2 - 1) / W2, tiles_y = (H / 2 + H2 - 1) / H2;
   if (max_dynamic_lds((const void *)head_fused16, LDS_BYTES) != hipSuccess) return DRBA_ELAUNCH;
   DRBA_LAUNCH(head_fused16, dim3(tiles_x * tiles_y, N), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, img,
-              reinterpret_cast<const u32x4 *>(packed_w), f_out, f_pair_out, H, W, tiles_x);
+              reinterpret_cast<const u32x4 *>(packed_w), f_out, f_pair_out, H, W, tiles_x, status_bytes());
   DRBA_CHECK_LAUNCH();
   return range_checked(DRBA_OK, f_pair_out, (size_t)N * 16 * H * W, stream);
 }

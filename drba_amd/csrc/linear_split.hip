@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256)
 linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                      float *__restrict__ out, int M, int K, int N, int ldx, int n_ntiles, const float *__restrict__ ln_w,
                      const float *__restrict__ ln_b, const float *__restrict__ residual, float eps,
-                     const float *__restrict__ x2, int ldx2, int q_split) {
+                     const float *__restrict__ x2, int ldx2, int q_split, unsigned char *status) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MTW = Cfg::MTW, NT = Cfg::NT, TM = Cfg::TM, WBUF = Cfg::WBUF, PL = Cfg::PL;
   __shared__ __attribute__((aligned(16))) u32x4 wl[2 * WBUF];
@@ -205,10 +205,16 @@ linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag
   }
 
   if constexpr (PL == 2) {  // join the two sums, undo the activation pre-scale (exact powers of two)
+    float nf = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (acc[mt][nt] + acl[mt][nt] * (1.f / 2048.f)) * (float)(1 << drba::kSplitActShift);
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[mt][nt] = (acc[mt][nt] + acl[mt][nt] * (1.f / 2048.f)) * (float)(1 << drba::kSplitActShift);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nf = drba::nf_fold(nf, acc[mt][nt][i]);  // the family's overflow report (common.hpp)
+      }
+    drba::nf_report(status, DRBA_STATUS_LINEAR, nf);
   }
   if constexpr (EPI == 2) {
     // a lane holds 32 of its token's 128 outputs (features 16*nt + 4*kq + i); the other 96 sit in the lanes with the
@@ -294,6 +300,7 @@ size_t drba_linear_split_packed_floats(int K, int N, int terms) {
 int drba_linear_split_pack(const float *w, float *packed, int K, int N, int terms) {
   using namespace drba_linear;
   if (!w || !packed || drba_linear_split_packed_floats(K, N, terms) == 0) return DRBA_EINVAL;
+  if (terms == 2 && !drba::two_term_weights_ok(w, (size_t)N * K)) return DRBA_EUNSUPPORTED;
   memset(packed, 0, sizeof(float) * drba_linear_split_packed_floats(K, N, terms));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   const int nft = (N + 15) / 16, nch = K / CK;
@@ -324,9 +331,10 @@ static int linear_launch(const float *x, const float *packed_w, const float *bia
   using Cfg = LinCfg<1, 8>;  // (tile geometry: the same for both forms)
   const int n_ntiles = (N + Cfg::TN - 1) / Cfg::TN, n_mtiles = (M + Cfg::TM - 1) / Cfg::TM;
   const dim3 grid((unsigned)(n_ntiles * n_mtiles));
+  unsigned char *status = terms == 2 ? drba::status_bytes() : nullptr;
 #define DRBA_LIN(E, P)                                                                                                      \
   DRBA_LAUNCH((linear_split_kernel<LinCfg<1, 8, P>, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
-                    ldx, n_ntiles, ln_w, ln_b, residual, eps, x2, ldx2, q_split)
+                    ldx, n_ntiles, ln_w, ln_b, residual, eps, x2, ldx2, q_split, status)
   if (terms == 3) {
     if (epi == 2) DRBA_LIN(2, 3);
     else if (epi == 1) DRBA_LIN(1, 3);

@@ -112,7 +112,7 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &h, uint32_t &
 template <int FMODE, class G_, bool X4>
 __global__ void __launch_bounds__(G_::THREADS, 4)  // 4 waves per SIMD = two workgroups per CU: <= 128 registers
 stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restrict__ wpk, const float *__restrict__ bias, int hp, int wp,
-             float inv_prev_scale, float prev_scale, int H, int W, int Ho, int Wo, int tiles_x, int n_items) {
+             float inv_prev_scale, float prev_scale, int H, int W, int Ho, int Wo, int tiles_x, int n_items, unsigned char *status) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool FOLD = FMODE != 0, WRITES = FMODE == 1, LAZY = FMODE == 2;
   constexpr int TOH = G_::TOH, NT = G_::NT, WR = G_::WR, THREADS = G_::THREADS, NPOS = G_::NPOS, NPOINTS = G_::NPOINTS;
@@ -480,13 +480,17 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
   if (wave < TOH) {
     const int oy = oy0 + wave, ox = ox0 + 4 * kq;
     if (oy < Ho && ox < Wo) {
+      float nf = 0.f;  // the family's overflow report (common.hpp): an operand past fp16's range has made the sums inf / NaN
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = 16 * n + m;
         const gptr dst = item.out + ((size_t)co * Ho + oy) * Wo + ox;
         f32x4 y = (hh[n] + lo[n] * (1.f / 2048.f)) * kUnscale;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) y[k] = lrelu02(y[k] + bs[n]);
+        for (int k = 0; k < 4; ++k) {
+          y[k] = lrelu02(y[k] + bs[n]);
+          nf = nf_fold(nf, y[k]);
+        }
         if ((Wo & 3) == 0) {
           *(__attribute__((address_space(1))) f32x4 *)dst = y;
         } else {
@@ -495,6 +499,7 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
             if (ox + k < Wo) dst[k] = y[k];
         }
       }
+      nf_report(status, DRBA_STATUS_STAGE, nf);
     }
   }
 #ifdef DRBA_SC16_CLOCKS
@@ -525,7 +530,8 @@ stage_conv16(const StageItems items, const FlowTermsArg T, const u32x4 *__restri
 template <class G_>
 __global__ void __launch_bounds__(G_::THREADS, 4)
 stage_conv16_s2(const StageItems items, const FlowTermsArg T, const u32x4 *__restrict__ wpk, const float *__restrict__ bias, int hp, int wp,
-                float inv_prev_scale, float prev_scale, int H, int W, int h, int w, int Ho, int Wo, int tiles_x, int n_items) {
+                float inv_prev_scale, float prev_scale, int H, int W, int h, int w, int Ho, int Wo, int tiles_x, int n_items,
+                unsigned char *status) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TOH = G_::TOH, NT = G_::NT, WR = G_::WR, THREADS = G_::THREADS, NPOS = G_::NPOS, NPOINTS = G_::NPOINTS;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
@@ -804,13 +810,17 @@ stage_conv16_s2(const StageItems items, const FlowTermsArg T, const u32x4 *__res
   if (wave < TOH) {
     const int oy = oy0 + wave, ox = ox0 + 4 * kq;
     if (oy < Ho && ox < Wo) {
+      float nf = 0.f;  // the family's overflow report (common.hpp): an operand past fp16's range has made the sums inf / NaN
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = 16 * n + m;
         const gptr dst = item.out + ((size_t)co * Ho + oy) * Wo + ox;
         f32x4 y = (hh[n] + lo[n] * (1.f / 2048.f)) * kUnscale;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) y[k] = lrelu02(y[k] + bs[n]);
+        for (int k = 0; k < 4; ++k) {
+          y[k] = lrelu02(y[k] + bs[n]);
+          nf = nf_fold(nf, y[k]);
+        }
         if ((Wo & 3) == 0) {
           *(__attribute__((address_space(1))) f32x4 *)dst = y;
         } else {
@@ -819,6 +829,7 @@ stage_conv16_s2(const StageItems items, const FlowTermsArg T, const u32x4 *__res
             if (ox + k < Wo) dst[k] = y[k];
         }
       }
+      nf_report(status, DRBA_STATUS_STAGE, nf);
     }
   }
 #endif
@@ -839,6 +850,7 @@ int drba_stage_conv16_pack(const float *w, int Cout, float *packed) {
   using namespace drba_stage_conv16;
   if (!w || !packed || (Cout != 16 && Cout != 32)) return DRBA_EINVAL;
   const int NT = Cout / 16;
+  if (!two_term_weights_ok(w, (size_t)Cout * CIN * 9)) return DRBA_EUNSUPPORTED;
   memset(packed, 0, sizeof(float) * drba_stage_conv16_packed_floats(Cout));
   unsigned short *dst = reinterpret_cast<unsigned short *>(packed);
   for (int g = 0; g < NG; ++g)
@@ -907,7 +919,7 @@ int drba_stage_conv16_batch(const drba_stage_item_t *items, int n_items, const d
       if (max_dynamic_lds((const void *)stage_conv16_s2<G_>, 160 * 1024) != hipSuccess) return DRBA_ELAUNCH;                       \
       DRBA_LAUNCH((stage_conv16_s2<G_>), dim3(tiles_x * tiles_y * n_items), dim3(G_::THREADS), (size_t)G_::LDS_UNITS * 16, s, its, T, \
                   reinterpret_cast<const drba_stage_conv16::u32x4 *>(packed_w), bias, hp, wp, 0.25f, prev_scale, H, W, h, w, Ho, Wo, \
-                  tiles_x, n_items);                                                                                              \
+                  tiles_x, n_items, status_bytes());                                                                              \
     } while (0)
     if (Cout == 16) DRBA_SC16_S2(1);
     else DRBA_SC16_S2(2);
@@ -928,7 +940,7 @@ int drba_stage_conv16_batch(const drba_stage_item_t *items, int n_items, const d
     const int tiles_x = (Wo + TOW - 1) / TOW, tiles_y = (Ho + G_::TOH - 1) / G_::TOH;                                   \
     DRBA_LAUNCH((stage_conv16<FO, G_, XX>), dim3(tiles_x * tiles_y * n_items), dim3(G_::THREADS), lds_bytes, s, its, T,        \
                 reinterpret_cast<const drba_stage_conv16::u32x4 *>(packed_w), bias, hp, wp, 0.5f, prev_scale, H, W, Ho, Wo, tiles_x,   \
-                n_items);                                                                                                  \
+                n_items, status_bytes());                                                                                  \
   } while (0)
 #define DRBA_SC16_GO(FO, NT_, TOH_)          \
   do {                                       \

@@ -298,7 +298,7 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned &h, unsigned 
 __global__ void __launch_bounds__(256, 2)  // two waves per SIMD = two workgroups per CU: <= 256 registers
 window_attention16_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                           float *__restrict__ out, Geometry g, int nwin, int qtiles, float scale, int ldq, int ldk, int ldv, int ksplit,
-                          float *__restrict__ part) {
+                          float *__restrict__ part, unsigned char *status) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
   u32x4 *KsH = lds16, *KsL = lds16 + kKeys * kKU;           // [key][kKU]
@@ -485,16 +485,30 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
         prow[0] = m_run;
         prow[1] = l_run;
       }
+      float nf = nf_fold(0.f, l_run);  // the family's overflow report (common.hpp): Q / K / V past fp16's range end up here
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4 *>(prow + 4 + 16 * dt + 4 * grp) = oh[dt] + ol[dt] * (1.f / 2048.f);
+      for (int dt = 0; dt < 8; ++dt) {
+        const f32x4 o = oh[dt] + ol[dt] * (1.f / 2048.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nf = nf_fold(nf, o[i]);
+        *reinterpret_cast<f32x4 *>(prow + 4 + 16 * dt + 4 * grp) = o;
+      }
+      nf_report(status, DRBA_STATUS_ATTENTION, nf);
     }
     return;
   }
   if (qlive) {
     const float inv = 1.f / l_run;
     float *orow = out + qrow * kC + 4 * grp;
+    float nf = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4 *>(orow + 16 * dt) = (oh[dt] + ol[dt] * (1.f / 2048.f)) * inv;
+    for (int dt = 0; dt < 8; ++dt) {
+      const f32x4 o = (oh[dt] + ol[dt] * (1.f / 2048.f)) * inv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nf = nf_fold(nf, o[i]);
+      *reinterpret_cast<f32x4 *>(orow + 16 * dt) = o;
+    }
+    nf_report(status, DRBA_STATUS_ATTENTION, nf);
   }
 #endif
 }
@@ -570,7 +584,7 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
     if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention16_kernel), drba_attn::kLds16Bytes) != hipSuccess)
       return DRBA_ELAUNCH;
     DRBA_LAUNCH(drba_attn::window_attention16_kernel, grid, dim3(kBlock), drba_attn::kLds16Bytes, (hipStream_t)stream, q, k, v,
-                      out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws);
+                      out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws, status_bytes());
   } else {
     if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention_kernel), drba_attn::kLdsBytes) != hipSuccess)
       return DRBA_ELAUNCH;

@@ -16,6 +16,8 @@ class GMFSS_UNION:
         device = _ops.default_device() if device is None else torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("drba_amd GMFSS_UNION runs on the MI355X HIP path only; there is no CPU fallback")
+        self.device = device
+        _ops.status_init(device)  # the two-term fp16 kernels report an overflow from now on (checked once per call)
         self.model = Model(union=True)
         if isinstance(weights, dict):  # already-loaded state dicts: flownet, metric, feat, fusion, rife
             self.model.load_state_dicts(weights["flownet"], weights["metric"], weights["feat"], weights["fusion"], device)
@@ -30,6 +32,7 @@ class GMFSS_UNION:
         self.pad_size = 128
 
     def inference_ts(self, I0, I1, ts):
+        _ops.check_overflow(getattr(self, "device", None))
         reuse = self.model.reuse(I0, I1, self.scale)
         output = []
         I0s = I1s = None
@@ -71,6 +74,7 @@ class GMFSS_UNION:
         """`lookahead` (not in the reference): the frame that will be I2 of the next call; its pair state
         model.reuse(I2, lookahead) -- FeatureNet, GMFlow in both directions, MetricNet: hundreds of small launches --
         is started on a side stream and overlaps this call's splats and GridNet."""
+        _ops.check_overflow(getattr(self, "device", None))
         reuseI1I0 = self.model.reuse(I1, I0, self.scale) if reuse is None else reuse
         reuseI1I2 = self._pair_state(I1, I2)
         lookahead, _ = split_lookahead(lookahead)

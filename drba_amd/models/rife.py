@@ -41,6 +41,7 @@ class RIFE:
         else:
             sd = convert(torch.load(os.path.join(weights, "flownet.pkl"), map_location="cpu"))
         self.device = device
+        _ops.status_init(device)  # the two-term fp16 kernels report an overflow from now on (checked once per call below)
         self.ifnet = IFNet().to(device).eval()
         self.ifnet.load_state_dict(sd, strict=False)
         self.scale = scale
@@ -58,6 +59,7 @@ class RIFE:
 
     def inference_ts(self, I0, I1, ts):
         """t == 0 / t == 1 return the input tensor objects themselves (reference rife.py:30-33)."""
+        _ops.check_overflow(self.device)
         output, items = [], []
         f0 = f1 = None
         for t in ts:
@@ -354,6 +356,7 @@ class RIFE:
         (next, ts1, next2, ts2, ...) -- the driver reading further ahead and vouching that the calls it announces are plain DRBA
         steps -- lets this call compute the next GROUP - 1 steps together with this one (_drba_group): the following calls
         then only collect their results."""
+        _ops.check_overflow(self.device)  # raises if a family-4 kernel of an earlier call stored inf / NaN (no synchronisation)
         if self._group_out:
             po, self._group_out = self._group_out[0], self._group_out[1:]
             if (reuse and po[0] is I0 and po[1] is I1 and po[2] is I2 and po[4][0] is reuse[0]

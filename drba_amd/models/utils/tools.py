@@ -75,7 +75,11 @@ def to_inp(npInp, dst_size, device=None):
 def to_out(tenInp, src_size, rgb=False):
     """to_cv2(resize(tenInp, src_size)) (tools.py:63-64) as one kernel + the D2H copy.  rgb=True returns the frame in RGB
     order (the flip the reference's writer thread does on the host, tools.py:202, done on the device instead)."""
-    return _ops.to_out(tenInp, src_size, rgb=rgb).cpu().numpy()
+    frame = _ops.to_out(tenInp, src_size, rgb=rgb).cpu().numpy()
+    # the copy has waited for every kernel behind this frame: had one of the two-term fp16 kernels overflowed on the way, its
+    # status byte is set by now -- raise here rather than hand the frame to the writer (ops.check_overflow: a host memory read)
+    _ops.check_overflow(tenInp.device)
+    return frame
 
 
 def distance_calculator(_x):

@@ -135,6 +135,55 @@ def _trace_pos():
     return _lib.load().drba_trace_count() if TRACE is not None else 0
 
 
+# ----------------------------------------------------------------------------- overflow report of kernel family 4
+# The two-term fp16 kernels overflow where fp32 does not (an activation of 65504 * 16 or more, an attention Q / V of 65504).  Every
+# one of them folds the values it stores into a NaN test and sets its byte of a host-mapped status word (include/drba_hip.h,
+# drba_status_word; ABI 8): no extra kernel, no synchronisation.  The model wrappers call status_init(device) when they are
+# built and check_overflow(device) once per step; a set byte raises instead of handing inf / NaN frames on.  The read sees every
+# kernel that has finished by then, a later one at the next step's read (sticky until cleared).
+STATUS_GROUPS = ("conv_split (conv3x3 / deconv4x4)", "conv_dma (32-channel conv3x3)", "conv_ks (K-split conv3x3)", "linear_split",
+                 "window_attention", "stage_conv16", "head_fused16")
+_status_words = {}
+
+
+def status_init(device=None):
+    """Ask the library for the current (or given) device's status word; from then on its family-4 kernels report into it."""
+    device = default_device() if device is None else torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _status_words:
+        return
+    ptr = C.c_void_p()
+    with torch.cuda.device(idx):
+        _lib.check(_lib.load().drba_status_word(C.byref(ptr)), "drba_status_word")
+    _status_words[idx] = C.c_uint64.from_address(ptr.value)
+
+
+def overflow_groups(device=None, clear=True):
+    """Names of the kernel groups that have stored a non-finite value since the last clear (no synchronisation: kernels still
+    in flight report at a later call)."""
+    if not _status_words:  # nobody asked for a status word (status_init): nothing is reported
+        return []
+    device = None if device is None else torch.device(device)
+    idx = device.index if (device is not None and device.index is not None) else torch.cuda.current_device()
+    word = _status_words.get(idx)
+    if word is None or word.value == 0:
+        return []
+    v = int(word.value)
+    if clear:
+        with torch.cuda.device(idx):
+            _lib.load().drba_status_clear()
+    return [STATUS_GROUPS[k] for k in range(len(STATUS_GROUPS)) if (v >> (8 * k)) & 0xff]
+
+
+def check_overflow(device=None):
+    bad = overflow_groups(device)
+    if bad:
+        raise _lib.DrbaHipError(
+            "non-finite values out of the two-term fp16 kernels (family 4): " + ", ".join(bad) + " -- an activation beyond "
+            "65504 * 16 (attention Q / V: 65504) overflowed fp16, or an input was already inf / NaN; the frames of this and the "
+            "previous step are not to be trusted.  drba_amd.ops.set_precision({0, 1, 2, 3}) keeps every operand at 24 bits")
+
+
 # ----------------------------------------------------------------------------- splat / warp / drm
 def softsplat(tenIn, tenFlow, tenMetric, strMode, out=None):
     """`out` (not in the reference): a contiguous [N,C,H,W] destination, e.g. a channel slice of a concatenation buffer."""
@@ -418,12 +467,26 @@ def set_precision(families):
     CONV_FAMILIES = {int(f) for f in families}
 
 
-def _tuned_get(shape_key):
-    return _tuned.get((shape_key, tuple(sorted(CONV_FAMILIES))))
+def two_term_ok(w):
+    """Can kernel family 4 hold these weights?  It keeps a weight as fp16(w) + 2^-11 fp16(...) without a pre-scale: |w| >= 65504 (or
+    a non-finite one) is beyond it -- the library's *_pack entry points refuse such a tensor (DRBA_EUNSUPPORTED, ABI 8) -- and the
+    layer is run by a 24-bit family instead (its own tuner entry: _families)."""
+    w = w.detach().float()
+    return bool(torch.isfinite(w).all()) and (w.numel() == 0 or float(w.abs().max()) < 65504.0)
 
 
-def _tune(shape_key, candidates, run, reps=3):
-    shape_key = (shape_key, tuple(sorted(CONV_FAMILIES)))  # a winner of one family set is not offered to another
+def _families(layer_ok=True):
+    """The kernel families a layer may use: CONV_FAMILIES, without family 4 for a layer whose weights it cannot hold."""
+    return CONV_FAMILIES if layer_ok else CONV_FAMILIES - {4}
+
+
+def _tuned_get(shape_key, families=None):
+    return _tuned.get((shape_key, tuple(sorted(CONV_FAMILIES if families is None else families))))
+
+
+def _tune(shape_key, candidates, run, reps=3, families=None):
+    # a winner of one family set is not offered to another
+    shape_key = (shape_key, tuple(sorted(CONV_FAMILIES if families is None else families)))
     if shape_key in _tuned:
         return _tuned[shape_key]
     best, best_ms = None, None
@@ -463,6 +526,7 @@ class Conv3x3:
         self.post_slope = float(post_slope)
         self.w_host = weight.detach().float().cpu().contiguous()
         self.cout, self.cin = self.w_host.shape[:2]
+        self.two_term_ok = two_term_ok(self.w_host)  # False: family 4 is not offered to this layer
         self.device = device
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
         self.beta = None if beta is None else beta.detach().float().reshape(-1).to(device).contiguous()
@@ -495,12 +559,13 @@ class Conv3x3:
         if self.force_cfg is not None:
             cfg = self.force_cfg
         elif AUTOTUNE and x.is_cuda:
+            fam = _families(self.two_term_ok)
             cands = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_stride(c) == self.stride
-                     and lib.drba_conv3x3_cfg_family(c) in CONV_FAMILIES
+                     and lib.drba_conv3x3_cfg_family(c) in fam
                      and lib.drba_conv3x3_packed_floats(self.cin, self.cout, c) > 0]  # 0: the config cannot run this layer
             cfg = _tune(("conv3x3", n, cin, self.cout, h, w, self.stride), cands, lambda c: lib.drba_conv3x3(
                 _p(x), _p(self._pack(c)), _p(self.bias), _p(self.beta), _p(res), _p(res2), _p(out), n, cin, h, w,
-                self.cout, self.stride, self.act, self.post_slope, pre, ps, c, _stream()))
+                self.cout, self.stride, self.act, self.post_slope, pre, ps, c, _stream()), families=fam)
             self._keep.add(cfg)  # a layer can have one winner per batch size (block0: N=1 in calc_flow, N=2 stacked)
             for c in [c for c in self._packed if c not in self._keep]:
                 del self._packed[c]  # drop the packings of the losing candidates
@@ -523,6 +588,7 @@ class Deconv4x4:
         self.pre_slope = None if pre_slope is None else float(pre_slope)
         self.w_host = weight.detach().float().cpu().contiguous()  # [Cin, Cout, 4, 4]
         self.cin, self.cout = self.w_host.shape[:2]
+        self.two_term_ok = two_term_ok(self.w_host)
         self.device = device
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
         self.ps = 1 if pixel_shuffle else 0
@@ -550,11 +616,12 @@ class Deconv4x4:
         if self.force_cfg is not None:
             cfg = self.force_cfg
         elif AUTOTUNE and x.is_cuda:
-            cands = [c for c in range(lib.drba_deconv4x4_num_cfgs()) if lib.drba_deconv4x4_cfg_family(c) in CONV_FAMILIES
+            fam = _families(self.two_term_ok)
+            cands = [c for c in range(lib.drba_deconv4x4_num_cfgs()) if lib.drba_deconv4x4_cfg_family(c) in fam
                      and lib.drba_deconv4x4_packed_floats(cin, self.cout, c) > 0]
             cfg = _tune(("deconv4x4", n, cin, self.cout, h, w, self.ps), cands,
                         lambda c: lib.drba_deconv4x4s2(_p(x), _p(self._pack(c)), _p(self.bias), _p(out), n, cin, h, w,
-                                                       self.cout, self.ps, pre, ps_, c, _stream()))
+                                                       self.cout, self.ps, pre, ps_, c, _stream()), families=fam)
             self._keep.add(cfg)
             for c in [c for c in self._packed if c not in self._keep]:
                 del self._packed[c]
@@ -594,7 +661,7 @@ class ConvChain:
             if isinstance(layer, Deconv4x4):
                 key = ("deconv4x4", n, layer.cin, layer.cout, hh, ww, layer.ps)
                 cfg = layer.force_cfg if layer.force_cfg is not None else (
-                    _tuned_get(key) if AUTOTUNE else lib.drba_deconv4x4_pick_cfg(layer.cin, layer.cout, hh, ww))
+                    _tuned_get(key, _families(layer.two_term_ok)) if AUTOTUNE else lib.drba_deconv4x4_pick_cfg(layer.cin, layer.cout, hh, ww))
                 if cfg is None or layer.pre_slope is not None:
                     return None
                 d.deconv, d.pixel_shuffle, d.stride, d.act, d.residual = 1, layer.ps, 1, 0, 0
@@ -606,7 +673,7 @@ class ConvChain:
                 key = ("conv3x3", n, layer.cin, layer.cout, hh, ww, layer.stride)
                 ho, wo = (hh - 1) // layer.stride + 1, (ww - 1) // layer.stride + 1
                 cfg = layer.force_cfg if layer.force_cfg is not None else (
-                    _tuned_get(key) if AUTOTUNE else lib.drba_conv3x3_pick_cfg(layer.cin, layer.cout, ho, wo, layer.stride))
+                    _tuned_get(key, _families(layer.two_term_ok)) if AUTOTUNE else lib.drba_conv3x3_pick_cfg(layer.cin, layer.cout, ho, wo, layer.stride))
                 if cfg is None or layer.pre_slope is not None or layer.post_slope != 0.0:
                     return None
                 d.deconv, d.pixel_shuffle, d.stride, d.act, d.residual = 0, 0, layer.stride, layer.act, 1 if res else 0
@@ -676,7 +743,7 @@ def head_fused(img, layers, holder, planar=True):
         return None
     lib = _lib.load()
     # the two-term fp16 form of the kernel (head_fused16.hip) when the conv tuner may use kernel family 4, else fp32 MFMA
-    two = HEAD_TWO_TERM if HEAD_TWO_TERM is not None else (4 in CONV_FAMILIES)
+    two = HEAD_TWO_TERM if HEAD_TWO_TERM is not None else (4 in CONV_FAMILIES and all(l.two_term_ok for l in layers))
     attr, sfx = ("_fused_pack16", "16") if two else ("_fused_pack", "")
     launch = getattr(lib, "drba_head_fused" + sfx)
     pk = getattr(holder, attr, None)
@@ -951,7 +1018,7 @@ STAGE_CONV_TWO_TERM = None  # None: follow CONV_FAMILIES (family 4 allowed -> st
 
 
 def _stage_conv_two_term(conv):
-    return bool(STAGE_CONV_TWO_TERM if STAGE_CONV_TWO_TERM is not None else (4 in CONV_FAMILIES))
+    return bool(STAGE_CONV_TWO_TERM if STAGE_CONV_TWO_TERM is not None else (4 in CONV_FAMILIES and conv.two_term_ok))
 
 
 STAGE_CONV_S2 = True  # the scale-2 stage fused the same way (stage_conv16_s2; A/B: tools/ab_bench.py --no-stage-conv-s2)
@@ -1256,6 +1323,7 @@ class LinearSplit:
         allows family 4."""
         self._w = weight.detach().float().cpu().contiguous()
         self.n, self.k = self._w.shape
+        self.two_term_ok = two_term_ok(self._w)  # False: three bf16 terms whatever CONV_FAMILIES says
         self._terms_arg = None if terms is None else int(terms)
         self._device, self._packs = device, {}
         if _lib.load().drba_linear_split_packed_floats(self.k, self.n, self.terms) == 0:
@@ -1266,7 +1334,7 @@ class LinearSplit:
     @property
     def terms(self):
         """Resolved at every call (ops.set_precision may change the family set while the object lives)."""
-        return self._terms_arg if self._terms_arg is not None else (2 if 4 in CONV_FAMILIES else 3)
+        return self._terms_arg if self._terms_arg is not None else (2 if (4 in CONV_FAMILIES and self.two_term_ok) else 3)
 
     @property
     def packed(self):

@@ -64,7 +64,7 @@ def ifnet_state_dict(seed=0):
         if key.endswith("beta"):
             t = torch.rand(shape, generator=g) * 0.5 + 0.25
         elif key.endswith("bias"):
-            t = torch.randn(shape, generator=g) * (0.002 if key == "backbone.conv2.bias" and damp_transformer else 0.02)
+            t = torch.randn(shape, generator=g) * 0.02
         else:
             if "lastconv" in key or "cnn3" in key:  # ConvTranspose2d: each output gets 2x2 taps
                 fan_in = shape[0] * 4

@@ -32,7 +32,9 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  7: drba_rife_splat_ws_floats -- the workspace of drba_flow_reverse / drba_drm_rife_linear(_batch) grew by a reach map in
+/* ABI version.  8: drba_status_word / drba_status_clear (the always-on, synchronisation-free overflow report of kernel family 4); the
+ * *_pack entry points of family 4 refuse (DRBA_EUNSUPPORTED) a weight the two-term fp16 form cannot hold (|w| >= 65504 or non-finite).
+ * 7: drba_rife_splat_ws_floats -- the workspace of drba_flow_reverse / drba_drm_rife_linear(_batch) grew by a reach map in
  * front (scratch) and one flag per 32 x 16 output tile behind (same zero-on-entry, zero-on-return contract for everything but the map).  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form, scale 1 and 2), drba_stage_item_t grew by
  * img0_x4 / img1_x4 ([H][W][4] frames), drba_to_inp_x4, drba_rgbx, drba_drm_rife_linear_batch, drba_set_range_check (debug).  5: kernel family 4 (two-term fp16 split; configuration ids appended behind every earlier id of drba_conv3x3 /
  * drba_deconv4x4s2, so no earlier id changes meaning), drba_deconv4x4_cfg_family, and a `terms` argument (3 or 2) on the
@@ -44,7 +46,7 @@ extern "C" {
  * workspace that must be ZERO on entry (they leave it zero on return: self-cleaning accumulator) instead of clearing it
  * themselves; batched stage entry points added; drba_conv3x3_cfg_family added and configuration ids 19 (LDS-DMA, 32
  * channels) / 20 (K split across waves) behind drba_conv3x3; the allocation exception above.  1: the first release. */
-#define DRBA_ABI_VERSION 7  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
+#define DRBA_ABI_VERSION 8  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 /* ABI 6, debug: with the range check on, every entry point that ran a kernel of family 4 (two fp16 terms per operand:
@@ -55,6 +57,24 @@ const char *drba_error_string(int code);
  * where families 0 - 3 keep fp32's range; a non-finite INPUT reads the same.  Returns the previous setting.  The Python
  * layer switches it on when DRBA_CHECK_RANGE=1 is set (drba_amd/_lib.py). */
 int drba_set_range_check(int on);
+/* ABI 8, always on once requested, no synchronisation: every kernel of family 4 (the list above) tests the values it STORES and,
+ * when one is inf / NaN, writes 1 into its byte of the current device's status word -- 8 bytes of host-mapped memory, one byte
+ * per kernel group (DRBA_STATUS_*), sticky until drba_status_clear().  The family's operands overflow fp16 where families 0 - 3
+ * keep fp32's range (an activation of |x| >= 65504 * 16, an attention Q / V of 65504; an overflowed or non-finite INPUT reads the
+ * same: it reaches the stored value), so a caller reads the word whenever it likes -- the model wrappers once per step -- and
+ * raises instead of handing inf on; it sees every kernel that has FINISHED by then, a later one at the next read.
+ * drba_status_word: allocates the word for the CURRENT device on the first call (hipHostMalloc: not inside a stream capture;
+ * never freed) and returns its HOST address; until it has been called for a device the kernels launched there report nothing.
+ * The cost on the kernels is one multiply-add per stored value in their epilogues. */
+#define DRBA_STATUS_CONV_SPLIT 0 /* drba_conv3x3 / drba_deconv4x4s2, family-4 ids of conv_split.hip */
+#define DRBA_STATUS_CONV_DMA 1   /* ... of conv_dma.hip (32 channels) */
+#define DRBA_STATUS_CONV_KS 2    /* ... of conv_ks.hip (K split) */
+#define DRBA_STATUS_LINEAR 3     /* drba_linear_split*, terms = 2 */
+#define DRBA_STATUS_ATTENTION 4  /* drba_window_attention, terms = 2 */
+#define DRBA_STATUS_STAGE 5      /* drba_stage_conv16_batch */
+#define DRBA_STATUS_HEAD 6       /* drba_head_fused16 */
+int drba_status_word(volatile unsigned long long **host_word);
+int drba_status_clear(void);
 
 /* ---- kernel trace (measurement only; bench.py's roofline object) ---------------------------
  * Between drba_trace_begin() and drba_trace_end() every kernel the library launches (on any stream, from the one host

@@ -1,1 +1,1 @@
-from drba_amd.models.model_gmfss_union.FeatureNet import FeatureNet  # noqa: F401
+from drba_amd.models.model_gmfss.FeatureNet import FeatureNet  # noqa: F401

@@ -1,1 +1,1 @@
-from drba_amd.models.model_gmfss_union.FusionNet import GridNet  # noqa: F401
+from drba_amd.models.model_gmfss.FusionNet import GridNet  # noqa: F401

@@ -1,1 +1,1 @@
-from drba_amd.models.model_gmfss_union.GMFSS import Model  # noqa: F401
+from drba_amd.models.model_gmfss.GMFSS import Model  # noqa: F401

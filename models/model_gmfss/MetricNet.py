@@ -1,1 +1,1 @@
-from drba_amd.models.model_gmfss_union.MetricNet import MetricNet  # noqa: F401
+from drba_amd.models.model_gmfss.MetricNet import MetricNet, backwarp  # noqa: F401

@@ -266,3 +266,93 @@ def test_abi_version_has_one_source():
     assert re.search(r"ABI version\.\s+%d:" % _lib.ABI_VERSION, hdr), "the header's version history lacks the current version"
     for fn in ("__graft_entry__.py", "bench.py", os.path.join("drba_amd", "csrc", "api_misc.hip")):
         assert not re.search(r"abi_version\(\)\s*(==|!=|>=)\s*\d", open(os.path.join(ROOT, fn)).read()), fn
+
+
+def test_family4_pack_refuses_weights_beyond_fp16():
+    """ABI 8: the two-term fp16 form holds a weight as fp16(w) + 2^-11 fp16(...) without a pre-scale, so every *_pack entry point
+    of kernel family 4 returns DRBA_EUNSUPPORTED for |w| >= 65504 or a non-finite weight (it used to pack inf silently), while the
+    24-bit families pack the same tensor; the host layer then never offers family 4 to that layer (ops.two_term_ok)."""
+    from drba_amd import ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+
+    def conv_rc(w, cfg):
+        cout, cin = w.shape[:2]
+        buf = torch.empty(lib.drba_conv3x3_packed_floats(cin, cout, cfg))
+        return lib.drba_conv3x3_pack(C.c_void_p(w.data_ptr()), C.c_void_p(buf.data_ptr()), cin, cout, cfg)
+
+    seen = set()
+    for cin, cout in ((32, 32), (64, 64), (192, 192), (52, 48)):
+        good = torch.randn(cout, cin, 3, 3, generator=g)
+        for bad_value in (65504.0, -1.0e5, float("inf"), float("nan")):
+            bad = good.clone()
+            bad[cout // 2, cin // 3, 1, 2] = bad_value
+            for cfg in range(lib.drba_conv3x3_num_cfgs()):
+                if lib.drba_conv3x3_packed_floats(cin, cout, cfg) == 0:
+                    continue
+                fam = lib.drba_conv3x3_cfg_family(cfg)
+                assert conv_rc(good, cfg) == 0, (cin, cout, cfg)
+                assert conv_rc(bad, cfg) == (-2 if fam == 4 else 0), (cin, cout, cfg, fam, bad_value)
+                seen.add(fam)
+        edge = good.clone()
+        edge[0, 0, 0, 0] = 65503.0  # the largest magnitudes the form holds stay packable
+        assert all(conv_rc(edge, c) == 0 for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_packed_floats(cin, cout, c) > 0)
+    assert seen >= {0, 1, 2, 3, 4}
+    # transposed convolution
+    wd = torch.randn(64, 52, 4, 4, generator=g)
+    wb = wd.clone()
+    wb[3, 5, 0, 1] = 7.0e4
+    fams = set()
+    for cfg in range(lib.drba_deconv4x4_num_cfgs()):
+        n = lib.drba_deconv4x4_packed_floats(64, 52, cfg)
+        if n == 0:
+            continue
+        buf = torch.empty(n)
+        fam = lib.drba_deconv4x4_cfg_family(cfg)
+        fams.add(fam)
+        assert lib.drba_deconv4x4_pack(C.c_void_p(wd.data_ptr()), C.c_void_p(buf.data_ptr()), 64, 52, cfg) == 0
+        assert lib.drba_deconv4x4_pack(C.c_void_p(wb.data_ptr()), C.c_void_p(buf.data_ptr()), 64, 52, cfg) == (-2 if fam == 4 else 0)
+    assert 4 in fams and len(fams) > 1
+    # linear layers: terms = 2 refuses, terms = 3 packs
+    wl = torch.randn(128, 256, generator=g)
+    wlb = wl.clone()
+    wlb[100, 17] = -65504.0
+    for terms in (2, 3):
+        buf = torch.empty(lib.drba_linear_split_packed_floats(256, 128, terms))
+        assert lib.drba_linear_split_pack(C.c_void_p(wl.data_ptr()), C.c_void_p(buf.data_ptr()), 256, 128, terms) == 0
+        assert lib.drba_linear_split_pack(C.c_void_p(wlb.data_ptr()), C.c_void_p(buf.data_ptr()), 256, 128, terms) == (-2 if terms == 2 else 0)
+    # the fused stage convolution and the fused encoder (two-term forms)
+    ws = torch.randn(16, 52, 3, 3, generator=g)
+    buf = torch.empty(lib.drba_stage_conv16_packed_floats(16))
+    assert lib.drba_stage_conv16_pack(C.c_void_p(ws.data_ptr()), 16, C.c_void_p(buf.data_ptr())) == 0
+    ws[15, 51, 2, 2] = 1.0e9
+    assert lib.drba_stage_conv16_pack(C.c_void_p(ws.data_ptr()), 16, C.c_void_p(buf.data_ptr())) == -2
+    hw = [torch.randn(16, 3, 3, 3, generator=g), torch.randn(16, generator=g), torch.randn(16, 16, 3, 3, generator=g), torch.randn(16, generator=g),
+          torch.randn(16, 16, 3, 3, generator=g), torch.randn(16, generator=g), torch.randn(16, 16, 4, 4, generator=g), torch.randn(16, generator=g)]
+    buf = torch.empty(lib.drba_head_fused16_packed_floats())
+    ptrs = lambda ts: [C.c_void_p(t.data_ptr()) for t in ts]  # noqa: E731
+    assert lib.drba_head_fused16_pack(*ptrs(hw), C.c_void_p(buf.data_ptr())) == 0
+    for k in (0, 2, 4, 6):
+        bad = [t.clone() for t in hw]
+        bad[k].view(-1)[7] = float("-inf")
+        assert lib.drba_head_fused16_pack(*ptrs(bad), C.c_void_p(buf.data_ptr())) == -2, k
+    buf32 = torch.empty(lib.drba_head_fused_packed_floats())
+    bad = [t.clone() for t in hw]
+    bad[2].view(-1)[7] = 1.0e6
+    assert lib.drba_head_fused_pack(*ptrs(bad), C.c_void_p(buf32.data_ptr())) == 0  # exact-fp32 form: fp32's range
+    # ... and the host layer's mirror of the rule: such a layer is never offered family 4
+    assert ops.two_term_ok(wl) and not ops.two_term_ok(wlb) and not ops.two_term_ok(torch.tensor([float("nan")]))
+    conv = ops.Conv3x3(wb[:52, :52, :3, :3].contiguous(), None, device="cpu")
+    assert not conv.two_term_ok and 4 not in ops._families(conv.two_term_ok) and 4 in ops._families(True)
+    lin = ops.LinearSplit(wlb, None, device="cpu")
+    assert lin.terms == 3 and ops.LinearSplit(wl, None, device="cpu").terms == 2
+
+
+def test_status_word_entry_points_without_gpu():
+    """drba_status_word / drba_status_clear (ABI 8) reject a null argument; without a GPU there is no device to allocate for."""
+    lib = _lib.load()
+    assert lib.drba_status_word(None) == -1
+    if not torch.cuda.is_available():
+        p = C.c_void_p()
+        assert lib.drba_status_word(C.byref(p)) != 0
+        assert lib.drba_status_clear() != 0

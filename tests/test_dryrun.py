@@ -186,3 +186,43 @@ def test_rife_many_items_and_scale_plumbing(dry, scale, n_items):
     else:  # one launch per group of items, no flow update pass at all
         assert dry.calls.get("drba_warp_blend_lazy_batch", 0) == 2 * groups and dry.calls.get("drba_ifblock_update_batch", 0) == 0
         assert dry.calls.get("drba_ifblock_input_lazy_batch", 0) > 0
+
+
+def test_non_union_module_paths_build_the_non_union_network(dry):
+    """The reference has TWO module trees: models/model_gmfss (GMFSS.py:19-24: GridNet(6*2, ...), MetricNet.py:23-44: no Tanh()*10)
+    and models/model_gmfss_union (GridNet(9, ...), Tanh()*10).  Every import path a reference user has resolves here, and the
+    non-union path builds the non-union network by DEFAULT (it used to alias the union classes with the union defaults)."""
+    import importlib
+    for mod, names in (("models.model_gmfss.GMFSS", ["Model"]), ("models.model_gmfss.MetricNet", ["MetricNet", "backwarp"]),
+                       ("models.model_gmfss.FeatureNet", ["FeatureNet"]), ("models.model_gmfss.FusionNet", ["GridNet"]),
+                       ("models.model_gmfss_union.GMFSS", ["Model"]), ("models.model_gmfss_union.MetricNet", ["MetricNet"]),
+                       ("models.model_gmfss_union.FeatureNet", ["FeatureNet"]), ("models.model_gmfss_union.FusionNet", ["GridNet"]),
+                       ("models.gmflow.gmflow", ["GMFlow"]), ("models.gmfss", ["GMFSS"]), ("models.gmfss_union", ["GMFSS_UNION"]),
+                       ("models.rife", ["RIFE"]), ("models.rife_426_heavy.IFNet_HDv3", ["IFNet"]),
+                       ("models.rife_426_heavy.warplayer", ["warp"]), ("models.softsplat.softsplat", ["softsplat"]),
+                       ("models.softsplat.softsplat_torch", ["softsplat"]), ("models.drm", ["calc_drm_rife", "calc_drm_gmfss", "get_drm_t"]),
+                       ("models.utils.tools", ["VideoFI_IO", "to_inp", "to_out", "check_scene", "TMapper"])):
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
+    from models.model_gmfss.GMFSS import Model
+    from models.model_gmfss.MetricNet import MetricNet
+    from models.model_gmfss_union.GMFSS import Model as UnionModel
+    from models.model_gmfss_union.MetricNet import MetricNet as UnionMetricNet
+    cpu = torch.device("cpu")
+    sds = synth.gmfss_union_state_dicts(0)
+    fusion12 = synth.seeded_state_dict(synth.gridnet_shapes(12, "head"), 0, "grid.")
+    m = Model()  # no arguments, as in the reference
+    assert m.union is False and UnionModel().union is True
+    m.load_state_dicts(sds["flownet"], sds["metric"], sds["feat"], fusion12, cpu)
+    assert m.fusionnet.head[0].first.cin == 12          # GridNet(6 * 2, ...): img0, I1t, I2t, img1
+    assert m.metricnet.conv_out.act == ops.Conv3x3.ACTS[None]          # metric_out ends on the convolution
+    assert MetricNet(sds["metric"], cpu).conv_out.act == ops.Conv3x3.ACTS[None]
+    assert UnionMetricNet(sds["metric"], cpu).conv_out.act == ops.Conv3x3.ACTS["tanh10"]
+    u = UnionModel()
+    u.load_state_dicts(sds["flownet"], sds["metric"], sds["feat"], sds["fusion"], cpu)
+    assert u.fusionnet.head[0].first.cin == 9 and u.metricnet.conv_out.act == ops.Conv3x3.ACTS["tanh10"]
+    # the splat stage hands the non-union GridNet its 12-channel input: [img0, I1t, I2t, img1]
+    I0, I1 = torch.rand(1, 3, 128, 256), torch.rand(1, 3, 128, 256)
+    bufs = m.fusion_inputs(I0, I1, m.reuse(I0, I1, 1.0), 0.4, 0.6)
+    assert bufs[0].shape == (1, 12, 64, 128) and [b.shape[1] for b in bufs[1:]] == [128, 256, 384]

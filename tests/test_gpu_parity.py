@@ -250,14 +250,20 @@ def test_two_term_and_three_term_conv_families_agree(hip_backend, monkeypatch):
     assert err <= 2e-5, err
 
 
-def test_family4_range_check_reports_overflow_instead_of_inf(hip_backend):
-    """Kernel family 4 holds an operand as fp16(x / 16) + ...: an activation of 65504 * 16 ~ 1.05e6 or more (a weight, an
-    attention Q / V of 65504 or more) overflows where families 0-3 keep fp32's range.  With the debug range check on
-    (drba_set_range_check / DRBA_CHECK_RANGE=1) the entry point returns DRBA_EUNSUPPORTED instead of handing inf / NaN on;
-    below the bound the same call passes, and the 24-bit families take the large input as it is."""
+def test_family4_overflow_is_reported_by_default_without_a_sync(hip_backend):
+    """Kernel family 4 holds an operand as fp16(x / 16) + ...: an activation of 65504 * 16 ~ 1.05e6 or more (an attention Q / V
+    of 65504 or more) overflows where families 0-3 keep fp32's range.  ALWAYS ON (ABI 8): every family-4 kernel sets its byte of
+    the device's host-mapped status word when a value it stores is inf / NaN -- no extra kernel, no synchronisation -- and
+    ops.check_overflow (called by the model wrappers once per call and by tools.to_out behind its copy) raises.  A weight
+    beyond fp16's range never reaches a family-4 kernel: its pack refuses it and the tuner is not offered family 4 for that
+    layer.  The debug range check (drba_set_range_check / DRBA_CHECK_RANGE=1: a scan + a stream sync per call) still turns
+    the overflow into an error at the call itself."""
     from drba_amd import _lib, ops
     lib = _lib.load()
     dev = hip_backend.dev
+    ops.status_init(dev)
+    torch.cuda.synchronize()
+    ops.overflow_groups(dev)  # whatever earlier tests left
     g = torch.Generator().manual_seed(3)
     f4 = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_family(c) == 4 and lib.drba_conv3x3_cfg_stride(c) == 1
           and lib.drba_conv3x3_packed_floats(64, 64, c) > 0]
@@ -268,31 +274,117 @@ def test_family4_range_check_reports_overflow_instead_of_inf(hip_backend):
     x_big = x_ok.clone()
     x_big[0, 5, 3, 7] = 2.0e6   # one activation past 65504 * 16
     ref = torch.nn.functional.conv2d(x_big.double(), wt.double(), None, padding=1)
+
+    def flagged(run):
+        """Did `run` set a status byte?  (the word is read after the stream has drained: no kernel of `run` is still in flight)"""
+        y = run()
+        torch.cuda.synchronize()
+        return ops.overflow_groups(dev), y
+
+    for cfg in f4:  # the default path: the overflow is reported, below the bound nothing is
+        conv = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=cfg)
+        groups, y = flagged(lambda: conv(x_ok.to(dev)))
+        assert groups == [] and bool(torch.isfinite(y).all()), (cfg, groups)
+        groups, y = flagged(lambda: conv(x_big.to(dev)))
+        assert len(groups) == 1 and groups[0].startswith("conv_"), (cfg, groups)
+        assert not bool(torch.isfinite(y).all())
+        conv(x_big.to(dev))
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.DrbaHipError, match="family 4"):
+            ops.check_overflow(dev)
+        ops.check_overflow(dev)  # cleared by the raise: sticky until read, not beyond
+        wb = wt.clone()
+        wb[3, 4, 1, 1] = 1.0e5  # a weight past fp16's range (no pre-scale on weights): refused at pack time ...
+        with pytest.raises(_lib.DrbaHipError, match="unsupported"):
+            ops.Conv3x3(wb, torch.zeros(64), 1, None, None, device=dev, cfg=cfg)(x_ok.to(dev) * 1e-6)
+    # ... and a layer built without a pinned configuration is tuned among the 24-bit families only
+    wb = wt.clone()
+    wb[3, 4, 1, 1] = 1.0e5
+    auto = ops.Conv3x3(wb, torch.zeros(64), 1, None, None, device=dev)
+    xs = x_ok * 1e-6
+    ya = auto(xs.to(dev))
+    refb = torch.nn.functional.conv2d(xs.double(), wb.double(), None, padding=1)
+    assert float((ya.double().cpu() - refb).abs().max()) <= 5e-6 * float(refb.abs().max())
+    assert all(lib.drba_conv3x3_cfg_family(c) != 4 for c in auto._keep)
+    got = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=f1[0])(x_big.to(dev))  # 24-bit family: fp32's range
+    torch.cuda.synchronize()
+    assert ops.overflow_groups(dev) == []
+    assert float((got.double().cpu() - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+    # linear layers, attention, the fused stage kernel and the fused encoder report into their own bytes
+    lin = ops.LinearSplit(torch.randn(128, 128, generator=g) / 11.0, None, device=dev, terms=2)
+    t = torch.randn(256, 128, generator=g)
+    groups, y = flagged(lambda: lin(t.to(dev)))
+    assert groups == [] and bool(torch.isfinite(y).all())
+    t[17, 5] = 2.0e6
+    groups, _ = flagged(lambda: lin(t.to(dev)))
+    assert groups == ["linear_split"], groups
+    groups, y = flagged(lambda: ops.LinearSplit(torch.randn(128, 128, generator=g) / 11.0, None, device=dev, terms=3)(t.to(dev)))
+    assert groups == [] and bool(torch.isfinite(y).all())
+    q, k, v = [torch.randn(1, 32 * 32, 128, generator=g) for _ in range(3)]
+    groups, _ = flagged(lambda: ops.window_attention(q.to(dev), k.to(dev), v.to(dev), 32, 32, 2, False, 128 ** -0.5, terms=2))
+    assert groups == [], groups
+    vb = v.clone()
+    vb[0, 100, 7] = 7.0e4  # an attention V past 65504
+    groups, _ = flagged(lambda: ops.window_attention(q.to(dev), k.to(dev), vb.to(dev), 32, 32, 2, False, 128 ** -0.5, terms=2))
+    assert groups == ["window_attention"], groups
+    from drba_amd.models.rife_426_heavy.IFNet_HDv3 import Head
+    from drba_amd.utils import synth
+    sd = synth.ifnet_state_dict(seed=0)
+    head = Head(sd, "encode.", dev)
+    img = torch.rand(1, 3, 64, 96, generator=g)
+    groups, _ = flagged(lambda: head(img.to(dev), planar=False))
+    assert groups == [], groups
+    imgb = img.clone()
+    imgb[0, 1, 20, 30] = 3.0e7  # (the encoder's first layer sees |x| * |w| summed: far beyond 65504 * 16)
+    groups, _ = flagged(lambda: head(imgb.to(dev), planar=False))
+    assert groups == ["head_fused16"], groups
+    sd_big = {kk: vv.clone() for kk, vv in sd.items()}
+    sd_big["encode.cnn1.weight"][2, 3, 1, 1] = 1.0e5  # an encoder weight beyond fp16: the exact-fp32 fused encoder takes the layer
+    hb = Head(sd_big, "encode.", dev)
+    groups, fb = flagged(lambda: hb(img.to(dev), planar=False))
+    assert groups == [] and bool(torch.isfinite(fb).all())
+    # the debug range check still raises at the call
     was = lib.drba_set_range_check(1)
     try:
-        for cfg in f4:
-            conv = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=cfg)
-            assert bool(torch.isfinite(conv(x_ok.to(dev))).all())
-            with pytest.raises(_lib.DrbaHipError, match="unsupported"):
-                conv(x_big.to(dev))
-            with pytest.raises(_lib.DrbaHipError, match="unsupported"):  # a weight past fp16's range (no pre-scale on weights)
-                wb = wt.clone()
-                wb[3, 4, 1, 1] = 1.0e5
-                ops.Conv3x3(wb, torch.zeros(64), 1, None, None, device=dev, cfg=cfg)(x_ok.to(dev) * 1e-6)
-        got = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=f1[0])(x_big.to(dev))  # 24-bit family: fp32's range
-        assert float((got.double().cpu() - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
-        lin = ops.LinearSplit(torch.randn(128, 128, generator=g) / 11.0, None, device=dev, terms=2)
-        t = torch.randn(256, 128, generator=g)
-        assert bool(torch.isfinite(lin(t.to(dev))).all())
-        t[17, 5] = 2.0e6
+        conv = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=f4[0])
         with pytest.raises(_lib.DrbaHipError, match="unsupported"):
-            lin(t.to(dev))
-        assert bool(torch.isfinite(ops.LinearSplit(torch.randn(128, 128, generator=g) / 11.0, None, device=dev, terms=3)(t.to(dev))).all())
+            conv(x_big.to(dev))
     finally:
         lib.drba_set_range_check(was)
-    # off (the default): the same overflow goes through silently -- what the check exists to catch
-    y = ops.Conv3x3(wt, torch.zeros(64), 1, None, None, device=dev, cfg=f4[0])(x_big.to(dev))
-    assert not bool(torch.isfinite(y).all())
+    torch.cuda.synchronize()
+    ops.overflow_groups(dev)
+
+
+def test_model_wrappers_raise_on_family4_overflow(hip_backend):
+    """RIFE end to end: a frame far outside [0, 1] overflows the two-term fp16 kernels; the wrapper's per-call check (and
+    tools.to_out behind its copy) raises instead of handing inf / NaN frames on -- and says which kernels; with the family
+    switched off (ops.set_precision({0, 1, 2, 3})) the same input goes through in fp32's range."""
+    from drba_amd import _lib, ops
+    from drba_amd.models.rife import RIFE
+    from drba_amd.models.utils import tools
+    from drba_amd.utils import synth
+    dev = hip_backend.dev
+    torch.cuda.synchronize()
+    ops.overflow_groups(dev)
+    sd = synth.ifnet_state_dict(seed=0)
+    m = RIFE(weights=sd, scale=1.0, device=dev)
+    clip = synth.make_clip(3, 128, 192, seed=1234)
+    fr = [torch.from_numpy(f.transpose(2, 0, 1)).unsqueeze(0).float().div(255.0).to(dev) for f in clip]
+    ts = np.array([0.75, 1.25])
+    out, reuse = m.inference_ts_drba(fr[0], fr[1], fr[2], ts, None, True)
+    assert tools.to_out(out[0], (128, 192)).shape == (128, 192, 3)  # in range: nothing raised
+    bad = [f.clone() for f in fr]
+    bad[1][0, 2, 40, 50] = 1.0e9
+    out, _ = m.inference_ts_drba(bad[0], bad[1], bad[2], ts, None, True)
+    with pytest.raises(_lib.DrbaHipError, match="family 4"):
+        tools.to_out(out[0], (128, 192))
+    m.inference_ts_drba(bad[0], bad[1], bad[2], ts, None, True)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.DrbaHipError, match="head_fused16|stage_conv16|conv_"):
+        m.inference_ts_drba(fr[0], fr[1], fr[2], ts, None, True)  # the NEXT call sees what the previous one left
+    out, _ = m.inference_ts_drba(fr[0], fr[1], fr[2], ts, None, True)  # (cleared by the raise)
+    torch.cuda.synchronize()
+    assert ops.overflow_groups(dev) == []
 
 
 def test_fused_stage_kernels_against_fp64(hip_backend):
