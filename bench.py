@@ -297,6 +297,15 @@ def _arithmetic_note():
             "conv_families": sorted(ops.CONV_FAMILIES)}
 
 
+def _dtype_note():
+    """The line's `dtype`: tensors, accumulation and outputs are fp32 either way; what the MFMA operands are depends on the
+    kernel families allowed (the `arithmetic` object spells it out)."""
+    from drba_amd import ops
+    if 4 in ops.CONV_FAMILIES:
+        return "f32 (2xfp16-term MFMA operands = 22 significand bits, fp32 accumulate)"
+    return "f32 (24-bit MFMA operands: fp32 MFMA / 3xbf16 terms, fp32 accumulate)"
+
+
 def _two_term(name):
     """True for the two-term fp16 instantiations of the split families (the last template argument, PL, is 2):
     conv_split_mfma<SplitCfg<M, RW, MW, NT, 2>, ...>, conv_dma1<PRE, RL, 2>, conv_ks<KW, PRE, RL, DW, 2>, linear_split_kernel<LinCfg<.., 2>, ..>;
@@ -1038,7 +1047,7 @@ def main():
             "warmup": args.warmup, "settle_steps": r["settle_steps"], "timed_blocks": r.get("blocks", 1),
             "timed_region_s": round(r["dt"], 4), "ms_per_step": round(r["dt"] / (args.steps * r.get("blocks", 1)) * 1e3, 3),
             "host_ms_per_step": None if r["host_dt"] is None else round(r["host_dt"] / (args.steps * r.get("blocks", 1)) * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _dtype_note(), "data": "synthetic",
             "config": {"workload": wl, "net_size": list(r["dst_size"]), "frames_per_step": len(TS),
                        "weights": "seeded random IFNet 4.26-heavy", "parallelism": f"frame-sharded dp{world}"},
             "arithmetic": _arithmetic_note(),

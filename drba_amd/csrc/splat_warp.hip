@@ -228,6 +228,7 @@ __global__ void __launch_bounds__(256) splat_long_prepass(const float *__restric
 // with plain LDS reads.  Sources beyond the LDS record capacity (strong local convergence) fall back to the same
 // global-atomic accumulator the long-flow pre-pass uses.
 constexpr int kSX = 32, kSY = 16;                       // output tile of the sorted kernel
+static_assert(kRMax <= kSY, "the reach map reads the 3 x 3 tiles around an output tile: a halo may not span more than one tile (DRBA_SPLAT_R)");
 constexpr int kKX = kSX + 1, kKY = kSY + 1;             // key grid: footprint origins (-1..kSX-1) x (-1..kSY-1)
 constexpr int kNKEY = kKX * kKY;
 constexpr int kCAP = 1536;                              // records held in LDS (3 per output pixel)

@@ -8,7 +8,7 @@ from drba_amd.models.drm import calc_drm_gmfss, calc_drm_rife_auxiliary
 from drba_amd.models.lookahead import Lookahead, split as split_lookahead
 from drba_amd.models.model_gmfss_union.GMFSS import Model, _half
 from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
-from drba_amd.models.utils.tools import convert, resize
+from drba_amd.models.utils.tools import convert, load_weights, resize
 
 
 class GMFSS_UNION:
@@ -24,7 +24,7 @@ class GMFSS_UNION:
             rife_sd = weights["rife"]
         else:
             self.model.load_model(weights, -1, device)
-            rife_sd = convert(torch.load(os.path.join(weights, "rife.pkl"), map_location="cpu"))
+            rife_sd = convert(load_weights(os.path.join(weights, "rife.pkl")))
         self.ifnet = IFNet().to(device).eval()
         self.ifnet.load_state_dict(rife_sd, strict=False)
         self.scale = scale

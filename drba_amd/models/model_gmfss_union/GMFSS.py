@@ -46,7 +46,8 @@ class Model:
     def load_model(self, path, rank=-1, device=None):
         """flownet.pkl / metric.pkl / feat.pkl / fusionnet.pkl (GMFSS.py:42-53); CUDA-tagged pickles load via map_location."""
         device = device or self._device or _ops.default_device()
-        ld = lambda n: torch.load(f"{path}/{n}.pkl", map_location="cpu")  # noqa: E731
+        from drba_amd.models.utils.tools import load_weights
+        ld = lambda n: load_weights(f"{path}/{n}.pkl")  # noqa: E731
         self.load_state_dicts(ld("flownet"), ld("metric"), ld("feat"), ld("fusionnet"), device)
 
     def _cached(self, frame, attr, key, make):

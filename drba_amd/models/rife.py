@@ -17,7 +17,7 @@ from drba_amd.models.lookahead import Lookahead, shared_stream
 from drba_amd.models.lookahead import split as split_lookahead
 from drba_amd.models.drm import calc_drm_rife
 from drba_amd.models.rife_426_heavy.IFNet_HDv3 import IFNet
-from drba_amd.models.utils.tools import convert
+from drba_amd.models.utils.tools import convert, load_weights
 
 
 class RIFE:
@@ -39,7 +39,7 @@ class RIFE:
         if isinstance(weights, dict):  # an already-loaded state dict (no 'module.' prefix)
             sd = weights
         else:
-            sd = convert(torch.load(os.path.join(weights, "flownet.pkl"), map_location="cpu"))
+            sd = convert(load_weights(os.path.join(weights, "flownet.pkl")))
         self.device = device
         _ops.status_init(device)  # the two-term fp16 kernels report an overflow from now on (checked once per call below)
         self.ifnet = IFNet().to(device).eval()

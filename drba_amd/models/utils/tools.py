@@ -45,6 +45,13 @@ def convert(param):
     return {k.replace("module.", ""): v for k, v in param.items() if "module." in k}
 
 
+def load_weights(path):
+    """torch.load of a checkpoint file the way the reference reads it (map_location='cpu': its shipped pickles carry CUDA-tagged
+    storages) but with weights_only=True: a state dict of tensors unpickles, arbitrary code in a downloaded .pkl does not run
+    (the reference's plain torch.load executes whatever the file holds, rife.py:19 / GMFSS.py:50-53)."""
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
 def to_tensor(img, device=None):
     """uint8 HWC -> fp32 [1,3,H,W] in [0,1] on the GPU (tools.py:33-34).  Channel order is kept."""
     device = _ops.default_device() if device is None else device

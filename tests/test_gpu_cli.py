@@ -160,3 +160,34 @@ def test_bench_two_rank_rehearsal_over_gloo():
     assert j["world_size"] == 2 and j["backend"].startswith("gloo") and [x["rank"] for x in j["devices"]] == [0, 1]
     assert len({x["pid"] for x in j["devices"]}) == 2 and all(x["rank_seconds"] > 0 for x in j["devices"])
     assert d["settle_steps"] > 0
+
+
+def test_infer_cli_pipes_rgb_frames_into_ffmpeg(tmp_path):
+    """`infer.py -m rife -i clip.npz -o out.mp4 -t 2` (and `-hw`) with a stub `ffmpeg` first on PATH: the encoder-pipe branch of
+    VideoFI_IO runs (reference tools.py:174-204), the bytes on the pipe are the frames of the .npz run in RGB order -- flipped by
+    the to_out kernel (rgb=True), not on the host -- and the command line is the reference's (tests/test_ffmpeg_sink.py compares it
+    token by token)."""
+    from tests import ffmpeg_stub
+    frames = synth.make_clip(6, 128, 192, seed=23)
+    want = _cli_clip(tmp_path, frames, 24.0, ["-t", "2"])  # BGR frames of the same run into a .npz sink
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    ffmpeg_stub.write_stub(bindir)
+    env = dict(os.environ, PATH=str(bindir) + os.pathsep + os.environ.get("PATH", ""))
+    inp = str(tmp_path / "in.npz")
+    for extra, name in (([], "out.mp4"), (["-hw"], "out_hw.mp4")):
+        out = str(tmp_path / name)
+        code = (
+            "import sys; sys.path.insert(0, %r)\n"
+            "import drba_amd.infer as I\n"
+            "a = I.parse_args(['-m','rife','-i',%r,'-o',%r,'-t','2'] + %r)\n"
+            "m = I.load_model(a.model_type, a.scale, weights=%r)\n"
+            "print('written', I.inference(m, a))\n" % (ROOT, inp, out, extra, str(tmp_path / "w")))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "written 12" in r.stdout
+        argv, data = ffmpeg_stub.recorded(out)
+        got = np.frombuffer(data, dtype=np.uint8).reshape(12, 128, 192, 3)
+        assert np.array_equal(got, want[:, :, :, ::-1])  # the same kernels on the same inputs: bit-identical, channel order flipped
+        assert argv[-1] == out and argv[argv.index("-s") + 1] == "192x128" and argv[argv.index("-r") + 1] == "48.0"
+        assert argv[argv.index("-c:v") + 1] == ("h264_vaapi" if extra else "libx264")
