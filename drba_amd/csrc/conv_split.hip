@@ -24,7 +24,11 @@
 #include "conv_split.hpp"
 
 #include <string.h>
+
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 using namespace drba;
 
@@ -533,11 +537,13 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
               }
           }
         };
-        // activations 0-3 are one form, v > 0 ? v : slope * v with slope 1 / 0.2 / post_slope / 0 (exact: v * 1 == v; ReLU
-        // keeps a NaN as torch.relu does); tanh is its own instantiation
-        const float slope = act == 1 ? 0.2f : act == 2 ? post_slope : act == 3 ? 0.f : 1.f;
+        // activations 0-2 are one form, v > 0 ? v : slope * v with slope 1 / 0.2 / post_slope (exact: v * 1 == v); ReLU and
+        // tanh are their own instantiations.  ReLU as torch.relu and the other families' fmaxf(v, 0) define it: +0 for every
+        // v <= 0 (slope 0 would hand on -0.0, and NaN for -inf), a NaN kept.
+        const float slope = act == 1 ? 0.2f : act == 2 ? post_slope : 1.f;
         auto with_act = [&](auto kind_) {
           if (act == 4) epilogue(kind_, [](float v) { return tanhf(v) * 10.f; });
+          else if (act == 3) epilogue(kind_, [](float v) { return v > 0.f ? v : (v != v ? v : 0.f); });
           else epilogue(kind_, [slope](float v) { return v > 0.f ? v : slope * v; });
         };
         if (beta) with_act(std::integral_constant<int, 3>{});
@@ -718,6 +724,20 @@ hipError_t lds_limit() {
   return max_dynamic_lds(reinterpret_cast<const void *>(conv_split_mfma<Cfg, PRE, RL>), Cfg::LDS_BYTES);
 }
 
+static int resident_per_cu(const void *kernel, int lds_bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, int> known;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(kernel, dev);
+  auto it = known.find(key);
+  if (it != known.end()) return it->second;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds_bytes) != hipSuccess || occ < 1) occ = 1;
+  return known[key] = occ > 3 ? 3 : occ;
+}
+
 template <class Cfg>
 int launch(const float *in, const float *wpk, const float *bias, const float *beta, const float *res, const float *res2,
            float *out, int N, int Cin, int H, int W, int Cout, int act, float post_slope, int pre_act, float pre_slope,
@@ -736,12 +756,9 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
     // multiple of 8.  A grid above the residency runs its surplus workgroups as a second round on half-empty CUs: the
     // 227-register 4 x 32 x 64 tile was launched 3 per CU by its LDS size alone while 2 fit (64 ch 136x240 N8: 95 -> 86 us,
     // tools/exp/split_per_cu.sh).
-    static int resident = 0;
-    if (!resident) {
-      int occ = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, Cfg::LDS_BYTES) != hipSuccess || occ < 1) occ = 1;
-      resident = occ > 3 ? 3 : occ;
-    }
+    // (asked once per kernel instantiation and device: the PRE / RL variants of a Cfg decay to one function-pointer type, so
+    // a static inside this lambda would be shared by all of them -- and by every GPU of the process)
+    const int resident = resident_per_cu(reinterpret_cast<const void *>(kernel), Cfg::LDS_BYTES);
     const int per_cu = env_int("DRBA_SPLIT_PER_CU", resident);
     long long grid = 256ll * per_cu;
     if (grid > total) grid = (total + 7) / 8 * 8;

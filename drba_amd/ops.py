@@ -212,11 +212,22 @@ def softsplat_many(inputs, tenFlow, tenMetric, strMode, outs=None, reuse_index=F
     # what the index in `ws` was built from: the flow / metric tensors (storage + version), mode, geometry, the buffer and stream.
     # reuse_index=True is honoured only while that still holds -- another user of the workspace, a regrown buffer, an in-place
     # update of the flow or a call from another stream drops the token and the index is rebuilt (it used to be trusted blindly)
+    # The token holds the flow / metric tensor OBJECTS (strong references: their storage cannot be freed and handed to another
+    # tensor while the token lives -- an address + version pair alone could match a different flow that the caching allocator put at
+    # the same address, the library's own kernels writing through raw pointers without bumping _version) and is not kept at all
+    # when _f32 had to copy an argument (the copy is a temporary nobody can name again).
     wkey = (f.device.index, _stream().value or 0)
-    token = (f.data_ptr(), f._version, None if m is None else (m.data_ptr(), m._version), strMode, n, h, w, ws.data_ptr())
-    if reuse_index and _ws_token.get(wkey) != token:
+    copied = f is not tenFlow or (m is not None and m is not tenMetric)
+    token = (f, f._version, m, None if m is None else m._version, strMode, n, h, w, ws.data_ptr())
+    old = _ws_token.get(wkey)
+    same = (old is not None and old[0] is token[0] and old[2] is token[2] and old[1] == token[1] and old[3] == token[3]
+            and old[4:] == token[4:])
+    if reuse_index and (copied or not same):
         reuse_index = False
-    _ws_token[wkey] = token
+    if copied:
+        _ws_token.pop(wkey, None)
+    else:
+        _ws_token[wkey] = token
     res = []
     for k, x in enumerate(xs):
         assert x.shape[0] == n and tuple(x.shape[2:]) == (h, w), (tuple(x.shape), (n, h, w))
