@@ -187,6 +187,25 @@ int drba_status_clear(void) {
   return DRBA_OK;
 }
 
+int drba_stream_create_cu_mask(const uint32_t *mask, int words, void **stream) {
+  if (!mask || words <= 0 || words > 32 || !stream) return DRBA_EINVAL;
+  bool any = false;
+  for (int i = 0; i < words; ++i) any |= mask[i] != 0;
+  if (!any) return DRBA_EINVAL;
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) != hipSuccess) {
+    (void)hipGetLastError();
+    return DRBA_ELAUNCH;
+  }
+  *stream = (void *)s;
+  return DRBA_OK;
+}
+
+int drba_stream_destroy(void *stream) {
+  if (!stream) return DRBA_EINVAL;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? DRBA_OK : DRBA_ELAUNCH;
+}
+
 int drba_trace_begin(void) {
   // events are created here, outside any timed region (hipEventCreate costs tens of microseconds each)
   for (int i = 0; i < 2048; ++i) {

@@ -17,6 +17,35 @@ ONE_STREAM = False  # measurement only (tools/step_timeline.py --one-stream): si
 PRIORITY = {}  # role -> HIP stream priority (-1 = high); experiments only (tools/ab_bench.py --prefetch-priority)
 
 
+# role -> (first CU, number of CUs) PER XCD (MI355X: 32 CUs on each of 8 XCDs): that role's stream is created with a CU mask
+# (drba_stream_create_cu_mask) and its kernels run on those CUs of every XCD only.  Experiments: tools/ab_bench.py --cu-mask.
+CU_MASK = {}
+N_XCD, CUS_PER_XCD = 8, 32
+
+
+def cu_mask_words(first, count):
+    """The mask of CUs [first, first + count) on every XCD: mask bit i is CU i // 8 of XCD i % 8 (tools/exp/cu_mask/census.hip)."""
+    import ctypes as C
+    words = (C.c_uint32 * (N_XCD * CUS_PER_XCD // 32))()
+    for cu in range(first, min(first + count, CUS_PER_XCD)):
+        for x in range(N_XCD):
+            b = cu * N_XCD + x
+            words[b >> 5] |= 1 << (b & 31)
+    return words
+
+
+def masked_stream(device, first, count):
+    """A torch stream object over a HIP stream restricted to CUs [first, first + count) of every XCD (never destroyed: the
+    handful of streams a process makes live as long as it does)."""
+    import ctypes as C
+    from drba_amd import _lib
+    words = cu_mask_words(first, count)
+    ptr = C.c_void_p()
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().drba_stream_create_cu_mask(words, len(words), C.byref(ptr)), "drba_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(ptr.value, device=device)
+
+
 def shared_stream(device, role):
     """ONE extra HIP stream per (device, role) for every model instance of the process ("side": the lookahead's chain,
     "prefetch": encoders / coarse flows of frames read ahead).  HIP multiplexes streams onto a handful of hardware queues;
@@ -28,7 +57,10 @@ def shared_stream(device, role):
     key = (device.index, role)
     s = _STREAMS.get(key)
     if s is None:
-        s = _STREAMS[key] = torch.cuda.Stream(device=device, priority=PRIORITY.get(role, 0))
+        if role in CU_MASK:
+            s = _STREAMS[key] = masked_stream(device, *CU_MASK[role])
+        else:
+            s = _STREAMS[key] = torch.cuda.Stream(device=device, priority=PRIORITY.get(role, 0))
     return s
 
 

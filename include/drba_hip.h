@@ -76,6 +76,15 @@ int drba_set_range_check(int on);
 int drba_status_word(volatile unsigned long long **host_word);
 int drba_status_clear(void);
 
+/* ABI 8, optional: a HIP stream restricted to a subset of the CUs (hipExtStreamCreateWithCUMask) for callers that partition
+ * the chip between the latency-bound low-resolution chain of the NEXT steps and the full-resolution kernels of the current
+ * ones (drba_amd/models/lookahead.py; not in the reference, which has one stream).  mask: `words` x 32 bits, bit i = CU i in
+ * the runtime's numbering (measured on MI355X, tools/exp/cu_mask/census.hip: consecutive bits go round the 8 XCDs, so a
+ * contiguous range of 8 k bits is k CUs on every XCD).  The stream belongs to the caller (drba_stream_destroy); every other
+ * entry point takes it like any stream. */
+int drba_stream_create_cu_mask(const uint32_t *mask, int words, void **stream);
+int drba_stream_destroy(void *stream);
+
 /* ---- kernel trace (measurement only; bench.py's roofline object) ---------------------------
  * Between drba_trace_begin() and drba_trace_end() every kernel the library launches (on any stream, from the one host
  * thread that drives it) carries an event pair on its own dispatch packet, i.e. each record is the kernel's own

@@ -188,6 +188,8 @@ def test_infer_cli_pipes_rgb_frames_into_ffmpeg(tmp_path):
         assert "written 12" in r.stdout
         argv, data = ffmpeg_stub.recorded(out)
         got = np.frombuffer(data, dtype=np.uint8).reshape(12, 128, 192, 3)
-        assert np.array_equal(got, want[:, :, :, ::-1])  # the same kernels on the same inputs: bit-identical, channel order flipped
+        # the same frames, channel order flipped (two processes: the autotuner's picks and the splats' summation order may differ
+        # in the last bits, i.e. by one LSB on a value sitting on an integer boundary)
+        _assert_frames_close(got, np.ascontiguousarray(want[:, :, :, ::-1]))
         assert argv[-1] == out and argv[argv.index("-s") + 1] == "192x128" and argv[argv.index("-r") + 1] == "48.0"
         assert argv[argv.index("-c:v") + 1] == ("h264_vaapi" if extra else "libx264")

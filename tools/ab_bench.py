@@ -40,6 +40,9 @@ def main():
     p.add_argument("--prefetch-priority", type=int, default=None)
     p.add_argument("--enc-main", action="store_true")
     p.add_argument("--side-stages", type=int, default=None)
+    p.add_argument("--cu-mask", default=None,
+                   help="role=first:count[,role=...] CUs PER XCD (of 32) for the side / prefetch / main streams, e.g. "
+                        "side=28:4,prefetch=28:4,main=0:28 (main: the whole benchmark runs inside a masked stream)")
     a, rest = p.parse_known_args()
     import bench
     from drba_amd import ops
@@ -68,9 +71,20 @@ def main():
         RIFE.ENC_ON_MAIN = True
     if a.side_stages is not None:
         RIFE.SIDE_STAGES = int(a.side_stages)
+    if a.cu_mask:
+        for part in a.cu_mask.split(","):
+            role, rng = part.split("=")
+            first, count = (int(v) for v in rng.split(":"))
+            lookahead.CU_MASK[role] = (first, count)
     bench.AB["no_lookahead"] = bool(a.no_lookahead)
     sys.argv = [os.path.join(ROOT, "bench.py")] + [x for x in rest if x != "--"]
-    bench.main()
+    if "main" in lookahead.CU_MASK:
+        import torch
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        with torch.cuda.stream(lookahead.masked_stream(dev, *lookahead.CU_MASK["main"])):
+            bench.main()
+    else:
+        bench.main()
 
 
 if __name__ == "__main__":
