@@ -81,6 +81,7 @@ TS = np.array([0.75, 1.25])  # what `-t 2` yields every step (infer.py:76-87)
 kTraceWarm, kTraceKeep = 3, 4
 kSettleSeconds = 0.5  # untimed steps after the W warm-up steps (step_loop) / minimum warm-up iterations of the clip legs
 kClipWarmup = 24
+kClipSteps = 40  # timed iterations of the driver-loop legs (extra_configs): 5 groups of 4 steps on each side of the planted cut
 SRC_FPS = 24.0
 kMinTimedSeconds = 0.25  # the K-step block is repeated until the timed region is at least this long (K = 20 steps at 2 ms are 40 ms: box-to-box noise)
 # SURVEY.md 8(d) / BASELINE.md 3: algorithmic work of ONE model-generated frame (warm), per config: (GFLOP, conv-boundary GB)
@@ -185,8 +186,11 @@ class _Counting:
     def warm_reuse(self, a, b):
         return self.m.warm_reuse(a, b)
 
-    def __getattr__(self, name):  # optional driver hooks (prefetch_frame): present only if the model has them
-        if name in ("prefetch_frame", "prefetch_pair"):
+    def __getattr__(self, name):  # optional driver hooks (prefetch_frame): present only if the model has them.  GROUP: what the
+        # drivers size their read-ahead by -- rounds 3-5 did not pass it on, so every driver-loop leg (configs 3, 4, 5 and the sharded
+        # legs) ran WITHOUT groups of steps (2-item launches, 83 kernels per step) while the shipped CLI, which hands the model itself
+        # to interpolate_stream, forms them: the 876 / 449 frames/s of BENCH_r05's configs 3 / 5 against 1139 / 562 were this wrapper
+        if name in ("prefetch_frame", "prefetch_pair", "GROUP", "stats"):
             return getattr(self.m, name)
         raise AttributeError(name)
 
@@ -675,7 +679,7 @@ def clip_leg(model, clip, dst_fps, times, scdet, args, label):
     io = _DevIO(clip, SRC_FPS)
     to_inp, to_out = _dev_hooks()
     W_, K = args.warmup, args.steps
-    st = {"t0": None, "t1": None, "g0": 0, "g1": 0, "w0": 0, "w1": 0, "first": None, "last": None}
+    st = {"t0": None, "t1": None, "g0": 0, "g1": 0, "w0": 0, "w1": 0, "first": None, "last": None, "host": 0.0, "stats0": {}, "path": None}
     ops.trace_begin()
     ops.trace_pause()
 
@@ -684,10 +688,13 @@ def clip_leg(model, clip, dst_fps, times, scdet, args, label):
         if j == 0:
             _quiet_gc()
             torch.cuda.synchronize()
+            st["stats0"] = dict(getattr(model, "stats", None) or {})
             st["t0"], st["g0"], st["w0"] = time.perf_counter(), cm.generated, io.written
         if j == K:  # the timed iterations are done; the clip's remaining iterations are the roofline block (all traced)
+            st["host"] = time.perf_counter() - st["t0"]  # every launch of the K iterations enqueued: the host side of the region
             torch.cuda.synchronize()
             st["t1"], st["g1"], st["w1"] = time.perf_counter(), cm.generated, io.written
+            st["path"] = {k: v - st["stats0"].get(k, 0) for k, v in (getattr(model, "stats", None) or {}).items()} or None
             ops.trace_resume()
         if j == K + kTraceWarm:
             st["first"] = ops._trace_pos()
@@ -701,8 +708,12 @@ def clip_leg(model, clip, dst_fps, times, scdet, args, label):
     recs = recs[st["first"]:st["last"]] if st["last"] is not None else []
     dt = st["t1"] - st["t0"]
     gen, wr = st["g1"] - st["g0"], st["w1"] - st["w0"]
+    # `path` (RIFE.stats over the timed iterations): how many of them ran as groups of steps, collected a step computed ahead, or
+    # fell to the one-step path (around the planted cut: the iterations whose lookahead window holds the cut, and the two calls
+    # inference_ts makes beside it); `host_ms_per_step`: launches enqueued, GPU possibly still working
     return {"workload": label, "value": round(gen / dt, 3), "unit": "frames/s", "steps": K, "warmup": W_,
-            "ms_per_step": round(dt / K * 1e3, 3), "frames_generated": gen, "frames_written": wr,
+            "ms_per_step": round(dt / K * 1e3, 3), "host_ms_per_step": round(st["host"] / K * 1e3, 3), "frames_generated": gen,
+            "frames_written": wr, "path": st["path"], "group": int(getattr(model, "GROUP", 1)),
             "roofline": roofline_from_trace(recs, kTraceKeep, _traffic_table())}
 
 
@@ -730,7 +741,10 @@ def extra_configs(args, dev):
     """BASELINE.json configs[2], [3], [4] at N = 1 (bounded: K steps each)."""
     from drba_amd.models.gmfss_union import GMFSS_UNION
     from drba_amd.models.rife import RIFE
-    args = argparse.Namespace(**{**vars(args), "warmup": max(args.warmup, kClipWarmup)})  # see step_loop: W is the minimum
+    # W is the minimum (see step_loop); the clip legs time at least kClipSteps iterations, so that the region holds >= 4 whole groups
+    # of steps on each side of the planted cut and the cut's recovery (cold calc_flow, one-step calls until a group is announced
+    # again) is a bounded share of it, as it is of a real clip
+    args = argparse.Namespace(**{**vars(args), "warmup": max(args.warmup, kClipWarmup), "steps": max(args.steps, kClipSteps)})
     n = args.warmup + args.steps + 3 + kTraceWarm + kTraceKeep + 1  # + the traced iterations of the roofline block
     out = {}
     cut = args.warmup + args.steps // 2 + 2

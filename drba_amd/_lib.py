@@ -48,6 +48,7 @@ SIGNATURES = {
     "drba_status_clear": (_i, []),
     "drba_stream_create_cu_mask": (_i, [C.POINTER(C.c_uint32), _i, C.POINTER(C.c_void_p)]),
     "drba_stream_destroy": (_i, [_p]),
+    "drba_conv_state_reset": (_i, [_p]),
     "drba_trace_begin": (_i, []),
     "drba_trace_end": (_i, []),
     "drba_trace_resume": (_i, []),

@@ -625,6 +625,17 @@ CounterSlot *counters_for(hipStream_t s, int *&mine, int *&next) {
   next = sl.base + 8 * ((sl.parity & 1u) ^ 1u);
   return &sl;
 }
+// drba_conv_state_reset (include/drba_hip.h): the stream's entry is made if it is missing (that part allocates), both sets are
+// zeroed ON THE STREAM and the roles start over -- the state every launch sequence can begin from, whatever ran before.
+int counters_reset(hipStream_t s) {
+  int *mine = nullptr, *next = nullptr;
+  CounterSlot *sl = counters_for(s, mine, next);
+  if (!sl) return DRBA_ELAUNCH;
+  if (hipMemsetAsync(sl->base, 0, 64, s) != hipSuccess) return DRBA_ELAUNCH;
+  std::lock_guard<std::mutex> lock(g_counter_mu);
+  sl->parity = 0u;
+  return DRBA_OK;
+}
 void counters_commit(CounterSlot *sl) {
   std::lock_guard<std::mutex> lock(g_counter_mu);
   sl->parity ^= 1u;
@@ -717,3 +728,5 @@ int conv_dma_launch(int id, const float *in, const float *packed_w, const float 
 }
 
 }  // namespace drba
+
+extern "C" int drba_conv_state_reset(void *stream) { return drba_conv_dma::counters_reset((hipStream_t)stream); }

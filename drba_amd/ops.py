@@ -523,6 +523,12 @@ def _tune(shape_key, candidates, run, reps=3, families=None):
     return best
 
 
+def conv_state_reset():
+    """drba_conv_state_reset on the current stream: the family-2 convolution's per-stream work counters back to their initial
+    state (first thing inside a stream capture, and before eager launches that follow a replayed graph)."""
+    _lib.check(_lib.load().drba_conv_state_reset(_stream()), "drba_conv_state_reset")
+
+
 class Conv3x3:
     """One 3x3 conv layer (pad 1) with fused epilogue; weights are packed per kernel config on first use."""
 

@@ -82,6 +82,13 @@ int drba_status_clear(void);
  * the runtime's numbering (measured on MI355X, tools/exp/cu_mask/census.hip: consecutive bits go round the 8 XCDs, so a
  * contiguous range of 8 k bits is k CUs on every XCD).  The stream belongs to the caller (drba_stream_destroy); every other
  * entry point takes it like any stream. */
+/* ABI 8: the per-(device, stream) work counters of the family-2 convolution (the allocation exception at the top) brought to
+ * their initial state ON `stream`: the entry is created if the stream has none yet (hipMalloc + a device synchronisation: call it
+ * once outside any capture), then one 64-byte memset is enqueued and the launch parity starts over.  A stream capture that
+ * begins with this call replays correctly whatever its number of family-2 launches (two counter sets alternate per launch and
+ * each launch clears the other set: a captured sequence with an odd count would otherwise start its second replay on a dirty
+ * set); call it again on the stream before eager launches follow a replayed graph. */
+int drba_conv_state_reset(void *stream);
 int drba_stream_create_cu_mask(const uint32_t *mask, int words, void **stream);
 int drba_stream_destroy(void *stream);
 
