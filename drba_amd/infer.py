@@ -104,19 +104,57 @@ def interpolate_stream(model, video_io, dst_fps, times=-1, enable_scdet=False, s
 
     prefetch_pair = getattr(model, "prefetch_pair", None) if prefetch is not None else None
     eof, last = [False], [I1]
+    # Frame intake on its own stream (a model that prefetches offers one: RIFE.intake_stream = its prefetch stream): to_inp, the
+    # scene test of the pair the new frame closes and the frame's encoder depend on nothing but the frame, and the driver needs the
+    # test's DECISION before it can announce the frame as part of a group of steps.  Enqueued on the caller's stream they sat behind
+    # every synthesis kernel issued so far, and waiting for the decision drained that whole queue once per iteration: with groups
+    # (a seven-frame window, the newest pair asked about at once) the host and the GPU ran in lock step -- 6.4 ms of host per
+    # 1080p step.  On the intake stream the decision is ~100 us away whatever the main stream has queued.
+    intake = getattr(model, "intake_stream", None) if prefetch is not None else None
+    intake_s = None
+    if intake is not None and getattr(I1, "is_cuda", False):
+        import torch
+        intake_s = intake(I1.device)
+        if intake_s is not None:
+            intake_s.wait_stream(torch.cuda.current_stream(I1.device))  # I1 (the first pair's older frame) was made on the caller's stream
+
+    def take_in(raw, made=None):
+        """to_inp + the pair's scene test + the model's prefetches for a newly read frame (made(x): called right behind to_inp)."""
+        x = to_inp(raw, dst_size)
+        if made is not None:
+            made(x)
+        if ahead_checks is not None and x.is_cuda:
+            ahead_checks.submit((id(last[0]), id(x)), last[0], x)  # the cut test of this pair: asked for in this or a later iteration
+        if prefetch is not None:
+            prefetch(x)
+            if prefetch_pair is not None:
+                prefetch_pair(last[0], x)
+        return x
 
     def read():  # -> (raw frame, network input); a model that can starts the new frame's encoder (and the coarse flow
         raw = None if eof[0] else video_io.read_frame()  # of the pair it forms with the frame before it) right away
         if raw is None:  # (the source is not asked again once it has ended)
             eof[0] = True
             return None, None
-        x = to_inp(raw, dst_size)
-        if ahead_checks is not None and x.is_cuda:
-            ahead_checks.submit((id(last[0]), id(x)), last[0], x)  # the cut test of this pair: needed up to three iterations later
-        if prefetch is not None:
-            prefetch(x)
-            if prefetch_pair is not None:
-                prefetch_pair(last[0], x)
+        if intake_s is not None:
+            import torch
+            main = torch.cuda.current_stream(I1.device)
+            def made(x):
+                # the frame is consumed on the caller's stream later (the model's kernels, to_out of a pass-through copy): that
+                # stream waits for to_inp -- an event wait behind a queue that is far from reaching the frame -- and the
+                # allocator is told about the second stream
+                if x.is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(intake_s)
+                    main.wait_event(ev)
+                    x.record_stream(main)
+                    x4 = getattr(x, "_drba_x4", None)
+                    if x4 is not None:
+                        x4[0].record_stream(main)
+            with torch.cuda.stream(intake_s):
+                x = take_in(raw, made)
+        else:
+            x = take_in(raw)
         last[0] = x
         return raw, x
 

@@ -140,6 +140,16 @@ class RIFE:
                 P[j] = r
         return P
 
+    def intake_stream(self, device):
+        """The stream a driver may run a newly read frame's to_inp and scene test on (the prefetch stream: the frame's encoder is
+        started there anyway, so everything that depends only on the frame stays clear of the synthesis queue).  None: no such
+        stream (the encoders run in the caller's stream)."""
+        if self.ENC_ON_MAIN:
+            return None
+        if getattr(self, "_enc_stream", None) is None:
+            self._enc_stream = shared_stream(device, "prefetch")
+        return self._enc_stream
+
     def prefetch_frame(self, I):
         """Optional (not in the reference): start the context encoder of a frame the driver has just read -- it depends on
         nothing but the frame -- on its own HIP stream.  The lookahead's serial chain (encoder -> block0 -> flow reversal ->

@@ -653,6 +653,9 @@ class Deconv4x4:
         return out
 
 
+CHAIN_SPLIT_BYTES = 0  # > 0: a chain whose widest intermediate tensor exceeds this runs as two half-batches (A/B switch, see ConvChain.__call__)
+
+
 class ConvChain:
     """A fixed sequence of Conv3x3 / Deconv4x4 layers (`residual=True` entries are ResConv layers adding their own
     input) issued by ONE library call (drba_conv_chain): the host cost of an IFBlock core drops from eleven
@@ -663,9 +666,32 @@ class ConvChain:
         self.layers = [(l, bool(r)) for l, r in layers]  # (layer, residual)
         self._plans = {}
 
-    def _eager(self, x):
-        for layer, res in self.layers:
-            x = layer(x, residual=x) if res else layer(x)
+    def _widest(self, n, h, w):
+        """Bytes of the largest tensor between two layers of the chain at this input size."""
+        best, hh, ww = 0, h, w
+        for layer, _ in self.layers:
+            if isinstance(layer, Deconv4x4):
+                hh, ww = 2 * hh, 2 * ww
+            else:
+                hh, ww = (hh - 1) // layer.stride + 1, (ww - 1) // layer.stride + 1
+            if layer is not self.layers[-1][0]:
+                best = max(best, 4 * n * layer.cout * hh * ww)
+        return best
+
+    def _out_shape(self, n, h, w):
+        hh, ww = h, w
+        for layer, _ in self.layers:
+            if isinstance(layer, Deconv4x4):
+                hh, ww = 2 * hh, 2 * ww
+            else:
+                hh, ww = (hh - 1) // layer.stride + 1, (ww - 1) // layer.stride + 1
+        last = self.layers[-1][0]
+        return (n, last.cout // 4, 2 * hh, 2 * ww) if (isinstance(last, Deconv4x4) and last.ps) else (n, last.cout, hh, ww)
+
+    def _eager(self, x, out=None):
+        for i, (layer, res) in enumerate(self.layers):
+            o = out if i == len(self.layers) - 1 else None
+            x = layer(x, residual=x, out=o) if res else layer(x, out=o)
         return x
 
     def _plan(self, n, h, w, device):
@@ -710,28 +736,40 @@ class ConvChain:
         return {"descs": descs, "keep": keep, "scratch": max(sizes[:-1]) if len(sizes) > 1 else 0, "out_shape": out_shape,
                 "bufs": {}, "tags": tags}
 
-    def __call__(self, x):
+    def __call__(self, x, out=None):
+        """out (optional): a contiguous float32 destination of the chain's output shape (a batch slice of a larger tensor)."""
         x = _f32(x)
         n, _, h, w = x.shape
+        if out is None and CHAIN_SPLIT_BYTES and n >= 2 and n % 2 == 0 and x.is_cuda and self._widest(n, h, w) > CHAIN_SPLIT_BYTES:
+            # the chain as two half-batches back to back (A/B: tools/ab_bench.py --chain-split MB): layer l + 1 reads what layer l
+            # wrote; with the batch's widest tensor above the threshold input + output of a layer exceed the 256 MB Infinity Cache
+            # and every layer streams from HBM, the halves fit
+            whole = torch.empty(self._out_shape(n, h, w), dtype=torch.float32, device=x.device)
+            self(x[:n // 2], out=whole[:n // 2])
+            self(x[n // 2:], out=whole[n // 2:])
+            return whole
         key = (n, h, w)
         plan = self._plans.get(key)
         if plan is None and key in self._plans:  # known: not chainable
-            return self._eager(x)
+            return self._eager(x, out)
         if not x.is_cuda:
-            return self._eager(x)
+            return self._eager(x, out)
         if plan is None:
             plan = self._plans[key] = self._plan(n, h, w, x.device)
             if plan is None:
                 if AUTOTUNE:
                     del self._plans[key]  # configurations not tuned yet: this eager call tunes them, retry next time
-                return self._eager(x)
+                return self._eager(x, out)
         stream = _stream()
         bufs = plan["bufs"].get(stream.value)
         if bufs is None:  # scratch per stream: the same block runs on the main and on the lookahead stream
             m = max(plan["scratch"], 1)
             bufs = plan["bufs"][stream.value] = (torch.empty(m, dtype=torch.float32, device=x.device),
                                                  torch.empty(m, dtype=torch.float32, device=x.device))
-        out = torch.empty(plan["out_shape"], dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(plan["out_shape"], dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != tuple(plan["out_shape"]) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise _lib.DrbaHipError("ConvChain: out must be a contiguous float32 tensor of the chain's output shape")
         first = _trace_pos()
         _lib.check(_lib.load().drba_conv_chain(_p(x), _p(out), _p(bufs[0]), _p(bufs[1]), plan["descs"], len(self.layers), n,
                                                h, w, stream), "drba_conv_chain")

@@ -80,10 +80,43 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
     mapper = _tools.TMapper(src_fps, dst_fps, times)
     cache = {}
 
+    intake = [None]  # the model's intake stream (RIFE: its prefetch stream), set where the loop starts reading ahead
+
     def inp(k):
         if k not in cache:
             cache[k] = to_inp(frames[k], dst_size)
         return cache[k]
+
+    def take_in(j):
+        """Frame j read ahead: to_inp, the scene test of the pair (j - 1, j) and the model's prefetches on the intake stream, clear
+        of the synthesis queue (drba_amd/infer.py `read`: the decision is needed before the frame can be announced as part of a
+        group of steps; behind the caller's queue, waiting for it put host and GPU in lock step)."""
+        s = intake[0]
+        if s is None or j in cache:
+            x = inp(j)
+            cm = None
+        else:
+            main = torch.cuda.current_stream(s.device)
+            cm = torch.cuda.stream(s)
+            cm.__enter__()
+            x = inp(j)
+            if x.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(s)
+                main.wait_event(ev)
+                x.record_stream(main)
+                x4 = getattr(x, "_drba_x4", None)
+                if x4 is not None:
+                    x4[0].record_stream(main)
+        try:
+            if ahead_checks is not None and j - 1 not in cuts:
+                ahead_checks.submit(j - 1, inp(j - 1), x)  # the cut test the iterations before j - 1 will ask for
+            prefetch(x)
+            if prefetch_pair is not None:
+                prefetch_pair(inp(j - 1), x)
+        finally:
+            if cm is not None:
+                cm.__exit__(None, None, None)
 
     cuts = {}
 
@@ -147,14 +180,14 @@ def interpolate_shard(model, frames, src_fps, dst_fps, rank, world, times=-1, en
             look = (inp(k + 3), _tools.calc_t(k + 1, times, mapper))
             if prefetch is not None:
                 far = min(k + 2 + depth, b + 1, n - 1)  # last frame this shard may name: iteration b - 1 reads frame b + 1
+                if intake[0] is None and getattr(model, "intake_stream", None) is not None and I2.is_cuda:
+                    intake[0] = model.intake_stream(I2.device)
+                    if intake[0] is not None:
+                        intake[0].wait_stream(torch.cuda.current_stream(I2.device))  # frames made on the caller's stream so far
                 for j in range(k + 3, far + 1):
                     if j not in prefetched:
                         prefetched.add(j)
-                        if ahead_checks is not None and j - 1 not in cuts:
-                            ahead_checks.submit(j - 1, inp(j - 1), inp(j))  # the cut test the iterations before j - 1 will ask for
-                        prefetch(inp(j))
-                        if prefetch_pair is not None:
-                            prefetch_pair(inp(j - 1), inp(j))
+                        take_in(j)
                 # the following iterations of this shard, as far as they are DRBA steps too (no cut up to the last frame named)
                 entries = []
                 for j in range(k + 3, far + 1):  # entry: iteration j - 2, whose I2 is frame j

@@ -40,6 +40,7 @@ def main():
     p.add_argument("--prefetch-priority", type=int, default=None)
     p.add_argument("--enc-main", action="store_true")
     p.add_argument("--side-stages", type=int, default=None)
+    p.add_argument("--chain-split", type=float, default=None, help="ops.CHAIN_SPLIT_BYTES in MB: conv chains with a wider tensor run as two half-batches")
     p.add_argument("--cu-mask", default=None,
                    help="role=first:count[,role=...] CUs PER XCD (of 32) for the side / prefetch / main streams, e.g. "
                         "side=28:4,prefetch=28:4,main=0:28 (main: the whole benchmark runs inside a masked stream)")
@@ -71,6 +72,8 @@ def main():
         RIFE.ENC_ON_MAIN = True
     if a.side_stages is not None:
         RIFE.SIDE_STAGES = int(a.side_stages)
+    if a.chain_split is not None:
+        ops.CHAIN_SPLIT_BYTES = int(a.chain_split * 1e6)
     if a.cu_mask:
         for part in a.cu_mask.split(","):
             role, rng = part.split("=")

@@ -81,7 +81,13 @@ def main():
         lines.append(f"| {m['name']} | `{m['symbol']}` | {m['label']} | {fv:.0f} | {wv:.0f} | {t / 1e6:.1f} | "
                      f"{'' if alg is None else f'{alg / 1e6:.1f}'} | {'' if alg is None else f'{t / alg:.2f}'} |")
     print("\n".join(lines))
-    json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.environ.get("DRBA_PMC_MERGE") == "1" and os.path.exists(path):  # a second target set (tools/pmc_targets_4k.py): add to the table
+        old = json.load(open(path))
+        for sym, labels in traffic.items():
+            old.setdefault(sym, {}).update(labels)
+        traffic = old
+    json.dump(traffic, open(path, "w"), indent=1)
     if len(sys.argv) > 4:
         open(sys.argv[4], "w").write("\n".join(lines) + "\n")
 
