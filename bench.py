@@ -166,7 +166,10 @@ class DeviceClip:
     def __getitem__(self, k):
         if not 0 <= k < self.n:
             raise IndexError(k)
-        src = self.other if (self.cut_at is not None and k >= self.cut_at) else self.base
+        if isinstance(self.cut_at, (list, tuple)):  # several cuts: the two scenes alternate
+            src = self.other if sum(1 for c in self.cut_at if k >= c) % 2 else self.base
+        else:
+            src = self.other if (self.cut_at is not None and k >= self.cut_at) else self.base
         if self.pingpong and len(src) > 1:
             period = 2 * len(src) - 2
             j = k % period
@@ -685,14 +688,17 @@ def clip_leg(model, clip, dst_fps, times, scdet, args, label):
     from drba_amd import ops
     to_inp, to_out = _dev_hooks()
     if scdet and getattr(clip, "cut_at", None) is not None:
-        # Untimed rehearsal: a 14-frame clip of the same size with a cut in the middle.  The planted cut of the timed clip lies INSIDE
-        # the timed region, and what a cut runs -- inference_ts on one pair (batch 1 and 2), a cold calc_flow, one-step DRBA calls
-        # until the next group is announced -- are launch shapes the warm-up iterations in front of it never see: the conv
-        # autotuner (a device synchronisation per candidate) and first-touch allocations of those shapes ran inside the region
-        # (6 ms of host per step on a fresh model; rounds 3-5 had them pre-tuned by accident: the cyclic clip's wrap-around
-        # every 8 frames read as a cut during the warm-up iterations)
+        # Untimed rehearsal: a 66-frame clip of the same size with four cuts, 13 / 14 / 15 / 16 frames apart.  The planted cut of the
+        # timed clip lies INSIDE the timed region, and what a cut runs are launch shapes the warm-up iterations in front of it
+        # never see: inference_ts on one pair (batch 1 and 2), a cold calc_flow, and the SHORTER groups of steps on either side of
+        # it (the driver announces frames only up to the cut: 2 or 3 steps = 4 or 6 samples per launch, depending on where the
+        # cut falls in the group phase -- hence the four spacings).  Their first launches run the conv autotuner (a device
+        # synchronisation per candidate) and pack this instance's weights: 0.2 s inside a 0.25 s region (profiled: 53 _tune calls),
+        # i.e. 6 ms of host per step -- what a long clip pays once per process.  Rounds 3-5 had the shapes tuned by accident: the
+        # cyclic clip's wrap-around every 8 frames read as a cut during the warm-up iterations.
         H_, W_px = clip.shape[0], clip.shape[1]
-        drv.interpolate_stream(_Counting(model), _DevIO(DeviceClip(14, H_, W_px, 977, model.device, cut_at=7, pingpong=True), SRC_FPS),
+        drv.interpolate_stream(_Counting(model), _DevIO(DeviceClip(66, H_, W_px, 977, model.device, cut_at=[13, 27, 42, 58], pingpong=True),
+                                                        SRC_FPS),
                                dst_fps, times=times, enable_scdet=True, to_inp=to_inp, to_out=to_out)
         torch.cuda.synchronize()
     cm = _Counting(model)
@@ -708,9 +714,20 @@ def clip_leg(model, clip, dst_fps, times, scdet, args, label):
             _quiet_gc()
             torch.cuda.synchronize()
             st["stats0"] = dict(getattr(model, "stats", None) or {})
+            if os.environ.get("DRBA_BENCH_PROFILE"):  # diagnostic: where the host time of the timed iterations goes
+                import cProfile
+                st["prof"] = cProfile.Profile()
+                st["prof"].enable()
             st["t0"], st["g0"], st["w0"] = time.perf_counter(), cm.generated, io.written
         if j == K:  # the timed iterations are done; the clip's remaining iterations are the roofline block (all traced)
             st["host"] = time.perf_counter() - st["t0"]  # every launch of the K iterations enqueued: the host side of the region
+            if st.get("prof") is not None:
+                import io as _io
+                import pstats
+                st["prof"].disable()
+                buf = _io.StringIO()
+                pstats.Stats(st["prof"], stream=buf).sort_stats("cumulative").print_stats(30)
+                log("host profile of the timed iterations of: " + label[:60] + "\n" + buf.getvalue())
             torch.cuda.synchronize()
             st["t1"], st["g1"], st["w1"] = time.perf_counter(), cm.generated, io.written
             st["path"] = {k: v - st["stats0"].get(k, 0) for k, v in (getattr(model, "stats", None) or {}).items()} or None

@@ -19,8 +19,10 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--pingpong", type=int, default=1)
     p.add_argument("--profile", action="store_true")
+    p.add_argument("--profile-rep", type=int, default=1)
     p.add_argument("--steps", type=int, default=40)
     p.add_argument("--size", default="1080p")
+    p.add_argument("--fresh", action="store_true", help="a new model instance per repetition (the situation of bench.py's extra configs: the tuner's table is warm, the instance is not)")
     a = p.parse_args()
     import bench
     from drba_amd.models.rife import RIFE
@@ -32,8 +34,10 @@ def main():
     (h, w), scale = ((1080, 1920), 1.0) if a.size == "1080p" else ((2160, 3840), 0.5)
     m = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=scale, device=dev)
     for rep in range(2):
+        if a.fresh and rep:
+            m = RIFE(weights=synth.ifnet_state_dict(seed=0), scale=scale, device=dev)
         clip = bench.DeviceClip(n, h, w, 1234, dev, cut_at=cut, pingpong=bool(a.pingpong))
-        prof = cProfile.Profile() if (a.profile and rep == 1) else None
+        prof = cProfile.Profile() if (a.profile and rep == a.profile_rep) else None
         if prof:
             prof.enable()
         r = bench.clip_leg(m, clip, 60.0, -1, True, args, "probe")
