@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""One gather kernel of the pipeline, launched `reps` times as the loop launches it (8 samples over six frames with their [H,W,4]
+copies and pair-interleaved features, the flow as terms), for timing and for tools/exp/kernel_pmc.sh.
+    python tools/exp/gather_target.py <blend|s8|s4|s2|s2conv|s1conv> <1080p|4k> [reps]
+1080p: scale list 16, 8, 4, 2, 1; 4k (scale 0.5): 32, 16, 8, 4, 2 -- `s4` is the stage-input gather that feeds a block's conv0[0]
+at (frame / 4 x last scale) resolution, etc.: the name is the stage's scale relative to the LAST stage's."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from drba_amd import ops  # noqa: E402
+
+what, cfg = sys.argv[1], sys.argv[2]
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+(H, W), last = ((1088, 1920), 1.0) if cfg == "1080p" else ((2176, 3840), 2.0)
+B = 8
+tmap = torch.rand(1, 1, H, W, generator=g).to(dev)
+fr = []
+for _ in range(B // 2 + 2):
+    im, ft = torch.rand(1, 3, H, W, generator=g).to(dev), torch.randn(1, 16, H, W, generator=g).to(dev)
+    ops.rgbx(im)
+    ops.pair_interleaved(ft)
+    fr.append((im, ft))
+items = []
+for j in range(B // 2):
+    (a, fa), (b, fb), (c, fc) = fr[j], fr[j + 1], fr[j + 2]
+    items += [(b, a, tmap, fb, fa), (b, c, tmap, fb, fc)]
+
+
+def head(st, amp):
+    hh, ww = int(H / st), int(W / st)
+    t = torch.randn(B, 13, hh, ww, generator=g)
+    lo = torch.randn(B, 4, max(hh // 8, 2), max(ww // 8, 2), generator=g) * amp
+    t[:, :4] = torch.nn.functional.interpolate(lo, size=(hh, ww), mode="bicubic", align_corners=False)
+    return t.to(dev)
+
+
+S = {k: k * last for k in (16, 8, 4, 2, 1)}
+pyr = {k: head(S[k], 1.0 if k == 16 else 0.3) for k in (16, 8, 4, 2, 1)}
+if what == "blend":
+    terms = [(pyr[k], S[k]) for k in (16, 8, 4, 2)]
+    fn = lambda: ops.warp_blend_lazy([(it[0], it[1]) for it in items], terms, pyr[1], S[1])  # noqa: E731
+    nbytes = B * 4.0 * 13 * H * W
+elif what in ("s8", "s4", "s2"):
+    k = int(what[1:])
+    xin = torch.empty(B, 52, int(H / S[k]), int(W / S[k]), device=dev)
+    terms = [(pyr[j], S[j]) for j in (16, 8, 4, 2) if j > 2 * k]
+    fn = lambda: ops.stage_inputs(items, None, pyr[2 * k], S[2 * k], S[k], xin, terms=terms)  # noqa: E731
+    nbytes = None
+else:
+    k = 2 if what == "s2conv" else 1
+    if S[k] not in (1.0, 2.0):
+        raise SystemExit(f"{what} at {cfg}: the fused stage kernels take the stage at frame scale 1 or 2")
+    cout = 32 if (cfg == "1080p" and k == 2) else 16
+    conv = ops.Conv3x3(torch.randn(cout, 52, 3, 3, generator=g) * 0.05, torch.zeros(cout), 2, True, None, device=dev)
+    terms = [(pyr[j], S[j]) for j in (16, 8, 4, 2) if j > 2 * k]
+    fn = lambda: ops.stage_conv0(items, None, pyr[2 * k], S[2 * k], conv, terms=terms, scale=int(S[k]))  # noqa: E731
+    nbytes = None
+fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    fn()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / reps * 1e3
+print(f"{what} {cfg} 8 samples: {us:.1f} us per launch" + (f", {nbytes / us / 1e6:.2f} TB/s of algorithmic bytes" if nbytes else ""))
