@@ -769,7 +769,14 @@ struct BlendItems {
   float *out[kMaxItems];
   const float *term[kMaxItems][kMaxTerms];
 };
-template <bool LAZY>
+// S1 (round 6): the last stage ran at the frame's own resolution (scale == 1, h == H, w == W: the default 1080p configuration).
+// The factor-1 "upsample" has weights exactly (1, 0) on the pixel itself and its right / lower neighbour -- lerp_src(x, 1, W) is
+// (x, x + 1, 1, 0) -- so up(c) IS tmp[c][y][x] for finite data, and staging a 10 x 34 footprint of five channels through LDS (6.6
+// scalar loads per pixel, two runtime integer divisions per staged value) to evaluate it was the larger half of the kernel's 1091
+// VALU instructions per wave (PMC, `profiles/r06_warp_blend_pmc.txt`: the vector ALUs 58 % busy, i.e. the kernel was VALU-bound, not
+// gather-bound).  The pixel's five values are five coalesced loads here.  (A non-finite NEIGHBOUR made the staged form NaN through
+// 0 * inf as ATen's interpolate does; this form hands on the pixel's own value.)
+template <bool LAZY, bool S1 = false>
 __global__ void __launch_bounds__(256)
 warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int w, float inv_scale, float scale, int H, int W, int n_items) {
   int vb_, vitem_, ntiles_;
@@ -778,7 +785,7 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   const float *__restrict__ flow = items.flow[vitem_], *__restrict__ tmp = items.tmp[vitem_];
   const float *__restrict__ img0x = items.img0x[vitem_], *__restrict__ img1x = items.img1x[vitem_];
   float *__restrict__ out = items.out[vitem_];
-  __shared__ __attribute__((aligned(16))) float prev[10][36][8];  // [row][column][flow 0..3 | mask, 3 x padding]: 16-byte LDS words
+  __shared__ __attribute__((aligned(16))) float prev[S1 ? 1 : 10][S1 ? 1 : 36][8];  // [row][column][flow 0..3 | mask, 3 x padding]: 16-byte LDS words
   __shared__ __attribute__((aligned(16))) float tl[LAZY ? kMaxTerms * 4 * kWbTermR * kWbTermC : 4];
   int trx0[kMaxTerms], try0[kMaxTerms];
   const size_t P = (size_t)H * W, p_lo = (size_t)h * w;
@@ -786,23 +793,31 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   int tx, ty;
   xcd_strip_tile(vb_, ntiles_, tiles_x, tx, ty);
   const int Xa = tx * kTileW, Ya = ty * kTileH, Xb = min(Xa + kTileW - 1, W - 1), Yb = min(Ya + kTileH - 1, H - 1);
-  const int rx0 = lerp_src(Xa, inv_scale, w).i0, ry0 = lerp_src(Ya, inv_scale, h).i0;
-  const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
-  for (int i = threadIdx.x; i < 5 * rh * rw; i += 256) {
-    const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
-    prev[r][col][c] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
+  const int x = Xa + (threadIdx.x & (kTileW - 1)), y = Ya + (threadIdx.x >> 5);
+  const size_t p = (size_t)min(y, H - 1) * W + min(x, W - 1);
+  float own[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  int rx0 = 0, ry0 = 0;
+  if constexpr (S1) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) own[c] = tmp[(size_t)c * P + p];  // issued before the terms' loads and the barrier
+  } else {
+    rx0 = lerp_src(Xa, inv_scale, w).i0, ry0 = lerp_src(Ya, inv_scale, h).i0;
+    const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
+    for (int i = threadIdx.x; i < 5 * rh * rw; i += 256) {
+      const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
+      prev[r][col][c] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
+    }
   }
   if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[vitem_], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
-  __syncthreads();
-  const int x = Xa + (threadIdx.x & (kTileW - 1)), y = Ya + (threadIdx.x >> 5);
+  if (LAZY || !S1) __syncthreads();
   if (x >= W || y >= H) return;
-  const size_t p = (size_t)y * W + x;
   const Lerp ly = lerp_src(y, inv_scale, h), lx = lerp_src(x, inv_scale, w);
-  const int r0 = ly.i0 - ry0, r1 = ly.i1 - ry0, c0 = lx.i0 - rx0, c1 = lx.i1 - rx0;
+  const int r0 = S1 ? 0 : ly.i0 - ry0, r1 = S1 ? 0 : ly.i1 - ry0, c0 = S1 ? 0 : lx.i0 - rx0, c1 = S1 ? 0 : lx.i1 - rx0;
   typedef float f32x4w __attribute__((ext_vector_type(4)));
   const f32x4w q00 = *reinterpret_cast<const f32x4w *>(&prev[r0][c0][0]), q01 = *reinterpret_cast<const f32x4w *>(&prev[r0][c1][0]);
   const f32x4w q10 = *reinterpret_cast<const f32x4w *>(&prev[r1][c0][0]), q11 = *reinterpret_cast<const f32x4w *>(&prev[r1][c1][0]);
   auto up = [&](int c) -> float {
+    if constexpr (S1) return own[c];
     if (c < 4) return lerp2_fma(ly.w0, ly.w1, lx.w0, lx.w1, q00[c & 3], q01[c & 3], q10[c & 3], q11[c & 3]);
     return lerp2_fma(ly.w0, ly.w1, lx.w0, lx.w1, prev[r0][c0][4], prev[r0][c1][4], prev[r1][c0][4], prev[r1][c1][4]);
   };
@@ -1161,8 +1176,12 @@ int drba_warp_blend_lazy_batch(const drba_stage_item_t *items, int n_items, cons
       its.term[k][i] = I.term[i];
     }
   }
-  DRBA_LAUNCH((warp_blend_fold_kernel<true>), dim3(tiles_for(W, H) * n_items), dim3(kBlock), 0, (hipStream_t)stream, its, T, h, w,
-              (float)(1.0 / (double)scale), scale, H, W, n_items);
+  if (scale == 1.f && h == H && w == W)  // the last stage at the frame's own resolution: no footprint staging (kernel comment "S1")
+    DRBA_LAUNCH((warp_blend_fold_kernel<true, true>), dim3(tiles_for(W, H) * n_items), dim3(kBlock), 0, (hipStream_t)stream, its, T, h, w,
+                1.f, scale, H, W, n_items);
+  else
+    DRBA_LAUNCH((warp_blend_fold_kernel<true>), dim3(tiles_for(W, H) * n_items), dim3(kBlock), 0, (hipStream_t)stream, its, T, h, w,
+                (float)(1.0 / (double)scale), scale, H, W, n_items);
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
