@@ -530,9 +530,27 @@ ifblock_input_lds(const StageItems items, const FlowTermsArg T, int hp, int wp, 
   const int Xb = SINGLE ? ox_b : lerp_src(ox_b, scale, W).i1, Yb = SINGLE ? oy_b : lerp_src(oy_b, scale, H).i1;
   const int rx0 = lerp_src(Xa, inv_prev_scale, wp).i0, ry0 = lerp_src(Ya, inv_prev_scale, hp).i0;
   const int rw = lerp_src(Xb, inv_prev_scale, wp).i1 - rx0 + 1, rh = lerp_src(Yb, inv_prev_scale, hp).i1 - ry0 + 1;
-  for (int i = threadIdx.x; i < (13 - C0) * rh * rw; i += 256) {
-    const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
-    prev[r][col][C0 + c] = tmp_prev[(size_t)(C0 + c) * p_prev + (size_t)(ry0 + r) * wp + rx0 + col];
+  {
+    // thread -> (footprint pixel e of the CAPACITY grid, half of the channels): compile-time divisors.  (The loop used to run over
+    // (13 - C0) * rh * rw values with two runtime integer divisions each -- ~70 VALU instructions per value, five values per thread.)
+    static_assert(kPrevRH * kPrevRW <= 128, "one footprint pixel per thread of a half workgroup");
+    constexpr int NCH = 13 - C0, HALF = (NCH + 1) / 2;
+    const int e = threadIdx.x & 127, cg = threadIdx.x >> 7;
+    const int r = e / kPrevRW, col = e - r * kPrevRW;
+    if (r < rh && col < rw) {
+      const float *src = tmp_prev + (size_t)(ry0 + r) * wp + rx0 + col;
+      float v[HALF];
+#pragma unroll
+      for (int k = 0; k < HALF; ++k) {
+        const int c = C0 + cg * HALF + k;
+        v[k] = c < 13 ? src[(size_t)c * p_prev] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < HALF; ++k) {
+        const int c = C0 + cg * HALF + k;
+        if (c < 13) prev[r][col][c] = v[k];
+      }
+    }
   }
   if (LAZY) terms_stage<kTermR, kTermC, 256>(tl, T, item_.term, Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
   __syncthreads();
@@ -803,9 +821,20 @@ warp_blend_fold_kernel(const BlendItems items, const FlowTermsArg T, int h, int 
   } else {
     rx0 = lerp_src(Xa, inv_scale, w).i0, ry0 = lerp_src(Ya, inv_scale, h).i0;
     const int rw = lerp_src(Xb, inv_scale, w).i1 - rx0 + 1, rh = lerp_src(Yb, inv_scale, h).i1 - ry0 + 1;
-    for (int i = threadIdx.x; i < 5 * rh * rw; i += 256) {
-      const int c = i / (rh * rw), r = (i - c * rh * rw) / rw, col = i - c * rh * rw - r * rw;
-      prev[r][col][c] = tmp[(size_t)c * p_lo + (size_t)(ry0 + r) * w + rx0 + col];
+    // footprint pixel e of the capacity grid per thread and round (compile-time divisors; the loop used to decompose a running
+    // index with two runtime integer divisions per staged value)
+#pragma unroll
+    for (int k = 0; k < (10 * 36 + 255) / 256; ++k) {
+      const int e = threadIdx.x + k * 256;
+      const int r = e / 36, col = e - r * 36;
+      if (r < rh && col < rw && r < 10) {
+        const float *src = tmp + (size_t)(ry0 + r) * w + rx0 + col;
+        float v[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) v[c] = src[(size_t)c * p_lo];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) prev[r][col][c] = v[c];
+      }
     }
   }
   if (LAZY) terms_stage<kWbTermR, kWbTermC, 256>(tl, T, items.term[vitem_], Xa, Ya, Xb, Yb, threadIdx.x, trx0, try0);
