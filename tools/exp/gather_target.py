@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One gather kernel of the pipeline, launched `reps` times as the loop launches it (8 samples over six frames with their [H,W,4]
 copies and pair-interleaved features, the flow as terms), for timing and for tools/exp/kernel_pmc.sh.
-    python tools/exp/gather_target.py <blend|s8|s4|s2|s2conv|s1conv> <1080p|4k> [reps]
+    python tools/exp/gather_target.py <blend|s8|s4|s2|s2conv|s1conv|drm|rev|head> <1080p|4k> [reps]
 1080p: scale list 16, 8, 4, 2, 1; 4k (scale 0.5): 32, 16, 8, 4, 2 -- `s4` is the stage-input gather that feeds a block's conv0[0]
 at (frame / 4 x last scale) resolution, etc.: the name is the stage's scale relative to the LAST stage's."""
 import os
@@ -41,7 +41,30 @@ def head(st, amp):
 
 S = {k: k * last for k in (16, 8, 4, 2, 1)}
 pyr = {k: head(S[k], 1.0 if k == 16 else 0.3) for k in (16, 8, 4, 2, 1)}
-if what == "blend":
+def smooth_flow(n, amp):
+    lo = torch.randn(n, 2, H // 64, W // 64, generator=g) * amp
+    return torch.nn.functional.interpolate(lo, size=(H, W), mode="bicubic", align_corners=False).to(dev).contiguous()
+
+
+if what in ("drm", "rev"):
+    fa, fb = smooth_flow(8, 3.0), smooth_flow(8, 3.0)
+    if what == "drm":
+        jobs = [(fa[k:k + 1], fb[k:k + 1], 0.25 + 0.05 * k) for k in range(8)]
+        fn = lambda: ops.drm_rife_linear_many(jobs, 1e-4)  # noqa: E731
+        nbytes = 8 * 20.0 * H * W
+    else:
+        fn = lambda: ops.flow_reverse(fa)  # noqa: E731
+        nbytes = 8 * 16.0 * H * W
+elif what == "head":
+    from drba_amd.models.rife_426_heavy.IFNet_HDv3 import Head
+    hsd = {"encode.cnn0.weight": torch.randn(16, 3, 3, 3, generator=g) / 27 ** 0.5, "encode.cnn0.bias": torch.zeros(16),
+           "encode.cnn1.weight": torch.randn(16, 16, 3, 3, generator=g) / 12, "encode.cnn1.bias": torch.zeros(16),
+           "encode.cnn2.weight": torch.randn(16, 16, 3, 3, generator=g) / 12, "encode.cnn2.bias": torch.zeros(16),
+           "encode.cnn3.weight": torch.randn(16, 16, 4, 4, generator=g) / 8, "encode.cnn3.bias": torch.zeros(16)}
+    head_net = Head(hsd, "encode.", dev)
+    fn = lambda: head_net(fr[0][0], planar=False)  # noqa: E731
+    nbytes = 4.0 * 19 * H * W
+elif what == "blend":
     terms = [(pyr[k], S[k]) for k in (16, 8, 4, 2)]
     fn = lambda: ops.warp_blend_lazy([(it[0], it[1]) for it in items], terms, pyr[1], S[1])  # noqa: E731
     nbytes = B * 4.0 * 13 * H * W
