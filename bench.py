@@ -45,6 +45,7 @@ Extra objects on the JSON line:
                 clip resident in HBM, each with its own roofline entry.
 """
 import argparse
+import collections
 import gc
 import json
 import os
@@ -81,6 +82,7 @@ TS = np.array([0.75, 1.25])  # what `-t 2` yields every step (infer.py:76-87)
 kTraceWarm, kTraceKeep = 3, 4
 kSettleSeconds = 0.5  # untimed steps after the W warm-up steps (step_loop) / minimum warm-up iterations of the clip legs
 kClipWarmup = 24
+kMaxStepsInFlight = 16  # step_loop: the host waits for the step this many steps back (four groups of steps stay queued on the GPU; 32: the 4K runs stall again)
 kClipSteps = 40  # timed iterations of the driver-loop legs (extra_configs): 5 groups of 4 steps on each side of the planted cut
 SRC_FPS = 24.0
 kMinTimedSeconds = 0.25  # the K-step block is repeated until the timed region is at least this long (K = 20 steps at 2 ms are 40 ms: box-to-box noise)
@@ -616,9 +618,27 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
     lookahead = not args.no_lookahead
     loop = AnnouncedLoop(model, to_inp, lambda k: TS, lookahead=lookahead)
 
+    # The host enqueues a step in a third of the time the GPU needs for it and nothing in this loop synchronises (the frames stay on
+    # the device): unthrottled it runs hundreds of steps ahead, every one holding its tensors -- at 4K, 6 GB per group of steps --
+    # until the caching allocator has the whole HBM in flight and falls back to freeing / synchronising on every allocation: a
+    # third of the 4K runs of round 6 ended at 6.4 ms per step instead of 3.5 (per-step log: the host time per group climbs
+    # from 1.2 to 25 ms mid-run).  A real driver is throttled by the copy of every written frame to the host; here the loop waits
+    # for the step kMaxStepsInFlight steps back, which leaves the GPU four groups of work queued.  The waits are not host work:
+    # `throttle_s` is subtracted from the host time of the region.
+    inflight, throttle = collections.deque(), [0.0]
+    max_inflight = int(os.environ.get("DRBA_BENCH_INFLIGHT", kMaxStepsInFlight))
+
     def step():
         out, _ = loop.step()
-        return [to_out(x) for x in out]
+        res = [to_out(x) for x in out]
+        ev = torch.cuda.Event()
+        ev.record()
+        inflight.append(ev)
+        if len(inflight) > max_inflight:
+            t_w = time.perf_counter()
+            inflight.popleft().synchronize()
+            throttle[0] += time.perf_counter() - t_w
+        return res
 
     for _ in range(args.warmup):
         step()
@@ -640,6 +660,7 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
     _quiet_gc()
     _fence(world)
     stats0 = dict(getattr(model, "stats", {}))
+    throttle[0] = 0.0
     t0 = time.perf_counter()
     per_step = []
     blocks = 0
@@ -650,7 +671,7 @@ def step_loop(model, frames, n_steps_total, args, world, trace=True, pcie=False,
         blocks += 1
         if world > 1 or not settle or not args.steps or time.perf_counter() - t0 >= kMinTimedSeconds or blocks >= 64:  # (N > 1: every rank times one block)
             break
-    t_host = time.perf_counter() - t0  # all launches enqueued: the host side of a step (the GPU may still be working)
+    t_host = time.perf_counter() - t0 - throttle[0]  # all launches enqueued: the host side of a step (the GPU may still be working)
     _fence(world)
     dt = time.perf_counter() - t0
     LAST_BLOCKS["n"] = blocks

@@ -153,7 +153,8 @@ class IFNet:
         pass over the full-resolution flow for the two full-resolution stages."""
         B = len(items)
         M = _lib.MAX_STAGE_ITEMS
-        if B > M:
+        wide = B > M and (state[3] == "lazy" if state is not None else self._lazy_ok(scale_list))
+        if B > M and not wide:
             # the batched glue launches take at most M items (drba_hip.h DRBA_MAX_STAGE_ITEMS): a step with more frames to
             # synthesise (`-t 6`, 24 -> 144 fps, ...) runs as independent groups of M -- the samples do not interact
             parts = []
@@ -229,34 +230,53 @@ class IFNet:
         """forward_pairs without a full-resolution flow tensor: IFNet_HDv3.py:146-160's flow = flow + up(tmp_i[:, :4]) * s_i is kept
         as the list of head outputs (`terms`, 1/32 .. 1/2 resolution) and evaluated by the kernels that need it, at their
         sample points -- no ifblock_update pass after a stage, no flow read or written by a gather, one warp_blend launch
-        for all items.  State between calls: (terms, newest head output, its scale, "lazy")."""
+        for all items.  State between calls: (terms, newest head output, its scale, "lazy").
+        More items than one glue launch takes (DRBA_MAX_STAGE_ITEMS; round 6): the glue kernels -- stage inputs, fused stage
+        convolutions, the final blend -- run in chunks of that many items on batch slices of the stage's tensors, the convolution
+        chains run ONCE over the whole batch (their layers are latency- / tail-bound on the small maps: 64 ch 136x240 runs at 105
+        TFLOP/s at N = 8 and 115 at N = 16, tools/exp/conv_batch_scaling.py)."""
         B = len(items)
+        M = _lib.MAX_STAGE_ITEMS
+        chunks = [(a, min(a + M, B)) for a in range(0, B, M)]
         _, _, H, W = items[0][0].shape
         dev = items[0][0].device
         terms, tmp, s_prev, _ = state if state is not None else ([], None, 1.0, "lazy")
         terms = list(terms)
+        cut = lambda a, b: [(t[a:b], sc) for t, sc in terms]  # noqa: E731
         for i in range(first, last):
             s = scale_list[i]
             h, w = int(np.floor(H * (1.0 / s))), int(np.floor(W * (1.0 / s)))
             if i == 0:
                 xin = torch.empty((B, 39, h, w), dtype=torch.float32, device=dev)
-                _ops.stage_inputs(items, None, None, s_prev, s, xin, lds=False)
+                for a, b in chunks:
+                    _ops.stage_inputs(items[a:b], None, None, s_prev, s, xin[a:b], lds=False)
                 tmp_new = self.block[i].core(xin)
             else:
                 final = i == 4  # the last stage: only flow and mask of its head output are read (IFBlock.lastconv5)
-                if s in (1, 2) and _ops.stage_conv0_ok(self.block[i].conv0_0, H, W, s, s_prev, items=items):
+                conv = self.block[i].conv0_0
+                if s in (1, 2) and _ops.stage_conv0_ok(conv, H, W, s, s_prev, items=items):
                     # scale 1, and scale 2 where the two-term kernel takes it (the flow as terms, frames with their [H,W,4] copies)
-                    y0, _ = _ops.stage_conv0(items, None, tmp, s_prev, self.block[i].conv0_0, terms=terms, scale=s)
+                    if len(chunks) == 1:
+                        y0, _ = _ops.stage_conv0(items, None, tmp, s_prev, conv, terms=terms, scale=s)
+                    else:
+                        hs, ws = H // int(s), W // int(s)
+                        y0 = torch.empty((B, conv.cout, (hs - 1) // 2 + 1, (ws - 1) // 2 + 1), dtype=torch.float32, device=dev)
+                        for a, b in chunks:
+                            _ops.stage_conv0(items[a:b], None, tmp[a:b], s_prev, conv, terms=cut(a, b), scale=s, out=y0[a:b])
                     tmp_new = (self.block[i].chain_tail5 if final else self.block[i].chain_tail)(y0)
                 else:
                     xin = torch.empty((B, 52, h, w), dtype=torch.float32, device=dev)
-                    _ops.stage_inputs(items, None, tmp, s_prev, s, xin, terms=terms)
+                    for a, b in chunks:
+                        _ops.stage_inputs(items[a:b], None, tmp[a:b], s_prev, s, xin[a:b], terms=cut(a, b))
                     tmp_new = (self.block[i].chain5 if final else self.block[i].chain)(xin)
                 terms.append((tmp, s_prev))
             tmp, s_prev = tmp_new, s
         if last < 5:
             return terms, tmp, s_prev, "lazy"
-        return _ops.warp_blend_lazy(items, terms, tmp, s_prev)
+        frames = []
+        for a, b in chunks:
+            frames += _ops.warp_blend_lazy(items[a:b], cut(a, b), tmp[a:b], s_prev)
+        return frames
 
     def __call__(self, x, timestep=0.5, scale_list=(8, 4, 2, 1), training=False, fastmode=True, ensemble=False,
                  f0=None, f1=None):

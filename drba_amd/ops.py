@@ -1103,7 +1103,7 @@ def stage_conv0_ok(conv, H, W, scale, prev_scale, items=None):
     return bool(lib.drba_stage_conv0_supported(H, W, float(scale), float(prev_scale), conv.cout))  # 16 output channels only
 
 
-def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None, scale=1):
+def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None, scale=1, out=None):
     """The scale-1 stage input of every item fused with `conv` (52 -> 16, stride 2, LeakyReLU): stage_inputs(..., scale=1)
     followed by conv(xin) without the 52-channel tensor (drba_stage_conv16_batch: two fp16 terms per operand, kernel family 4;
     drba_stage_conv0_batch: exact fp32 products, when family 4 is not allowed).  Returns (y0 [B,16,Ho,Wo], folded flows
@@ -1137,7 +1137,10 @@ def stage_conv0(items, flows, tmp_prev, prev_scale, conv, fold=False, terms=None
     packed = getattr(conv, attr)
     tmp_prev = _f32(tmp_prev)
     hp, wp = tmp_prev.shape[2], tmp_prev.shape[3]
-    out = torch.empty((B, conv.cout, Ho, Wo), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((B, conv.cout, Ho, Wo), dtype=torch.float32, device=dev)
+    elif tuple(out.shape) != (B, conv.cout, Ho, Wo) or not out.is_contiguous() or out.dtype != torch.float32:  # a batch slice of a wider tensor
+        raise _lib.DrbaHipError(f"stage_conv0: out must be a contiguous float32 [{B},{conv.cout},{Ho},{Wo}] tensor")
     flow_out = torch.empty((B, 4, H, W), dtype=torch.float32, device=dev) if fold else None
     arr = (_lib.StageItem * B)()
     keep = []

@@ -55,6 +55,23 @@ if what in ("drm", "rev"):
     else:
         fn = lambda: ops.flow_reverse(fa)  # noqa: E731
         nbytes = 8 * 16.0 * H * W
+elif what in ("conv64g", "conv64r", "conv32r", "deconv4"):
+    if what == "deconv4":
+        x = torch.randn(8, 32, 272, 480, generator=g).to(dev)
+        layer = ops.Deconv4x4(torch.randn(32, 20, 4, 4, generator=g) * 0.05, torch.zeros(20), pixel_shuffle=True, device=dev)
+        fn = lambda: layer(x)  # noqa: E731
+    else:
+        n, c, h, w, pre = {"conv64g": (1, 64, 576, 960, 0.25), "conv64r": (8, 64, 136, 240, None), "conv32r": (8, 32, 272, 480, None)}[what]
+        x = torch.randn(n, c, h, w, generator=g).to(dev)
+        if pre is None:
+            layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, True, torch.ones(1, c, 1, 1), device=dev)
+            out = torch.empty_like(x)
+            fn = lambda: layer(x, residual=x, out=out)  # noqa: E731
+        else:
+            layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, None, None, device=dev, pre_slope=pre)
+            out = torch.empty_like(x)
+            fn = lambda: layer(x, residual=x, out=out)  # noqa: E731
+    nbytes = None
 elif what == "head":
     from drba_amd.models.rife_426_heavy.IFNet_HDv3 import Head
     hsd = {"encode.cnn0.weight": torch.randn(16, 3, 3, 3, generator=g) / 27 ** 0.5, "encode.cnn0.bias": torch.zeros(16),
