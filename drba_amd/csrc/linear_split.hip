@@ -75,7 +75,7 @@ struct LinCfg {
 // EPI 0: + bias.  EPI 1: + bias, GELU.  EPI 2 (N == the workgroup's 128 features): + bias, LayerNorm over the row
 // (nn.LayerNorm(128): biased variance, eps) * ln_w + ln_b, + residual row -- transformer.py:178-185, :203-207.
 template <class Cfg, int EPI>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, Cfg::MTW >= 2 ? 2 : 1)  // the 128-token tile: two workgroups per CU (<= 256 registers)
 linear_split_kernel(const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                      float *__restrict__ out, int M, int K, int N, int ldx, int n_ntiles, const float *__restrict__ ln_w,
                      const float *__restrict__ ln_b, const float *__restrict__ residual, float eps,
@@ -328,21 +328,30 @@ static int linear_launch(const float *x, const float *packed_w, const float *bia
   if (x2 && (K1 <= 0 || K1 >= K || K1 % CK || (ldx2 & 3) || ldx2 < K - K1)) return DRBA_EINVAL;
   const int q_split = x2 ? K1 / CK : K / CK;
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(packed_w);
-  using Cfg = LinCfg<1, 8>;  // (tile geometry: the same for both forms)
-  const int n_ntiles = (N + Cfg::TN - 1) / Cfg::TN, n_mtiles = (M + Cfg::TM - 1) / Cfg::TM;
+  // 64 tokens x 128 features per workgroup; 128 tokens (two 16-token tiles per wave) for the two-term form on large token counts:
+  // a chunk's 16 KB of weight fragments and its barrier + global-load wait are then paid once per 48 MFMAs of a wave instead of 24
+  // (same-box A/B, 69 120 tokens: 256 -> 1024 + GELU 312 -> 289 us; with one feature tile -- the 128-feature LayerNorm epilogue --
+  // the wider tile halves the workgroups and loses, 27.7 -> 34 us: taken only where >= 1536 workgroups remain)
+  const bool wide = terms == 2 && (long long)((M + 127) / 128) * ((N + 127) / 128) >= 1536;
+  const int TM = wide ? 128 : 64, TN = 128;
+  const int n_ntiles = (N + TN - 1) / TN, n_mtiles = (M + TM - 1) / TM;
   const dim3 grid((unsigned)(n_ntiles * n_mtiles));
   unsigned char *status = terms == 2 ? drba::status_bytes() : nullptr;
-#define DRBA_LIN(E, P)                                                                                                      \
-  DRBA_LAUNCH((linear_split_kernel<LinCfg<1, 8, P>, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
+#define DRBA_LIN(E, P, MT)                                                                                                   \
+  DRBA_LAUNCH((linear_split_kernel<LinCfg<MT, 8, P>, E>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, wf, bias, out, M, K, N, \
                     ldx, n_ntiles, ln_w, ln_b, residual, eps, x2, ldx2, q_split, status)
   if (terms == 3) {
-    if (epi == 2) DRBA_LIN(2, 3);
-    else if (epi == 1) DRBA_LIN(1, 3);
-    else DRBA_LIN(0, 3);
+    if (epi == 2) DRBA_LIN(2, 3, 1);
+    else if (epi == 1) DRBA_LIN(1, 3, 1);
+    else DRBA_LIN(0, 3, 1);
+  } else if (wide) {
+    if (epi == 2) DRBA_LIN(2, 2, 2);
+    else if (epi == 1) DRBA_LIN(1, 2, 2);
+    else DRBA_LIN(0, 2, 2);
   } else {
-    if (epi == 2) DRBA_LIN(2, 2);
-    else if (epi == 1) DRBA_LIN(1, 2);
-    else DRBA_LIN(0, 2);
+    if (epi == 2) DRBA_LIN(2, 2, 1);
+    else if (epi == 1) DRBA_LIN(1, 2, 1);
+    else DRBA_LIN(0, 2, 1);
   }
 #undef DRBA_LIN
   DRBA_CHECK_LAUNCH();

@@ -72,6 +72,20 @@ elif what in ("conv64g", "conv64r", "conv32r", "deconv4"):
             out = torch.empty_like(x)
             fn = lambda: layer(x, residual=x, out=out)  # noqa: E731
     nbytes = None
+elif what in ("attn", "mlp", "merge"):
+    if what == "attn":  # GMFlow's fine-scale window attention at 1080p: 2 x 34560 tokens, 8 x 8 windows (18 x 30 tokens each), shifted
+        qkv = torch.randn(2, 144 * 240, 384, generator=g).to(dev)
+        fn = lambda: ops.window_attention(qkv[..., 0:128], qkv[..., 128:256], qkv[..., 256:384], 144, 240, 8, True, 128 ** -0.5)  # noqa: E731
+    elif what == "mlp":
+        lin = ops.LinearSplit(torch.randn(1024, 256, generator=g) * 0.05, torch.zeros(1024), gelu=True, device=dev)
+        xt = torch.randn(2 * 144 * 240, 256, generator=g).to(dev)
+        fn = lambda: lin(xt)  # noqa: E731
+    else:
+        lin = ops.LinearSplit(torch.randn(128, 128, generator=g) * 0.05, None, device=dev)
+        xt = torch.randn(2 * 144 * 240, 128, generator=g).to(dev)
+        lw, lb = torch.ones(128).to(dev), torch.zeros(128).to(dev)
+        fn = lambda: lin.layernorm(xt, lw, lb, residual=xt)  # noqa: E731
+    nbytes = None
 elif what == "head":
     from drba_amd.models.rife_426_heavy.IFNet_HDv3 import Head
     hsd = {"encode.cnn0.weight": torch.randn(16, 3, 3, 3, generator=g) / 27 ** 0.5, "encode.cnn0.bias": torch.zeros(16),
