@@ -7,7 +7,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $(dirname $0)/..
 if [ "$2" != "skip-tests" ]; then
-  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1
+  rm -f $OUT/parity_report.txt
+  DRBA_PARITY_REPORT=$OUT/parity_report.txt timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1
   echo "pytest exit $?" >> $OUT/pytest_gpu.txt
   tail -3 $OUT/pytest_gpu.txt
 fi
@@ -29,6 +30,16 @@ if [ -n "$F" ] && [ -n "$Wc" ]; then
   python tools/pmc_traffic.py $F $Wc $OUT/pmc_manifest.json $OUT/pmc_traffic.md && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 fi
 rm -rf $OUT/pmc_fetch/*kernel_trace.csv $OUT/pmc_write/*kernel_trace.csv
+# the 4K scale-0.5 geometry (round 6): its own target set, merged into the same table
+python tools/pmc_targets_4k.py > /dev/null 2>&1
+(cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc4k_fetch -o f -- python $REPO/tools/pmc_targets_4k.py > /dev/null 2> $OUT/pmc4k_fetch.err; echo "pmc 4k fetch exit $?")
+(cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc4k_write -o w -- python $REPO/tools/pmc_targets_4k.py > /dev/null 2> $OUT/pmc4k_write.err; echo "pmc 4k write exit $?")
+cp gpurun_out/pmc_manifest_4k.json $OUT/ 2>/dev/null
+F4=$(ls $OUT/pmc4k_fetch/*counter_collection.csv 2>/dev/null | head -1); W4=$(ls $OUT/pmc4k_write/*counter_collection.csv 2>/dev/null | head -1)
+if [ -n "$F4" ] && [ -n "$W4" ]; then
+  DRBA_PMC_MERGE=1 python tools/pmc_traffic.py $F4 $W4 $OUT/pmc_manifest_4k.json $OUT/pmc_traffic_4k.md > /dev/null && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+fi
+rm -rf $OUT/pmc4k_fetch/*kernel_trace.csv $OUT/pmc4k_write/*kernel_trace.csv
 timeout 900 python bench.py > $OUT/bench_1080p.json 2> $OUT/bench_1080p.err; echo "bench exit $?"
 for c in 4k 480p 4k_s1; do
   timeout 600 python bench.py --config $c --no-extra --no-cpu-baseline > $OUT/bench_$c.json 2>> $OUT/bench_other.err
