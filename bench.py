@@ -42,7 +42,11 @@ Extra objects on the JSON line:
   max_abs_vs_oracle  max |HIP frame - oracle frame| over the frames of the cpu_baseline sample, same uint8 inputs
                 (fp32 at network size), plus the largest difference of the uint8 outputs in LSB.
   extra_configs BASELINE.json configs[2], [3], [4] at N = 1 through the real driver loop (interpolate_stream) with the
-                clip resident in HBM, each with its own roofline entry.
+                clip resident in HBM, each with its own roofline entry, `path` (which of the model's paths the timed calls
+                took), `host_ms_per_step` and `group`; 40 timed iterations, an untimed rehearsal clip in front of the
+                scene-detection legs (clip_leg).
+  The timed `-t 2` loop keeps at most kMaxStepsInFlight steps queued (step_loop): the frames stay on the device, so nothing
+  else would stop the host from queueing the whole HBM full of pending steps at 4K.
 """
 import argparse
 import collections
