@@ -550,9 +550,12 @@ static int first_f16_dma_cfg() { return first_f16_cfg() + (split_enabled() ? con
 static int first_f16_ks_cfg() { return first_f16_dma_cfg() + (split_enabled() ? conv_dma_num_cfgs() : 0); }
 // ... and its stride-2 tiles (family 4, stride 2: conv_split.hip MODE 2)
 static int first_f16_s2_cfg() { return first_f16_ks_cfg() + (split_enabled() ? conv_ks_num_cfgs() : 0); }
-int drba_conv3x3_num_cfgs(void) { return first_f16_s2_cfg() + (split_enabled() ? conv_split_s2_num_cfgs() : 0); }
+// ... and (round 6) its stride-1 tiles whose waves split rows and couts (conv_split.hip CS = 2): appended, family 4, stride 1
+static int first_f16_cs_cfg() { return first_f16_s2_cfg() + (split_enabled() ? conv_split_s2_num_cfgs() : 0); }
+int drba_conv3x3_num_cfgs(void) { return first_f16_cs_cfg() + (split_enabled() ? conv_split_cs_num_cfgs() : 0); }
 int drba_conv3x3_cfg_stride(int cfg) {
-  if (cfg >= first_f16_s2_cfg() && cfg < drba_conv3x3_num_cfgs()) return 2;
+  if (cfg >= first_f16_cs_cfg() && cfg < drba_conv3x3_num_cfgs()) return conv_split_cfg_stride(cfg - first_f16_cs_cfg() + conv_split_cs_first());
+  if (cfg >= first_f16_s2_cfg() && cfg < first_f16_cs_cfg()) return 2;
   if (cfg >= kNumConvCfg && cfg < drba_conv3x3_num_cfgs()) return 1;
   return (cfg < 0 || cfg >= kNumConvCfg) ? DRBA_EINVAL : kConv[cfg].S;
 }
@@ -560,7 +563,7 @@ int drba_conv3x3_cfg_family(int cfg) {
   if (cfg < 0 || cfg >= drba_conv3x3_num_cfgs()) return DRBA_EINVAL;
   return cfg < kNumConvCfg ? 0 : (cfg < first_dma_cfg() ? 1 : (cfg < first_ks_cfg() ? 2 : (cfg < first_f16_cfg() ? 3 : 4)));
 }
-int drba_deconv4x4_num_cfgs(void) { return kNumDeconvCfg + (split_enabled() ? 2 * deconv_split_num_cfgs() : 0); }
+int drba_deconv4x4_num_cfgs(void) { return kNumDeconvCfg + (split_enabled() ? deconv_split_total_cfgs() : 0); }
 int drba_deconv4x4_cfg_family(int cfg) {
   if (cfg < 0 || cfg >= drba_deconv4x4_num_cfgs()) return DRBA_EINVAL;
   return cfg < kNumDeconvCfg ? 0 : (cfg - kNumDeconvCfg < deconv_split_f16_first() ? 1 : 4);
@@ -576,8 +579,10 @@ int drba_conv3x3_pick_cfg(int Cin, int Cout, int Ho, int Wo, int stride) {
 }
 
 size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
+  if (cfg >= first_f16_cs_cfg())
+    return cfg < drba_conv3x3_num_cfgs() ? conv_split_packed_floats(Cin, Cout, cfg - first_f16_cs_cfg() + conv_split_cs_first()) : 0;
   if (cfg >= first_f16_s2_cfg())
-    return cfg < drba_conv3x3_num_cfgs() ? conv_split_packed_floats(Cin, Cout, cfg - first_f16_s2_cfg() + conv_split_s2_first()) : 0;
+    return conv_split_packed_floats(Cin, Cout, cfg - first_f16_s2_cfg() + conv_split_s2_first());
   if (cfg >= first_f16_ks_cfg()) return conv_ks_packed_floats(Cin, Cout, cfg - first_f16_ks_cfg() + conv_ks_f16_first());
   if (cfg >= first_f16_dma_cfg()) return conv_dma_packed_floats(Cin, Cout, cfg - first_f16_dma_cfg() + conv_dma_f16_first());
   if (cfg >= first_f16_cfg()) return conv_split_packed_floats(Cin, Cout, cfg - first_f16_cfg() + conv_split_f16_first());
@@ -591,7 +596,9 @@ size_t drba_conv3x3_packed_floats(int Cin, int Cout, int cfg) {
 // fragment order: packed[(((cz*nchunks + q)*9 + tap)*CG + cg)*NT + nt][lane] =
 //   w[cz*NTC + nt*16 + (lane&15)][q*CK + cg*4 + (lane>>4)][tap], zero outside Cout/Cin
 int drba_conv3x3_pack(const float *w, float *packed, int Cin, int Cout, int cfg) {
-  if (cfg >= first_f16_s2_cfg() && cfg < drba_conv3x3_num_cfgs())
+  if (cfg >= first_f16_cs_cfg() && cfg < drba_conv3x3_num_cfgs())
+    return conv_split_pack(w, packed, Cin, Cout, cfg - first_f16_cs_cfg() + conv_split_cs_first());
+  if (cfg >= first_f16_s2_cfg() && cfg < first_f16_cs_cfg())
     return conv_split_pack(w, packed, Cin, Cout, cfg - first_f16_s2_cfg() + conv_split_s2_first());
   if (cfg >= first_f16_ks_cfg() && cfg < first_f16_s2_cfg())
     return conv_ks_pack(w, packed, Cin, Cout, cfg - first_f16_ks_cfg() + conv_ks_f16_first());
@@ -629,7 +636,12 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
   if (act < 0 || act > 4) return DRBA_EINVAL;
   // (family 4: with drba_set_range_check on, the output is scanned for the inf / NaN an fp16 overflow of an operand leaves)
   const size_t n_out = (size_t)N * Cout * ((H - 1) / (stride > 0 ? stride : 1) + 1) * ((W - 1) / (stride > 0 ? stride : 1) + 1);
-  if (cfg >= first_f16_s2_cfg() && cfg < drba_conv3x3_num_cfgs()) {
+  if (cfg >= first_f16_cs_cfg() && cfg < drba_conv3x3_num_cfgs()) {
+    if (stride != conv_split_cfg_stride(cfg - first_f16_cs_cfg() + conv_split_cs_first())) return DRBA_EINVAL;
+    return range_checked(conv_split_launch(cfg - first_f16_cs_cfg() + conv_split_cs_first(), in, packed_w, bias, beta, residual, residual2, out, N,
+                                           Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream), out, n_out, stream);
+  }
+  if (cfg >= first_f16_s2_cfg() && cfg < first_f16_cs_cfg()) {
     if (stride != 2) return DRBA_EINVAL;
     return range_checked(conv_split_launch(cfg - first_f16_s2_cfg() + conv_split_s2_first(), in, packed_w, bias, beta, residual, residual2, out, N,
                                            Cin, H, W, Cout, act, post_slope, pre_act, pre_slope, stream), out, n_out, stream);

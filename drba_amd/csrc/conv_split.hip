@@ -48,11 +48,18 @@ constexpr int CK = 32;  // channels per chunk = the K of one bf16 MFMA
 // MODE 0: conv3x3 stride 1.  MODE 1: one row phase py (both column phases px) of ConvTranspose2d(k=4, s=2, p=1), a
 // 2x2-tap convolution over the same haloed window (tap offsets and phase algebra as in conv.hip).
 // PL = 3: the three-term bf16 split above.  PL = 2: the two-term fp16 split (header comment "Two-term form").
-template <int MODE_, int RW_, int MW_, int NT_, int PL_ = 3>
+// CS (round 6): the four waves of a workgroup split the tile's ROWS 4 / CS ways and its COUT tiles CS ways -- CS = 2: two row
+// groups x two cout halves -- instead of rows only.  A wave then works RW = 2 rows against NT = 2 cout tiles where the plain 4 x 32 x 64
+// tile works 1 row against 4: the same tile, the same staged window, but a weight fragment a wave fetches feeds FOUR MFMA sets
+// instead of two and a wave fetches half of them -- the per-wave weight stream through the vector L1 (every wave fetches its
+// fragments itself: 2.07 GB per 64-channel 136 x 240 N8 launch, 49 of the L1's 64 bytes per clock and CU averaged over the whole
+// launch, PMC `SQ_INSTS_VMEM_RD`) halves, and so do the accumulators (64 registers instead of 128).
+template <int MODE_, int RW_, int MW_, int NT_, int PL_ = 3, int CS_ = 1>
 struct SplitCfg {
-  static constexpr int MODE = MODE_, RW = RW_, MW = MW_, NT = NT_, PL = PL_;
+  static constexpr int MODE = MODE_, RW = RW_, MW = MW_, NT = NT_, PL = PL_, CS = CS_;
+  static constexpr int NTT = NT * CS;  // cout tiles of the workgroup's tile (NT: of one wave)
   static constexpr int NTAP = MODE != 1 ? 9 : 4, NPX = MODE != 1 ? 1 : 2;
-  static constexpr int TH = 4 * RW, TW = 16 * MW, NTC = 16 * NT;
+  static constexpr int TH = (4 / CS) * RW, TW = 16 * MW, NTC = 16 * NTT;
   static constexpr int TR = MODE == 2 ? 2 * TH + 1 : TH + 2, TC = MODE == 2 ? 2 * TW + 1 : TW + 2, NPIX = TR * TC;
   // LDS: [plane PL][group 4][NPIXP][8 x 16 bit]; NPIXP*16 bytes == 64 (mod 256) spreads the four channel groups of a wave
   // read over distinct banks
@@ -60,7 +67,7 @@ struct SplitCfg {
   static constexpr int LDS_BYTES = PL * 4 * NPIXP * 16;
   static constexpr int ITEMS = NPIX * 4;                 // (pixel, channel group) staging items per chunk
   static constexpr int LIT = (ITEMS + 255) / 256;        // per thread
-  static constexpr int FRAG_U4 = NTAP * NT * PL * 64;    // 16-byte units of packed weights per (cout tile[, phase], chunk)
+  static constexpr int FRAG_U4 = NTAP * NTT * PL * 64;   // 16-byte units of packed weights per (cout tile[, phase], chunk)
 #ifndef DRBA_SPLIT_BDEPTH_BIG
 #define DRBA_SPLIT_BDEPTH_BIG 2
 #endif
@@ -77,7 +84,8 @@ struct SplitCfg {
 #define DRBA_SPLIT_MINB3 1
 #endif
   // workgroups per CU the register allocation aims at: the 4x32x32 tile needs 170 registers, two short of three per CU
-  static constexpr int MINB = (DRBA_SPLIT_MINB3 && MODE == 0 && RW * MW * NT <= 4 && PL == 3) ? 3 : 2;
+  // (CS = 2 at three workgroups per CU: 168 registers with 372 bytes of scratch per lane, 81 against 74 us on the 64-channel N8 layer)
+  static constexpr int MINB = (DRBA_SPLIT_MINB3 && MODE == 0 && RW * MW * NT <= 4 && PL == 3 && CS == 1) ? 3 : 2;
 };
 
 // fp32 -> (h, m, l) bf16 with round-to-nearest-even at every step; returns the three terms of 2 values packed
@@ -163,7 +171,9 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
   const int m = lane & 15, kq = lane >> 4;
   const size_t HW = (size_t)H * W, HWi = (size_t)Hi * Wi;
   const int nchunks = (Cin + CK - 1) / CK;
-  const int row0 = wave * RW;
+  constexpr int CS = Cfg::CS, NTT = Cfg::NTT;
+  const int row0 = (CS == 1 ? wave : wave % (4 / CS)) * RW;   // this wave's rows of the tile ...
+  const int nt0 = CS == 1 ? 0 : (wave / (4 / CS)) * NT;      // ... and its first cout tile (CS > 1: the waves also split the couts)
 
   // Persistent workgroups: work item i of workgroup b is tile xcd_band(b + i * gridDim.x) -- gridDim.x is a multiple
   // of 8, so a workgroup stays inside its XCD's contiguous band of tiles (cout tile innermost, see conv.hip) -- and
@@ -276,7 +286,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     float bs[NT], bt[NT], bs2[NT], bt2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int co = ctx.cz * Cfg::NTC + nt * 16 + (regroup ? (lane >> 3) : m), co2 = co + 8;
+      const int co = ctx.cz * Cfg::NTC + (nt0 + nt) * 16 + (regroup ? (lane >> 3) : m), co2 = co + 8;
       bs[nt] = (bias && co < Cout) ? bias[co] : 0.f;
       bt[nt] = (beta && co < Cout) ? beta[co] : 0.f;
       bs2[nt] = (regroup && bias && co2 < Cout) ? bias[co2] : 0.f;
@@ -299,7 +309,8 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       const int px_bytes = nchunks * (Cfg::FRAG_U4 * 16);
       auto wload = [&](int step, int pl) -> u32x4 {
         const int p = step / (NTAP * NT), r = step - p * (NTAP * NT);  // r = tap * NT + nt
-        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wq + p * px_bytes + (r * PL + pl) * 1024, 0);
+        const int tap = r / NT, nt = r - tap * NT;                      // packed per tap: NTT fragments of the whole tile
+        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, wq + p * px_bytes + ((tap * NTT + nt0 + nt) * PL + pl) * 1024, 0);
       };
       u32x4 bw[D][PL];
 #pragma unroll
@@ -443,7 +454,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
         const __amdgpu_buffer_rsrc_t r2rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)((res2 ? res2 : out) + img), 0, res2 ? obytes : 0u, 0x00020000);
         auto offs = [&](int nt, int rw, int j, unsigned &oa, unsigned &ob) {
-          const int coA = ctx.cz * Cfg::NTC + nt * 16 + c8;
+          const int coA = ctx.cz * Cfg::NTC + (nt0 + nt) * 16 + c8;
           const int y = ctx.y0 + row0 + rw;
           const int xb = ctx.x0 + (2 * j + blk) * 16 + q4 * 4;
           const bool in_img = y < H && xb < W;
@@ -560,7 +571,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 #pragma unroll
               for (int mw = 0; mw < MW; ++mw) {
                 const f32x4 v = acc[0][rw][mw][nt];
-                const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
+                const int co = ctx.cz * Cfg::NTC + (nt0 + nt) * 16 + m;
                 const int y = ctx.y0 + row0 + rw;
                 const int xb = ctx.x0 + mw * 16 + kq * 4;
                 if (co >= Cout || y >= H || xb >= W) continue;
@@ -616,7 +627,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               f32x4 v = acc[0][rw][mw][nt], v1 = acc[NPX - 1][rw][mw][nt];
-              const int co = ctx.cz * Cfg::NTC + nt * 16 + m;
+              const int co = ctx.cz * Cfg::NTC + (nt0 + nt) * 16 + m;
               const int y = ctx.y0 + row0 + rw;
               const int xb = ctx.x0 + mw * 16 + kq * 4;
               const int oy = 2 * y + ctx.py;
@@ -706,17 +717,24 @@ using X1 = SplitCfg<2, 1, 2, 4, 2>;  // 4x32 x 64
 using X2 = SplitCfg<2, 1, 1, 2, 2>;  // 4x16 x 32 (window 9 x 33)
 using X3 = SplitCfg<2, 1, 1, 4, 2>;  // 4x16 x 64
 constexpr int kNumX = 4;
+// appended behind them (round 6; stride 1 again): the 4 x 32 x 64 tile with the waves splitting rows AND couts (CS = 2)
+using Y0 = SplitCfg<0, 2, 2, 2, 2, 2>;  // 4x32 px x 64 cout
+using Y1 = SplitCfg<0, 2, 2, 3, 2, 2>;  // 4x32 px x 96 cout
+using Y2 = SplitCfg<2, 2, 2, 2, 2, 2>;  // stride 2: 4x32 output px x 64 cout (window 9 x 65, as X1)
+constexpr int kNumY = 3;
 struct Info {
   int NT, NTC, frag_u4, PL;
 };
 template <class C>
 constexpr Info info() {
-  return {C::NT, C::NTC, C::FRAG_U4, C::PL};
+  return {C::NTT, C::NTC, C::FRAG_U4, C::PL};  // (NT here: the cout tiles of a packed tile)
 }
-const Info kInfo[2 * kNum + kNumX] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>(),
-                                      info<F0>(), info<F1>(), info<F2>(), info<F3>(), info<F4>(),
-                                      info<X0>(), info<X1>(), info<X2>(), info<X3>()};
-const Info kInfoT[2 * kNumT] = {info<T0>(), info<T1>(), info<G0>(), info<G1>()};
+const Info kInfo[2 * kNum + kNumX + kNumY] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>(),
+                                              info<F0>(), info<F1>(), info<F2>(), info<F3>(), info<F4>(),
+                                              info<X0>(), info<X1>(), info<X2>(), info<X3>(), info<Y0>(), info<Y1>(), info<Y2>()};
+using Z0 = SplitCfg<1, 2, 2, 2, 2, 2>;  // transposed, two-term, the waves split rows and couts: 4x32 input px x 64 cout (round 6)
+constexpr int kNumZ = 1;
+const Info kInfoT[2 * kNumT + kNumZ] = {info<T0>(), info<T1>(), info<G0>(), info<G1>(), info<Z0>()};
 
 template <class Cfg, bool PRE, bool RL = false>
 hipError_t lds_limit() {
@@ -790,10 +808,16 @@ int conv_split_num_cfgs() { return drba_conv_split::kNum; }
 int conv_split_f16_first() { return drba_conv_split::kNum; }
 int conv_split_s2_first() { return 2 * drba_conv_split::kNum; }
 int conv_split_s2_num_cfgs() { return drba_conv_split::kNumX; }
+int conv_split_cs_first() { return 2 * drba_conv_split::kNum + drba_conv_split::kNumX; }
+int conv_split_cs_num_cfgs() { return drba_conv_split::kNumY; }
+int conv_split_cfg_stride(int id) { return (id >= 2 * drba_conv_split::kNum && id != 14 && id != 15) ? 2 : 1; }  // (Y2 = id 16 is a stride-2 tile)
 
 bool conv_split_supports(int Cin, int Cout, int id) {
-  if (id >= 2 * drba_conv_split::kNum) return id < 2 * drba_conv_split::kNum + drba_conv_split::kNumX && Cin > 0 && Cout > 0;
-  return id >= 0 && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
+  using namespace drba_conv_split;
+  if (id >= 2 * kNum + kNumX)  // two-term, CS = 2: the stride-1 tiles need whole chunks, the stride-2 tile takes any Cin
+    return id < 2 * kNum + kNumX + kNumY && Cin > 0 && Cout > 0 && (conv_split_cfg_stride(id) == 2 || Cin % CK == 0);
+  if (id >= 2 * kNum) return Cin > 0 && Cout > 0;
+  return id >= 0 && Cin > 0 && Cout > 0 && Cin % CK == 0;
 }
 
 size_t conv_split_packed_floats(int Cin, int Cout, int id) {
@@ -861,6 +885,9 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
     DRBA_CASE(11, X1)
     DRBA_CASE(12, X2)
     DRBA_CASE(13, X3)
+    DRBA_CASE(14, Y0)
+    DRBA_CASE(15, Y1)
+    DRBA_CASE(16, Y2)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;
@@ -871,8 +898,9 @@ int deconv_split_num_cfgs() { return drba_conv_split::kNumT; }
 
 int deconv_split_f16_first() { return drba_conv_split::kNumT; }
 
+int deconv_split_total_cfgs() { return 2 * drba_conv_split::kNumT + drba_conv_split::kNumZ; }  // ids >= 2 kNumT: two-term, CS = 2
 bool deconv_split_supports(int Cin, int Cout, int id) {
-  return id >= 0 && id < 2 * drba_conv_split::kNumT && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
+  return id >= 0 && id < deconv_split_total_cfgs() && Cin > 0 && Cout > 0 && Cin % drba_conv_split::CK == 0;
 }
 
 size_t deconv_split_packed_floats(int Cin, int Cout, int id) {
@@ -935,6 +963,7 @@ int deconv_split_launch(int id, const float *in, const float *packed_w, const fl
     DRBA_CASE(1, T1)
     DRBA_CASE(2, G0)
     DRBA_CASE(3, G1)
+    DRBA_CASE(4, Z0)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;

@@ -37,6 +37,9 @@ int conv_split_num_cfgs();   // ids 0 .. n-1: three-term bf16 split; ids n .. 2n
 int conv_split_f16_first();  // = n
 int conv_split_s2_first();   // = 2n: then conv_split_s2_num_cfgs() stride-2 tiles in the two-term form (any Cin; H, W = the INPUT map)
 int conv_split_s2_num_cfgs();
+int conv_split_cs_first();     // behind the stride-2 tiles: stride-1 two-term tiles whose waves split rows and couts (round 6)
+int conv_split_cs_num_cfgs();
+int conv_split_cfg_stride(int id);  // 1 or 2, for any id of this file's table
 bool conv_split_supports(int Cin, int Cout, int id);  // stride 1, Cin a multiple of 32
 size_t conv_split_packed_floats(int Cin, int Cout, int id);
 int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id);
@@ -70,6 +73,7 @@ int conv_ks_launch(int id, const float *in, const float *packed_w, const float *
 // transposed convolution 4x4 s2 p1 (cfg ids after conv.hip's fp32 deconv table)
 int deconv_split_num_cfgs();   // as above: n three-term ids, then n two-term ones
 int deconv_split_f16_first();
+int deconv_split_total_cfgs();  // 2 n + the two-term tiles whose waves split rows and couts (appended, round 6)
 bool deconv_split_supports(int Cin, int Cout, int id);
 size_t deconv_split_packed_floats(int Cin, int Cout, int id);
 int deconv_split_pack(const float *w, float *packed, int Cin, int Cout, int id);
