@@ -329,11 +329,12 @@ def _dtype_note():
 
 def _two_term(name):
     """True for the two-term fp16 instantiations of the split families (the last template argument, PL, is 2):
-    conv_split_mfma<SplitCfg<M, RW, MW, NT, 2>, ...>, conv_dma1<PRE, RL, 2>, conv_ks<KW, PRE, RL, DW, 2>, linear_split_kernel<LinCfg<.., 2>, ..>;
+    conv_split_mfma<SplitCfg<M, RW, MW, NT, 2[, CS]>, ...>, conv_dma1<PRE, RL, 2>, conv_ks<KW, PRE, RL, DW, 2>, linear_split_kernel<LinCfg<.., 2>, ..>;
     window_attention16_kernel, head_fused16 and stage_conv16 exist in that form only.  A kernel that runs on the 16-bit matrix
     pipe is never priced against the fp32-MFMA peak."""
     import re
-    return bool(re.search(r"SplitCfg<[^<>]*, 2>", name) or re.search(r"conv_dma1<[^<>]*, 2>", name)
+    # (SplitCfg<MODE, RW, MW, NT, PL[, CS]>: PL is the FIFTH argument -- since round 6 a sixth, CS, follows it in every printed name)
+    return bool(re.search(r"SplitCfg<-?\d+, \d+, \d+, \d+, 2(, \d+)?>", name) or re.search(r"conv_dma1<[^<>]*, 2>", name)
                 or re.search(r"conv_ks<\d+, \w+, \w+, \w+, 2>", name) or re.search(r"LinCfg<[^<>]*, 2>", name)
                 or "window_attention16" in name or "head_fused16" in name or "stage_conv16" in name)
 
