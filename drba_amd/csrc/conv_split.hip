@@ -733,8 +733,9 @@ const Info kInfo[2 * kNum + kNumX + kNumY] = {info<S0>(), info<S1>(), info<S2>()
                                               info<F0>(), info<F1>(), info<F2>(), info<F3>(), info<F4>(),
                                               info<X0>(), info<X1>(), info<X2>(), info<X3>(), info<Y0>(), info<Y1>(), info<Y2>()};
 using Z0 = SplitCfg<1, 2, 2, 2, 2, 2>;  // transposed, two-term, the waves split rows and couts: 4x32 input px x 64 cout (round 6)
-constexpr int kNumZ = 1;
-const Info kInfoT[2 * kNumT + kNumZ] = {info<T0>(), info<T1>(), info<G0>(), info<G1>(), info<Z0>()};
+using Z1 = SplitCfg<1, 2, 2, 1, 2, 2>;  // ... x 32 cout
+constexpr int kNumZ = 2;
+const Info kInfoT[2 * kNumT + kNumZ] = {info<T0>(), info<T1>(), info<G0>(), info<G1>(), info<Z0>(), info<Z1>()};
 
 template <class Cfg, bool PRE, bool RL = false>
 hipError_t lds_limit() {
@@ -964,6 +965,7 @@ int deconv_split_launch(int id, const float *in, const float *packed_w, const fl
     DRBA_CASE(2, G0)
     DRBA_CASE(3, G1)
     DRBA_CASE(4, Z0)
+    DRBA_CASE(5, Z1)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;
