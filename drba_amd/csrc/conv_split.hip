@@ -54,11 +54,17 @@ constexpr int CK = 32;  // channels per chunk = the K of one bf16 MFMA
 // instead of two and a wave fetches half of them -- the per-wave weight stream through the vector L1 (every wave fetches its
 // fragments itself: 2.07 GB per 64-channel 136 x 240 N8 launch, 49 of the L1's 64 bytes per clock and CU averaged over the whole
 // launch, PMC `SQ_INSTS_VMEM_RD`) halves, and so do the accumulators (64 registers instead of 128).
-template <int MODE_, int RW_, int MW_, int NT_, int PL_ = 3, int CS_ = 1>
+// BP (MODE 1, round 6): BOTH row phases of a transposed-convolution tile in one work item.  The two phases of a window were two
+// work items back to back (the second found the window in L2) -- and each loaded, split and staged the whole window again: with one
+// 32-channel chunk a work item is ~5 k clocks of staging for ~1.5 k of MFMAs.  Here the staged window serves the four (row phase,
+// column phase) accumulator sets (NPX = 4: p = 2 py + px).
+template <int MODE_, int RW_, int MW_, int NT_, int PL_ = 3, int CS_ = 1, int BP_ = 0>
 struct SplitCfg {
   static constexpr int MODE = MODE_, RW = RW_, MW = MW_, NT = NT_, PL = PL_, CS = CS_;
+  static constexpr bool BP = BP_ != 0;
+  static_assert(!BP || MODE == 1, "row phases exist in the transposed form only");
   static constexpr int NTT = NT * CS;  // cout tiles of the workgroup's tile (NT: of one wave)
-  static constexpr int NTAP = MODE != 1 ? 9 : 4, NPX = MODE != 1 ? 1 : 2;
+  static constexpr int NTAP = MODE != 1 ? 9 : 4, NPX = MODE != 1 ? 1 : (BP ? 4 : 2);
   static constexpr int TH = (4 / CS) * RW, TW = 16 * MW, NTC = 16 * NTT;
   static constexpr int TR = MODE == 2 ? 2 * TH + 1 : TH + 2, TC = MODE == 2 ? 2 * TW + 1 : TW + 2, NPIX = TR * TC;
   // LDS: [plane PL][group 4][NPIXP][8 x 16 bit]; NPIXP*16 bytes == 64 (mod 256) spreads the four channel groups of a wave
@@ -183,7 +189,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     int t = xcd_band(work, total);
     TileCtx c;
     c.py = 0;
-    if (MODE == 1) {  // the two row phases of a window back to back: the second one finds it in L2
+    if (MODE == 1 && !Cfg::BP) {  // the two row phases of a window back to back: the second one finds it in L2
       c.py = t & 1;
       t >>= 1;
     }
@@ -340,8 +346,8 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       u32x4 af[RW][MW][PL];
       auto load_piece = [&](int ts, int rw, int mw) {
         const int p = ts / NTAP, tap = ts - p * NTAP;
-        const int ro = MODE != 1 ? tap / 3 : ((tap >> 1) ? 0 : 1) + ctx.py;
-        const int co = MODE != 1 ? tap % 3 : ((tap & 1) ? 0 : 1) + p;
+        const int ro = MODE != 1 ? tap / 3 : ((tap >> 1) ? 0 : 1) + (Cfg::BP ? (p >> 1) : ctx.py);
+        const int co = MODE != 1 ? tap % 3 : ((tap & 1) ? 0 : 1) + (Cfg::BP ? (p & 1) : p);
         const int slot = MODE == 2 ? kq * NPIXP + (2 * (row0 + rw) + ro) * TC + 2 * (mw * 16 + m) + co
                                    : kq * NPIXP + (row0 + rw + ro) * TC + mw * 16 + m + co;
 #pragma unroll
@@ -621,16 +627,18 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
       auto epilogue_t = [&](auto ps_) {
         constexpr bool PS = decltype(ps_)::value;
 #pragma unroll
+        for (int pyi = 0; pyi < (Cfg::BP ? 2 : 1); ++pyi)
+#pragma unroll
         for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-              f32x4 v = acc[0][rw][mw][nt], v1 = acc[NPX - 1][rw][mw][nt];
+              f32x4 v = acc[Cfg::BP ? 2 * pyi : 0][rw][mw][nt], v1 = acc[Cfg::BP ? 2 * pyi + 1 : NPX - 1][rw][mw][nt];
               const int co = ctx.cz * Cfg::NTC + (nt0 + nt) * 16 + m;
               const int y = ctx.y0 + row0 + rw;
               const int xb = ctx.x0 + mw * 16 + kq * 4;
-              const int oy = 2 * y + ctx.py;
+              const int oy = 2 * y + (Cfg::BP ? pyi : ctx.py);
               const float b0 = bs[nt];
               const bool inside = co < Cout && y < H && xb < W;
 #pragma unroll
@@ -734,8 +742,10 @@ const Info kInfo[2 * kNum + kNumX + kNumY] = {info<S0>(), info<S1>(), info<S2>()
                                               info<X0>(), info<X1>(), info<X2>(), info<X3>(), info<Y0>(), info<Y1>(), info<Y2>()};
 using Z0 = SplitCfg<1, 2, 2, 2, 2, 2>;  // transposed, two-term, the waves split rows and couts: 4x32 input px x 64 cout (round 6)
 using Z1 = SplitCfg<1, 2, 2, 1, 2, 2>;  // ... x 32 cout
-constexpr int kNumZ = 2;
-const Info kInfoT[2 * kNumT + kNumZ] = {info<T0>(), info<T1>(), info<G0>(), info<G1>(), info<Z0>(), info<Z1>()};
+using Z2 = SplitCfg<1, 2, 2, 1, 2, 2, 1>;  // Z1 with both row phases per work item (BP)
+using Z3 = SplitCfg<1, 1, 2, 2, 2, 1, 1>;  // G0 with both row phases per work item
+constexpr int kNumZ = 4;
+const Info kInfoT[2 * kNumT + kNumZ] = {info<T0>(), info<T1>(), info<G0>(), info<G1>(), info<Z0>(), info<Z1>(), info<Z2>(), info<Z3>()};
 
 template <class Cfg, bool PRE, bool RL = false>
 hipError_t lds_limit() {
@@ -765,7 +775,7 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
   const int Hi = H, Wi = W;  // the input map; the tiles are laid over the OUTPUT of a stride-2 layer
   if (Cfg::MODE == 2) H = (Hi - 1) / 2 + 1, W = (Wi - 1) / 2 + 1;
   const int nbx = (W + Cfg::TW - 1) / Cfg::TW, nby = (H + Cfg::TH - 1) / Cfg::TH;
-  const long long total = (long long)nbx * nby * N * n_ct * (Cfg::MODE != 1 ? 1 : 2);  // x2: row phases
+  const long long total = (long long)nbx * nby * N * n_ct * ((Cfg::MODE != 1 || Cfg::BP) ? 1 : 2);  // x2: row phases as work items
   if (total >= (1ll << 31)) return DRBA_EUNSUPPORTED;
   const u32x4 *wf = reinterpret_cast<const u32x4 *>(wpk);
   unsigned char *status = Cfg::PL == 2 ? status_bytes() : nullptr;
@@ -966,6 +976,8 @@ int deconv_split_launch(int id, const float *in, const float *packed_w, const fl
     DRBA_CASE(3, G1)
     DRBA_CASE(4, Z0)
     DRBA_CASE(5, Z1)
+    DRBA_CASE(6, Z2)
+    DRBA_CASE(7, Z3)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;

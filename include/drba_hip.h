@@ -33,7 +33,7 @@ extern "C" {
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
 /* ABI version.  8: configuration ids appended behind every earlier id of drba_conv3x3 (three, family 4: the waves of a workgroup split rows and
- * cout tiles) and drba_deconv4x4s2 (one); drba_status_word / drba_status_clear (the always-on, synchronisation-free overflow report of kernel family 4); the
+ * cout tiles) and drba_deconv4x4s2 (four: rows and couts split across the waves, both row phases per work item); drba_status_word / drba_status_clear (the always-on, synchronisation-free overflow report of kernel family 4); the
  * *_pack entry points of family 4 refuse (DRBA_EUNSUPPORTED) a weight the two-term fp16 form cannot hold (|w| >= 65504 or non-finite).
  * 7: drba_rife_splat_ws_floats -- the workspace of drba_flow_reverse / drba_drm_rife_linear(_batch) grew by a reach map in
  * front (scratch) and one flag per 32 x 16 output tile behind (same zero-on-entry, zero-on-return contract for everything but the map).  6: drba_stage_conv16_* (the fused stage input + first convolution in the two-term fp16 form, scale 1 and 2), drba_stage_item_t grew by
