@@ -333,8 +333,8 @@ def _two_term(name):
     window_attention16_kernel, head_fused16 and stage_conv16 exist in that form only.  A kernel that runs on the 16-bit matrix
     pipe is never priced against the fp32-MFMA peak."""
     import re
-    # (SplitCfg<MODE, RW, MW, NT, PL[, CS]>: PL is the FIFTH argument -- since round 6 a sixth, CS, follows it in every printed name)
-    return bool(re.search(r"SplitCfg<-?\d+, \d+, \d+, \d+, 2(, \d+)?>", name) or re.search(r"conv_dma1<[^<>]*, 2>", name)
+    # (SplitCfg<MODE, RW, MW, NT, PL[, CS]>: PL is the FIFTH argument -- since round 6 CS and BP follow it in every printed name)
+    return bool(re.search(r"SplitCfg<-?\d+, \d+, \d+, \d+, 2(, \d+)*>", name) or re.search(r"conv_dma1<[^<>]*, 2>", name)
                 or re.search(r"conv_ks<\d+, \w+, \w+, \w+, 2>", name) or re.search(r"LinCfg<[^<>]*, 2>", name)
                 or "window_attention16" in name or "head_fused16" in name or "stage_conv16" in name)
 

@@ -744,8 +744,9 @@ using Z0 = SplitCfg<1, 2, 2, 2, 2, 2>;  // transposed, two-term, the waves split
 using Z1 = SplitCfg<1, 2, 2, 1, 2, 2>;  // ... x 32 cout
 using Z2 = SplitCfg<1, 2, 2, 1, 2, 2, 1>;  // Z1 with both row phases per work item (BP)
 using Z3 = SplitCfg<1, 1, 2, 2, 2, 1, 1>;  // G0 with both row phases per work item
-constexpr int kNumZ = 4;
-const Info kInfoT[2 * kNumT + kNumZ] = {info<T0>(), info<T1>(), info<G0>(), info<G1>(), info<Z0>(), info<Z1>(), info<Z2>(), info<Z3>()};
+using Z4 = SplitCfg<1, 2, 1, 2, 2, 2, 1>;  // 4x16 input px x 64 cout, rows and couts split across the waves, both row phases
+constexpr int kNumZ = 5;
+const Info kInfoT[2 * kNumT + kNumZ] = {info<T0>(), info<T1>(), info<G0>(), info<G1>(), info<Z0>(), info<Z1>(), info<Z2>(), info<Z3>(), info<Z4>()};
 
 template <class Cfg, bool PRE, bool RL = false>
 hipError_t lds_limit() {
@@ -978,6 +979,7 @@ int deconv_split_launch(int id, const float *in, const float *packed_w, const fl
     DRBA_CASE(5, Z1)
     DRBA_CASE(6, Z2)
     DRBA_CASE(7, Z3)
+    DRBA_CASE(8, Z4)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;
