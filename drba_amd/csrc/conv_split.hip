@@ -729,7 +729,9 @@ constexpr int kNumX = 4;
 using Y0 = SplitCfg<0, 2, 2, 2, 2, 2>;  // 4x32 px x 64 cout
 using Y1 = SplitCfg<0, 2, 2, 3, 2, 2>;  // 4x32 px x 96 cout
 using Y2 = SplitCfg<2, 2, 2, 2, 2, 2>;  // stride 2: 4x32 output px x 64 cout (window 9 x 65, as X1)
-constexpr int kNumY = 3;
+using Y3 = SplitCfg<2, 2, 1, 2, 2, 2>;  // stride 2: 4x16 output px x 64 cout (window 9 x 33, as X3: a fragment feeds 2 MFMA sets instead of 1)
+using Y4 = SplitCfg<2, 2, 1, 3, 2, 2>;  // stride 2: 4x16 output px x 96 cout
+constexpr int kNumY = 5;
 struct Info {
   int NT, NTC, frag_u4, PL;
 };
@@ -739,7 +741,7 @@ constexpr Info info() {
 }
 const Info kInfo[2 * kNum + kNumX + kNumY] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>(),
                                               info<F0>(), info<F1>(), info<F2>(), info<F3>(), info<F4>(),
-                                              info<X0>(), info<X1>(), info<X2>(), info<X3>(), info<Y0>(), info<Y1>(), info<Y2>()};
+                                              info<X0>(), info<X1>(), info<X2>(), info<X3>(), info<Y0>(), info<Y1>(), info<Y2>(), info<Y3>(), info<Y4>()};
 using Z0 = SplitCfg<1, 2, 2, 2, 2, 2>;  // transposed, two-term, the waves split rows and couts: 4x32 input px x 64 cout (round 6)
 using Z1 = SplitCfg<1, 2, 2, 1, 2, 2>;  // ... x 32 cout
 using Z2 = SplitCfg<1, 2, 2, 1, 2, 2, 1>;  // Z1 with both row phases per work item (BP)
@@ -822,7 +824,7 @@ int conv_split_s2_first() { return 2 * drba_conv_split::kNum; }
 int conv_split_s2_num_cfgs() { return drba_conv_split::kNumX; }
 int conv_split_cs_first() { return 2 * drba_conv_split::kNum + drba_conv_split::kNumX; }
 int conv_split_cs_num_cfgs() { return drba_conv_split::kNumY; }
-int conv_split_cfg_stride(int id) { return (id >= 2 * drba_conv_split::kNum && id != 14 && id != 15) ? 2 : 1; }  // (Y2 = id 16 is a stride-2 tile)
+int conv_split_cfg_stride(int id) { return (id >= 2 * drba_conv_split::kNum && id != 14 && id != 15) ? 2 : 1; }  // (Y0, Y1 = ids 14, 15 are the stride-1 tiles behind the X's)
 
 bool conv_split_supports(int Cin, int Cout, int id) {
   using namespace drba_conv_split;
@@ -900,6 +902,8 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
     DRBA_CASE(14, Y0)
     DRBA_CASE(15, Y1)
     DRBA_CASE(16, Y2)
+    DRBA_CASE(17, Y3)
+    DRBA_CASE(18, Y4)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;

@@ -55,6 +55,13 @@ if what in ("drm", "rev"):
     else:
         fn = lambda: ops.flow_reverse(fa)  # noqa: E731
         nbytes = 8 * 16.0 * H * W
+elif what in ("s2c52", "s2c32", "s2c48", "s2c39", "s2c64"):  # the stride-2 convolutions of the IFBlocks (conv0[0] / conv0[1]), 8 samples
+    cin, cout, h, w = {"s2c52": (52, 48, 272, 480), "s2c32": (32, 64, 272, 480), "s2c48": (48, 96, 136, 240), "s2c39": (39, 96, 68, 120),
+                       "s2c64": (64, 128, 68, 120)}[what]
+    x = torch.randn(8, cin, h, w, generator=g).to(dev)
+    layer = ops.Conv3x3(torch.randn(cout, cin, 3, 3, generator=g) * 0.05, torch.zeros(cout), 2, True, None, device=dev)
+    fn = lambda: layer(x)  # noqa: E731
+    nbytes = None
 elif what in ("conv64g", "conv64r", "conv32r", "deconv4"):
     if what == "deconv4":
         x = torch.randn(8, 32, 272, 480, generator=g).to(dev)
