@@ -582,10 +582,20 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
                 const int xb = ctx.x0 + mw * 16 + kq * 4;
                 if (co >= Cout || y >= H || xb >= W) continue;
                 const size_t idx = img + ((size_t)co * H + y) * W + xb;
-                if ((W & 3) == 0 && !res && !res2) {  // (odd MW tiles on aligned maps, no residual: one 16-byte store per lane)
-                  f32x4 o;
+                if ((W & 3) == 0) {  // (odd MW tiles on aligned maps: one 16-byte store -- and residual load -- per lane)
+                  f32x4 o, r1 = (f32x4){0.f, 0.f, 0.f, 0.f}, r2 = r1;
+                  if (res) r1 = *reinterpret_cast<const f32x4 *>(res + idx);
+                  if (res2) r2 = *reinterpret_cast<const f32x4 *>(res2 + idx);
 #pragma unroll
-                  for (int k = 0; k < 4; ++k) o[k] = post(v[k] + bs[nt]);
+                  for (int k = 0; k < 4; ++k) {
+                    float u = v[k] + bs[nt];
+                    if (beta) u = u * bt[nt] + r1[k];
+                    else {
+                      if (res) u = u + r1[k];
+                      if (res2) u = u + r2[k];
+                    }
+                    o[k] = post(u);
+                  }
                   *reinterpret_cast<f32x4 *>(out + idx) = o;
                   continue;
                 }
@@ -731,7 +741,8 @@ using Y1 = SplitCfg<0, 2, 2, 3, 2, 2>;  // 4x32 px x 96 cout
 using Y2 = SplitCfg<2, 2, 2, 2, 2, 2>;  // stride 2: 4x32 output px x 64 cout (window 9 x 65, as X1)
 using Y3 = SplitCfg<2, 2, 1, 2, 2, 2>;  // stride 2: 4x16 output px x 64 cout (window 9 x 33, as X3: a fragment feeds 2 MFMA sets instead of 1)
 using Y4 = SplitCfg<2, 2, 1, 3, 2, 2>;  // stride 2: 4x16 output px x 96 cout
-constexpr int kNumY = 5;
+using Y5 = SplitCfg<0, 2, 1, 3, 2, 2>;  // stride 1: 4x16 px x 96 cout (one staged window for all couts of a 96-channel layer)
+constexpr int kNumY = 6;  // (the same tile with 128 couts: 32.5 against 32.5 us on the 128-channel 34 x 60 layer -- not built)
 struct Info {
   int NT, NTC, frag_u4, PL;
 };
@@ -741,7 +752,7 @@ constexpr Info info() {
 }
 const Info kInfo[2 * kNum + kNumX + kNumY] = {info<S0>(), info<S1>(), info<S2>(), info<S3>(), info<S4>(),
                                               info<F0>(), info<F1>(), info<F2>(), info<F3>(), info<F4>(),
-                                              info<X0>(), info<X1>(), info<X2>(), info<X3>(), info<Y0>(), info<Y1>(), info<Y2>(), info<Y3>(), info<Y4>()};
+                                              info<X0>(), info<X1>(), info<X2>(), info<X3>(), info<Y0>(), info<Y1>(), info<Y2>(), info<Y3>(), info<Y4>(), info<Y5>()};
 using Z0 = SplitCfg<1, 2, 2, 2, 2, 2>;  // transposed, two-term, the waves split rows and couts: 4x32 input px x 64 cout (round 6)
 using Z1 = SplitCfg<1, 2, 2, 1, 2, 2>;  // ... x 32 cout
 using Z2 = SplitCfg<1, 2, 2, 1, 2, 2, 1>;  // Z1 with both row phases per work item (BP)
@@ -824,7 +835,7 @@ int conv_split_s2_first() { return 2 * drba_conv_split::kNum; }
 int conv_split_s2_num_cfgs() { return drba_conv_split::kNumX; }
 int conv_split_cs_first() { return 2 * drba_conv_split::kNum + drba_conv_split::kNumX; }
 int conv_split_cs_num_cfgs() { return drba_conv_split::kNumY; }
-int conv_split_cfg_stride(int id) { return (id >= 2 * drba_conv_split::kNum && id != 14 && id != 15) ? 2 : 1; }  // (Y0, Y1 = ids 14, 15 are the stride-1 tiles behind the X's)
+int conv_split_cfg_stride(int id) { return (id >= 2 * drba_conv_split::kNum && id != 14 && id != 15 && id < 19) ? 2 : 1; }  // (Y0, Y1 = ids 14, 15 are the stride-1 tiles behind the X's)
 
 bool conv_split_supports(int Cin, int Cout, int id) {
   using namespace drba_conv_split;
@@ -904,6 +915,7 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
     DRBA_CASE(16, Y2)
     DRBA_CASE(17, Y3)
     DRBA_CASE(18, Y4)
+    DRBA_CASE(19, Y5)
   }
 #undef DRBA_CASE
   return DRBA_EUNSUPPORTED;

@@ -55,20 +55,21 @@ if what in ("drm", "rev"):
     else:
         fn = lambda: ops.flow_reverse(fa)  # noqa: E731
         nbytes = 8 * 16.0 * H * W
-elif what in ("s2c52", "s2c32", "s2c48", "s2c39", "s2c64"):  # the stride-2 convolutions of the IFBlocks (conv0[0] / conv0[1]), 8 samples
+elif what in ("s2c52", "s2c32", "s2c48", "s2c39", "s2c64", "s2c16"):  # the stride-2 convolutions of the IFBlocks (conv0[0] / conv0[1]), 8 samples
     cin, cout, h, w = {"s2c52": (52, 48, 272, 480), "s2c32": (32, 64, 272, 480), "s2c48": (48, 96, 136, 240), "s2c39": (39, 96, 68, 120),
-                       "s2c64": (64, 128, 68, 120)}[what]
+                       "s2c64": (64, 128, 68, 120), "s2c16": (16, 32, 544, 960)}[what]
     x = torch.randn(8, cin, h, w, generator=g).to(dev)
     layer = ops.Conv3x3(torch.randn(cout, cin, 3, 3, generator=g) * 0.05, torch.zeros(cout), 2, True, None, device=dev)
     fn = lambda: layer(x)  # noqa: E731
     nbytes = None
-elif what in ("conv64g", "conv64r", "conv32r", "deconv4"):
+elif what in ("conv64g", "conv64r", "conv32r", "deconv4", "conv96r", "conv128r", "conv192r", "conv96g"):
     if what == "deconv4":
         x = torch.randn(8, 32, 272, 480, generator=g).to(dev)
         layer = ops.Deconv4x4(torch.randn(32, 20, 4, 4, generator=g) * 0.05, torch.zeros(20), pixel_shuffle=True, device=dev)
         fn = lambda: layer(x)  # noqa: E731
     else:
-        n, c, h, w, pre = {"conv64g": (1, 64, 576, 960, 0.25), "conv64r": (8, 64, 136, 240, None), "conv32r": (8, 32, 272, 480, None)}[what]
+        n, c, h, w, pre = {"conv64g": (1, 64, 576, 960, 0.25), "conv64r": (8, 64, 136, 240, None), "conv32r": (8, 32, 272, 480, None), "conv96r": (8, 96, 68, 120, None),
+                               "conv128r": (8, 128, 34, 60, None), "conv192r": (8, 192, 17, 30, None), "conv96g": (1, 96, 288, 480, 0.25)}[what]
         x = torch.randn(n, c, h, w, generator=g).to(dev)
         if pre is None:
             layer = ops.Conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.zeros(c), 1, True, torch.ones(1, c, 1, 1), device=dev)
