@@ -508,10 +508,7 @@ def _tune(shape_key, candidates, run, reps=3, families=None):
     shape_key = (shape_key, tuple(sorted(CONV_FAMILIES if families is None else families)))
     if shape_key in _tuned:
         return _tuned[shape_key]
-    best, best_ms = None, None
-    for cfg in candidates:
-        if run(cfg) != 0:  # warm: packs weights, faults pages; a configuration that refuses the shape is not a candidate
-            continue
+    def timed(cfg):
         # the candidates are timed on an otherwise idle device: the first call for a shape usually comes from inside the
         # three-stream pipeline, and a candidate timed beside another stream's kernels loses to one that was not (round 4: a
         # 590 us stride-2 tile picked over a 321 us one for the largest conv0 layer, -1.5 % on the step)
@@ -522,11 +519,18 @@ def _tune(shape_key, candidates, run, reps=3, families=None):
             run(cfg)
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1)
-        if best_ms is None or ms < best_ms:
-            best, best_ms = cfg, ms
-    if best is None:
+        return e0.elapsed_time(e1)
+
+    ok = [cfg for cfg in candidates if run(cfg) == 0]  # warm: packs weights, faults pages; a configuration that refuses the shape is not a candidate
+    if not ok:
         raise _lib.DrbaHipError(f"no kernel configuration accepts {shape_key}")
+    first = {cfg: timed(cfg) for cfg in ok}
+    # second look at the leaders (round 6: 38 convolution configurations, several within a few percent of each other on most
+    # layers -- one 3-launch timing each picked a 4 % slower tile for a layer in some runs): everything within 15 % of the best
+    # is timed again, in reverse order, and the smaller of its two readings counts
+    lead = min(first.values())
+    second = {cfg: timed(cfg) for cfg in reversed(ok) if first[cfg] <= 1.15 * lead}
+    best = min(second, key=lambda c: min(first[c], second[c]))
     _tuned[shape_key] = best
     return best
 
