@@ -27,6 +27,8 @@
 // chunk's keys over two waves (8-wave workgroups) was tried to raise the waves per SIMD there and was slower (365 us).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 using namespace drba;
@@ -264,20 +266,32 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
 // ---------------------------------------------------------------------------------------------------------------------
 // The same kernel in the two-term fp16 form (kernel family 4; conv_split.hip "Two-term form"): every fp32 operand of the two
 // GEMMs is taken as h + 2^-11 l with two fp16 terms and contracted with v_mfma_f32_16x16x32_f16 (three products per fragment
-// pair, the cross products in a second accumulator), 48 + 48 MFMAs of ~17 clocks per 64-key chunk and wave instead of
+// pair, the cross products in a second accumulator), 48 + 48 MFMAs of 16 clocks per 64-key chunk and wave instead of
 // 128 + 128 fp32 ones of 32.  Scores, masks, the online softmax and the running rescale stay fp32 as above.
-//   * K of a chunk lives in LDS as two fp16 planes [key][128 ch] (row stride 272 bytes); a lane's A operand for the 32-channel
-//     step j of key tile t is one 16-byte read.  K is pre-scaled by 2^-4 (undone with the 1 / sqrt(C) factor), Q is split once
-//     into registers;
-//   * the MFMA's K index is free as long as both operands agree, and so is the key a score row stands for: a loader thread
-//     holds 8 CONSECUTIVE keys of 4 channels, which is exactly the 8 k-values a lane supplies to one PV MFMA -- V goes to LDS
-//     TRANSPOSED as [channel][key unit of 8][8 x fp16] with one 16-byte write per channel and plane, no 2-byte scatter --, and
-//     score row 4 g + i of tile t stands for key 32 (t >> 1) + 8 g + 4 (t & 1) + i, so that lane group g leaves the softmax
-//     holding the probabilities of keys 32 ss + 8 g .. + 7 in PV-operand order;
+//   * K of a chunk lives in LDS as two fp16 planes [key][16 segments of 16 bytes]; a lane's A operand for the 32-channel step j
+//     of key tile t is one 16-byte read.  K is pre-scaled by 2^-4 (undone with the 1 / sqrt(C) factor), Q is split once into
+//     registers;
+//   * the MFMA's K index is free as long as both operands agree, and so is the key a score row stands for: score row n of
+//     tile t is key 16 t + n, lane group g leaves the softmax with keys 16 t + 4 g + i of tiles 2 ss, 2 ss + 1 as its 8 k-values
+//     of PV step ss -- so V goes to LDS TRANSPOSED as [channel][unit U = 4 ss + g][8 x fp16] with element e of unit U standing
+//     for key 32 (U >> 2) + 16 (e >> 2) + 4 (U & 3) + (e & 3), and a loader thread holds exactly those keys of 4 channels: 16-byte
+//     writes, no 2-byte scatter;
 //   * O^T tiles hold channels 16 dt + 4 g + i: 16-byte stores of consecutive channels.
-constexpr int kKU = 17;                    // 16-byte units per K row: 128 halves + 16 bytes (row r and r + 16 still share a slot: 2-way)
-constexpr int kVU = 9;                     // 16-byte units per V^T row: 64 keys + 16 bytes (9 m mod 16 distinct: conflict-free reads)
-constexpr int kLds16Bytes = (2 * kKeys * kKU + 2 * kC * kVU) * 16 + kKeys * 4;  // 34816 + 36864 + 256 = 71.9 KB: two workgroups per CU
+// LDS banks (tools/exp/attn/lds_banks.py evaluates the guide's lane-group rules): segment s of key k sits at s ^ (k & 15), unit u
+// of channel c at u ^ ((c >> 1) & 7) ^ ((c >> 4) & 1): every read and write below is conflict-free.  (Rows padded by 16 bytes --
+// the form up to round 5 -- cost 2 x on both 16-byte reads, whose lane groups are not 16 consecutive lanes, and 4 x on the V^T
+// writes: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE, the LDS busy 42 % of the launch.)
+// More waves per staged chunk (6 or 8 waves of 16 query rows, three or four per SIMD; 8: a thread stages 4 keys instead of 8) do not
+// fit: the O^T accumulators (64), the split Q (32) and the chunk in flight (64 / 32) leave the S / PV working set nothing under 168 /
+// 128 registers -- 138 / 131 spilled, 301 / 326 us against 148 (profiles/HISTORY.md, round 6).
+constexpr int kKU = 16;                    // 16-byte units per K row (128 halves)
+constexpr int kVU = 8;                     // 16-byte units per V^T row (64 keys)
+constexpr int kLds16Bytes = (2 * kKeys * kKU + 2 * kC * kVU) * 16 + kKeys * 4;  // 32768 + 32768 + 256 = 64.25 KB: two workgroups per CU
+// Token table: the source row and mask region of every key a workgroup walks, worked out once (token_row: a multiply-high
+// division, the roll and the region compares -- 8 per loader thread and chunk otherwise, ~15 % of the kernel's VALU work) and
+// kept behind the chunk image as row | region << 28.  Two workgroups per CU leave room for kTabCap keys; longer walks (or
+// arrays of 2^24 rows / 4 GB and more) evaluate token_row per chunk as before.
+constexpr int kTabCap = 3968;  // 62 chunks: 2 x (65792 + 15872) = 163328 of 163840 bytes
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -288,23 +302,28 @@ template <int SHIFT>  // (a, b) * 2^-SHIFT -> packed fp16 h and packed (remainde
 __device__ __forceinline__ void split2h(float a, float b, unsigned &h, unsigned &l) {
   const f32x2 v = (f32x2){a, b} * (1.f / (float)(1 << SHIFT));
   const f16x2 hh = __builtin_convertvector(v, f16x2);
-  const f32x2 r = (v - __builtin_convertvector(hh, f32x2)) * 2048.f;
+  // (v - h) * 2048 as fma(h, -2048, 2048 v): v - h is exact in fp32 (h is v rounded to 11 bits) and so is the scaling, so the single
+  // rounding of the fma returns the same bits -- and the fp16 operand goes into v_fma_mix_f32 without a conversion of its own
+  const f32x2 v2k = (f32x2){a, b} * (2048.f / (float)(1 << SHIFT));
+  const f32x2 r = {__builtin_fmaf((float)hh[0], -2048.f, v2k[0]), __builtin_fmaf((float)hh[1], -2048.f, v2k[1])};
   const f16x2 ll = __builtin_convertvector(r, f16x2);
   h = __builtin_bit_cast(unsigned, hh);
   l = __builtin_bit_cast(unsigned, ll);
 }
 [[maybe_unused]] constexpr int kKShift = 4;
+__device__ __forceinline__ int vt_swz(int ch) { return ((ch >> 1) & 7) ^ ((ch >> 4) & 1); }
 
 __global__ void __launch_bounds__(256, 2)  // two waves per SIMD = two workgroups per CU: <= 256 registers
 window_attention16_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                           float *__restrict__ out, Geometry g, int nwin, int qtiles, float scale, int ldq, int ldk, int ldv, int ksplit,
-                          float *__restrict__ part, unsigned char *status) {
+                          float *__restrict__ part, unsigned char *status, int tab_keys) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
   u32x4 *KsH = lds16, *KsL = lds16 + kKeys * kKU;           // [key][kKU]
   u32x4 *VtH = lds16 + 2 * kKeys * kKU, *VtL = VtH + kC * kVU;  // [channel][kVU]
   int *Kreg = reinterpret_cast<int *>(VtL + kC * kVU);
-  constexpr int TPW = 4, LIT = 8;
+  int *tab = Kreg + kKeys;  // [tab_keys] (0: none)
+  constexpr int TPW = 4, LIT = 8, ROWS = kRows;  // LIT: keys a loader thread holds
 
   const int lin = blockIdx.x;
   const int xcd = lin & 7;
@@ -318,9 +337,10 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, grp = lane >> 4;
+  const bool wlive = qt * ROWS + wave * 16 < g.L;  // a wave past the window's last query row only helps staging
 
   // ---- this lane's query row: B operand of S^T = K Q^T, channels 32 j + 8 grp .. + 7 for step j, split once
-  const int qtok = qt * kRows + wave * 16 + n16;
+  const int qtok = qt * ROWS + wave * 16 + n16;
   const bool qlive = qtok < g.L;
   int qreg;
   const size_t qrow = token_row(g, wd, min(qtok, g.L - 1), qreg);
@@ -336,34 +356,63 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
     split2h<0>(b[2], b[3], h, l), qh[j][3] = h, ql[j][3] = l;
   }
 
-  // ---- chunk loader: thread -> (keys 8 * (tid / 32) + it, it = 0..7; 4 channels at 4 * (tid % 32))
-  const int lkey = tid >> 5, lc4 = (tid & 31) * 4;
+  // ---- chunk loader: thread -> V^T unit lU = tid / 32, 4 channels at 4 * lq, the unit's 8 keys
+  const int lq = tid & 31, lc4 = lq * 4, lU = tid >> 5;
+  auto key_of = [&](int it) { return 32 * (lU >> 2) + 16 * (it >> 2) + 4 * (lU & 3) + (it & 3); };
   f32x4 pk[LIT], pv[LIT];
+  const int all_chunks = (g.L + kKeys - 1) / kKeys, per = (all_chunks + ksplit - 1) / ksplit;
+  const int ch0 = ks * per, chunks = min(all_chunks, ch0 + per);
+  const bool use_tab = tab_keys > 0;  // (the host sizes it for `per` chunks or passes 0)
+  if (use_tab) {
+    for (int i = tid; i < (chunks - ch0) * kKeys; i += 256) {
+      int region;
+      const unsigned row = token_row(g, wd, min(ch0 * kKeys + i, g.L - 1), region);
+      tab[i] = (int)(row | (unsigned)region << 28);
+    }
+    __syncthreads();
+  }
   auto fetch = [&](int chunk) {
+    if (use_tab) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int4 r = *reinterpret_cast<const int4 *>(&tab[(chunk - ch0) * kKeys + key_of(4 * half)]);
+        const int rows[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // 32-bit byte offsets from a full-rate 24-bit multiply (the host offers the table only when they fit): the loads
+          // take the scalar base + 32-bit offset form instead of 64-bit multiply-adds per key
+          const unsigned row = (unsigned)rows[i] & 0x00ffffffu;
+          pk[4 * half + i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(k) + 4u * (__umul24(row, (unsigned)ldk) + (unsigned)lc4));
+          pv[4 * half + i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(v) + 4u * (__umul24(row, (unsigned)ldv) + (unsigned)lc4));
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < LIT; ++it) {
       int unused;
-      const size_t row = token_row(g, wd, min(chunk * kKeys + 8 * lkey + it, g.L - 1), unused);
+      const size_t row = token_row(g, wd, min(chunk * kKeys + key_of(it), g.L - 1), unused);
       pk[it] = *reinterpret_cast<const f32x4 *>(k + row * ldk + lc4);
       pv[it] = *reinterpret_cast<const f32x4 *>(v + row * ldv + lc4);
     }
   };
   auto stage = [&](int chunk) {
-    // K: [key][channel] planes, 8 bytes (4 channels) per plane and key
+    // K: [key][segment ^ (key & 15)] planes, 8 bytes (4 channels) per plane and key
 #pragma unroll
     for (int it = 0; it < LIT; ++it) {
-      const int key = 8 * lkey + it;
+      const int key = key_of(it);
       u32x2 h, l;
       unsigned a, b;
       split2h<kKShift>(pk[it][0], pk[it][1], a, b), h[0] = a, l[0] = b;
       split2h<kKShift>(pk[it][2], pk[it][3], a, b), h[1] = a, l[1] = b;
-      unsigned char *dst = reinterpret_cast<unsigned char *>(KsH + key * kKU) + lc4 * 2;
+      unsigned char *dst = reinterpret_cast<unsigned char *>(KsH + key * kKU + ((lq >> 1) ^ (key & 15))) + 8 * (lq & 1);
       *reinterpret_cast<u32x2 *>(dst) = h;
       *reinterpret_cast<u32x2 *>(dst + kKeys * kKU * 16) = l;
     }
-    // V^T: this thread's 8 consecutive keys of channel lc4 + c are one 16-byte unit [channel][key unit lkey]
+    // V^T: this thread's 8 keys of channel lc4 + c are one 16-byte unit [channel][unit lU ^ swizzle]
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+      const int ch = lc4 + c, u = ch * kVU + (lU ^ vt_swz(ch));
       u32x4 h, l;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -371,10 +420,10 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
         split2h<0>(pv[2 * p][c], pv[2 * p + 1][c], a, b);
         h[p] = a, l[p] = b;
       }
-      VtH[(lc4 + c) * kVU + lkey] = h;
-      VtL[(lc4 + c) * kVU + lkey] = l;
+      VtH[u] = h;
+      VtL[u] = l;
     }
-    if (g.shift && tid < kKeys) {
+    if (g.shift && !use_tab && tid < kKeys) {
       int region;
       token_row(g, wd, min(chunk * kKeys + tid, g.L - 1), region);
       Kreg[tid] = region;
@@ -386,30 +435,28 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
   for (int dt = 0; dt < 8; ++dt) oh[dt] = ol[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int all_chunks = (g.L + kKeys - 1) / kKeys, per = (all_chunks + ksplit - 1) / ksplit;
-  const int ch0 = ks * per, chunks = min(all_chunks, ch0 + per);
   const float s_scale = (float)(1 << kKShift) / scale;  // undoes K's pre-scale, applies 1 / sqrt(C)
-  // key a score row stands for: tile t, row 4 g + i  <->  key 32 (t >> 1) + 8 g + 4 (t & 1) + i
-  int krow[TPW];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) krow[t] = (32 * (t >> 1) + 8 * (n16 >> 2) + 4 * (t & 1) + (n16 & 3)) * kKU + grp;
+  const int vsw = (n16 >> 1) & 7;  // vt_swz(16 dt + n16) = vsw ^ (dt & 1)
   if (ch0 < chunks) fetch(ch0);
   for (int ch = ch0; ch < chunks; ++ch) {
     __syncthreads();  // every wave is done reading the previous chunk
     stage(ch);
     __syncthreads();
     if (ch + 1 < chunks) fetch(ch + 1);
+    if (!wlive) continue;
 
-    // ---- S^T tiles: A = K rows (16 keys of tile t, channels 32 j + 8 kq ..), B = this lane's Q fragment of step j
+    // ---- S^T tiles: A = K rows (keys 16 t + n16, channels 32 j + 8 grp ..), B = this lane's Q fragment of step j
     f32x4 sh[TPW], sl[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) sh[t] = sl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f16x8 bh = __builtin_bit_cast(f16x8, qh[j]), bl = __builtin_bit_cast(f16x8, ql[j]);
+      const int seg = (4 * j + grp) ^ n16;
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, KsH[krow[t] + 4 * j]), al = __builtin_bit_cast(f16x8, KsL[krow[t] + 4 * j]);
+        const int u = (16 * t + n16) * kKU + seg;
+        const f16x8 ah = __builtin_bit_cast(f16x8, KsH[u]), al = __builtin_bit_cast(f16x8, KsL[u]);
         sl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, sl[t], 0, 0, 0);
         sl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, sl[t], 0, 0, 0);
         sh[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, sh[t], 0, 0, 0);
@@ -419,19 +466,23 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
     // ---- scale, mask, online softmax (fp32)
     float s[TPW][4];
     float mx = -INFINITY;
+    const bool tail = (ch + 1) * kKeys > g.L;  // only the window's last chunk can hold keys past its end
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const int key0 = 32 * (t >> 1) + 8 * grp + 4 * (t & 1);  // this lane's 4 keys of tile t
+      const int key0 = 16 * t + 4 * grp;  // this lane's 4 keys of tile t
       int krs[4] = {0, 0, 0, 0};
       if (g.shift) {
-        const int4 kr = *reinterpret_cast<const int4 *>(&Kreg[key0]);
+        const int4 kr = *reinterpret_cast<const int4 *>(use_tab ? &tab[(ch - ch0) * kKeys + key0] : &Kreg[key0]);
         krs[0] = kr.x, krs[1] = kr.y, krs[2] = kr.z, krs[3] = kr.w;
+        if (use_tab)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) krs[i] = (int)((unsigned)krs[i] >> 28);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float x = (sh[t][i] + sl[t][i] * (1.f / 2048.f)) * s_scale;  // scores / sqrt(C) (transformer.py:91)
         if (g.shift && krs[i] != qreg) x += -100.f;
-        if (ch * kKeys + key0 + i >= g.L) x = -INFINITY;
+        if (tail && ch * kKeys + key0 + i >= g.L) x = -INFINITY;
         s[t][i] = x;
         mx = fmaxf(mx, x);
       }
@@ -455,7 +506,7 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) oh[dt] *= alpha, ol[dt] *= alpha;
 
-    // ---- O^T += V^T P^T: step ss contracts keys 32 ss + 8 kq + i; B = this lane's probabilities of tiles 2 ss, 2 ss + 1
+    // ---- O^T += V^T P^T: step ss contracts unit 4 ss + grp; B = this lane's probabilities of tiles 2 ss, 2 ss + 1
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       u32x4 ph, pl;
@@ -468,7 +519,7 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
       const f16x8 bh = __builtin_bit_cast(f16x8, ph), bl = __builtin_bit_cast(f16x8, pl);
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
-        const int u = (16 * dt + n16) * kVU + 4 * ss + grp;
+        const int u = (16 * dt + n16) * kVU + ((4 * ss + grp) ^ vsw ^ (dt & 1));
         const f16x8 ah = __builtin_bit_cast(f16x8, VtH[u]), al = __builtin_bit_cast(f16x8, VtL[u]);
         ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, ol[dt], 0, 0, 0);
         ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, ol[dt], 0, 0, 0);
@@ -543,11 +594,11 @@ window_attention_merge(const float *__restrict__ part, float *__restrict__ out, 
 
 // floats of workspace drba_window_attention needs for this shape (0: none)
 static int attn_ksplit(int nwin, int L) {
-  const int qtiles = (L + drba_attn::kRows - 1) / drba_attn::kRows, chunks = (L + drba_attn::kKeys - 1) / drba_attn::kKeys;
+  const int rows = drba_attn::kRows, qtiles = (L + rows - 1) / rows, chunks = (L + drba_attn::kKeys - 1) / drba_attn::kKeys;
   const long long wgs = (long long)((nwin + 7) / 8) * 8 * qtiles;
-  if (wgs >= 2 * 256 || chunks < 8) return 1;  // two workgroups per CU already, or too few chunks to share out
   static const int force = env_int("DRBA_ATTN_KSPLIT", 0);  // (TUNING builds only)
   if (force > 0) return force;
+  if (wgs >= 2 * 256 || chunks < 8) return 1;  // two workgroups per CU already, or too few chunks to share out
   return chunks >= 16 ? 4 : 2;  // measured on 8 windows x 2160 tokens: 349 us unsplit, 287 us in two runs, 260 us in four
 }
 
@@ -581,10 +632,15 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
   const dim3 grid((unsigned)(groups * 8 * qtiles * ksplit));
   // beyond the default 64 KB dynamic-LDS limit
   if (terms == 2) {
-    if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention16_kernel), drba_attn::kLds16Bytes) != hipSuccess)
+    const int all_chunks = (g.L + drba_attn::kKeys - 1) / drba_attn::kKeys, walk = (all_chunks + ksplit - 1) / ksplit * drba_attn::kKeys;
+    const long long rows_all = (long long)B * H * W;
+    const bool fits = rows_all < (1ll << 24) && rows_all * std::max(ldk, ldv) < (1ll << 30) && ldk < (1 << 24) && ldv < (1 << 24);
+    const int tab_keys = walk <= drba_attn::kTabCap && fits ? walk : 0;
+    const int lds_bytes = drba_attn::kLds16Bytes + tab_keys * 4;
+    if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention16_kernel), lds_bytes) != hipSuccess)
       return DRBA_ELAUNCH;
-    DRBA_LAUNCH(drba_attn::window_attention16_kernel, grid, dim3(kBlock), drba_attn::kLds16Bytes, (hipStream_t)stream, q, k, v,
-                      out, g, nwin, qtiles, scale, ldq, ldk, ldv, ksplit, ws, status_bytes());
+    DRBA_LAUNCH(drba_attn::window_attention16_kernel, grid, dim3(kBlock), lds_bytes, (hipStream_t)stream, q, k, v, out, g, nwin,
+                qtiles, scale, ldq, ldk, ldv, ksplit, ws, status_bytes(), tab_keys);
   } else {
     if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention_kernel), drba_attn::kLdsBytes) != hipSuccess)
       return DRBA_ELAUNCH;
