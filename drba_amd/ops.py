@@ -529,7 +529,8 @@ def _tune(shape_key, candidates, run, reps=3, families=None):
     # layers -- one 3-launch timing each picked a 4 % slower tile for a layer in some runs): everything within 15 % of the best
     # is timed again, in reverse order, and the smaller of its two readings counts
     lead = min(first.values())
-    second = {cfg: timed(cfg) for cfg in reversed(ok) if first[cfg] <= 1.15 * lead}
+    close = [cfg for cfg in reversed(ok) if first[cfg] <= 1.15 * lead]
+    second = {cfg: timed(cfg) for cfg in close} if len(close) > 1 else {close[0]: first[close[0]]}  # a lone leader needs no second look
     best = min(second, key=lambda c: min(first[c], second[c]))
     _tuned[shape_key] = best
     return best
