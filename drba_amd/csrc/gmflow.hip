@@ -320,6 +320,123 @@ local_corr_flow_kernel(const float *__restrict__ f0, const float *__restrict__ f
   out[P + p] = ay / s - (float)y;
 }
 
+// The same on the fp32 matrix cores (C == 128; the kernel above stays for other channel counts).  The one-lane-per-pixel form
+// issues (2r+1)^2 scattered 4-byte loads per channel and lane -- 5.6 M wave-level loads at 144 x 240 x 128, 431 us per direction
+// in the GMFSS_UNION step -- for 1.4 GFLOP.  Here a wave owns 16 pixels of ROWS rows: their feature0 columns are the A operand
+// (pixels x channels, held in registers for the whole kernel), a feature1 row segment of 32 columns (x0 - 4 .. x0 + 27) is the
+// B operand, and v_mfma_f32_16x16x4_f32 forms all 16 x 32 pixel pairs of (target row, feature1 row) over the 128 channels; the
+// 9 in-window pairs of each row are parked in LDS as [pixel][dy][dx].  28 % of the products are used -- the matrix pipe is idle
+// otherwise.  Masking, softmax and the expected offset are the epilogue above with the 81 taps of a pixel dealt to 4 / ROWS
+// lanes (partial maxima and sums combined by xor-shuffles: the sums associate differently, nothing else changes).
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int R, int ROWS>
+__global__ void __launch_bounds__(256)
+local_corr_flow_mfma_kernel(const float *__restrict__ f0, const float *__restrict__ f1, float *__restrict__ out, int H, int W,
+                            float scale) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int N = 2 * R + 1, KS = 32;  // KS: k-steps of 4 channels (C == 128: straight-line loads)
+  constexpr int ITEMS = 2 * (N + ROWS - 1), LPP = 4 / ROWS;  // (feature1 row, column block) pairs; lanes per pixel in the epilogue
+  static_assert(R == 4 && (ROWS == 1 || ROWS == 2), "the 32-column feature1 segment covers x0 - 4 .. x0 + 15 + 4");
+  __shared__ float sc[4][ROWS][16][N * N + 1];
+  const size_t P = (size_t)H * W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n16 = lane & 15, grp = lane >> 4;
+  const int tiles_x = (W + 63) / 64;
+  const int t = xcd_band(blockIdx.x, gridDim.x);
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int x0 = tx * 64 + wave * 16, y0 = ty * ROWS;
+  // A: feature0 of target pixel (x0 + n16, y0 + tr), channels 4 s + grp
+  float a[ROWS][KS];
+  {
+    const int xa = min(x0 + n16, W - 1);
+#pragma unroll
+    for (int tr = 0; tr < ROWS; ++tr) {
+      const float *src = f0 + (size_t)grp * P + (size_t)min(y0 + tr, H - 1) * W + xa;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) a[tr][s] = src[(size_t)(4 * s) * P];
+    }
+  }
+  int qx[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) qx[nt] = min(max(x0 - R + 16 * nt + n16, 0), W - 1);
+  // (feature1 row, column block) pairs in order, the next pair's 32 fragments in flight under this pair's MFMAs
+  auto fetch = [&](int it, float (&b)[KS]) {
+    const int r = it >> 1, nt = it & 1;
+    const int yy = min(max(y0 - R + r, 0), H - 1);
+    const float *src = f1 + (size_t)grp * P + (size_t)yy * W + qx[nt];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[s] = src[(size_t)(4 * s) * P];
+  };
+  auto work = [&](int it, const float (&b)[KS]) {  // feature1 row y0 - R + r: dy = r - tr for target row tr
+    const int r = it >> 1, nt = it & 1;
+    f32x4m acc[ROWS];
+#pragma unroll
+    for (int tr = 0; tr < ROWS; ++tr) acc[tr] = (f32x4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int tr = 0; tr < ROWS; ++tr)  // (ROWS 2: the first / last row's unused product costs less than a branch around it)
+        acc[tr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr][s], b[s], acc[tr], 0, 0, 0);
+    // lane (n16, grp) holds pairs (target m = 4 grp + i, feature1 column x0 - R + 16 nt + n16): dx index = 16 nt + n16 - m
+#pragma unroll
+    for (int tr = 0; tr < ROWS; ++tr) {
+      const int dy = r - tr;
+      if (dy < 0 || dy >= N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 4 * grp + i, dxi = 16 * nt + n16 - m;
+        if (dxi >= 0 && dxi < N) sc[wave][tr][m][dy * N + dxi] = acc[tr][i];
+      }
+    }
+  };
+  float b0[KS], b1[KS];
+  fetch(0, b0);
+  for (int it = 0; it < ITEMS; it += 2) {
+    fetch(it + 1, b1);
+    work(it, b0);
+    if (it + 2 < ITEMS) fetch(it + 2, b0);
+    work(it + 1, b1);
+  }
+  __syncthreads();
+  const int px = lane / LPP, part = lane - px * LPP;
+  const int tr = px >> 4, m = px & 15;
+  const int x = x0 + m, y = y0 + tr;
+  const float *sv = sc[wave][tr][m];
+  constexpr int TPL = (N * N + LPP - 1) / LPP;  // taps per lane: k = part + LPP j
+  float v[TPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < TPL; ++j) {
+    const int k = part + LPP * j, dy = k / N, dx = k - dy * N;
+    const int yy = y + dy - R, xx = x + dx - R;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    v[j] = k >= N * N ? -INFINITY : in ? sv[min(k, N * N - 1)] / scale : -1e4f;
+    mx = fmaxf(mx, v[j]);
+  }
+#pragma unroll
+  for (int d = 1; d < LPP; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+  float s = 0.f, ax = 0.f, ay = 0.f;
+#pragma unroll
+  for (int j = 0; j < TPL; ++j) {
+    const int k = part + LPP * j, dy = k / N, dx = k - dy * N;
+    const float e = expf(v[j] - mx);  // (a tap past the 81st: exp(-inf) = 0)
+    s += e;
+    ax += e * (float)(x + dx - R);
+    ay += e * (float)(y + dy - R);
+  }
+#pragma unroll
+  for (int d = 1; d < LPP; d <<= 1) {
+    s += __shfl_xor(s, d, 64);
+    ax += __shfl_xor(ax, d, 64);
+    ay += __shfl_xor(ay, d, 64);
+  }
+  if (part != 0 || x >= W || y >= H) return;
+  const size_t p = (size_t)y * W + x;
+  out[p] = ax / s - (float)x;
+  out[P + p] = ay / s - (float)y;
+#endif
+}
+
 // transformer.py:374-409 (local_window_radius r): q . k over the (2r+1)^2 zero-padded window (out-of-image keys are
 // zero vectors: score 0, NOT masked), softmax, weighted sum of the zero-padded flow window.
 __global__ void __launch_bounds__(256)
@@ -601,8 +718,16 @@ int drba_softmax_rows(float *x, const float *mask, size_t rows, int cols, int ro
 int drba_local_corr_flow(const float *f0, const float *f1, float *out, int C, int H, int W, int radius, void *stream) {
   if (!f0 || !f1 || !out || C <= 0 || H <= 0 || W <= 0 || radius <= 0) return DRBA_EINVAL;
   if (radius != 4) return DRBA_EUNSUPPORTED;  // the radius GMFlow's refinement stage uses (gmflow.py corr_radius_list)
-  DRBA_LAUNCH(local_corr_flow_kernel<4>, dim3((unsigned)(((W + 31) / 32) * ((H + 1) / 2))), dim3(kBlock), 0,
-                     (hipStream_t)stream, f0, f1, out, C, H, W, sqrtf((float)C));
+  static const int rows = env_int("DRBA_LCORR_ROWS", 1);  // (TUNING builds only)
+  if (C == 128 && rows == 2)
+    DRBA_LAUNCH((local_corr_flow_mfma_kernel<4, 2>), dim3((unsigned)(((W + 63) / 64) * ((H + 1) / 2))), dim3(kBlock), 0, (hipStream_t)stream,
+                f0, f1, out, H, W, sqrtf((float)C));
+  else if (C == 128)  // (GMFlow's feature channels)
+    DRBA_LAUNCH((local_corr_flow_mfma_kernel<4, 1>), dim3((unsigned)(((W + 63) / 64) * H)), dim3(kBlock), 0, (hipStream_t)stream, f0, f1,
+                out, H, W, sqrtf((float)C));
+  else
+    DRBA_LAUNCH(local_corr_flow_kernel<4>, dim3((unsigned)(((W + 31) / 32) * ((H + 1) / 2))), dim3(kBlock), 0,
+                       (hipStream_t)stream, f0, f1, out, C, H, W, sqrtf((float)C));
   DRBA_CHECK_LAUNCH();
   return DRBA_OK;
 }
