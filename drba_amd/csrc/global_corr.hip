@@ -212,9 +212,21 @@ bmm_naive_kernel(const float *__restrict__ a, const float *__restrict__ b, float
 
 static int pick_ksplit(int L) {
   const int qtiles = (L + kRows - 1) / kRows, chunks = (L + kKeys - 1) / kKeys;
-  int ks = 1;
-  while (qtiles * ks < 512 && ks < 8 && chunks / (2 * ks) >= 4) ks *= 2;
-  return ks;
+  static const int force = env_int("DRBA_GCORR_KSPLIT", 0);  // (TUNING builds only)
+  if (force > 0) return force;
+  // 125 registers and 34 KB of LDS: three workgroups per CU.  The launch ends when the fullest CU does -- (workgroups on it) x
+  // (chunks per workgroup) -- so the split is the one that minimises that product among those that stay resident, not the first
+  // power of two past 512 workgroups: 8640 tokens = 135 query tiles, 4 runs put 3 workgroups of 34 chunks on 28 CUs (267 us),
+  // 5 runs 3 x 27 on 163 (221 us; same-box sweep of 1..12 runs, tools/exp/gcorr_target.py).  + 2: a workgroup's fixed cost
+  // (query fragments, first fetch, partial write) in chunk times.
+  int best = 1, best_cost = 0x7fffffff;
+  for (int ks = 1; ks <= 12 && chunks / ks >= 4; ++ks) {
+    const int per_cu = (qtiles * ks + 255) / 256;
+    if (per_cu > 3 && ks > 1) break;
+    const int cost = per_cu * ((chunks + ks - 1) / ks + 2);
+    if (cost < best_cost) best = ks, best_cost = cost;
+  }
+  return best;
 }
 
 }  // namespace drba_gcorr
