@@ -85,6 +85,7 @@ SIGNATURES = {
     "drba_conv3x3_packed_floats": (_z, [_i, _i, _i]),
     "drba_conv3x3_pack": (_i, [_p, _p, _i, _i, _i]),
     "drba_conv3x3": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p]),
+    "drba_conv3x3_shuffle": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "drba_deconv4x4_pick_cfg": (_i, [_i, _i, _i, _i]),
     "drba_deconv4x4_packed_floats": (_z, [_i, _i, _i]),
     "drba_deconv4x4_pack": (_i, [_p, _p, _i, _i, _i]),

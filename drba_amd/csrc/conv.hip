@@ -774,6 +774,23 @@ int drba_deconv4x4s2(const float *in, const float *packed_w, const float *bias, 
   return DRBA_EUNSUPPORTED;
 }
 
+// drba_conv3x3 (stride 1, bias, activation; no residual operands, no pre-activation) storing through PixelShuffle(2):
+// out is [N, Cout / 4, 2H, 2W].  Only configurations whose tile carries that store form accept (two-term 4 x 32 x 64 tiles of
+// conv_split.hip); every other id returns DRBA_EUNSUPPORTED, and the caller runs drba_conv3x3 + drba_pixel_shuffle2 instead.
+int drba_conv3x3_shuffle(const float *in, const float *packed_w, const float *bias, float *out, int N, int Cin, int H, int W,
+                         int Cout, int act, float post_slope, int cfg, void *stream) {
+  if (!in || !packed_w || !out || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DRBA_EINVAL;
+  if (act < 0 || act > 4) return DRBA_EINVAL;
+  if ((Cout & 3) || (W & 3)) return DRBA_EUNSUPPORTED;
+  const size_t n_out = (size_t)N * Cout * H * W;
+  int id = -1;
+  if (cfg >= first_f16_cs_cfg() && cfg < drba_conv3x3_num_cfgs()) id = cfg - first_f16_cs_cfg() + conv_split_cs_first();
+  else if (cfg >= first_f16_cfg() && cfg < first_f16_dma_cfg()) id = cfg - first_f16_cfg() + conv_split_f16_first();
+  if (id < 0 || conv_split_cfg_stride(id) != 1) return DRBA_EUNSUPPORTED;
+  return range_checked(conv_split_launch(id, in, packed_w, bias, nullptr, nullptr, nullptr, out, N, Cin, H, W, Cout, act, post_slope, 0,
+                                         0.f, stream, 1), out, n_out, stream);
+}
+
 // A chain of convolutions launched from one call (the IFBlock cores and the context encoder are 4..11 dependent
 // layers; issuing them from C++ costs a few microseconds per launch instead of a Python/ctypes round trip each, which
 // is what bounds the step once the GPU side is below 4 ms).  Layer i reads the previous layer's output (layer 0 reads

@@ -158,7 +158,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // tile, and x = h + m + l holds exactly (8 + 8 + 8 mantissa bits, each remainder exact), so the epilogue rebuilds it from
 // the three bf16 planes the tile's LAST chunk left in LDS instead of reading it from HBM again.  The chunks of a tile
 // are therefore taken in rotated order so that the last one is the chunk of the tile's own 32 output channels.
-template <class Cfg, bool PRE, bool RL = false>
+template <class Cfg, bool PRE, bool RL = false, bool PSH = false>  // PSH: MODE 0 with the PixelShuffle(2) store form (its own instantiation)
 __global__ void __launch_bounds__(256, Cfg::MINB)  // at least two workgroups per CU: <= 256 registers
 conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                 const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ res2,
@@ -251,7 +251,7 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     }
   };
 
-  const bool vec = (W & 3) == 0 && (MW & 1) == 0;  // (the regrouped stores pair column blocks 2j, 2j + 1)
+  const bool vec = !PSH && (W & 3) == 0 && (MW & 1) == 0;  // (the regrouped stores pair column blocks 2j, 2j + 1)
 
   int work = blockIdx.x;
   if (work >= total) return;
@@ -430,7 +430,45 @@ conv_split_mfma(const float *__restrict__ in, const u32x4 *__restrict__ wfrag, c
     // the post activation: act 0 none, 1 LeakyReLU(0.2), 2 PReLU(post_slope), 3 ReLU, 4 tanh(y)*10.  The activation is
     // selected ONCE around the tile loops: selected per element, the inlined copies of the switch (each with a tanhf
     // expansion to jump over) made the epilogue 10k instructions and as slow as the tile's MFMAs.
-    if constexpr (MODE != 1) {
+    if constexpr (MODE != 1 && PSH) {
+      // conv + PixelShuffle(2) (GridNet's tail, FusionNet.py:100-103): cout = 4 c13 + 2 si + sj lands at row 2y + si, column
+      // 2x + sj of plane c13.  Lanes m and m ^ 1 (sj = 0 / 1: same plane and row) exchange their 4 pixels, after which the even
+      // lane holds output columns 2 xb .. 2 xb + 3 and the odd one 2 xb + 4 .. + 7: one 16-byte store each, 128 contiguous bytes
+      // per (plane, row) and wave instruction.  W % 4 == 0 and Cout % 4 == 0 (the launcher checks), no residual operands.
+      const unsigned obytes = (unsigned)((size_t)Cout * HW * 4);
+      const __amdgpu_buffer_rsrc_t orsrc =
+          __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)ctx.n * Cout * HW), 0, obytes, 0x00020000);
+      auto epilogue_ps = [&](auto post) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+            for (int mw = 0; mw < MW; ++mw) {
+              f32x4 v = acc[0][rw][mw][nt], o;
+              const int co = ctx.cz * Cfg::NTC + (nt0 + nt) * 16 + m;
+              const int y = ctx.y0 + row0 + rw;
+              const int xb = ctx.x0 + mw * 16 + kq * 4;
+              const bool inside = co < Cout && y < H && xb < W;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[k] = post(v[k] + bs[nt]);
+                o[k] = quad_xor1(v[k]);
+              }
+              const int c13 = co >> 2, si = (co >> 1) & 1, sj = co & 1;
+              const f32x4 qv = sj ? (f32x4){o[2], v[2], o[3], v[3]} : (f32x4){v[0], o[0], v[1], o[1]};
+              const unsigned base = (unsigned)(((c13 * (2 * H) + (2 * y + si)) * (2 * W) + 2 * xb) * 4);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qv), orsrc, inside ? base + 16u * sj : 0xffffffffu, 0, 0);
+            }
+      };
+      switch (act) {
+        case 1: epilogue_ps([](float v) { return lrelu02(v); }); break;
+        case 2: epilogue_ps([post_slope](float v) { return v > 0.f ? v : post_slope * v; }); break;
+        case 3: epilogue_ps([](float v) { return fmaxf(v, 0.f); }); break;
+        case 4: epilogue_ps([](float v) { return tanhf(v) * 10.f; }); break;
+        default: epilogue_ps([](float v) { return v; }); break;
+      }
+    } else if constexpr (MODE != 1) {
       const size_t img = (size_t)ctx.n * Cout * HW;
       if (vec) {
         // Whole-line stores and residual reads.  The accumulator leaves lane (m, kq) with 4 consecutive x of ONE cout:
@@ -761,11 +799,14 @@ using Z4 = SplitCfg<1, 2, 1, 2, 2, 2, 1>;  // 4x16 input px x 64 cout, rows and 
 constexpr int kNumZ = 5;
 const Info kInfoT[2 * kNumT + kNumZ] = {info<T0>(), info<T1>(), info<G0>(), info<G1>(), info<Z0>(), info<Z1>(), info<Z2>(), info<Z3>(), info<Z4>()};
 
-template <class Cfg, bool PRE, bool RL = false>
+template <class Cfg, bool PRE, bool RL = false, bool PSH = false>
 hipError_t lds_limit() {
   if (Cfg::LDS_BYTES <= 64 * 1024) return hipSuccess;
-  return max_dynamic_lds(reinterpret_cast<const void *>(conv_split_mfma<Cfg, PRE, RL>), Cfg::LDS_BYTES);
+  return max_dynamic_lds(reinterpret_cast<const void *>(conv_split_mfma<Cfg, PRE, RL, PSH>), Cfg::LDS_BYTES);
 }
+// the tiles that carry the PixelShuffle store form of MODE 0 (one more instantiation each): the two-term 4 x 32 x 64 ones
+template <class Cfg>
+constexpr bool kHasShuffle = Cfg::MODE == 0 && Cfg::PL == 2 && Cfg::RW * Cfg::MW == 2 * Cfg::CS && Cfg::NTT == 4 && Cfg::MW == 2;
 
 static int resident_per_cu(const void *kernel, int lds_bytes) {
   static std::mutex mu;
@@ -810,7 +851,14 @@ int launch(const float *in, const float *wpk, const float *bias, const float *be
     return DRBA_OK;
   };
   int rc;
-  if constexpr (Cfg::MODE == 0 && Cfg::NTC == CK && Cfg::PL == 3) {
+  if (Cfg::MODE == 0 && pixel_shuffle) {
+    if constexpr (kHasShuffle<Cfg>) {
+      if (res || res2 || beta || pre_act || (W & 3) || (Cout & 3)) return DRBA_EUNSUPPORTED;
+      rc = go(conv_split_mfma<Cfg, false, false, true>, lds_limit<Cfg, false, false, true>());
+    } else {
+      return DRBA_EUNSUPPORTED;
+    }
+  } else if constexpr (Cfg::MODE == 0 && Cfg::NTC == CK && Cfg::PL == 3) {
     // ResConv shape (the residual is the layer's own input): rebuilt from the bf16 planes in LDS, no second read
     const bool rl = res && res == in && !res2 && !pre_act && Cin == Cout && (W & 3) == 0;
     rc = rl ? go(conv_split_mfma<Cfg, false, true>, lds_limit<Cfg, false, true>())
@@ -885,7 +933,7 @@ int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id) {
 
 int conv_split_launch(int id, const float *in, const float *packed_w, const float *bias, const float *beta,
                       const float *residual, const float *residual2, float *out, int N, int Cin, int H, int W, int Cout,
-                      int act, float post_slope, int pre_act, float pre_slope, void *stream) {
+                      int act, float post_slope, int pre_act, float pre_slope, void *stream, int pixel_shuffle) {
   using namespace drba_conv_split;
   if (!conv_split_supports(Cin, Cout, id)) return DRBA_EUNSUPPORTED;
   if ((size_t)Cin * H * W * 4 >= (1ull << 31)) return DRBA_EUNSUPPORTED;  // 32-bit byte offsets inside an image
@@ -894,7 +942,7 @@ int conv_split_launch(int id, const float *in, const float *packed_w, const floa
 #define DRBA_CASE(ID, T) \
   case ID:               \
     return launch<T>(in, packed_w, bias, beta, residual, residual2, out, N, Cin, H, W, Cout, act, post_slope, pre_act, \
-                     pre_slope, 0, s);
+                     pre_slope, pixel_shuffle, s);
   switch (id) {
     DRBA_CASE(0, S0)
     DRBA_CASE(1, S1)

@@ -45,7 +45,8 @@ size_t conv_split_packed_floats(int Cin, int Cout, int id);
 int conv_split_pack(const float *w, float *packed, int Cin, int Cout, int id);
 int conv_split_launch(int id, const float *in, const float *packed_w, const float *bias, const float *beta,
                       const float *residual, const float *residual2, float *out, int N, int Cin, int H, int W, int Cout,
-                      int act, float post_slope, int pre_act, float pre_slope, void *stream);
+                      int act, float post_slope, int pre_act, float pre_slope, void *stream, int pixel_shuffle = 0);
+// (pixel_shuffle: MODE 0 tiles that carry the PixelShuffle(2) store form -- the two-term 4 x 32 x 64 ones -- else DRBA_EUNSUPPORTED)
 
 
 // the same arithmetic with every operand streamed by LDS-DMA and the activations split on the way into the MFMAs

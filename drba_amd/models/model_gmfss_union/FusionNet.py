@@ -52,7 +52,7 @@ class GridNet:
         X04 = r["04"](X01, add=X01, add2=u["04"](X14))
         X15 = r["15"](X14, add=X14, add2=u["15"](X25))
         X05 = r["05"](X04, add=X04, add2=u["05"](X15))
-        t = self.tail_up(self.tail_a(X05))
-        return self.tail_last(_ops.pixel_shuffle2(t))
+        # upsample conv + nn.PixelShuffle(2) (FusionNet.py:100-103): the shuffle is the convolution's store where a tile has that form
+        return self.tail_last(_ops.conv3x3_shuffle(self.tail_up, self.tail_a(X05)))
 
     forward = __call__

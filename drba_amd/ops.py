@@ -610,6 +610,32 @@ class Conv3x3:
         return out
 
 
+def conv3x3_shuffle(layer, x):
+    """pixel_shuffle2(layer(x)) with the shuffle in the convolution's store (drba_conv3x3_shuffle: GridNet's tail, 2 x 1.1 GB of
+    traffic per 1080p frame less).  The configurations that carry the store form are a subset of family 4: when none of them
+    accepts the layer (family 4 off, weights out of its range, ragged width) the two kernels run as before."""
+    x = _f32(x)
+    n, cin, h, w = x.shape
+    lib = _lib.load()
+    usable = (layer.stride == 1 and layer.pre_slope is None and layer.beta is None and layer.cout % 4 == 0 and w % 4 == 0
+              and x.is_cuda and AUTOTUNE and layer.force_cfg is None and 4 in _families(layer.two_term_ok))
+    if not usable:
+        return pixel_shuffle2(layer(x))
+    out = torch.empty((n, layer.cout // 4, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    cands = [c for c in range(lib.drba_conv3x3_num_cfgs()) if lib.drba_conv3x3_cfg_stride(c) == 1
+             and lib.drba_conv3x3_cfg_family(c) == 4 and lib.drba_conv3x3_packed_floats(layer.cin, layer.cout, c) > 0]
+    run = lambda c: lib.drba_conv3x3_shuffle(_p(x), _p(layer._pack(c)), _p(layer.bias), _p(out), n, cin, h, w, layer.cout,  # noqa: E731
+                                             layer.act, layer.post_slope, c, _stream())
+    try:
+        cfg = _tune(("conv3x3_shuffle", n, cin, layer.cout, h, w), cands, run, families=(4,))
+    except _lib.DrbaHipError:
+        return pixel_shuffle2(layer(x))
+    layer._keep.add(cfg)
+    _lib.check(_timed("conv3x3", (cfg, cin, layer.cout, h, w, 1, n, "ps"), 2.0 * layer.cout * cin * 9 * h * w * n, "flop", lambda: run(cfg)),
+               "drba_conv3x3_shuffle")
+    return out
+
+
 class Deconv4x4:
     """ConvTranspose2d(k=4, s=2, p=1), optionally fused with PixelShuffle(2)."""
 

@@ -32,7 +32,7 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  8: configuration ids appended behind every earlier id of drba_conv3x3 (three, family 4: the waves of a workgroup split rows and
+/* ABI version.  9: drba_conv3x3_shuffle (a 3x3 convolution storing through PixelShuffle(2): GridNet's tail).  8: configuration ids appended behind every earlier id of drba_conv3x3 (three, family 4: the waves of a workgroup split rows and
  * cout tiles) and drba_deconv4x4s2 (four: rows and couts split across the waves, both row phases per work item); drba_status_word / drba_status_clear (the always-on, synchronisation-free overflow report of kernel family 4); the
  * *_pack entry points of family 4 refuse (DRBA_EUNSUPPORTED) a weight the two-term fp16 form cannot hold (|w| >= 65504 or non-finite).
  * 7: drba_rife_splat_ws_floats -- the workspace of drba_flow_reverse / drba_drm_rife_linear(_batch) grew by a reach map in
@@ -47,7 +47,7 @@ extern "C" {
  * workspace that must be ZERO on entry (they leave it zero on return: self-cleaning accumulator) instead of clearing it
  * themselves; batched stage entry points added; drba_conv3x3_cfg_family added and configuration ids 19 (LDS-DMA, 32
  * channels) / 20 (K split across waves) behind drba_conv3x3; the allocation exception above.  1: the first release. */
-#define DRBA_ABI_VERSION 8  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
+#define DRBA_ABI_VERSION 9  /* the ONE place the number lives: api_misc.hip returns it, drba_amd/_lib.py parses it */
 int drba_abi_version(void);
 const char *drba_error_string(int code);
 /* ABI 6, debug: with the range check on, every entry point that ran a kernel of family 4 (two fp16 terms per operand:
@@ -225,6 +225,14 @@ int drba_conv3x3(const float *in, const float *packed_w, const float *bias, cons
                  const float *residual, const float *residual2, float *out, int N, int Cin, int H, int W,
                  int Cout, int stride, int act, float post_slope, int pre_act, float pre_slope, int cfg,
                  void *stream);
+
+/* ABI 9.  drba_conv3x3 (stride 1, bias, activation; no residual operands, no pre-activation) storing through
+ * PixelShuffle(2): out is [N, Cout / 4, 2H, 2W] (reference: models/model_gmfss_union/FusionNet.py:100-103, GridNet's
+ * upsample conv + nn.PixelShuffle(2)).  packed_w is drba_conv3x3_pack's output for the same cfg.  Only configurations whose
+ * tile carries that store form accept (today: the two-term 4 x 32 x 64 tiles); every other id returns DRBA_EUNSUPPORTED and
+ * the caller runs drba_conv3x3 + drba_pixel_shuffle2.  W % 4 == 0, Cout % 4 == 0. */
+int drba_conv3x3_shuffle(const float *in, const float *packed_w, const float *bias, float *out, int N, int Cin, int H, int W,
+                         int Cout, int act, float post_slope, int cfg, void *stream);
 
 /* ConvTranspose2d(k=4, s=2, p=1) as four 2x2 phase convolutions; pixel_shuffle=1 writes
  * PixelShuffle(2) of the result directly (IFNet_HDv3.py:79-82), else plain [Cout,2H,2W]. */

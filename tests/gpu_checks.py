@@ -297,6 +297,37 @@ def check_conv_layers(dev):
         rows.append(("head_fused", float("inf"), 0.0, f"EXC {type(e).__name__}: {e}"))
     finally:
         ops.HEAD_FUSED, ops.HEAD_TWO_TERM = True, None
+    # conv3x3 + PixelShuffle(2) in the convolution's store (drba_conv3x3_shuffle, GridNet's tail): every configuration that
+    # accepts, pinned, on ragged tiles (and N = 2) against the fp64 convolution + F.pixel_shuffle; then the ops-level helper
+    import ctypes as C
+    accepted = 0
+    for (nb, cin, cout, h, w, act) in ((1, 64, 256, 11, 44, 0), (2, 32, 72, 9, 68, 1), (1, 64, 64, 5, 132, 0)):
+        x = torch.randn(nb, cin, h, w, generator=g) * 3.0
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        y = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+        ref = F.pixel_shuffle(F.leaky_relu(y, 0.2) if act else y, 2)
+        layer = ops.Conv3x3(wt, b, 1, bool(act), None, device=dev)
+        xg = x.to(dev)
+        for cfg in range(lib.drba_conv3x3_num_cfgs()):
+            if lib.drba_conv3x3_cfg_family(cfg) != 4 or lib.drba_conv3x3_cfg_stride(cfg) != 1 or lib.drba_conv3x3_packed_floats(cin, cout, cfg) == 0:
+                continue
+            out = torch.full((nb, cout // 4, 2 * h, 2 * w), float("nan"), device=dev)
+            rc = lib.drba_conv3x3_shuffle(C.c_void_p(xg.data_ptr()), C.c_void_p(layer._pack(cfg).data_ptr()), C.c_void_p(layer.bias.data_ptr()),
+                                          C.c_void_p(out.data_ptr()), nb, cin, h, w, cout, layer.act, 0.0, cfg, ops._stream())
+            if rc != 0:
+                continue  # (DRBA_EUNSUPPORTED: the tile has no shuffle store form)
+            accepted += 1
+            rows.append((f"conv+shuffle cfg{cfg} [{nb}x{cin}->{cout} {h}x{w}] (vs fp64)", _diff(out, ref.float()), 2e-5 * max(1.0, float(ref.abs().max())), ""))
+        rows.append((f"ops.conv3x3_shuffle [{nb}x{cin}->{cout} {h}x{w}] (vs fp64)", _diff(ops.conv3x3_shuffle(layer, xg), ref.float()),
+                     2e-5 * max(1.0, float(ref.abs().max())), ""))
+    rows.append(("conv+shuffle: configurations that accept", 0.0 if accepted >= 6 else float("inf"), 1.0, f"{accepted} (cfg, shape) pairs"))
+    # a ragged width (W % 4 != 0) has no shuffle form: the helper falls back to the two kernels
+    x = torch.randn(1, 32, 6, 10, generator=g)
+    wt = torch.randn(8, 32, 3, 3, generator=g) / 17.0
+    layer = ops.Conv3x3(wt, None, 1, None, None, device=dev)
+    ref = F.pixel_shuffle(F.conv2d(x.double(), wt.double(), padding=1), 2)
+    rows.append(("ops.conv3x3_shuffle ragged width (fallback) (vs fp64)", _diff(ops.conv3x3_shuffle(layer, x.to(dev)), ref.float()), 2e-5, ""))
     return rows
 
 
