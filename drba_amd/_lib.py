@@ -59,6 +59,9 @@ SIGNATURES = {
     "drba_softsplat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "drba_softsplat_ws_floats": (_z, [_i, _i, _i, _i]),
     "drba_softsplat_again": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "drba_quad_interleave": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "drba_softsplat_index": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "drba_softsplat_gather_quad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "drba_backwarp": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "drba_flow_distance": (_i, [_p, _p, _i, _i, _i, _p]),
     "drba_flow_reverse": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -150,17 +150,17 @@ class Model:
             if maps:
                 ins.append(ts)
                 outs.append(None)
-            r = _ops.softsplat_many(ins, F, Z, "soft", outs)
+            r = _ops.softsplat_many(ins, F, Z, "soft", outs, keep_quad=True)  # (the pyramid levels are per-frame caches: _features)
             cov = None
             if maps:  # t.clone() * 0 + 1 splatted along the same flow (GMFSS.py:116-117)
                 cov = _ops.softsplat_many([_ops.affine(r[2], 0.0, 1.0)], F, Z, "soft", reuse_index=True)[0]
             return r, cov
         (I1t, a1, *ta), cov0 = side(img0, f11, timestep0, F1t, Z1t, xa, p1[:, :c1])
         (I2t, b1, *tb), cov1 = side(img1, f21, timestep1, F2t, Z2t, xb, p1[:, c1:])
-        a2 = warp(f12, *down(F1t, Z1t, 0.5), "soft", out=dst(p2[:, :c2]))
-        b2 = warp(f22, *down(F2t, Z2t, 0.5), "soft", out=dst(p2[:, c2:]))
-        a3 = warp(f13, *down(F1t, Z1t, 0.25), "soft", out=dst(p3[:, :c3]))
-        b3 = warp(f23, *down(F2t, Z2t, 0.25), "soft", out=dst(p3[:, c3:]))
+        a2 = warp(f12, *down(F1t, Z1t, 0.5), "soft", out=dst(p2[:, :c2]), keep_quad=True)
+        b2 = warp(f22, *down(F2t, Z2t, 0.5), "soft", out=dst(p2[:, c2:]), keep_quad=True)
+        a3 = warp(f13, *down(F1t, Z1t, 0.25), "soft", out=dst(p3[:, :c3]), keep_quad=True)
+        b3 = warp(f23, *down(F2t, Z2t, 0.25), "soft", out=dst(p3[:, c3:]), keep_quad=True)
         if maps:
             t0, t1 = _ops.timestep_fix(ta[0], tb[0], cov0, cov1)
             _ops.swap_select(I1t, I2t, t0, t1, 25.0, out=(xa, xb))

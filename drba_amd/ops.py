@@ -193,17 +193,37 @@ def check_overflow(device=None):
 
 
 # ----------------------------------------------------------------------------- splat / warp / drm
-def softsplat(tenIn, tenFlow, tenMetric, strMode, out=None):
-    """`out` (not in the reference): a contiguous [N,C,H,W] destination, e.g. a channel slice of a concatenation buffer."""
-    return softsplat_many([tenIn], tenFlow, tenMetric, strMode, None if out is None else [out])[0]
+def softsplat(tenIn, tenFlow, tenMetric, strMode, out=None, keep_quad=False):
+    """`out` (not in the reference): a contiguous [N,C,H,W] destination, e.g. a channel slice of a concatenation buffer.
+    keep_quad: see softsplat_many."""
+    return softsplat_many([tenIn], tenFlow, tenMetric, strMode, None if out is None else [out], keep_quad=keep_quad)[0]
 
 
-def softsplat_many(inputs, tenFlow, tenMetric, strMode, outs=None, reuse_index=False):
+def quad_interleaved(x):
+    """[N,C,H,W] (C >= 16, C % 4 == 0) -> the [N][C/4][H*W][4] copy the feature gathers of the splat read, made once per tensor
+    and kept on it (with the tensor's version: a tensor written in place since gets a new copy), or None for other channel
+    counts.  The caller vouches that nothing writes the tensor through the library's raw pointers afterwards (those writes do not
+    bump the version): GMFSS's cached FeatureNet pyramids are such tensors."""
+    n, c, h, w = x.shape
+    if c < 16 or c % 4:
+        return None
+    q = getattr(x, "_drba_quad", None)
+    if q is None or q[1] != x._version:
+        qt = torch.empty((n, c // 4, h * w, 4), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().drba_quad_interleave(_p(x), _p(qt), n, c, h, w, _stream()), "drba_quad_interleave")
+        q = x._drba_quad = (qt, x._version)
+    return q[0]
+
+
+def softsplat_many(inputs, tenFlow, tenMetric, strMode, outs=None, reuse_index=False, keep_quad=False):
     """softsplat(x, tenFlow, tenMetric, strMode) for every x of `inputs` (same N, H, W; any channel counts): the sorted
     index of the (flow, metric, mode) is built once and every input is gathered through it (drba_softsplat_again) -- the
     count / scan / fill launches of the reference's one-call-per-tensor form are not repeated.  -> list of outputs.
     reuse_index=True: the caller vouches that the LAST splat on this stream used the same (flow, metric, mode, N, H, W) and
-    channel counts no larger than before (the index is still in the stream's workspace): not even the first input rebuilds it."""
+    channel counts no larger than before (the index is still in the stream's workspace): not even the first input rebuilds it.
+    keep_quad=True: feature inputs (C >= 16, C % 4 == 0) are gathered from their quad-interleaved copies, made once per tensor
+    and kept on it (quad_interleaved) instead of rewritten into the workspace by every call -- for inputs that outlive the call
+    and are splatted again (GMFSS: every pyramid level of a frame, once per output frame of two consecutive steps)."""
     parts = strMode.split("-")
     main, sub = parts[0], (parts[1] if len(parts) > 1 else None)
     assert main in ("sum", "avg", "linear", "soft")
@@ -245,7 +265,13 @@ def softsplat_many(inputs, tenFlow, tenMetric, strMode, outs=None, reuse_index=F
             out = torch.empty_like(x)
         elif tuple(out.shape) != tuple(x.shape) or not out.is_contiguous() or out.dtype != torch.float32:
             raise _lib.DrbaHipError("softsplat: out must be a contiguous float32 tensor of the input's shape")
-        if k == 0 and not reuse_index:
+        xq = quad_interleaved(inputs[k]) if keep_quad and inputs[k] is x else None  # (x is a private copy: nothing to keep it on)
+        if xq is not None:
+            if k == 0 and not reuse_index:
+                _lib.check(lib.drba_softsplat_index(_p(f), _p(m), _p(ws), n, h, w, _MODES[main], _stream()), "drba_softsplat_index")
+            _lib.check(lib.drba_softsplat_gather_quad(_p(xq), _p(out), _p(ws), n, c, h, w, _MODES[main], _EPS.get(sub, 0), _stream()),
+                       "drba_softsplat_gather_quad")
+        elif k == 0 and not reuse_index:
             _lib.check(lib.drba_softsplat(_p(x), _p(f), _p(m), _p(out), _p(ws), n, c, h, w, _MODES[main], _EPS.get(sub, 0),
                                           _stream()), "drba_softsplat")
         else:

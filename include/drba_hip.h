@@ -32,7 +32,7 @@ extern "C" {
 #define DRBA_EUNSUPPORTED (-2) /* shape/config outside what the kernels were built for */
 #define DRBA_ELAUNCH (-3)  /* hipGetLastError() reported a launch failure */
 
-/* ABI version.  9: drba_conv3x3_shuffle (a 3x3 convolution storing through PixelShuffle(2): GridNet's tail).  8: configuration ids appended behind every earlier id of drba_conv3x3 (three, family 4: the waves of a workgroup split rows and
+/* ABI version.  9: drba_conv3x3_shuffle (a 3x3 convolution storing through PixelShuffle(2): GridNet's tail); drba_quad_interleave / drba_softsplat_index / drba_softsplat_gather_quad (drba_softsplat in pieces: the interleaved copy of a feature tensor kept by the caller).  8: configuration ids appended behind every earlier id of drba_conv3x3 (three, family 4: the waves of a workgroup split rows and
  * cout tiles) and drba_deconv4x4s2 (four: rows and couts split across the waves, both row phases per work item); drba_status_word / drba_status_clear (the always-on, synchronisation-free overflow report of kernel family 4); the
  * *_pack entry points of family 4 refuse (DRBA_EUNSUPPORTED) a weight the two-term fp16 form cannot hold (|w| >= 65504 or non-finite).
  * 7: drba_rife_splat_ws_floats -- the workspace of drba_flow_reverse / drba_drm_rife_linear(_batch) grew by a reach map in
@@ -121,6 +121,16 @@ size_t drba_softsplat_ws_floats(int N, int C, int H, int W);
  * count / scan / fill launches are not repeated.  GMFSS_UNION splats a frame, its 64-channel features, the timestep map and
  * the ones-mask along one (flow, metric) pair (model_gmfss_union/GMFSS.py:92-117). */
 int drba_softsplat_again(const float *in, float *out, float *ws, int N, int C, int H, int W, int mode, int eps, void *stream);
+/* ABI 9: drba_softsplat in pieces, for a caller that keeps the quad-interleaved copy of a feature tensor across calls (the
+ * gathers of inputs with C >= 16, C % 4 == 0 read [N][C/4][H*W][4]; drba_softsplat / _again rewrite that copy into `ws` on every
+ * call, and GMFSS splats each pyramid level of a frame once per output frame of two consecutive steps):
+ *   drba_quad_interleave         [N,C,H,W] -> [N][C/4][H*W][4] (C % 4 == 0);
+ *   drba_softsplat_index         the sorted index of (flow, metric, mode) into `ws`, no gather (ws: drba_softsplat_ws_floats);
+ *   drba_softsplat_gather_quad   drba_softsplat_again for a source already in that layout (DRBA_EUNSUPPORTED for other C). */
+int drba_quad_interleave(const float *in, float *out, int N, int C, int H, int W, void *stream);
+int drba_softsplat_index(const float *flow, const float *metric, float *ws, int N, int H, int W, int mode, void *stream);
+int drba_softsplat_gather_quad(const float *in_quad, float *out, float *ws, int N, int C, int H, int W, int mode, int eps,
+                               void *stream);
 
 /* ---- backward warp -----------------------------------------------------------------------
  * replaces: models/rife_426_heavy/warplayer.py:8-22 (padding 0 = border) and

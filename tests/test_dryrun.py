@@ -135,7 +135,8 @@ def test_gmfss_union_pipeline_plumbing(dry, monkeypatch, scale, size):
     for k in ("drba_conv_direct", "drba_instance_norm", "drba_linear_split_layernorm", "drba_linear_split", "drba_window_attention",
               "drba_global_expect2", "drba_local_corr_flow", "drba_local_attn_flow", "drba_convex_upsample",
               "drba_flow_warp", "drba_resize_bilinear_ac", "drba_metric_input", "drba_pixel_shuffle2",
-              "drba_timestep_fix", "drba_swap_select", "drba_clamp", "drba_channel_normalize3", "drba_add_act"):
+              "drba_timestep_fix", "drba_swap_select", "drba_clamp", "drba_channel_normalize3", "drba_add_act",
+              "drba_quad_interleave", "drba_softsplat_index", "drba_softsplat_gather_quad"):
         assert dry.calls.get(k, 0) > 0, k
 
 

@@ -563,6 +563,34 @@ def test_feature_splat_quad_source(hip_backend):
     _assert_rows(gpu_checks.check_splat_quad(hip_backend.dev))
 
 
+@pytest.mark.gpu
+def test_kept_quad_source_equals_the_rewritten_one(hip_backend):
+    """softsplat(..., keep_quad=True) gathers a feature tensor from the interleaved copy kept on it (drba_softsplat_index +
+    drba_softsplat_gather_quad): same kernels on the same values as drba_softsplat's own copy -- equal bit for bit up to the
+    gather's segment order (the sort's slots are claimed by atomics), i.e. to rounding; a tensor rewritten in place gets a new copy."""
+    from drba_amd import ops
+    dev = hip_backend.dev
+    g = torch.Generator().manual_seed(5)
+    for (c, h, w) in ((64, 37, 52), (20, 16, 24)):
+        x = torch.randn(1, c, h, w, generator=g).to(dev)
+        flow = (torch.randn(1, 2, h, w, generator=g) * 3.0).to(dev)
+        z = torch.randn(1, 1, h, w, generator=g).to(dev)
+        ref = ops.softsplat(x, flow, z, "soft")
+        got = ops.softsplat(x, flow, z, "soft", keep_quad=True)
+        assert getattr(x, "_drba_quad", None) is not None
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        kept = x._drba_quad[0]
+        assert ops.softsplat(x, flow, z, "soft", keep_quad=True) is not None and x._drba_quad[0] is kept  # reused, not remade
+        x.mul_(2.0)  # a torch in-place write bumps the version: the copy is remade
+        got2 = ops.softsplat(x, flow, z, "soft", keep_quad=True)
+        assert x._drba_quad[0] is not kept
+        assert float((got2 - 2.0 * ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    small = torch.randn(1, 3, 9, 12, generator=g).to(dev)  # not a feature tensor: the ordinary path, nothing kept
+    fl = torch.zeros(1, 2, 9, 12, device=dev)
+    ops.softsplat(small, fl, None, "avg", keep_quad=True)
+    assert getattr(small, "_drba_quad", None) is None
+
+
 @pytest.mark.parametrize("scale,n_ts", [(1.0, 7), (1.0, 10), (2.0, 2), (2.0, 5)])
 def test_rife_many_timesteps_and_model_scale_above_one(hip_backend, oracle_backend, scale, n_ts):
     """A step with more frames to synthesise than one batched glue launch takes (DRBA_MAX_STAGE_ITEMS = 8: the 10-timestep case;
