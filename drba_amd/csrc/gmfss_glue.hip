@@ -96,12 +96,16 @@ timestep_fix_kernel(const float *__restrict__ t0, const float *__restrict__ t1, 
 
 // GMFSS.py:125-150: x[m0], y[m1] = y[m0], x[m1] with m0 = t0/t1 > thr, m1 = t1/t0 > thr (maps broadcast over C)
 __global__ void __launch_bounds__(256)
-swap_select_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ t0,
-                   const float *__restrict__ t1, float *__restrict__ ox, float *__restrict__ oy, int C, size_t P,
+swap_select_kernel(const float *x, const float *y, const float *__restrict__ t0,  // (x / ox and y / oy may be the same arrays)
+                   const float *__restrict__ t1, float *ox, float *oy, int C, size_t P,
                    float thr) {
+  const bool inplace = x == ox && y == oy;
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
     const float a = t0[p], b = t1[p];
     const bool m0 = (a / b) > thr, m1 = (b / a) > thr;
+    // in place (ox == x, oy == y: the splats wrote GridNet's input slices themselves) a pixel neither mask selects has nothing to
+    // move -- the masks mark scene changes, i.e. almost no pixel of almost every frame: the pass reads the two maps and little else
+    if (inplace && !m0 && !m1) continue;
     for (int c = 0; c < C; ++c) {
       const float xv = x[(size_t)c * P + p], yv = y[(size_t)c * P + p];
       ox[(size_t)c * P + p] = m0 ? yv : xv;

@@ -105,6 +105,7 @@ class Model:
     # against 43.2 / 42.9 frames/s per frame -- alone the N = 2 layers are 10 % faster per FLOP, beside the lookahead stream's GMFlow
     # the longer launches overlap worse), so the frames go through GridNet one by one; True is kept for A/B runs (--batch-fusion).
     BATCH_FUSION = False
+    SWAP_IN_PLACE = True  # tools/gmfss_bench.py --swap-copies: the splats go to temporaries and swap_select writes every pixel (round 5's form)
 
     def inference_many(self, jobs):
         """inference(*job) for every job of a step -- [(img0, img1, reuse_things, timestep0, timestep1, rife), ...], frames of one
@@ -138,7 +139,8 @@ class Model:
         x, p1, p2, p3 = (t[k:k + 1] for t in bufs)
         c1, c2, c3 = f11.shape[1], f12.shape[1], f13.shape[1]
         xa, xb = (x[:, 0:3], x[:, 6:9]) if self.union else (x[:, 3:6], x[:, 6:9])
-        dst = lambda t: None if maps else t  # noqa: E731  (with maps the splats go to temporaries, swap_select writes the slices)
+        # the splats write the slices; with maps swap_select then exchanges the selected pixels in place (False: temporaries, A/B runs)
+        dst = (lambda t: t) if self.SWAP_IN_PLACE or not maps else (lambda t: None)  # noqa: E731
 
         def down(flow, z, s):
             return _ops.affine(_half(flow, s), s, 0.0), _half(z, s)

@@ -564,6 +564,34 @@ def test_feature_splat_quad_source(hip_backend):
 
 
 @pytest.mark.gpu
+def test_swap_select_in_place_equals_the_reference_assignment(hip_backend):
+    """GMFSS.py:137-150: x[m0], y[m1] = y[m0], x[m1] with m0 = t0 / t1 > 25, m1 = t1 / t0 > 25 -- bit-exact (a selection), out of
+    place and in place (the form GMFSS uses: the splats wrote the destination slices, only selected pixels move), including pixels
+    where both masks hold (negative ratios cannot, zeros can: x / 0 = inf > 25 on one side, 0 / x = 0 on the other)."""
+    from drba_amd import ops
+    dev = hip_backend.dev
+    g = torch.Generator().manual_seed(11)
+    c, h, w = 7, 19, 33
+    x, y = torch.randn(1, c, h, w, generator=g), torch.randn(1, c, h, w, generator=g)
+    t0 = torch.rand(1, 1, h, w, generator=g) + 0.01
+    t1 = torch.rand(1, 1, h, w, generator=g) + 0.01
+    t0[0, 0, 3:6, 4:20] *= 100.0   # m0 region
+    t1[0, 0, 10:15, 8:30] *= 100.0  # m1 region
+    t1[0, 0, 0, 0:5] = 0.0          # t0 / 0 = inf
+    m0, m1 = (t0 / t1 > 25).repeat(1, c, 1, 1), (t1 / t0 > 25).repeat(1, c, 1, 1)
+    assert int(m0.sum()) > 0 and int(m1.sum()) > 0
+    rx, ry = x.clone(), y.clone()
+    rx[m0], ry[m1] = y[m0], x[m1]
+    gx, gy = ops.swap_select(x.to(dev), y.to(dev), t0.to(dev), t1.to(dev), 25.0)
+    assert torch.equal(gx.cpu(), rx) and torch.equal(gy.cpu(), ry)
+    buf = torch.cat([x, y], dim=1).to(dev)  # in place, on channel slices of one buffer
+    xs, ys = buf[:, :c], buf[:, c:]
+    ox, oy = ops.swap_select(xs, ys, t0.to(dev), t1.to(dev), 25.0, out=(xs, ys))
+    assert ox.data_ptr() == xs.data_ptr()
+    assert torch.equal(buf[:, :c].cpu(), rx) and torch.equal(buf[:, c:].cpu(), ry)
+
+
+@pytest.mark.gpu
 def test_kept_quad_source_equals_the_rewritten_one(hip_backend):
     """softsplat(..., keep_quad=True) gathers a feature tensor from the interleaved copy kept on it (drba_softsplat_index +
     drba_softsplat_gather_quad): same kernels on the same values as drba_softsplat's own copy -- equal bit for bit up to the

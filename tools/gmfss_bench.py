@@ -32,10 +32,14 @@ def main():
     p.add_argument("--table", action="store_true",
                    help="after the timed steps: 2 more steps on ONE stream with every launch traced -> per-symbol kernel time per step")
     p.add_argument("--batch-fusion", action="store_true", help="A/B: one GridNet pass over the frames of a step instead of one per frame")
+    p.add_argument("--swap-copies", action="store_true", help="A/B: splats into temporaries + a full swap_select pass (Model.SWAP_IN_PLACE = False)")
     a = p.parse_args()
     if a.batch_fusion:
         from drba_amd.models.model_gmfss_union.GMFSS import Model
         Model.BATCH_FUSION = True
+    if a.swap_copies:
+        from drba_amd.models.model_gmfss_union.GMFSS import Model
+        Model.SWAP_IN_PLACE = False
     dev = torch.device("cuda", 0)
     sds = synth.gmfss_union_state_dicts(0)
     if a.model == "gmfss_union":
