@@ -281,9 +281,10 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
 // of channel c at u ^ ((c >> 1) & 7) ^ ((c >> 4) & 1): every read and write below is conflict-free.  (Rows padded by 16 bytes --
 // the form up to round 5 -- cost 2 x on both 16-byte reads, whose lane groups are not 16 consecutive lanes, and 4 x on the V^T
 // writes: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE, the LDS busy 42 % of the launch.)
-// More waves per staged chunk (6 or 8 waves of 16 query rows, three or four per SIMD; 8: a thread stages 4 keys instead of 8) do not
-// fit: the O^T accumulators (64), the split Q (32) and the chunk in flight (64 / 32) leave the S / PV working set nothing under 168 /
-// 128 registers -- 138 / 131 spilled, 301 / 326 us against 148 (profiles/HISTORY.md, round 6).
+// WAVES = 8: 128 query rows share a staged chunk -- a loader thread converts 4 keys instead of 8, half the LDS writes and L2 reads per
+// query row -- as ONE workgroup per CU at the same two waves per SIMD (256 registers; three or four waves per SIMD do not fit: the
+// O^T accumulators (64), the split Q (32) and the chunk in flight leave the S / PV working set nothing under 168 / 128 registers --
+// 138 / 131 spilled, 2 x slower).  8 windows x 2160 tokens 150 -> 126 us, 128 windows x 540 140 -> 134 (same box).
 constexpr int kKU = 16;                    // 16-byte units per K row (128 halves)
 constexpr int kVU = 8;                     // 16-byte units per V^T row (64 keys)
 constexpr int kLds16Bytes = (2 * kKeys * kKU + 2 * kC * kVU) * 16 + kKeys * 4;  // 32768 + 32768 + 256 = 64.25 KB: two workgroups per CU
@@ -313,7 +314,8 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned &h, unsigned 
 [[maybe_unused]] constexpr int kKShift = 4;
 __device__ __forceinline__ int vt_swz(int ch) { return ((ch >> 1) & 7) ^ ((ch >> 4) & 1); }
 
-__global__ void __launch_bounds__(256, 2)  // two waves per SIMD = two workgroups per CU: <= 256 registers
+template <int WAVES>  // 4: two workgroups per CU; 8: one (128 query rows share a staged chunk, a loader thread stages 4 keys)
+__global__ void __launch_bounds__(64 * WAVES, 2)  // two waves per SIMD either way: <= 256 registers
 window_attention16_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                           float *__restrict__ out, Geometry g, int nwin, int qtiles, float scale, int ldq, int ldk, int ldv, int ksplit,
                           float *__restrict__ part, unsigned char *status, int tab_keys) {
@@ -323,7 +325,7 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
   u32x4 *VtH = lds16 + 2 * kKeys * kKU, *VtL = VtH + kC * kVU;  // [channel][kVU]
   int *Kreg = reinterpret_cast<int *>(VtL + kC * kVU);
   int *tab = Kreg + kKeys;  // [tab_keys] (0: none)
-  constexpr int TPW = 4, LIT = 8, ROWS = kRows;  // LIT: keys a loader thread holds
+  constexpr int TPW = 4, LIT = 32 / WAVES, ROWS = 16 * WAVES, NTH = 64 * WAVES;  // LIT: keys a loader thread holds
 
   const int lin = blockIdx.x;
   const int xcd = lin & 7;
@@ -356,15 +358,17 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
     split2h<0>(b[2], b[3], h, l), qh[j][3] = h, ql[j][3] = l;
   }
 
-  // ---- chunk loader: thread -> V^T unit lU = tid / 32, 4 channels at 4 * lq, the unit's 8 keys
-  const int lq = tid & 31, lc4 = lq * 4, lU = tid >> 5;
-  auto key_of = [&](int it) { return 32 * (lU >> 2) + 16 * (it >> 2) + 4 * (lU & 3) + (it & 3); };
+  // ---- chunk loader: thread -> V^T unit lU = tid / 32 (mod 8), 4 channels at 4 * lq, the unit's 8 keys -- or, with 8 waves, 4 of
+  // them: elements e0 .. e0 + 3, the halves crossed over at lq bit 3 (16 distinct bank pairs per 8-byte write group)
+  const int lq = tid & 31, lc4 = lq * 4, lU = (tid >> 5) & 7;
+  const int e0 = WAVES == 8 ? 4 * ((tid >> 8) ^ ((lq >> 3) & 1)) : 0;
+  auto key_of = [&](int it) { return 32 * (lU >> 2) + 16 * ((e0 + it) >> 2) + 4 * (lU & 3) + (it & 3); };
   f32x4 pk[LIT], pv[LIT];
   const int all_chunks = (g.L + kKeys - 1) / kKeys, per = (all_chunks + ksplit - 1) / ksplit;
   const int ch0 = ks * per, chunks = min(all_chunks, ch0 + per);
   const bool use_tab = tab_keys > 0;  // (the host sizes it for `per` chunks or passes 0)
   if (use_tab) {
-    for (int i = tid; i < (chunks - ch0) * kKeys; i += 256) {
+    for (int i = tid; i < (chunks - ch0) * kKeys; i += NTH) {
       int region;
       const unsigned row = token_row(g, wd, min(ch0 * kKeys + i, g.L - 1), region);
       tab[i] = (int)(row | (unsigned)region << 28);
@@ -374,7 +378,7 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
   auto fetch = [&](int chunk) {
     if (use_tab) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < LIT / 4; ++half) {
         const int4 r = *reinterpret_cast<const int4 *>(&tab[(chunk - ch0) * kKeys + key_of(4 * half)]);
         const int rows[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -413,15 +417,25 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ch = lc4 + c, u = ch * kVU + (lU ^ vt_swz(ch));
-      u32x4 h, l;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      if constexpr (WAVES == 8) {
+        u32x2 h, l;
         unsigned a, b;
-        split2h<0>(pv[2 * p][c], pv[2 * p + 1][c], a, b);
-        h[p] = a, l[p] = b;
+        split2h<0>(pv[0][c], pv[1][c], a, b), h[0] = a, l[0] = b;
+        split2h<0>(pv[2][c], pv[3][c], a, b), h[1] = a, l[1] = b;
+        unsigned char *dst = reinterpret_cast<unsigned char *>(VtH + u) + 2 * e0;
+        *reinterpret_cast<u32x2 *>(dst) = h;
+        *reinterpret_cast<u32x2 *>(dst + kC * kVU * 16) = l;
+      } else {
+        u32x4 h, l;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          unsigned a, b;
+          split2h<0>(pv[(2 * p) % LIT][c], pv[(2 * p + 1) % LIT][c], a, b);
+          h[p] = a, l[p] = b;
+        }
+        VtH[u] = h;
+        VtL[u] = l;
       }
-      VtH[u] = h;
-      VtL[u] = l;
     }
     if (g.shift && !use_tab && tid < kKeys) {
       int region;
@@ -592,20 +606,45 @@ window_attention_merge(const float *__restrict__ part, float *__restrict__ out, 
 
 }  // namespace drba_attn
 
-// floats of workspace drba_window_attention needs for this shape (0: none)
+// Waves per workgroup of the two-term kernel: 8 (128 query rows per staged chunk, one workgroup per CU) from 192 tokens per window
+// on -- below that half of an 8-wave workgroup would only help staging.  Same box, 8 windows x 2160 tokens: 150 -> 126 us, 128
+// windows x 540: 140 -> 134 (tools/exp/attn/waves_sweep.sh).
+static int attn16_waves(int L) {
+  static const int w = env_int("DRBA_ATTN_WAVES", 0);  // (TUNING builds only)
+  if (w == 4 || w == 8) return w;
+  return L >= 192 ? 8 : 4;
+}
+// key runs per window (separate workgroups, merged by window_attention_merge), fp32 kernel: the rule it was measured with
 static int attn_ksplit(int nwin, int L) {
   const int rows = drba_attn::kRows, qtiles = (L + rows - 1) / rows, chunks = (L + drba_attn::kKeys - 1) / drba_attn::kKeys;
   const long long wgs = (long long)((nwin + 7) / 8) * 8 * qtiles;
-  static const int force = env_int("DRBA_ATTN_KSPLIT", 0);  // (TUNING builds only)
-  if (force > 0) return force;
   if (wgs >= 2 * 256 || chunks < 8) return 1;  // two workgroups per CU already, or too few chunks to share out
   return chunks >= 16 ? 4 : 2;  // measured on 8 windows x 2160 tokens: 349 us unsplit, 287 us in two runs, 260 us in four
 }
+// two-term kernel: the launch ends with the fullest CU, i.e. after (rounds of resident workgroups) x (a workgroup's chunks + its
+// fixed cost of ~2.5 chunk times); a split pays the partial rows and the merge launch once more.  8 windows x 2160 tokens, 8 waves
+// (136 workgroups per run on 256 slots), runs 1..10: 143 / 159 / 126 / 143 / 127 / 142 / 133 / 155 / 144 / 148 us -- the model's
+// order; 128 windows x 540: every split slower than none (tools/exp/attn/waves8_ksplit.sh).
+static int attn16_ksplit(int nwin, int L, int waves) {
+  static const int force = env_int("DRBA_ATTN_KSPLIT", 0);  // (TUNING builds only)
+  if (force > 0) return force;
+  const int rows = 16 * waves, qtiles = (L + rows - 1) / rows, chunks = (L + drba_attn::kKeys - 1) / drba_attn::kKeys;
+  const long long per_run = (long long)((nwin + 7) / 8) * 8 * qtiles, slots = 256 * (waves == 8 ? 1 : 2);
+  int best = 1;
+  long long best_cost = -1;
+  for (int ks = 1; ks <= 10 && (ks == 1 || chunks / ks >= 4); ++ks) {
+    const long long rounds = (per_run * ks + slots - 1) / slots;
+    const long long cost = rounds * (2 * ((chunks + ks - 1) / ks) + 5) + (ks > 1 ? 3 : 0);
+    if (best_cost < 0 || cost < best_cost) best = ks, best_cost = cost;
+  }
+  return best;
+}
 
+// floats of workspace drba_window_attention needs for this shape (0: none); `terms` is not known here: the larger of the two forms'
 extern "C" size_t drba_window_attention_ws_floats(int B, int H, int W, int splits) {
   if (B <= 0 || H <= 0 || W <= 0 || splits <= 0 || H % splits || W % splits) return 0;
   const int nwin = B * splits * splits, L = (H / splits) * (W / splits);
-  const int ks = attn_ksplit(nwin, L);
+  const int ks = std::max(attn_ksplit(nwin, L), attn16_ksplit(nwin, L, attn16_waves(L)));
   return ks > 1 ? (size_t)nwin * L * ks * 132 : 0;
 }
 
@@ -626,9 +665,11 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
   if (g.shift && (g.sh == 0 || g.sw == 0)) return DRBA_EUNSUPPORTED;
   g.ww_magic = g.ww == 1 ? 0u : (unsigned)(((1ull << 32) + g.ww - 1) / g.ww);
   const int nwin = B * splits * splits;
-  const int qtiles = (g.L + drba_attn::kRows - 1) / drba_attn::kRows;
+  const int waves = terms == 2 ? attn16_waves(g.L) : 4, rows = 16 * waves;
+  const int qtiles = (g.L + rows - 1) / rows;
   const int groups = (nwin + 7) / 8;
-  const int ksplit = ws ? attn_ksplit(nwin, g.L) : 1;  // without a workspace every workgroup walks all keys
+  // without a workspace every workgroup walks all keys
+  const int ksplit = !ws ? 1 : terms == 2 ? attn16_ksplit(nwin, g.L, waves) : attn_ksplit(nwin, g.L);
   const dim3 grid((unsigned)(groups * 8 * qtiles * ksplit));
   // beyond the default 64 KB dynamic-LDS limit
   if (terms == 2) {
@@ -637,10 +678,14 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
     const bool fits = rows_all < (1ll << 24) && rows_all * std::max(ldk, ldv) < (1ll << 30) && ldk < (1 << 24) && ldv < (1 << 24);
     const int tab_keys = walk <= drba_attn::kTabCap && fits ? walk : 0;
     const int lds_bytes = drba_attn::kLds16Bytes + tab_keys * 4;
-    if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention16_kernel), lds_bytes) != hipSuccess)
-      return DRBA_ELAUNCH;
-    DRBA_LAUNCH(drba_attn::window_attention16_kernel, grid, dim3(kBlock), lds_bytes, (hipStream_t)stream, q, k, v, out, g, nwin,
-                qtiles, scale, ldq, ldk, ldv, ksplit, ws, status_bytes(), tab_keys);
+    auto go = [&](auto kern) -> int {
+      if (max_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes) != hipSuccess) return DRBA_ELAUNCH;
+      DRBA_LAUNCH(kern, grid, dim3(64 * waves), lds_bytes, (hipStream_t)stream, q, k, v, out, g, nwin, qtiles, scale, ldq, ldk, ldv,
+                  ksplit, ws, status_bytes(), tab_keys);
+      return DRBA_OK;
+    };
+    const int rc = waves == 8 ? go(drba_attn::window_attention16_kernel<8>) : go(drba_attn::window_attention16_kernel<4>);
+    if (rc != DRBA_OK) return rc;
   } else {
     if (max_dynamic_lds(reinterpret_cast<const void *>(drba_attn::window_attention_kernel), drba_attn::kLdsBytes) != hipSuccess)
       return DRBA_ELAUNCH;
