@@ -332,7 +332,8 @@ static int linear_launch(const float *x, const float *packed_w, const float *bia
   // a chunk's 16 KB of weight fragments and its barrier + global-load wait are then paid once per 48 MFMAs of a wave instead of 24
   // (same-box A/B, 69 120 tokens: 256 -> 1024 + GELU 312 -> 289 us; with one feature tile -- the 128-feature LayerNorm epilogue --
   // the wider tile halves the workgroups and loses, 27.7 -> 34 us: taken only where >= 1536 workgroups remain)
-  const bool wide = terms == 2 && (long long)((M + 127) / 128) * ((N + 127) / 128) >= 1536;
+  static const int wide_min = env_int("DRBA_LIN_WIDE_MIN", 1536);  // (TUNING builds only)
+  const bool wide = terms == 2 && (long long)((M + 127) / 128) * ((N + 127) / 128) >= wide_min;
   const int TM = wide ? 128 : 64, TN = 128;
   const int n_ntiles = (N + TN - 1) / TN, n_mtiles = (M + TM - 1) / TM;
   const dim3 grid((unsigned)(n_ntiles * n_mtiles));
