@@ -892,7 +892,10 @@ def check_window_attention(dev):
     from oracle import gmflow as ogm
     rows = []
     shapes = [(2, 36, 60, 2, True), (2, 36, 60, 2, False), (1, 24, 40, 8, True), (1, 16, 32, 2, True), (1, 16, 24, 1, False),
-              (1, 72, 120, 2, True), (2, 144, 240, 8, True), (1, 16, 8, 8, False)]
+              (1, 72, 120, 2, True), (2, 144, 240, 8, True), (1, 16, 8, 8, False),
+              # the 8-wave form of the two-term kernel (>= 192 tokens per window): a last query tile with dead waves (L = 220), and
+              # few windows of 9 chunks -- key runs + merge with 128-row tiles (L = 560)
+              (1, 20, 44, 2, True), (1, 40, 56, 2, True)]
     for idx, (b, h, w, splits, shift) in enumerate(shapes):
         q, k, v = [cases.rnd((b, h * w, 128), 70 + 3 * idx + j, 1.5) for j in range(3)]
         wh, ww = h // splits, w // splits
