@@ -551,13 +551,13 @@ def _tune(shape_key, candidates, run, reps=3, families=None):
     if not ok:
         raise _lib.DrbaHipError(f"no kernel configuration accepts {shape_key}")
     first = {cfg: timed(cfg) for cfg in ok}
-    # second look at the leaders (round 6: 38 convolution configurations, several within a few percent of each other on most
-    # layers -- one 3-launch timing each picked a 4 % slower tile for a layer in some runs): everything within 15 % of the best
-    # is timed again, in reverse order, and the smaller of its two readings counts
-    lead = min(first.values())
-    close = [cfg for cfg in reversed(ok) if first[cfg] <= 1.15 * lead]
-    second = {cfg: timed(cfg) for cfg in close} if len(close) > 1 else {close[0]: first[close[0]]}  # a lone leader needs no second look
-    best = min(second, key=lambda c: min(first[c], second[c]))
+    # Every candidate is read twice (the second pass in reverse order) and its smaller reading counts.  Round 6: 38 convolution
+    # configurations, several within a few percent of each other on most layers, and one reading in a few hundred carries a one-off
+    # delay of milliseconds (tools/exp/cfg37_probe.py: the same launch 94 us and 4111 us) -- a single pass picked a 4 % slower
+    # tile for a layer in some runs and could lose the true best to such a reading (the 24-bit headline leg read 880 once, 950-976
+    # otherwise).  ~20 ms per layer shape, once per process.
+    second = {cfg: timed(cfg) for cfg in reversed(ok)} if len(ok) > 1 else first
+    best = min(ok, key=lambda c: min(first[c], second[c]))
     _tuned[shape_key] = best
     return best
 
