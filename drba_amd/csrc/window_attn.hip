@@ -284,7 +284,9 @@ window_attention_kernel(const float *__restrict__ q, const float *__restrict__ k
 // WAVES = 8: 128 query rows share a staged chunk -- a loader thread converts 4 keys instead of 8, half the LDS writes and L2 reads per
 // query row -- as ONE workgroup per CU at the same two waves per SIMD (256 registers; three or four waves per SIMD do not fit: the
 // O^T accumulators (64), the split Q (32) and the chunk in flight leave the S / PV working set nothing under 168 / 128 registers --
-// 138 / 131 spilled, 2 x slower).  8 windows x 2160 tokens 150 -> 126 us, 128 windows x 540 140 -> 134 (same box).
+// 138 / 131 spilled, 2 x slower).  8 windows x 2160 tokens 150 -> 126 us, 128 windows x 540 140 -> 134 (same box).  With the CU's LDS to
+// itself that workgroup keeps two chunk images (128.5 KB): chunk c + 1 is converted and written while chunk c is worked on, one
+// barrier per chunk instead of two -- 128 -> 123 us, 135 -> 129.
 constexpr int kKU = 16;                    // 16-byte units per K row (128 halves)
 constexpr int kVU = 8;                     // 16-byte units per V^T row (64 keys)
 constexpr int kLds16Bytes = (2 * kKeys * kKU + 2 * kC * kVU) * 16 + kKeys * 4;  // 32768 + 32768 + 256 = 64.25 KB: two workgroups per CU
@@ -321,10 +323,10 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
                           float *__restrict__ part, unsigned char *status, int tab_keys) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
-  u32x4 *KsH = lds16, *KsL = lds16 + kKeys * kKU;           // [key][kKU]
-  u32x4 *VtH = lds16 + 2 * kKeys * kKU, *VtL = VtH + kC * kVU;  // [channel][kVU]
-  int *Kreg = reinterpret_cast<int *>(VtL + kC * kVU);
-  int *tab = Kreg + kKeys;  // [tab_keys] (0: none)
+  // chunk image: K planes [key][kKU], V^T planes [channel][kVU], key regions; WAVES = 8 (one workgroup per CU) keeps TWO images: chunk
+  // c + 1 is converted and written while chunk c is worked on, one barrier per chunk instead of two
+  constexpr int NBUF = WAVES == 8 ? 2 : 1, IMG = kLds16Bytes / 16;  // 16-byte units per image
+  int *tab = reinterpret_cast<int *>(lds16 + NBUF * IMG);  // [tab_keys] (0: none), behind the image(s)
   constexpr int TPW = 4, LIT = 32 / WAVES, ROWS = 16 * WAVES, NTH = 64 * WAVES;  // LIT: keys a loader thread holds
 
   const int lin = blockIdx.x;
@@ -400,7 +402,9 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
       pv[it] = *reinterpret_cast<const f32x4 *>(v + row * ldv + lc4);
     }
   };
-  auto stage = [&](int chunk) {
+  auto stage = [&](int chunk, int b) {  // into image b
+    u32x4 *KsH = lds16 + b * IMG, *VtH = KsH + 2 * kKeys * kKU, *VtL = VtH + kC * kVU;
+    int *Kreg = reinterpret_cast<int *>(VtL + kC * kVU);
     // K: [key][segment ^ (key & 15)] planes, 8 bytes (4 channels) per plane and key
 #pragma unroll
     for (int it = 0; it < LIT; ++it) {
@@ -452,12 +456,27 @@ window_attention16_kernel(const float *__restrict__ q, const float *__restrict__
   const float s_scale = (float)(1 << kKShift) / scale;  // undoes K's pre-scale, applies 1 / sqrt(C)
   const int vsw = (n16 >> 1) & 7;  // vt_swz(16 dt + n16) = vsw ^ (dt & 1)
   if (ch0 < chunks) fetch(ch0);
+  if (NBUF == 2 && ch0 < chunks) {
+    stage(ch0, 0);
+    if (ch0 + 1 < chunks) fetch(ch0 + 1);
+  }
   for (int ch = ch0; ch < chunks; ++ch) {
-    __syncthreads();  // every wave is done reading the previous chunk
-    stage(ch);
-    __syncthreads();
-    if (ch + 1 < chunks) fetch(ch + 1);
+    const int cb = NBUF == 2 ? (ch - ch0) & 1 : 0;
+    if (NBUF == 2) {
+      __syncthreads();  // image cb is written, every wave is done reading image cb ^ 1 (chunk ch - 1)
+      if (ch + 1 < chunks) {
+        stage(ch + 1, cb ^ 1);
+        if (ch + 2 < chunks) fetch(ch + 2);
+      }
+    } else {
+      __syncthreads();  // every wave is done reading the previous chunk
+      stage(ch, 0);
+      __syncthreads();
+      if (ch + 1 < chunks) fetch(ch + 1);
+    }
     if (!wlive) continue;
+    const u32x4 *KsH = lds16 + cb * IMG, *KsL = KsH + kKeys * kKU, *VtH = KsH + 2 * kKeys * kKU, *VtL = VtH + kC * kVU;
+    const int *Kreg = reinterpret_cast<const int *>(VtL + kC * kVU);
 
     // ---- S^T tiles: A = K rows (keys 16 t + n16, channels 32 j + 8 grp ..), B = this lane's Q fragment of step j
     f32x4 sh[TPW], sl[TPW];
@@ -677,7 +696,7 @@ extern "C" int drba_window_attention(const float *q, const float *k, const float
     const long long rows_all = (long long)B * H * W;
     const bool fits = rows_all < (1ll << 24) && rows_all * std::max(ldk, ldv) < (1ll << 30) && ldk < (1 << 24) && ldv < (1 << 24);
     const int tab_keys = walk <= drba_attn::kTabCap && fits ? walk : 0;
-    const int lds_bytes = drba_attn::kLds16Bytes + tab_keys * 4;
+    const int lds_bytes = drba_attn::kLds16Bytes * (waves == 8 ? 2 : 1) + tab_keys * 4;
     auto go = [&](auto kern) -> int {
       if (max_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes) != hipSuccess) return DRBA_ELAUNCH;
       DRBA_LAUNCH(kern, grid, dim3(64 * waves), lds_bytes, (hipStream_t)stream, q, k, v, out, g, nwin, qtiles, scale, ldq, ldk, ldv,
